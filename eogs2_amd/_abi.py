@@ -1,0 +1,88 @@
+"""ctypes prototypes for the C-ABI declared in include/eogs_rast.h.
+
+One `RastABI` instance wraps one loaded shared library. The product path only
+ever wraps the HIP library (see `_lib.py`); tests may wrap the CPU oracle, which
+exports the same symbols over host pointers.
+"""
+import ctypes as C
+
+ABI_VERSION = 1
+
+EOGS_OK = 0
+ERR_NAMES = {
+    -1: "EOGS_ERR_INVALID_ARG",
+    -2: "EOGS_ERR_DEVICE",
+    -3: "EOGS_ERR_WORKSPACE",
+    -4: "EOGS_ERR_ALTITUDE",
+    -5: "EOGS_ERR_OVERFLOW",
+    -6: "EOGS_ERR_NO_COLORS",
+}
+FLAG_ANTIALIASING = 1
+FLAG_DEBUG = 2
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+_u = C.c_uint
+_z = C.c_size_t
+_i64 = C.c_int64
+
+# name -> (restype, argtypes); the order is exactly include/eogs_rast.h
+SIGNATURES = {
+    "eogs_rast_last_error": (C.c_char_p, []),
+    "eogs_rast_abi_version": (_i, []),
+    "eogs_rast_backend": (C.c_char_p, []),
+    "eogs_rast_geom_bytes": (_i, [_i, C.POINTER(_z)]),
+    "eogs_rast_image_bytes": (_i, [_i, _i, C.POINTER(_z)]),
+    "eogs_rast_binning_bytes": (_i, [_i, _i, _i, _i64, C.POINTER(_z)]),
+    "eogs_rast_forward_prepare": (
+        _i,
+        [_i, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _u, _p, _p, _z, C.POINTER(_i64), _p],
+    ),
+    "eogs_rast_forward_render": (
+        _i,
+        [_i, _i, _i, _i64, _p, _p, _u, _p, _z, _p, _z, _p, _z, _p, _p, _p],
+    ),
+    "eogs_rast_backward": (
+        _i,
+        [_i, _i, _i, _i64]
+        + [_p] * 7  # bg, means3D, radii, colors, opacities, scales, rotations
+        + [_f, _p, _p, _p, _u]  # scale_modifier, cov3D_precomp, viewmatrix, projmatrix, flags
+        + [_p] * 4  # out_color, out_invdepth, dL_dout_color, dL_dout_invdepth
+        + [_p, _z, _p, _z, _p, _z]  # geom, binning, image workspaces
+        + [_p] * 9  # 7 gradients + dL_dT_sum + dL_dvm_mean
+        + [_p],  # stream
+    ),
+    "eogs_rast_mark_visible": (_i, [_i, _p, _p, _p, _p, _p]),
+}
+
+
+class RastError(RuntimeError):
+    """A C-ABI call returned a negative status."""
+
+    def __init__(self, code, message):
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {message}")
+        self.code = code
+
+
+class RastABI:
+    def __init__(self, path):
+        self.path = str(path)
+        self.cdll = C.CDLL(self.path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(self.cdll, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        v = self.cdll.eogs_rast_abi_version()
+        if v != ABI_VERSION:
+            raise RuntimeError(f"{path}: ABI version {v}, expected {ABI_VERSION}")
+        self.backend = self.cdll.eogs_rast_backend().decode()
+        # which torch device type this library's pointers live on
+        self.device_type = "cpu" if self.backend == "cpu-oracle" else "cuda"
+
+    def check(self, code):
+        if code != EOGS_OK:
+            raise RastError(code, self.cdll.eogs_rast_last_error().decode())
+
+    def __getattr__(self, name):
+        return getattr(self.cdll, "eogs_rast_" + name)

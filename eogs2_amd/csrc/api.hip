@@ -1,0 +1,206 @@
+// api.hip — the extern "C" boundary declared in include/eogs_rast.h (device pointers + hipStream_t).
+// Orchestration only: argument checks, workspace carving, kernel launches. The library never allocates
+// device memory; the only host allocation is a small pinned staging buffer for the num_rendered readback.
+#include <stdio.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+thread_local uint32_t* g_pinned = nullptr;  // MISC_WORDS u32, pinned host memory (one per calling thread)
+
+int fail(int code, const char* fmt, const char* detail = "") {
+  snprintf(g_err, sizeof g_err, fmt, detail);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) return fail(EOGS_ERR_DEVICE, #expr ": %s", hipGetErrorString(e_)); \
+  } while (0)
+
+// after a group of launches: always catch launch errors; in debug mode also synchronise (auxiliary.h:178-185)
+int check_launch(hipStream_t s, bool debug, const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && debug) e = hipStreamSynchronize(s);
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+    return EOGS_ERR_DEVICE;
+  }
+  return EOGS_OK;
+}
+#define LAUNCH_TRY(s, dbg, what)              \
+  do {                                        \
+    int rc_ = check_launch((s), (dbg), what); \
+    if (rc_ != EOGS_OK) return rc_;           \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+const char* eogs_rast_last_error(void) { return g_err; }
+int eogs_rast_abi_version(void) { return EOGS_RAST_ABI_VERSION; }
+const char* eogs_rast_backend(void) { return "hip-gfx950"; }
+
+int eogs_rast_geom_bytes(int P, size_t* bytes) {
+  if (P < 0 || !bytes) return fail(EOGS_ERR_INVALID_ARG, "geom_bytes: bad argument");
+  *bytes = geom_layout(nullptr, P).bytes;
+  return EOGS_OK;
+}
+int eogs_rast_image_bytes(int H, int W, size_t* bytes) {
+  if (H < 0 || W < 0 || !bytes) return fail(EOGS_ERR_INVALID_ARG, "image_bytes: bad argument");
+  *bytes = img_layout(nullptr, H, W).bytes;
+  return EOGS_OK;
+}
+int eogs_rast_binning_bytes(int P, int H, int W, int64_t R, size_t* bytes) {
+  (void)P;
+  if (R < 0 || H < 0 || W < 0 || !bytes) return fail(EOGS_ERR_INVALID_ARG, "binning_bytes: bad argument");
+  *bytes = bin_layout(nullptr, H, W, R).bytes;
+  return EOGS_OK;
+}
+
+int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const float* scales, const float* rotations,
+                              const float* cov3D_precomp, const float* opacities, float scale_modifier,
+                              const float* viewmatrix, const float* projmatrix, unsigned flags, int* radii, void* geom,
+                              size_t geom_bytes, int64_t* num_rendered, void* stream) {
+  (void)projmatrix;
+  g_err[0] = 0;
+  if (P < 0 || H <= 0 || W <= 0 || !num_rendered) return fail(EOGS_ERR_INVALID_ARG, "forward_prepare: bad sizes");
+  *num_rendered = 0;
+  if (P == 0) return EOGS_OK;
+  if (((W + TILE - 1) / TILE) > 65535 || ((H + TILE - 1) / TILE) > 65535)
+    return fail(EOGS_ERR_INVALID_ARG, "forward_prepare: image too large for 16-bit tile coordinates");
+  if (!means3D || !opacities || !viewmatrix || !radii || !geom) return fail(EOGS_ERR_INVALID_ARG, "forward_prepare: NULL input");
+  const bool have_sr = scales && rotations, have_cov = cov3D_precomp != nullptr;
+  if (have_sr == have_cov || (!!scales != !!rotations))
+    return fail(EOGS_ERR_INVALID_ARG,
+                "forward_prepare: provide exactly one of either scale/rotation pair or precomputed 3D covariance");
+  char* base = ws_base(geom);
+  const GeomWS g = geom_layout(base, P);
+  if ((size_t)(base - (char*)geom) + g.bytes - 256 > geom_bytes)
+    return fail(EOGS_ERR_WORKSPACE, "forward_prepare: geom workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const bool debug = flags & EOGS_FLAG_DEBUG;
+  if (!g_pinned) HIP_TRY(hipHostMalloc((void**)&g_pinned, MISC_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+
+  HIP_TRY(hipMemsetAsync(g.misc, 0, MISC_WORDS * sizeof(uint32_t), s));
+  FwdPrepArgs a{P, H, W, means3D, scales, rotations, cov3D_precomp, opacities, viewmatrix, scale_modifier,
+                (flags & EOGS_FLAG_ANTIALIASING) != 0, radii};
+  launch_preprocess_fwd(a, g, s);
+  LAUNCH_TRY(s, debug, "preprocess_fwd");
+  HIP_TRY(hipMemcpyAsync(g_pinned, g.misc, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  // the depth sort does not depend on num_rendered: it runs while the host waits for the readback
+  launch_depth_sort(g, P, s);
+  LAUNCH_TRY(s, debug, "depth_sort");
+  HIP_TRY(hipStreamSynchronize(s));
+  if (g_pinned[MISC_ERR] & 1u) return fail(EOGS_ERR_ALTITUDE, "Point is too high: altitude > 200");
+  const uint64_t total = (uint64_t)g_pinned[MISC_TOTAL_LO] | ((uint64_t)g_pinned[MISC_TOTAL_HI] << 32);
+  if (total >= ((uint64_t)1 << 31)) return fail(EOGS_ERR_OVERFLOW, "num_rendered overflows 31 bits");
+  *num_rendered = (int64_t)total;
+  return EOGS_OK;
+}
+
+int eogs_rast_forward_render(int P, int H, int W, int64_t R, const float* colors, const float* bg, unsigned flags,
+                             void* geom, size_t geom_bytes, void* binning, size_t binning_bytes, void* image,
+                             size_t image_bytes, float* out_color, float* out_invdepth, void* stream) {
+  g_err[0] = 0;
+  if (P < 0 || H <= 0 || W <= 0 || R < 0 || !out_color || !bg || !image)
+    return fail(EOGS_ERR_INVALID_ARG, "forward_render: bad argument");
+  if (P > 0 && !colors) return fail(EOGS_ERR_NO_COLORS, "For non-RGB, provide precomputed Gaussian colors!");
+  if (R > 0 && (P == 0 || !geom || !binning)) return fail(EOGS_ERR_INVALID_ARG, "forward_render: NULL workspace");
+  hipStream_t s = (hipStream_t)stream;
+  const bool debug = flags & EOGS_FLAG_DEBUG;
+  char* ibase = ws_base(image);
+  const ImgWS im = img_layout(ibase, H, W);
+  if ((size_t)(ibase - (char*)image) + im.bytes - 256 > image_bytes)
+    return fail(EOGS_ERR_WORKSPACE, "forward_render: image workspace too small");
+  GeomWS g = geom_layout(nullptr, 0);
+  BinWS b = bin_layout(nullptr, H, W, 0);
+  if (P > 0) {
+    char* gb = ws_base(geom);
+    g = geom_layout(gb, P);
+    if ((size_t)(gb - (char*)geom) + g.bytes - 256 > geom_bytes)
+      return fail(EOGS_ERR_WORKSPACE, "forward_render: geom workspace too small");
+  }
+  if (R > 0) {
+    char* bb = ws_base(binning);
+    b = bin_layout(bb, H, W, R);
+    if ((size_t)(bb - (char*)binning) + b.bytes - 256 > binning_bytes)
+      return fail(EOGS_ERR_WORKSPACE, "forward_render: binning workspace too small");
+  }
+  launch_binning(g, b, im, P, H, W, R, s);
+  LAUNCH_TRY(s, debug, "binning");
+  launch_render_fwd(g, b, im, H, W, colors, bg, out_color, out_invdepth, s);
+  LAUNCH_TRY(s, debug, "render_fwd");
+  return EOGS_OK;
+}
+
+int eogs_rast_backward(int P, int H, int W, int64_t R, const float* bg, const float* means3D, const int* radii,
+                       const float* colors, const float* opacities, const float* scales, const float* rotations,
+                       float scale_modifier, const float* cov3D_precomp, const float* viewmatrix,
+                       const float* projmatrix, unsigned flags, const float* out_color, const float* out_invdepth,
+                       const float* dL_dout_color, const float* dL_dout_invdepth, const void* geom, size_t geom_bytes,
+                       const void* binning, size_t binning_bytes, const void* image, size_t image_bytes,
+                       float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D,
+                       float* dL_dscales, float* dL_drotations, float* dL_dT_sum, float* dL_dvm_mean, void* stream) {
+  (void)bg;
+  g_err[0] = 0;
+  if (P < 0 || H <= 0 || W <= 0 || R < 0) return fail(EOGS_ERR_INVALID_ARG, "backward: bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  const bool debug = flags & EOGS_FLAG_DEBUG;
+  if (P == 0) {
+    if (dL_dT_sum) HIP_TRY(hipMemsetAsync(dL_dT_sum, 0, 6 * sizeof(float), s));
+    if (dL_dvm_mean) HIP_TRY(hipMemsetAsync(dL_dvm_mean, 0, 12 * sizeof(float), s));
+    return EOGS_OK;
+  }
+  if (!means3D || !radii || !colors || !opacities || !viewmatrix || !projmatrix || !dL_dout_color || !out_color ||
+      !geom || !image || !dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !dL_dcov3D)
+    return fail(EOGS_ERR_INVALID_ARG, "backward: NULL argument");
+  if (dL_dout_invdepth && !out_invdepth) return fail(EOGS_ERR_INVALID_ARG, "backward: out_invdepth required with dL_dout_invdepth");
+  const bool have_sr = scales && rotations;
+  if (have_sr == (cov3D_precomp != nullptr)) return fail(EOGS_ERR_INVALID_ARG, "backward: scale/rotation xor cov3D_precomp");
+  if (have_sr && (!dL_dscales || !dL_drotations)) return fail(EOGS_ERR_INVALID_ARG, "backward: NULL scale/rotation gradient");
+  if (R > 0 && !binning) return fail(EOGS_ERR_INVALID_ARG, "backward: NULL binning workspace");
+
+  char* gb = ws_base(geom);
+  const GeomWS g = geom_layout(gb, P);
+  char* ib = ws_base(image);
+  const ImgWS im = img_layout(ib, H, W);
+  BinWS b = bin_layout(nullptr, H, W, 0);
+  if (R > 0) {
+    char* bb = ws_base(binning);
+    b = bin_layout(bb, H, W, R);
+    if ((size_t)(bb - (char*)binning) + b.bytes - 256 > binning_bytes)
+      return fail(EOGS_ERR_WORKSPACE, "backward: binning workspace too small");
+  }
+  if ((size_t)(gb - (char*)geom) + g.bytes - 256 > geom_bytes || (size_t)(ib - (char*)image) + im.bytes - 256 > image_bytes)
+    return fail(EOGS_ERR_WORKSPACE, "backward: workspace too small");
+
+  if (R > 0) {
+    launch_render_bwd(g, b, im, H, W, colors, out_color, out_invdepth, dL_dout_color, dL_dout_invdepth, s);
+    LAUNCH_TRY(s, debug, "render_bwd");
+  }
+  GaussBwdArgs a{P, H, W, means3D, have_sr ? scales : nullptr, have_sr ? rotations : nullptr, cov3D_precomp, opacities,
+                 viewmatrix, projmatrix, radii, scale_modifier, (flags & EOGS_FLAG_ANTIALIASING) != 0,
+                 dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, have_sr ? dL_dscales : nullptr,
+                 have_sr ? dL_drotations : nullptr, dL_dT_sum, dL_dvm_mean};
+  launch_gaussian_bwd(a, g, b, s);
+  LAUNCH_TRY(s, debug, "gaussian_bwd");
+  return EOGS_OK;
+}
+
+// checkFrustum's predicate has its culling commented out (DGR/cuda_rasterizer/auxiliary.h:151-176): all visible.
+int eogs_rast_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                           uint8_t* present, void* stream) {
+  (void)means3D; (void)viewmatrix; (void)projmatrix;
+  g_err[0] = 0;
+  if (P < 0 || (P > 0 && !present)) return fail(EOGS_ERR_INVALID_ARG, "mark_visible: bad argument");
+  if (P > 0) HIP_TRY(hipMemsetAsync(present, 1, (size_t)P, (hipStream_t)stream));
+  return EOGS_OK;
+}
+
+}  // extern "C"

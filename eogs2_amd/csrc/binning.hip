@@ -1,0 +1,293 @@
+// binning.hip — builds the per-tile, depth-ordered Gaussian lists.
+//
+// Replaces InclusiveSum + duplicateWithKeys + cub::DeviceRadixSort::SortPairs(64-bit keys, 32+log2(T) bits) +
+// identifyTileRanges (DGR/cuda_rasterizer/rasterizer_impl.cu:70-138,280-320) with a pipeline that produces
+// the SAME list order — by tile, then depth bits ascending, then Gaussian index — while moving far fewer bytes:
+//
+//   1. depth sort of the P Gaussians: stable LSD radix on the 32 depth bits, payload = Gaussian id (8 B/item,
+//      4 passes over P items instead of 6 passes over R pairs of 12 B);
+//   2. expand in depth order: pair slot = exclusive scan of tiles_touched over the depth-sorted Gaussians; a
+//      load-balanced workgroup expansion writes (tile id, Gaussian id) with contiguous lanes;
+//   3. stable LSD radix on the tile id only (ceil(log2 T) bits, 1-2 passes, 8 B/pair): stability keeps the
+//      depth order inside every tile;
+//   4. tile ranges from the sorted tile ids.
+// A (tile, Gaussian) pair is unique, so (tile, depth bits, index) is a total order and the result is
+// bit-identical to the reference's stable 64-bit-key sort.
+//
+// All kernels: 256-thread workgroups (4 wave64), wave-level ranking by ballot/match, LDS only for
+// histograms and workgroup scans.  HBM-bound integer work.
+#include "common.h"
+
+namespace {
+
+__device__ inline uint32_t wave_incl_scan_u32(uint32_t v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t n = __shfl_up(v, o, 64);
+    if (lane >= o) v += n;
+  }
+  return v;
+}
+
+// Exclusive scan across the 256 threads of a workgroup; `total` = sum over the workgroup. s_w: 4 words of LDS.
+__device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, uint32_t& total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t inc = wave_incl_scan_u32(v);
+  if (lane == 63) s_w[w] = inc;
+  __syncthreads();
+  const uint32_t w0 = s_w[0], w1 = s_w[1], w2 = s_w[2], w3 = s_w[3];
+  const uint32_t pre = (w > 0 ? w0 : 0u) + (w > 1 ? w1 : 0u) + (w > 2 ? w2 : 0u);
+  total = w0 + w1 + w2 + w3;
+  __syncthreads();
+  return pre + inc - v;
+}
+
+}  // namespace
+
+// ---- radix pass, kernel 1: per-workgroup digit histogram, written digit-major hist[d][blk] ----
+template <int ITEMS>
+__global__ __launch_bounds__(BLK) void radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift,
+                                                         uint32_t mask, uint32_t* __restrict__ hist, uint32_t nblk) {
+  __shared__ uint32_t h[256];
+  const int t = threadIdx.x;
+  h[t] = 0;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * (uint32_t)(BLK * ITEMS);
+#pragma unroll
+  for (int i = 0; i < ITEMS; i++) {
+    const uint32_t k = base + i * BLK + t;
+    if (k < n) atomicAdd(&h[(keys[k] >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  if ((uint32_t)t <= mask) hist[(size_t)t * nblk + blockIdx.x] = h[t];
+}
+
+// ---- radix pass, kernel 2: one workgroup per digit scans that digit's row over workgroups (exclusive) ----
+__global__ __launch_bounds__(BLK) void radix_rowscan_kernel(uint32_t* __restrict__ hist, uint32_t nblk,
+                                                            uint32_t* __restrict__ dtotal) {
+  __shared__ uint32_t s_w[4];
+  uint32_t* row = hist + (size_t)blockIdx.x * nblk;
+  uint32_t carry = 0;
+  for (uint32_t b0 = 0; b0 < nblk; b0 += BLK) {
+    const uint32_t i = b0 + threadIdx.x;
+    const uint32_t v = i < nblk ? row[i] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan(v, s_w, tot);
+    if (i < nblk) row[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) dtotal[blockIdx.x] = carry;
+}
+
+// ---- radix pass, kernel 3: stable scatter ----
+// Round i handles keys [base + i*256, base + (i+1)*256): lane order == key order, so ranking by
+// (rounds, waves, lanes) is stable. Per round: wave-level match by ballot on the digit bits, per-wave digit
+// counts in LDS, prefix over earlier waves, running per-digit count over earlier rounds.
+template <int ITEMS>
+__global__ __launch_bounds__(BLK) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
+                                                            const uint32_t* __restrict__ vals_in,
+                                                            uint32_t* __restrict__ keys_out,
+                                                            uint32_t* __restrict__ vals_out, uint32_t n, int shift,
+                                                            int nbits, const uint32_t* __restrict__ hist,
+                                                            uint32_t nblk, const uint32_t* __restrict__ dtotal) {
+  __shared__ uint32_t s_gbase[256];    // global output base of each digit for this workgroup
+  __shared__ uint32_t s_run[256];      // keys of each digit seen in earlier rounds
+  __shared__ uint32_t s_cnt[4][256];   // per-wave digit counts of the current round
+  __shared__ uint32_t s_w[4];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const uint32_t mask = (1u << nbits) - 1u;
+
+  // digit base = exclusive scan of digit totals + this workgroup's offset inside the digit
+  {
+    const uint32_t tot = (uint32_t)t <= mask ? dtotal[t] : 0u;
+    uint32_t all;
+    const uint32_t ex = block_excl_scan(tot, s_w, all);
+    s_gbase[t] = (uint32_t)t <= mask ? ex + hist[(size_t)t * nblk + blockIdx.x] : 0u;
+    s_run[t] = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) s_cnt[k][t] = 0;
+  }
+  __syncthreads();
+
+  const uint32_t base = blockIdx.x * (uint32_t)(BLK * ITEMS);
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int i = 0; i < ITEMS; i++) {
+    const uint32_t k = base + i * BLK + t;
+    const bool live = k < n;
+    uint32_t key = 0, val = 0, d = 0;
+    if (live) {
+      key = keys_in[k];
+      val = vals_in[k];
+      d = (key >> shift) & mask;
+    }
+    // lanes of this wave holding the same digit
+    unsigned long long peers = __ballot(live);
+    for (int b = 0; b < nbits; b++) {
+      const unsigned long long m = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? m : ~m;
+    }
+    const uint32_t rank_in_wave = (uint32_t)__popcll(peers & lt_mask);
+    if (live && rank_in_wave == 0) s_cnt[w][d] = (uint32_t)__popcll(peers);  // one leader per digit per wave
+    __syncthreads();
+    if (live) {
+      uint32_t pre = s_run[d];
+      if (w > 0) pre += s_cnt[0][d];
+      if (w > 1) pre += s_cnt[1][d];
+      if (w > 2) pre += s_cnt[2][d];
+      const uint32_t pos = s_gbase[d] + pre + rank_in_wave;
+      keys_out[pos] = key;
+      vals_out[pos] = val;
+    }
+    __syncthreads();
+    {  // thread t owns digit t: fold this round into the running count and clear the per-wave slots
+      s_run[t] += s_cnt[0][t] + s_cnt[1][t] + s_cnt[2][t] + s_cnt[3][t];
+      s_cnt[0][t] = 0; s_cnt[1][t] = 0; s_cnt[2][t] = 0; s_cnt[3][t] = 0;
+    }
+    __syncthreads();
+  }
+}
+
+template <int ITEMS>
+static void radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, uint32_t n, int shift,
+                       int nbits, uint32_t* hist, uint32_t nblk, uint32_t* dtotal, hipStream_t s) {
+  const uint32_t mask = (1u << nbits) - 1u;
+  hipLaunchKernelGGL((radix_hist_kernel<ITEMS>), dim3(nblk), dim3(BLK), 0, s, kin, n, shift, mask, hist, nblk);
+  hipLaunchKernelGGL(radix_rowscan_kernel, dim3(mask + 1), dim3(BLK), 0, s, hist, nblk, dtotal);
+  hipLaunchKernelGGL((radix_scatter_kernel<ITEMS>), dim3(nblk), dim3(BLK), 0, s, kin, vin, kout, vout, n, shift, nbits,
+                     hist, nblk, dtotal);
+}
+
+// Depth sort: 4 stable passes over the 32 depth bits; result (ids in depth order) lands back in svalA.
+void launch_depth_sort(const GeomWS& g, int P, hipStream_t s) {
+  uint32_t *ka = g.skeyA, *kb = g.skeyB, *va = g.svalA, *vb = g.svalB;
+  for (int pass = 0; pass < 4; pass++) {
+    radix_pass<SORTP_ITEMS>(ka, va, kb, vb, (uint32_t)P, 8 * pass, 8, g.hist, g.nblkP, g.dtotal, s);
+    uint32_t* tk = ka; ka = kb; kb = tk;
+    uint32_t* tv = va; va = vb; vb = tv;
+  }
+}
+
+// ---- expand step A: pair count of each chunk of 1024 depth-sorted Gaussians ----
+__global__ __launch_bounds__(BLK) void expand_count_kernel(const uint32_t* __restrict__ sorted_ids,
+                                                           const uint32_t* __restrict__ tiles, uint32_t P,
+                                                           uint32_t* __restrict__ blocksum) {
+  __shared__ uint32_t s_w[4];
+  const uint32_t base = blockIdx.x * (uint32_t)(BLK * EXPAND_ITEMS);
+  uint32_t v = 0;
+#pragma unroll
+  for (int i = 0; i < EXPAND_ITEMS; i++) {
+    const uint32_t k = base + i * BLK + threadIdx.x;
+    if (k < P) v += tiles[sorted_ids[k]];
+  }
+  uint32_t tot;
+  (void)block_excl_scan(v, s_w, tot);
+  if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
+}
+
+// ---- expand step B: exclusive scan of the chunk counts (single workgroup; nblk <= a few thousand) ----
+__global__ __launch_bounds__(BLK) void expand_scan_kernel(uint32_t* __restrict__ blocksum, uint32_t nblk) {
+  __shared__ uint32_t s_w[4];
+  uint32_t carry = 0;
+  for (uint32_t b0 = 0; b0 < nblk; b0 += BLK) {
+    const uint32_t i = b0 + threadIdx.x;
+    const uint32_t v = i < nblk ? blocksum[i] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan(v, s_w, tot);
+    if (i < nblk) blocksum[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) blocksum[nblk] = carry;
+}
+
+// ---- expand step C: load-balanced emission of (tile id, Gaussian id) in depth order ----
+__global__ __launch_bounds__(BLK) void expand_kernel(const uint32_t* __restrict__ sorted_ids,
+                                                     const uint32_t* __restrict__ tiles,
+                                                     const uint2* __restrict__ rect,
+                                                     const uint32_t* __restrict__ blocksum, uint32_t P, uint32_t gx,
+                                                     uint32_t* __restrict__ slot_base, uint32_t* __restrict__ tkey,
+                                                     uint32_t* __restrict__ tval) {
+  constexpr int N = BLK * EXPAND_ITEMS;
+  __shared__ uint32_t s_lo[N + 1];  // exclusive pair offset of each Gaussian of the chunk
+  __shared__ uint32_t s_id[N];
+  __shared__ uint32_t s_x0w[N];     // x0 | width << 16
+  __shared__ uint32_t s_y0[N];
+  __shared__ uint32_t s_w[4];
+  const int t = threadIdx.x;
+  const uint32_t base = blockIdx.x * (uint32_t)N;
+  const uint32_t gbase = blocksum[blockIdx.x];
+  uint32_t carry = 0;
+  for (int i = 0; i < EXPAND_ITEMS; i++) {
+    const uint32_t j = i * BLK + t, k = base + j;
+    uint32_t id = 0, c = 0;
+    uint2 r = make_uint2(0, 0);
+    if (k < P) {
+      id = sorted_ids[k];
+      c = tiles[id];
+      if (c) r = rect[id];
+    }
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan(c, s_w, tot);
+    s_lo[j] = carry + ex;
+    s_id[j] = id;
+    const uint32_t x0 = r.x & 0xFFFFu, x1 = r.x >> 16;
+    s_x0w[j] = x0 | ((x1 - x0) << 16);
+    s_y0[j] = r.y & 0xFFFFu;
+    if (k < P && c) slot_base[id] = gbase + carry + ex;
+    carry += tot;
+  }
+  if (t == 0) s_lo[N] = carry;
+  __syncthreads();
+  const uint32_t total = carry;
+  for (uint32_t sidx = t; sidx < total; sidx += BLK) {
+    // largest j in [0,N) with s_lo[j] <= sidx (its count is > 0 because s_lo[j+1] > sidx)
+    uint32_t lo = 0, hi = N;  // invariant: s_lo[lo] <= sidx < s_lo[hi]
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (s_lo[mid] <= sidx) lo = mid; else hi = mid;
+    }
+    const uint32_t q = sidx - s_lo[lo];
+    const uint32_t x0 = s_x0w[lo] & 0xFFFFu, wdt = s_x0w[lo] >> 16;
+    const uint32_t row = q / wdt, col = q - row * wdt;
+    tkey[gbase + sidx] = (s_y0[lo] + row) * gx + x0 + col;
+    tval[gbase + sidx] = s_id[lo];
+  }
+}
+
+// ---- tile ranges from the sorted tile ids (identifyTileRanges, rasterizer_impl.cu:116-138) ----
+__global__ __launch_bounds__(BLK) void tile_ranges_kernel(const uint32_t* __restrict__ skeys, uint32_t R,
+                                                          uint2* __restrict__ ranges) {
+  const uint32_t i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= R) return;
+  const uint32_t cur = skeys[i];
+  if (i == 0) ranges[cur].x = 0;
+  else {
+    const uint32_t prev = skeys[i - 1];
+    if (cur != prev) {
+      ranges[prev].y = i;
+      ranges[cur].x = i;
+    }
+  }
+  if (i == R - 1) ranges[cur].y = R;
+}
+
+void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, hipStream_t s) {
+  const uint32_t gx = (uint32_t)((W + TILE - 1) / TILE), gy = (uint32_t)((H + TILE - 1) / TILE);
+  (void)hipMemsetAsync(im.ranges, 0, (size_t)gx * gy * sizeof(uint2), s);
+  if (R <= 0) return;
+  hipLaunchKernelGGL(expand_count_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.svalA, g.tiles, (uint32_t)P, g.blocksum);
+  hipLaunchKernelGGL(expand_scan_kernel, dim3(1), dim3(BLK), 0, s, g.blocksum, g.nblkE);
+  hipLaunchKernelGGL(expand_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.svalA, g.tiles, g.rect, g.blocksum, (uint32_t)P, gx,
+                     g.slot_base, b.tkeyA, b.tvalA);
+  uint32_t *ka = b.tkeyA, *kb = b.tkeyB, *va = b.tvalA, *vb = b.tvalB;
+  int shift = 0;
+  for (int pass = 0; pass < b.passes; pass++) {
+    const int nbits = (b.tile_bits - shift) < b.bits_per_pass ? (b.tile_bits - shift) : b.bits_per_pass;
+    radix_pass<SORTR_ITEMS>(ka, va, kb, vb, (uint32_t)R, shift, nbits, b.hist, b.nblkR, b.dtotal, s);
+    shift += nbits;
+    uint32_t* tk = ka; ka = kb; kb = tk;
+    uint32_t* tv = va; va = vb; vb = tv;
+  }
+  hipLaunchKernelGGL(tile_ranges_kernel, dim3(ceil_div_u32((uint64_t)R, BLK)), dim3(BLK), 0, s, b.sorted_keys,
+                     (uint32_t)R, im.ranges);
+}

@@ -1,0 +1,171 @@
+// common.h — shared definitions for the gfx950 rasterizer library (host + device).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "eogs_rast.h"
+
+#define NCH EOGS_RAST_CHANNELS  // 5 feature channels
+#define TILE EOGS_RAST_TILE     // 16x16 pixel tiles
+#define BLK 256                 // threads per workgroup everywhere (4 wave64)
+#define NFEAT 6                 // staged per-Gaussian features: 5 colours + 1/depth
+#define REC 12                  // floats per (tile,Gaussian) gradient record (48 B, 11 used)
+
+// ---- misc[] slots (u32) in the geometry workspace ----
+#define MISC_TOTAL_LO 0  // sum of tiles_touched (u64, lo/hi)
+#define MISC_TOTAL_HI 1
+#define MISC_ERR 2       // bit0: altitude > 200
+#define MISC_WORDS 64
+
+// ---- radix sort geometry ----
+#define SORTP_ITEMS 8    // depth sort of P Gaussians: 2048 keys per workgroup
+#define SORTR_ITEMS 16   // tile sort of R pairs: 4096 keys per workgroup
+#define EXPAND_ITEMS 4   // expand: 1024 depth-sorted Gaussians per workgroup
+
+static inline size_t ws_align(size_t x) { return (x + 255u) & ~(size_t)255u; }
+
+template <typename T>
+static inline size_t ws_carve(char* base, size_t off, T*& p, size_t count) {
+  off = ws_align(off);
+  p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+  return off + count * sizeof(T);
+}
+
+static inline uint32_t ceil_div_u32(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// Geometry workspace: everything that is O(P). SoA, every array 256-B aligned.
+struct GeomWS {
+  float2* means2D;      // pixel centre
+  float* depth;         // 200 - altitude
+  float4* conic_o;      // conic (a,b,c) + effective opacity
+  uint2* rect;          // x0 | x1<<16 , y0 | y1<<16 (tile units)
+  uint32_t* tiles;      // tiles touched (0 = culled)
+  uint32_t* slot_base;  // first pair slot of this Gaussian in depth-expanded order
+  uint32_t* skeyA;      // depth-sort ping-pong (keys = depth bits, vals = Gaussian id)
+  uint32_t* skeyB;
+  uint32_t* svalA;
+  uint32_t* svalB;
+  uint32_t* hist;       // radix histograms [256][nblkP]
+  uint32_t* dtotal;     // per-digit totals [256]
+  uint32_t* blocksum;   // expand: per-workgroup pair counts / offsets [nblkE + 1]
+  uint32_t* misc;       // MISC_WORDS
+  uint32_t nblkP, nblkE;
+  size_t bytes;
+};
+
+static inline GeomWS geom_layout(char* base, int P) {
+  GeomWS g;
+  size_t n = (size_t)P, o = 0;
+  g.nblkP = ceil_div_u32(n, BLK * SORTP_ITEMS);
+  g.nblkE = ceil_div_u32(n, BLK * EXPAND_ITEMS);
+  o = ws_carve(base, o, g.means2D, n);
+  o = ws_carve(base, o, g.depth, n);
+  o = ws_carve(base, o, g.conic_o, n);
+  o = ws_carve(base, o, g.rect, n);
+  o = ws_carve(base, o, g.tiles, n);
+  o = ws_carve(base, o, g.slot_base, n);
+  o = ws_carve(base, o, g.skeyA, n);
+  o = ws_carve(base, o, g.skeyB, n);
+  o = ws_carve(base, o, g.svalA, n);
+  o = ws_carve(base, o, g.svalB, n);
+  o = ws_carve(base, o, g.hist, (size_t)256 * g.nblkP);
+  o = ws_carve(base, o, g.dtotal, 256);
+  o = ws_carve(base, o, g.blocksum, (size_t)g.nblkE + 1);
+  o = ws_carve(base, o, g.misc, MISC_WORDS);
+  g.bytes = ws_align(o) + 256;  // slack so a base that is only 1-aligned still fits after rounding
+  return g;
+}
+
+// Binning workspace: everything that is O(R) (R = number of (tile,Gaussian) pairs).
+struct BinWS {
+  uint32_t* tkeyA;  // tile ids, ping-pong
+  uint32_t* tkeyB;
+  uint32_t* tvalA;  // Gaussian ids, ping-pong
+  uint32_t* tvalB;
+  uint32_t* hist;   // [nbins][nblkR]
+  uint32_t* dtotal; // [256]
+  float* records;   // backward scratch: REC floats per pair slot
+  uint32_t nblkR;
+  int tile_bits, passes, bits_per_pass;
+  uint32_t* point_list;  // = tval buffer holding the sorted result
+  uint32_t* sorted_keys; // = tkey buffer holding the sorted result
+  size_t bytes;
+};
+
+static inline int ceil_log2_u32(uint32_t n) {  // smallest b with (1<<b) >= n
+  int b = 0;
+  while (((uint64_t)1 << b) < n) b++;
+  return b;
+}
+
+static inline BinWS bin_layout(char* base, int H, int W, int64_t R) {
+  BinWS b;
+  size_t n = (size_t)R, o = 0;
+  uint32_t T = (uint32_t)((W + TILE - 1) / TILE) * (uint32_t)((H + TILE - 1) / TILE);
+  b.tile_bits = ceil_log2_u32(T) < 1 ? 1 : ceil_log2_u32(T);
+  b.passes = (b.tile_bits + 7) / 8;
+  b.bits_per_pass = (b.tile_bits + b.passes - 1) / b.passes;
+  b.nblkR = ceil_div_u32(n, BLK * SORTR_ITEMS);
+  o = ws_carve(base, o, b.tkeyA, n);
+  o = ws_carve(base, o, b.tkeyB, n);
+  o = ws_carve(base, o, b.tvalA, n);
+  o = ws_carve(base, o, b.tvalB, n);
+  o = ws_carve(base, o, b.hist, (size_t)256 * (b.nblkR ? b.nblkR : 1));
+  o = ws_carve(base, o, b.dtotal, 256);
+  o = ws_carve(base, o, b.records, n * REC);
+  b.point_list = (b.passes & 1) ? b.tvalB : b.tvalA;
+  b.sorted_keys = (b.passes & 1) ? b.tkeyB : b.tkeyA;
+  b.bytes = ws_align(o) + 256;
+  return b;
+}
+
+// Image workspace: O(H*W) + O(tiles).
+struct ImgWS {
+  uint2* ranges;       // per tile [start,end) into point_list
+  float* final_T;      // transmittance after the last blended Gaussian
+  uint32_t* n_contrib; // 1 + list index of the last blended Gaussian
+  size_t bytes;
+};
+
+static inline ImgWS img_layout(char* base, int H, int W) {
+  ImgWS im;
+  size_t n = (size_t)H * W, o = 0;
+  size_t T = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+  o = ws_carve(base, o, im.ranges, T);
+  o = ws_carve(base, o, im.final_T, n);
+  o = ws_carve(base, o, im.n_contrib, n);
+  im.bytes = ws_align(o) + 256;
+  return im;
+}
+
+static inline char* ws_base(const void* p) {  // round the caller's pointer up to 256 B
+  return reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 255u) & ~(uintptr_t)255u);
+}
+
+// ---- launch entry points implemented in the .hip files (host functions) ----
+struct FwdPrepArgs {
+  int P, H, W;
+  const float *means3D, *scales, *rotations, *cov3D_precomp, *opacities, *viewmatrix;
+  float scale_modifier;
+  bool antialiasing;
+  int* radii;
+};
+void launch_preprocess_fwd(const FwdPrepArgs& a, const GeomWS& g, hipStream_t s);
+void launch_depth_sort(const GeomWS& g, int P, hipStream_t s);
+void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, hipStream_t s);
+void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, int W, const float* colors,
+                       const float* bg, float* out_color, float* out_invdepth, hipStream_t s);
+void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, int W, const float* colors,
+                       const float* out_color, const float* out_invdepth, const float* dL_dcolor,
+                       const float* dL_dinvdepth, hipStream_t s);
+struct GaussBwdArgs {
+  int P, H, W;
+  const float *means3D, *scales, *rotations, *cov3D_precomp, *opacities, *viewmatrix, *projmatrix;
+  const int* radii;
+  float scale_modifier;
+  bool antialiasing;
+  float *dL_dmeans2D, *dL_dcolors, *dL_dopacity, *dL_dmeans3D, *dL_dcov3D, *dL_dscales, *dL_drotations;
+  float *dL_dT_sum, *dL_dvm_mean;
+};
+void launch_gaussian_bwd(const GaussBwdArgs& a, const GeomWS& g, const BinWS& b, hipStream_t s);

@@ -1,0 +1,417 @@
+// preprocess.hip — per-Gaussian kernels (one lane per Gaussian, wave64).
+//
+//  preprocess_fwd_kernel : affine projection, Sigma = R S^2 R^T, cov2D = T Sigma T^T + 0.3 I, conic,
+//                          radius, tile rect, depth key.  Reference semantics:
+//                          DGR/cuda_rasterizer/forward.cu:154-283 (+ auxiliary.h:40-55,70-78).
+//  gaussian_bwd_kernel   : sums the per-(tile,Gaussian) gradient records written by render_bwd, then
+//                          dL/dconic -> dL/dcov2D -> dL/dSigma (+ dL/dT), dL/dmean3D, dL/dscale, dL/dquat.
+//                          Reference semantics: DGR/cuda_rasterizer/backward.cu:147-327 (computeCov2DCUDA),
+//                          :399-454 (preprocessCUDA), :331-394 (computeCov3D) fused into one kernel, plus the
+//                          wrapper-side reductions of DGR/diff_gaussian_rasterization/__init__.py:179-201.
+//
+// HBM-bound, O(P): inputs arrive as the reference's AoS [P,3]/[P,4] rows; the 12-byte rows are staged
+// through LDS so that every global access is a contiguous dword/quad per lane.
+#include "common.h"
+
+namespace {
+
+struct Mat3 {
+  float m[3][3];
+};
+
+// Rotation "math" matrix used by the reference: Rm[r][c] = R_glm[c][r] (forward.cu:126-137, glm is column-major).
+__device__ inline Mat3 quat_to_Rm(float r, float x, float y, float z) {
+  Mat3 R;
+  R.m[0][0] = 1.f - 2.f * (y * y + z * z); R.m[1][0] = 2.f * (x * y - r * z); R.m[2][0] = 2.f * (x * z + r * y);
+  R.m[0][1] = 2.f * (x * y + r * z); R.m[1][1] = 1.f - 2.f * (x * x + z * z); R.m[2][1] = 2.f * (y * z - r * x);
+  R.m[0][2] = 2.f * (x * z - r * y); R.m[1][2] = 2.f * (y * z + r * x); R.m[2][2] = 1.f - 2.f * (x * x + y * y);
+  return R;
+}
+
+// Sigma (upper triangle) = M^T M, M = diag(mod*s) Rm   (forward.cu:117-151)
+__device__ inline void cov3d_from_scale_rot(const float s[3], float mod, const float q[4], float c6[6]) {
+  Mat3 R = quat_to_Rm(q[0], q[1], q[2], q[3]);
+  float sc[3] = {mod * s[0], mod * s[1], mod * s[2]};
+  float M[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) M[i][j] = sc[i] * R.m[i][j];
+  float S[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = i; j < 3; j++) S[i][j] = M[0][i] * M[0][j] + M[1][i] * M[1][j] + M[2][i] * M[2][j];
+  c6[0] = S[0][0]; c6[1] = S[0][1]; c6[2] = S[0][2]; c6[3] = S[1][1]; c6[4] = S[1][2]; c6[5] = S[2][2];
+}
+
+// Trow[i][k] = vm[4k+i] * s_i, s = (W/2, H/2)   (forward.cu:93-102)
+__device__ inline void build_T(const float* __restrict__ vm, int W, int H, float T[2][3]) {
+  const float sx = (float)(W / 2.0), sy = (float)(H / 2.0);
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    T[0][k] = vm[4 * k + 0] * sx;
+    T[1][k] = vm[4 * k + 1] * sy;
+  }
+}
+
+// cov2D = T Sigma T^T (2x2), evaluated as (T Sigma) T^T like glm's left-to-right product (forward.cu:109).
+__device__ inline void cov2d(const float T[2][3], const float c6[6], float& cxx, float& cxy, float& cyy) {
+  const float V[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+  float A[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int l = 0; l < 3; l++) A[i][l] = T[i][0] * V[0][l] + T[i][1] * V[1][l] + T[i][2] * V[2][l];
+  cxx = A[0][0] * T[0][0] + A[0][1] * T[0][1] + A[0][2] * T[0][2];
+  cxy = A[1][0] * T[0][0] + A[1][1] * T[0][1] + A[1][2] * T[0][2];
+  cyy = A[1][0] * T[1][0] + A[1][1] * T[1][1] + A[1][2] * T[1][2];
+}
+
+__device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// Cooperative load of `rows` consecutive 3-float rows (12 B, AoS) into LDS with dword-contiguous lanes.
+__device__ inline void stage_rows3(const float* __restrict__ src, size_t row0, int rows, float* s_dst) {
+  const int t = threadIdx.x, n = rows * 3;
+  const float* p = src + row0 * 3;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    int e = i * BLK + t;
+    if (e < n) s_dst[e] = p[e];
+  }
+}
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
+    int P, int H, int W, int gx, int gy,
+    const float* __restrict__ means3D, const float* __restrict__ scales, const float* __restrict__ rotations,
+    const float* __restrict__ cov3D_precomp, const float* __restrict__ opacities, const float* __restrict__ vm,
+    float scale_modifier, int antialiasing,
+    int* __restrict__ radii, float2* __restrict__ means2D, float* __restrict__ depth_out,
+    float4* __restrict__ conic_o, uint2* __restrict__ rect, uint32_t* __restrict__ tiles,
+    uint32_t* __restrict__ skey, uint32_t* __restrict__ sval, uint32_t* __restrict__ misc) {
+  __shared__ float s_m[3 * BLK];
+  __shared__ float s_s[3 * BLK];
+  __shared__ uint32_t s_cnt[BLK / 64];
+  const int t = threadIdx.x;
+  const size_t row0 = (size_t)blockIdx.x * BLK;
+  const int rows = (int)(((size_t)P - row0) < (size_t)BLK ? ((size_t)P - row0) : (size_t)BLK);
+  stage_rows3(means3D, row0, rows, s_m);
+  if (scales) stage_rows3(scales, row0, rows, s_s);
+  __syncthreads();
+
+  const size_t idx = row0 + t;
+  uint32_t my_tiles = 0;
+  if (t < rows) {
+    const float p[3] = {s_m[3 * t], s_m[3 * t + 1], s_m[3 * t + 2]};
+    // transformPoint4x3 (auxiliary.h:70-78)
+    float pv[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) pv[i] = vm[i] * p[0] + vm[4 + i] * p[1] + vm[8 + i] * p[2] + vm[12 + i];
+
+    float c6[6];
+    if (cov3D_precomp) {
+      const float2* c2 = reinterpret_cast<const float2*>(cov3D_precomp + 6 * idx);
+      float2 a = c2[0], b = c2[1], c = c2[2];
+      c6[0] = a.x; c6[1] = a.y; c6[2] = b.x; c6[3] = b.y; c6[4] = c.x; c6[5] = c.y;
+    } else {
+      const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
+      const float s[3] = {s_s[3 * t], s_s[3 * t + 1], s_s[3 * t + 2]};
+      const float qq[4] = {q.x, q.y, q.z, q.w};
+      cov3d_from_scale_rot(s, scale_modifier, qq, c6);
+    }
+    float T[2][3];
+    build_T(vm, W, H, T);
+    float cx, cy, cz;
+    cov2d(T, c6, cx, cy, cz);
+
+    const float h_var = 0.3f;
+    const float det_cov = cx * cz - cy * cy;
+    cx += h_var;
+    cz += h_var;
+    const float det = cx * cz - cy * cy;
+    float hcs = 1.0f;
+    if (antialiasing) hcs = sqrtf(fmaxf(0.000025f, det_cov / det));
+
+    int radius = 0;
+    if (det != 0.0f) {
+      const float det_inv = 1.f / det;
+      const float mid = 0.5f * (cx + cz);
+      const float root = sqrtf(fmaxf(0.1f, mid * mid - det));
+      const float lambda1 = mid + root, lambda2 = mid - root;
+      const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+      // ndc2Pix in double (auxiliary.h:40-43)
+      const float px = (float)((((double)pv[0] + 1.0) * W - 1.0) * 0.5);
+      const float py = (float)((((double)pv[1] + 1.0) * H - 1.0) * 0.5);
+      const int r = (int)my_radius;
+      // getRect (auxiliary.h:45-55): truncating float->int division
+      const int x0 = clampi((int)((px - r) / TILE), 0, gx);
+      const int y0 = clampi((int)((py - r) / TILE), 0, gy);
+      const int x1 = clampi((int)((px + r + TILE - 1) / TILE), 0, gx);
+      const int y1 = clampi((int)((py + r + TILE - 1) / TILE), 0, gy);
+      const int area = (x1 - x0) * (y1 - y0);
+      if (area != 0) {
+        radius = r;
+        my_tiles = (uint32_t)area;
+        const float d = (float)(200.0 - (double)pv[2]);  // forward.cu:267
+        if (d < 0) atomicOr(&misc[MISC_ERR], 1u);
+        means2D[idx] = make_float2(px, py);
+        depth_out[idx] = d;
+        conic_o[idx] = make_float4(cz * det_inv, -cy * det_inv, cx * det_inv, opacities[idx] * hcs);
+        rect[idx] = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16));
+        skey[idx] = __float_as_uint(d);
+      }
+    }
+    if (my_tiles == 0) skey[idx] = 0xFFFFFFFFu;  // culled Gaussians sort last and emit nothing
+    radii[idx] = radius;
+    tiles[idx] = my_tiles;
+    sval[idx] = (uint32_t)idx;
+  }
+  // num_rendered: one 64-bit atomic per workgroup
+  uint32_t v = my_tiles;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((t & 63) == 0) s_cnt[t >> 6] = v;
+  __syncthreads();
+  if (t == 0) {
+    unsigned long long tot = (unsigned long long)s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (tot) atomicAdd(reinterpret_cast<unsigned long long*>(misc + MISC_TOTAL_LO), tot);
+  }
+}
+
+void launch_preprocess_fwd(const FwdPrepArgs& a, const GeomWS& g, hipStream_t s) {
+  const int gx = (a.W + TILE - 1) / TILE, gy = (a.H + TILE - 1) / TILE;
+  const uint32_t nblk = ceil_div_u32((uint64_t)a.P, BLK);
+  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nblk), dim3(BLK), 0, s, a.P, a.H, a.W, gx, gy, a.means3D, a.scales,
+                     a.rotations, a.cov3D_precomp, a.opacities, a.viewmatrix, a.scale_modifier, (int)a.antialiasing,
+                     a.radii, g.means2D, g.depth, g.conic_o, g.rect, g.tiles, g.skeyA, g.svalA, g.misc);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Backward, per Gaussian.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
+    int P, int H, int W,
+    const float* __restrict__ means3D, const float* __restrict__ scales, const float* __restrict__ rotations,
+    const float* __restrict__ cov3D_precomp, const float* __restrict__ opacities, const float* __restrict__ vm,
+    const float* __restrict__ proj, const int* __restrict__ radii, float scale_modifier, int antialiasing,
+    const uint32_t* __restrict__ tiles, const uint32_t* __restrict__ slot_base, const float* __restrict__ records,
+    float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
+    float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscales,
+    float* __restrict__ dL_drotations, float* __restrict__ dL_dT_sum, float* __restrict__ dL_dvm_mean) {
+  __shared__ float s_m[3 * BLK];
+  __shared__ float s_s[3 * BLK];
+  __shared__ float s_red[BLK / 64][18];
+  const int t = threadIdx.x;
+  const size_t row0 = (size_t)blockIdx.x * BLK;
+  const int rows = (int)(((size_t)P - row0) < (size_t)BLK ? ((size_t)P - row0) : (size_t)BLK);
+  stage_rows3(means3D, row0, rows, s_m);
+  if (scales) stage_rows3(scales, row0, rows, s_s);
+  __syncthreads();
+
+  const size_t idx = row0 + t;
+  float vmsum[18];
+#pragma unroll
+  for (int k = 0; k < 18; k++) vmsum[k] = 0.f;
+
+  if (t < rows) {
+    float acc[REC];
+#pragma unroll
+    for (int k = 0; k < REC; k++) acc[k] = 0.f;
+    const bool visible = radii[idx] > 0;
+    if (visible) {
+      // fixed-order sum of this Gaussian's (tile,Gaussian) records: deterministic, no atomics
+      const uint32_t n = tiles[idx];
+      const float4* r4 = reinterpret_cast<const float4*>(records + (size_t)slot_base[idx] * REC);
+      for (uint32_t q = 0; q < n; q++) {
+        const float4 a = r4[3 * q], b = r4[3 * q + 1], c = r4[3 * q + 2];
+        acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+        acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+        acc[8] += c.x; acc[9] += c.y; acc[10] += c.z;
+      }
+    }
+    // record layout: 0,1 = dL/dmean2D (NDC units)  2,3,4 = dL/dconic (a,b,c)  5 = dL/dopacity  6..10 = dL/dcolor
+    const float gxn = acc[0], gyn = acc[1];
+    float dop = acc[5];
+    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dmean3[3] = {0.f, 0.f, 0.f};
+    float dscale[3] = {0.f, 0.f, 0.f};
+    float dq[4] = {0.f, 0.f, 0.f, 0.f};
+    const float m[3] = {s_m[3 * t], s_m[3 * t + 1], s_m[3 * t + 2]};
+
+    if (visible) {
+      float c6[6];
+      float q[4] = {1.f, 0.f, 0.f, 0.f};
+      float s3[3] = {0.f, 0.f, 0.f};
+      if (cov3D_precomp) {
+        const float2* c2 = reinterpret_cast<const float2*>(cov3D_precomp + 6 * idx);
+        float2 a = c2[0], b = c2[1], c = c2[2];
+        c6[0] = a.x; c6[1] = a.y; c6[2] = b.x; c6[3] = b.y; c6[4] = c.x; c6[5] = c.y;
+      } else {
+        const float4 qq = reinterpret_cast<const float4*>(rotations)[idx];
+        q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w;
+        s3[0] = s_s[3 * t]; s3[1] = s_s[3 * t + 1]; s3[2] = s_s[3 * t + 2];
+        cov3d_from_scale_rot(s3, scale_modifier, q, c6);  // recomputed instead of stored: saves 48 B/Gaussian of HBM traffic
+      }
+      float T[2][3];
+      build_T(vm, W, H, T);
+      float c_xx, c_xy, c_yy;
+      cov2d(T, c6, c_xx, c_xy, c_yy);
+      const float dLc[3] = {acc[2], acc[3], acc[4]};
+
+      // ---- computeCov2DCUDA (backward.cu:194-272) ----
+      const float h_var = 0.3f;
+      float d_inside_root = 0.f;
+      if (antialiasing) {
+        const float det_cov = c_xx * c_yy - c_xy * c_xy;
+        c_xx += h_var;
+        c_yy += h_var;
+        const float det_p = c_xx * c_yy - c_xy * c_xy;
+        const float hcs = sqrtf(fmaxf(0.000025f, det_cov / det_p));
+        const float d_hcs = dop * opacities[idx];
+        dop = dop * hcs;
+        d_inside_root = (det_cov / det_p) <= 0.000025f ? 0.f : d_hcs / (2 * hcs);
+      } else {
+        c_xx += h_var;
+        c_yy += h_var;
+      }
+      float dxx = 0.f, dxy = 0.f, dyy = 0.f;
+      if (antialiasing) {
+        const float x = c_xx, y = c_yy, z = c_xy, w = h_var;
+        const float sqv = w * w + w * (x + y) + x * y - z * z;
+        const float denom_f = d_inside_root / (sqv * sqv);
+        dxx = w * (w * y + y * y + z * z) * denom_f;
+        dyy = w * (w * x + x * x + z * z) * denom_f;
+        dxy = -2.f * w * z * (w + x + y) * denom_f;
+      }
+      const float denom = c_xx * c_yy - c_xy * c_xy;
+      const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+      if (denom2inv != 0) {
+        dxx += denom2inv * (-c_yy * c_yy * dLc[0] + 2 * c_xy * c_yy * dLc[1] + (denom - c_xx * c_yy) * dLc[2]);
+        dyy += denom2inv * (-c_xx * c_xx * dLc[2] + 2 * c_xx * c_xy * dLc[1] + (denom - c_xx * c_yy) * dLc[0]);
+        dxy += denom2inv * 2 * (c_xy * c_yy * dLc[0] - (denom + 2 * c_xy * c_xy) * dLc[1] + c_xx * c_xy * dLc[2]);
+        dcov[0] = (T[0][0] * T[0][0] * dxx + T[0][0] * T[1][0] * dxy + T[1][0] * T[1][0] * dyy);
+        dcov[3] = (T[0][1] * T[0][1] * dxx + T[0][1] * T[1][1] * dxy + T[1][1] * T[1][1] * dyy);
+        dcov[5] = (T[0][2] * T[0][2] * dxx + T[0][2] * T[1][2] * dxy + T[1][2] * T[1][2] * dyy);
+        dcov[1] = 2 * T[0][0] * T[0][1] * dxx + (T[0][0] * T[1][1] + T[0][1] * T[1][0]) * dxy + 2 * T[1][0] * T[1][1] * dyy;
+        dcov[2] = 2 * T[0][0] * T[0][2] * dxx + (T[0][0] * T[1][2] + T[0][2] * T[1][0]) * dxy + 2 * T[1][0] * T[1][2] * dyy;
+        dcov[4] = 2 * T[0][2] * T[0][1] * dxx + (T[0][1] * T[1][2] + T[0][2] * T[1][1]) * dxy + 2 * T[1][1] * T[1][2] * dyy;
+      }
+      // ---- dL/dT (backward.cu:276-287), reduced over Gaussians instead of stored as [P,6] ----
+      if (dL_dT_sum) {
+        const float V[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
+        float TV[2][3];
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+          for (int k = 0; k < 3; k++) TV[r][k] = T[r][0] * V[k][0] + T[r][1] * V[k][1] + T[r][2] * V[k][2];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          vmsum[k] = 2 * TV[0][k] * dxx + TV[1][k] * dxy;
+          vmsum[3 + k] = 2 * TV[1][k] * dyy + TV[0][k] * dxy;
+        }
+      }
+      // ---- dL/dmean3D = A[0:2,:]^T g   (backward.cu:439-445; the cov2D kernel contributes zero, :313-317) ----
+      dmean3[0] = proj[0] * gxn + proj[1] * gyn;
+      dmean3[1] = proj[4] * gxn + proj[5] * gyn;
+      dmean3[2] = proj[8] * gxn + proj[9] * gyn;
+
+      // ---- computeCov3D backward (backward.cu:331-394) ----
+      if (!cov3D_precomp) {
+        const Mat3 R = quat_to_Rm(q[0], q[1], q[2], q[3]);
+        const float s[3] = {scale_modifier * s3[0], scale_modifier * s3[1], scale_modifier * s3[2]};
+        float M[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) M[a][c] = s[a] * R.m[a][c];
+        const float dS[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
+                                {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
+                                {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
+        float dM[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+          for (int c = 0; c < 3; c++)
+            dM[a][c] = (2.0f * M[a][0]) * dS[0][c] + (2.0f * M[a][1]) * dS[1][c] + (2.0f * M[a][2]) * dS[2][c];
+#pragma unroll
+        for (int k = 0; k < 3; k++) dscale[k] = R.m[k][0] * dM[k][0] + R.m[k][1] * dM[k][1] + R.m[k][2] * dM[k][2];
+        float D[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) D[a][c] = dM[a][c] * s[a];
+        const float r = q[0], x = q[1], y = q[2], z = q[3];
+        dq[0] = 2 * z * (D[0][1] - D[1][0]) + 2 * y * (D[2][0] - D[0][2]) + 2 * x * (D[1][2] - D[2][1]);
+        dq[1] = 2 * y * (D[1][0] + D[0][1]) + 2 * z * (D[2][0] + D[0][2]) + 2 * r * (D[1][2] - D[2][1]) - 4 * x * (D[2][2] + D[1][1]);
+        dq[2] = 2 * x * (D[1][0] + D[0][1]) + 2 * r * (D[2][0] - D[0][2]) + 2 * z * (D[1][2] + D[2][1]) - 4 * y * (D[2][2] + D[0][0]);
+        dq[3] = 2 * r * (D[0][1] - D[1][0]) + 2 * x * (D[2][0] + D[0][2]) + 2 * y * (D[1][2] + D[2][1]) - 4 * z * (D[1][1] + D[0][0]);
+      }
+    }
+    // every output row is written (zeros for culled Gaussians): no memset pass over 144 B/Gaussian
+    dL_dmeans2D[3 * idx] = gxn; dL_dmeans2D[3 * idx + 1] = gyn; dL_dmeans2D[3 * idx + 2] = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) dL_dcolors[NCH * idx + ch] = acc[6 + ch];
+    dL_dopacity[idx] = dop;
+#pragma unroll
+    for (int k = 0; k < 3; k++) dL_dmeans3D[3 * idx + k] = dmean3[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) dL_dcov3D[6 * idx + k] = dcov[k];
+    if (dL_dscales) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) dL_dscales[3 * idx + k] = dscale[k];
+    }
+    if (dL_drotations) reinterpret_cast<float4*>(dL_drotations)[idx] = make_float4(dq[0], dq[1], dq[2], dq[3]);
+
+    if (dL_dvm_mean) {  // means3D^T @ dL_dmeans2D and sum dL_dmeans2D (__init__.py:193-201); z column is zero
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        vmsum[6 + 3 * a + 0] = m[a] * gxn;
+        vmsum[6 + 3 * a + 1] = m[a] * gyn;
+      }
+      vmsum[15] = gxn;
+      vmsum[16] = gyn;
+    }
+  }
+
+  if (dL_dT_sum || dL_dvm_mean) {  // wave-uniform: kernel arguments
+#pragma unroll
+    for (int k = 0; k < 18; k++) {
+      float v = wave_sum(vmsum[k]);
+      if ((t & 63) == 0) s_red[t >> 6][k] = v;
+    }
+    __syncthreads();
+    if (t < 18) {
+      const float v = s_red[0][t] + s_red[1][t] + s_red[2][t] + s_red[3][t];
+      if (t < 6) {
+        if (dL_dT_sum) atomicAdd(&dL_dT_sum[t], v);
+      } else if (dL_dvm_mean) {
+        // vmsum[6..14] -> 3x3 (third column stays 0), vmsum[15..17] -> sum
+        const int k = t - 6;
+        if (k < 9) {
+          const int a = k / 3, c = k % 3;
+          if (c < 2) atomicAdd(&dL_dvm_mean[3 * a + c], v);
+        } else if (k - 9 < 2) {
+          atomicAdd(&dL_dvm_mean[9 + (k - 9)], v);
+        }
+      }
+    }
+  }
+}
+
+void launch_gaussian_bwd(const GaussBwdArgs& a, const GeomWS& g, const BinWS& b, hipStream_t s) {
+  if (a.dL_dT_sum) (void)hipMemsetAsync(a.dL_dT_sum, 0, 6 * sizeof(float), s);
+  if (a.dL_dvm_mean) (void)hipMemsetAsync(a.dL_dvm_mean, 0, 12 * sizeof(float), s);
+  const uint32_t nblk = ceil_div_u32((uint64_t)a.P, BLK);
+  hipLaunchKernelGGL(gaussian_bwd_kernel, dim3(nblk), dim3(BLK), 0, s, a.P, a.H, a.W, a.means3D, a.scales, a.rotations,
+                     a.cov3D_precomp, a.opacities, a.viewmatrix, a.projmatrix, a.radii, a.scale_modifier,
+                     (int)a.antialiasing, g.tiles, g.slot_base, b.records, a.dL_dmeans2D, a.dL_dcolors, a.dL_dopacity,
+                     a.dL_dmeans3D, a.dL_dcov3D, a.dL_dscales, a.dL_drotations, a.dL_dT_sum, a.dL_dvm_mean);
+}

@@ -1,0 +1,358 @@
+"""Host side of the drop-in rasterizer: the reference's Python interface over the C-ABI.
+
+Mirrors DGR/diff_gaussian_rasterization/__init__.py (DGR/ =
+src/gaussiansplatting/submodules/diff-gaussian-rasterization/ in the reference):
+
+* `GaussianRasterizationSettings`  — __init__.py:219-232 (same 13 fields, same order)
+* `rasterize_gaussians`            — __init__.py:26-48 (viewmatrix passed as differentiable input)
+* `_RasterizeGaussians`            — __init__.py:51-216 (10 inputs, 3 outputs, 10 grads)
+* `GaussianRasterizer`             — __init__.py:235-300 (forward + markVisible, same exceptions)
+
+and the torch marshalling of DGR/rasterize_points.cu:35-245 (shape check, output
+allocation, the three opaque workspaces), done here with `torch.empty` because the
+C-ABI library never allocates device memory.
+
+PyTorch is plumbing only (device memory, streams, autograd wiring): every
+arithmetic step runs in the HIP library reached through `_lib.get()`. There is no
+CPU fallback; a missing library raises.
+"""
+import ctypes
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._abi import FLAG_ANTIALIASING, FLAG_DEBUG, RastError
+
+NUM_CHANNELS = 5  # DGR/cuda_rasterizer/config.h:15
+
+
+def _backend():
+    return _lib.get()
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+    antialiasing: bool
+
+
+def _flags(rs):
+    return (FLAG_ANTIALIASING if rs.antialiasing else 0) | (FLAG_DEBUG if rs.debug else 0)
+
+
+def _f32(t, dev):
+    """Contiguous fp32 view on `dev` of a non-empty tensor, else None (-> NULL)."""
+    if t is None or t.numel() == 0:
+        return None
+    if t.device != dev:
+        raise RuntimeError(f"rasterizer input on {t.device}, expected {dev}")
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class _Ctx:
+    """device guard + stream for one call"""
+
+    def __init__(self, abi, dev):
+        self.abi = abi
+        if dev.type != abi.device_type:
+            raise RuntimeError(
+                f"rasterizer tensors live on '{dev.type}' but the loaded library ({abi.backend}) works on "
+                f"'{abi.device_type}' memory; there is no CPU fallback"
+            )
+        self.dev = dev
+        self.guard = torch.cuda.device(dev) if dev.type == "cuda" else None
+
+    def __enter__(self):
+        if self.guard is not None:
+            self.guard.__enter__()
+            self.stream = ctypes.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        else:
+            self.stream = None
+        return self
+
+    def __exit__(self, *a):
+        if self.guard is not None:
+            self.guard.__exit__(*a)
+
+
+def rasterize_gaussians(
+    means3D,
+    means2D,
+    sh,
+    colors_precomp,
+    opacities,
+    scales,
+    rotations,
+    cov3Ds_precomp,
+    raster_settings,
+):
+    return _RasterizeGaussians.apply(
+        means3D,
+        means2D,
+        sh,
+        colors_precomp,
+        opacities,
+        scales,
+        rotations,
+        cov3Ds_precomp,
+        raster_settings.viewmatrix,
+        raster_settings,
+    )
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(
+        ctx,
+        means3D,
+        means2D,
+        sh,
+        colors_precomp,
+        opacities,
+        scales,
+        rotations,
+        cov3Ds_precomp,
+        viewmat,
+        raster_settings,
+    ):
+        abi = _backend()
+        rs = raster_settings
+        # DGR/rasterize_points.cu:58-60
+        if means3D.ndim != 2 or means3D.shape[1] != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")
+        dev = means3D.device
+        P = means3D.shape[0]
+        H, W = int(rs.image_height), int(rs.image_width)
+        flags = _flags(rs)
+
+        with _Ctx(abi, dev) as cx:
+            # outputs as DGR/rasterize_points.cu:69-76 (zero images when P == 0: forward is skipped)
+            color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+            invdepths = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+            radii = torch.empty((P,), dtype=torch.int32, device=dev)
+            empty_u8 = torch.empty((0,), dtype=torch.uint8, device=dev)
+            geom = binning = img = empty_u8
+            num_rendered = 0
+            if P == 0:
+                color.zero_()
+                invdepths.zero_()
+            else:
+                # DGR/cuda_rasterizer/rasterizer_impl.cu:244-247
+                if colors_precomp is None or colors_precomp.numel() == 0:
+                    raise RuntimeError("For non-RGB, provide precomputed Gaussian colors!")
+                if colors_precomp.shape[0] != P or colors_precomp.shape[-1] != NUM_CHANNELS:
+                    raise RuntimeError(f"colors_precomp must have dimensions (num_points, {NUM_CHANNELS})")
+                m3 = _f32(means3D, dev)
+                col = _f32(colors_precomp, dev)
+                opa = _f32(opacities, dev)
+                sc = _f32(scales, dev)
+                rot = _f32(rotations, dev)
+                cov = _f32(cov3Ds_precomp, dev)
+                vm = _f32(viewmat, dev)
+                pm = _f32(rs.projmatrix, dev)
+                bg = _f32(rs.bg, dev)
+                if opa is None or opa.numel() != P:
+                    raise RuntimeError("opacities must have num_points elements")
+                if bg is None or bg.numel() != NUM_CHANNELS:
+                    raise RuntimeError(f"bg must have {NUM_CHANNELS} elements")
+
+                nbytes = ctypes.c_size_t()
+                abi.check(abi.geom_bytes(P, ctypes.byref(nbytes)))
+                geom = torch.empty((nbytes.value,), dtype=torch.uint8, device=dev)
+                abi.check(abi.image_bytes(H, W, ctypes.byref(nbytes)))
+                img = torch.empty((nbytes.value,), dtype=torch.uint8, device=dev)
+
+                R = ctypes.c_int64()
+                abi.check(
+                    abi.forward_prepare(
+                        P, H, W, _ptr(m3), _ptr(sc), _ptr(rot), _ptr(cov), _ptr(opa),
+                        float(rs.scale_modifier), _ptr(vm), _ptr(pm), flags,
+                        _ptr(radii), _ptr(geom), geom.numel(), ctypes.byref(R), cx.stream,
+                    )
+                )
+                num_rendered = R.value
+                abi.check(abi.binning_bytes(P, H, W, num_rendered, ctypes.byref(nbytes)))
+                binning = torch.empty((nbytes.value,), dtype=torch.uint8, device=dev)
+                abi.check(
+                    abi.forward_render(
+                        P, H, W, num_rendered, _ptr(col), _ptr(bg), flags,
+                        _ptr(geom), geom.numel(), _ptr(binning), binning.numel(), _ptr(img), img.numel(),
+                        _ptr(color), _ptr(invdepths), cx.stream,
+                    )
+                )
+
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(radii)
+        ctx.save_for_backward(
+            colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities,
+            geom, binning, img, color, invdepths,
+        )
+        return color, radii, invdepths
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _, grad_out_depth):
+        abi = _backend()
+        rs = ctx.raster_settings
+        (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities,
+         geom, binning, img, color, invdepths) = ctx.saved_tensors
+        dev = means3D.device
+        P = means3D.shape[0]
+        H, W = int(rs.image_height), int(rs.image_width)
+        f32 = dict(dtype=torch.float32, device=dev)
+        want_vm = ctx.needs_input_grad[8]
+
+        grad_viewmatrix = torch.zeros_like(rs.viewmatrix) if want_vm else None
+        if P == 0:
+            z = lambda *s: torch.zeros(s, **f32)
+            return (z(0, 3), z(0, 3), None, z(0, NUM_CHANNELS), z(*opacities.shape), z(*scales.shape) if scales.numel() else None,
+                    z(*rotations.shape) if rotations.numel() else None, None, grad_viewmatrix, None)
+
+        with _Ctx(abi, dev) as cx:
+            g_color = _f32(grad_out_color, dev)
+            if g_color is None:
+                g_color = torch.zeros((NUM_CHANNELS, H, W), **f32)
+            # the reference always receives a materialised (usually all-zero) invdepth gradient;
+            # here an unused invdepth output arrives as None and its work is skipped
+            g_depth = _f32(grad_out_depth, dev)
+            have_sr = scales is not None and scales.numel() != 0
+
+            d_means2D = torch.empty((P, 3), **f32)
+            d_colors = torch.empty((P, NUM_CHANNELS), **f32)
+            d_opacity = torch.empty((P, 1), **f32)
+            d_means3D = torch.empty((P, 3), **f32)
+            d_cov3D = torch.empty((P, 6), **f32)
+            d_scales = torch.empty((P, 3), **f32) if have_sr else None
+            d_rot = torch.empty((P, 4), **f32) if have_sr else None
+            dT_sum = torch.empty((6,), **f32) if want_vm else None
+            dvm_mean = torch.empty((12,), **f32) if want_vm else None
+
+            abi.check(
+                abi.backward(
+                    P, H, W, ctx.num_rendered,
+                    _ptr(_f32(rs.bg, dev)), _ptr(_f32(means3D, dev)), _ptr(radii), _ptr(_f32(colors_precomp, dev)),
+                    _ptr(_f32(opacities, dev)), _ptr(_f32(scales, dev)), _ptr(_f32(rotations, dev)),
+                    float(rs.scale_modifier), _ptr(_f32(cov3Ds_precomp, dev)),
+                    _ptr(_f32(rs.viewmatrix, dev)), _ptr(_f32(rs.projmatrix, dev)), _flags(rs),
+                    _ptr(color), _ptr(invdepths), _ptr(g_color), _ptr(g_depth),
+                    _ptr(geom), geom.numel(), _ptr(binning), binning.numel(), _ptr(img), img.numel(),
+                    _ptr(d_means2D), _ptr(d_colors), _ptr(d_opacity), _ptr(d_means3D), _ptr(d_cov3D),
+                    _ptr(d_scales), _ptr(d_rot), _ptr(dT_sum), _ptr(dvm_mean), cx.stream,
+                )
+            )
+
+            if want_vm:
+                # DGR/diff_gaussian_rasterization/__init__.py:174-202, on the reduced sums.
+                # (NCD2Screen @ dL_dT^T).sum(0): row k of the (3,2) result is scaled by NCD2Screen[k,k].
+                with torch.no_grad():
+                    ncd = torch.tensor([W / 2, H / 2, 1.0], **f32)
+                    dL_dA = ncd[:, None] * dT_sum.view(2, 3).t()
+                    grad_viewmatrix[:3, :2] += dL_dA.to(grad_viewmatrix.dtype)
+                    grad_viewmatrix[:3, :3] += dvm_mean[:9].view(3, 3).to(grad_viewmatrix.dtype)
+                    grad_viewmatrix[-1, :3] += dvm_mean[9:].to(grad_viewmatrix.dtype)
+
+        return (
+            d_means3D,
+            d_means2D,
+            None,  # sh: always the empty tensor on this 5-channel build (DGR/cuda_rasterizer/rasterizer_impl.cu:244-247)
+            d_colors,
+            d_opacity.view(opacities.shape),
+            d_scales,
+            d_rot,
+            d_cov3D if not have_sr else None,
+            grad_viewmatrix,
+            None,
+        )
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        # DGR/diff_gaussian_rasterization/__init__.py:240-248 -> DGR/rasterize_points.cu:226-245
+        abi = _backend()
+        with torch.no_grad():
+            rs = self.raster_settings
+            P = positions.shape[0]
+            present = torch.empty((P,), dtype=torch.bool, device=positions.device)
+            if P:
+                with _Ctx(abi, positions.device) as cx:
+                    abi.check(
+                        abi.mark_visible(
+                            P, _ptr(_f32(positions, positions.device)), _ptr(_f32(rs.viewmatrix, positions.device)),
+                            _ptr(_f32(rs.projmatrix, positions.device)), _ptr(present), cx.stream,
+                        )
+                    )
+        return present
+
+    def forward(
+        self,
+        means3D,
+        means2D,
+        opacities,
+        shs=None,
+        colors_precomp=None,
+        scales=None,
+        rotations=None,
+        cov3D_precomp=None,
+    ):
+        raster_settings = self.raster_settings
+
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+            (scales is not None or rotations is not None) and cov3D_precomp is not None
+        ):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+
+        if shs is None:
+            shs = torch.Tensor([])
+        if colors_precomp is None:
+            colors_precomp = torch.Tensor([])
+        if scales is None:
+            scales = torch.Tensor([])
+        if rotations is None:
+            rotations = torch.Tensor([])
+        if cov3D_precomp is None:
+            cov3D_precomp = torch.Tensor([])
+
+        return rasterize_gaussians(
+            means3D,
+            means2D,
+            shs,
+            colors_precomp,
+            opacities,
+            scales,
+            rotations,
+            cov3D_precomp,
+            raster_settings,
+        )
+
+
+__all__ = [
+    "GaussianRasterizationSettings",
+    "GaussianRasterizer",
+    "rasterize_gaussians",
+    "RastError",
+    "NUM_CHANNELS",
+]

@@ -1,0 +1,133 @@
+/*
+ * eogs_rast.h — C-ABI of the MI355X-native differentiable Gaussian-splatting
+ * rasterizer (drop-in for the hot path of gardiens/EOGS2).
+ *
+ * Every entry point takes plain pointers + sizes (no torch types) and returns
+ * an int status (0 = ok, <0 = error; message via eogs_rast_last_error()).
+ * The HIP library (eogs2_amd/csrc -> libeogs_rast_hip.so) takes DEVICE pointers
+ * and a hipStream_t passed as `void* stream`.  The CPU oracle
+ * (oracle/ -> librast_oracle.so, test infrastructure only) exports the same
+ * symbols over HOST pointers and ignores `stream`.
+ *
+ * Path shorthands for the reference interface each entry point replaces:
+ *   DGR/ = src/gaussiansplatting/submodules/diff-gaussian-rasterization/
+ *
+ * Layout contract (identical to the reference at the API):
+ *   means3D   f32[P,3] row-major        scales   f32[P,3]     rotations f32[P,4] (r,x,y,z)
+ *   opacities f32[P]                    colors   f32[P,5]     cov3D_precomp f32[P,6] or NULL
+ *   viewmatrix / projmatrix f32[16] = the torch tensor's row-major storage, which holds the
+ *     TRANSPOSED affine [[A^T,0],[b^T,1]]: uva = xyz @ vm[:3,:3] + vm[3,:3]
+ *   bg f32[5]; out_color f32[5,H,W] planar; out_invdepth f32[1,H,W]; radii i32[P]
+ * The three workspaces (geom, binning, image) are opaque byte buffers owned by
+ * the caller, sized by the *_bytes queries, written by forward and re-read by
+ * backward (the reference's geomBuffer / binningBuffer / imgBuffer,
+ * DGR/rasterize_points.cu:78-85).  The library never allocates device memory.
+ */
+#ifndef EOGS_RAST_H_INCLUDED
+#define EOGS_RAST_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EOGS_RAST_ABI_VERSION 1
+#define EOGS_RAST_CHANNELS 5 /* DGR/cuda_rasterizer/config.h:15 NUM_CHANNELS */
+#define EOGS_RAST_TILE 16    /* DGR/cuda_rasterizer/config.h:16-17 BLOCK_X/BLOCK_Y */
+
+/* status codes */
+#define EOGS_OK 0
+#define EOGS_ERR_INVALID_ARG (-1) /* bad shape / NULL where data is required            */
+#define EOGS_ERR_DEVICE (-2)      /* a HIP call or kernel failed                        */
+#define EOGS_ERR_WORKSPACE (-3)   /* workspace smaller than the *_bytes query           */
+#define EOGS_ERR_ALTITUDE (-4)    /* a Gaussian's altitude > 200 (DGR/cuda_rasterizer/forward.cu:267-272 traps) */
+#define EOGS_ERR_OVERFLOW (-5)    /* num_rendered does not fit 31 bits                  */
+#define EOGS_ERR_NO_COLORS (-6)   /* colors_precomp missing (DGR/cuda_rasterizer/rasterizer_impl.cu:244-247 throws) */
+
+/* flags */
+#define EOGS_FLAG_ANTIALIASING 1u /* raster_settings.antialiasing */
+#define EOGS_FLAG_DEBUG 2u        /* raster_settings.debug: sync + check after every kernel (DGR/cuda_rasterizer/auxiliary.h:178-185) */
+
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char* eogs_rast_last_error(void);
+int eogs_rast_abi_version(void);
+/* "hip-gfx950" for the product library, "cpu-oracle" for the test oracle. */
+const char* eogs_rast_backend(void);
+
+/* Workspace size queries.
+ * Replace required<GeometryState/ImageState/BinningState>() —
+ * DGR/cuda_rasterizer/rasterizer_impl.h:64-72, rasterizer_impl.cu:155-194,227,240,286. */
+int eogs_rast_geom_bytes(int P, size_t* bytes);
+int eogs_rast_image_bytes(int H, int W, size_t* bytes);
+int eogs_rast_binning_bytes(int P, int H, int W, int64_t num_rendered, size_t* bytes);
+
+/* Forward, phase 1: per-Gaussian preprocess + overlap count.
+ * Replaces the first half of CudaRasterizer::Rasterizer::forward
+ * (DGR/cuda_rasterizer/rasterizer_impl.cu:198-288: FORWARD::preprocess, InclusiveSum,
+ * and the blocking 4-byte D2H of num_rendered at :284 — this call synchronises
+ * `stream` once for the same reason: the binning workspace size depends on it).
+ * Exactly one of (scales, rotations) / cov3D_precomp must be non-NULL.
+ * Writes radii[P] and *num_rendered (host). */
+int eogs_rast_forward_prepare(
+    int P, int H, int W,
+    const float* means3D, const float* scales, const float* rotations,
+    const float* cov3D_precomp, const float* opacities, float scale_modifier,
+    const float* viewmatrix, const float* projmatrix, unsigned flags,
+    int* radii, void* geom, size_t geom_bytes,
+    int64_t* num_rendered, void* stream);
+
+/* Forward, phase 2: duplicate-with-keys, (tile,depth) sort, tile ranges, alpha blend.
+ * Replaces DGR/cuda_rasterizer/rasterizer_impl.cu:290-340 (duplicateWithKeys,
+ * cub::DeviceRadixSort::SortPairs, identifyTileRanges, FORWARD::render).
+ * out_invdepth may be NULL. Asynchronous on `stream`. */
+int eogs_rast_forward_render(
+    int P, int H, int W, int64_t num_rendered,
+    const float* colors, const float* bg, unsigned flags,
+    void* geom, size_t geom_bytes, void* binning, size_t binning_bytes,
+    void* image, size_t image_bytes,
+    float* out_color, float* out_invdepth, void* stream);
+
+/* Backward.
+ * Replaces CudaRasterizer::Rasterizer::backward (DGR/cuda_rasterizer/rasterizer_impl.cu:345-452:
+ * BACKWARD::render, computeCov2DCUDA, BACKWARD::preprocessCUDA) and the zero-filled
+ * gradient allocation of DGR/rasterize_points.cu:163-174 — every gradient output is
+ * fully (over)written here, the caller may pass uninitialised memory.
+ *   out_color      forward's rendered image f32[5,H,W] (ignored by the oracle)
+ *   out_invdepth   forward's inverse-depth image f32[H,W]; only read when dL_dout_invdepth != NULL
+ *   dL_dout_color  f32[5,H,W];  dL_dout_invdepth f32[H,W] or NULL
+ *   dL_dmeans2D f32[P,3] (NDC units, z = 0)  dL_dcolors f32[P,5]  dL_dopacity f32[P]
+ *   dL_dmeans3D f32[P,3]  dL_dcov3D f32[P,6]  dL_dscales f32[P,3]  dL_drotations f32[P,4]
+ *     (dL_dscales/dL_drotations may be NULL when cov3D_precomp is used)
+ *   dL_dT_sum  f32[6] or NULL: sum over Gaussians of dL/dT (2x3, row-major), T = diag(W/2,H/2)·A[0:2,:],
+ *     i.e. the reduction the reference wrapper performs on its [P,6] dL_dT tensor
+ *     (DGR/diff_gaussian_rasterization/__init__.py:179-190) under the intended 6*idx layout
+ *     (the reference kernel writes dL_dT[idx+k], DGR/cuda_rasterizer/backward.cu:320-325).
+ *   dL_dvm_mean f32[12] or NULL: [0:9] = means3D^T @ dL_dmeans2D (3x3 row-major), [9:12] = sum_P dL_dmeans2D
+ *     (DGR/diff_gaussian_rasterization/__init__.py:193-201).
+ */
+int eogs_rast_backward(
+    int P, int H, int W, int64_t num_rendered,
+    const float* bg, const float* means3D, const int* radii, const float* colors,
+    const float* opacities, const float* scales, const float* rotations,
+    float scale_modifier, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, unsigned flags,
+    const float* out_color, const float* out_invdepth,
+    const float* dL_dout_color, const float* dL_dout_invdepth,
+    const void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes,
+    const void* image, size_t image_bytes,
+    float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity,
+    float* dL_dmeans3D, float* dL_dcov3D, float* dL_dscales, float* dL_drotations,
+    float* dL_dT_sum, float* dL_dvm_mean, void* stream);
+
+/* Replaces CudaRasterizer::Rasterizer::markVisible (DGR/cuda_rasterizer/rasterizer_impl.cu:141-153).
+ * The reference predicate has its culling commented out (DGR/cuda_rasterizer/auxiliary.h:151-176),
+ * so every Gaussian is reported visible: present[i] = 1. */
+int eogs_rast_mark_visible(int P, const float* means3D, const float* viewmatrix,
+                           const float* projmatrix, uint8_t* present, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EOGS_RAST_H_INCLUDED */

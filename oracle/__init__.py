@@ -1,0 +1,34 @@
+"""CPU oracle package — TEST INFRASTRUCTURE ONLY (see rast_oracle.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this package; the product path (eogs2_amd/, diff_gaussian_rasterization/) never does.
+"""
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librast_oracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "rast_oracle.c")
+    hdr = os.path.join(_HERE, "..", "include", "eogs_rast.h")
+    stale = (not os.path.exists(LIB_PATH)) or any(
+        os.path.getmtime(p) > os.path.getmtime(LIB_PATH) for p in (src, hdr)
+    )
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+_abi = None
+
+
+def abi():
+    """RastABI over librast_oracle.so (host pointers)."""
+    global _abi
+    if _abi is None:
+        from eogs2_amd._abi import RastABI
+
+        _abi = RastABI(build())
+    return _abi

@@ -1,0 +1,691 @@
+/*
+ * rast_oracle.c — CPU restatement of the reference rasterizer hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (eogs2_amd/,
+ * diff_gaussian_rasterization/) may import, link or call this file; only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and
+ * only as the checker.
+ *
+ * PARITY PIN: the reference's arithmetic is CUDA-only (nvcc + CUB + un-vendored
+ * glm) and its tests hold no golden vectors for this path,
+ * so this oracle cannot be checked against reference outputs.  It is pinned
+ * instead (tests/test_oracle_pins.py) against (1) an independent dense
+ * PyTorch/autograd renderer (oracle/torch_dense.py) on forward and on every
+ * gradient, and (2) the reference's own Python wrapper
+ * (DGR/diff_gaussian_rasterization/__init__.py) imported with `_C` stubbed by
+ * this library, which pins argument/tuple order and the grad_viewmatrix
+ * assembly (fixtures under tests/golden/).
+ *
+ * It exports the same C-ABI as include/eogs_rast.h, over HOST pointers.
+ * Each function cites the reference lines it follows.  DGR/ =
+ * src/gaussiansplatting/submodules/diff-gaussian-rasterization/.
+ *
+ * Arithmetic: fp32 exactly where the reference is fp32, double temporaries
+ * exactly where the reference promotes (ndc2Pix, depth).  The only deliberate
+ * deviation: per-Gaussian gradient sums over pixels, which the reference
+ * accumulates with fp32 atomicAdd in non-deterministic order
+ * (DGR/cuda_rasterizer/backward.cu:598-640), are accumulated here in double
+ * and rounded once, i.e. the order-independent value every fp32 ordering
+ * approximates.
+ *
+ * Build: gcc -O2 -ffp-contract=off -shared -fPIC (oracle/Makefile).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/eogs_rast.h"
+
+#define C_ EOGS_RAST_CHANNELS
+#define TILE EOGS_RAST_TILE
+#define BATCH (TILE * TILE)
+
+static __thread char g_err[256];
+
+static int fail(int code, const char* msg) {
+  snprintf(g_err, sizeof g_err, "%s", msg);
+  return code;
+}
+
+const char* eogs_rast_last_error(void) { return g_err; }
+int eogs_rast_abi_version(void) { return EOGS_RAST_ABI_VERSION; }
+const char* eogs_rast_backend(void) { return "cpu-oracle"; }
+
+/* ---- workspace carving (same idea as DGR/cuda_rasterizer/rasterizer_impl.h:22-28 `obtain`) ---- */
+static size_t align_up(size_t x) { return (x + 127u) & ~(size_t)127u; }
+
+typedef struct {
+  float* means2D;       /* [P,2] pixel centre  */
+  float* depths;        /* [P]   200 - altitude */
+  float* cov3D;         /* [P,6] */
+  float* conic_opacity; /* [P,4] */
+  uint32_t* tiles_touched; /* [P] */
+  uint32_t* point_offsets; /* [P] inclusive scan */
+  int* radii;              /* [P] internal copy (GeometryState::internal_radii, rasterizer_impl.h:38) */
+} Geom;
+
+typedef struct {
+  uint64_t* keys;     /* [R] sorted */
+  uint32_t* values;   /* [R] sorted = point_list */
+  uint64_t* keys_tmp;
+  uint32_t* values_tmp;
+} Binning;
+
+typedef struct {
+  uint32_t* ranges;   /* [T,2] */
+  float* final_T;     /* [H*W] */
+  uint32_t* n_contrib; /* [H*W] */
+} Image;
+
+static size_t carve(char* base, size_t off, void** p, size_t bytes) {
+  off = align_up(off);
+  if (base) *p = base + off;
+  return off + bytes;
+}
+
+static size_t geom_layout(char* base, int P, Geom* g) {
+  size_t o = 0, n = (size_t)P;
+  Geom d;
+  o = carve(base, o, (void**)&d.means2D, n * 2 * 4);
+  o = carve(base, o, (void**)&d.depths, n * 4);
+  o = carve(base, o, (void**)&d.cov3D, n * 6 * 4);
+  o = carve(base, o, (void**)&d.conic_opacity, n * 4 * 4);
+  o = carve(base, o, (void**)&d.tiles_touched, n * 4);
+  o = carve(base, o, (void**)&d.point_offsets, n * 4);
+  o = carve(base, o, (void**)&d.radii, n * 4);
+  if (g) *g = d;
+  return align_up(o) + 128;
+}
+
+static size_t binning_layout(char* base, int64_t R, Binning* b) {
+  size_t o = 0, n = (size_t)R;
+  Binning d;
+  o = carve(base, o, (void**)&d.keys, n * 8);
+  o = carve(base, o, (void**)&d.values, n * 4);
+  o = carve(base, o, (void**)&d.keys_tmp, n * 8);
+  o = carve(base, o, (void**)&d.values_tmp, n * 4);
+  if (b) *b = d;
+  return align_up(o) + 128;
+}
+
+static size_t image_layout(char* base, int H, int W, Image* im) {
+  size_t o = 0, n = (size_t)H * W;
+  size_t T = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+  Image d;
+  o = carve(base, o, (void**)&d.ranges, T * 2 * 4);
+  o = carve(base, o, (void**)&d.final_T, n * 4);
+  o = carve(base, o, (void**)&d.n_contrib, n * 4);
+  if (im) *im = d;
+  return align_up(o) + 128;
+}
+
+int eogs_rast_geom_bytes(int P, size_t* bytes) {
+  if (P < 0 || !bytes) return fail(EOGS_ERR_INVALID_ARG, "geom_bytes: bad argument");
+  *bytes = geom_layout(NULL, P, NULL);
+  return EOGS_OK;
+}
+int eogs_rast_image_bytes(int H, int W, size_t* bytes) {
+  if (H < 0 || W < 0 || !bytes) return fail(EOGS_ERR_INVALID_ARG, "image_bytes: bad argument");
+  *bytes = image_layout(NULL, H, W, NULL);
+  return EOGS_OK;
+}
+int eogs_rast_binning_bytes(int P, int H, int W, int64_t R, size_t* bytes) {
+  (void)P; (void)H; (void)W;
+  if (R < 0 || !bytes) return fail(EOGS_ERR_INVALID_ARG, "binning_bytes: bad argument");
+  *bytes = binning_layout(NULL, R, NULL);
+  return EOGS_OK;
+}
+
+/* ---- small helpers ---- */
+
+/* DGR/cuda_rasterizer/auxiliary.h:40-43 — evaluated in double (the literals are double), then narrowed. */
+static float ndc2pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
+
+static int imin(int a, int b) { return a < b ? a : b; }
+static int imax(int a, int b) { return a > b ? a : b; }
+
+/* DGR/cuda_rasterizer/auxiliary.h:45-55 — truncating float->int division by the tile size, clamped to the grid. */
+static void get_rect(float px, float py, int max_radius, int gx, int gy,
+                     int* x0, int* y0, int* x1, int* y1) {
+  *x0 = imin(gx, imax(0, (int)((px - max_radius) / TILE)));
+  *y0 = imin(gy, imax(0, (int)((py - max_radius) / TILE)));
+  *x1 = imin(gx, imax(0, (int)((px + max_radius + TILE - 1) / TILE)));
+  *y1 = imin(gy, imax(0, (int)((py + max_radius + TILE - 1) / TILE)));
+}
+
+/* Rotation as the reference builds it (DGR/cuda_rasterizer/forward.cu:126-137): glm::mat3 is filled
+ * column-major, so the glm matrix R satisfies R[c][r]; we keep "math" row-major Rm[r][c] = R_glm[c][r]. */
+static void quat_to_Rm(const float q[4], float Rm[3][3]) {
+  float r = q[0], x = q[1], y = q[2], z = q[3];
+  /* glm column 0 = (1-2(yy+zz), 2(xy-rz), 2(xz+ry)) -> math column 0 */
+  Rm[0][0] = 1.f - 2.f * (y * y + z * z); Rm[1][0] = 2.f * (x * y - r * z); Rm[2][0] = 2.f * (x * z + r * y);
+  Rm[0][1] = 2.f * (x * y + r * z); Rm[1][1] = 1.f - 2.f * (x * x + z * z); Rm[2][1] = 2.f * (y * z - r * x);
+  Rm[0][2] = 2.f * (x * z - r * y); Rm[1][2] = 2.f * (y * z + r * x); Rm[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+
+/* DGR/cuda_rasterizer/forward.cu:117-151 computeCov3D: M = S*R, Sigma = M^T M, upper triangle.
+ * The quaternion is NOT renormalised (:126). */
+static void cov3d_from_scale_rot(const float s[3], float mod, const float q[4], float out[6]) {
+  float Rm[3][3], M[3][3], Sg[3][3];
+  quat_to_Rm(q, Rm);
+  float sc[3] = {mod * s[0], mod * s[1], mod * s[2]};
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) M[i][j] = sc[i] * Rm[i][j];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      Sg[i][j] = M[0][i] * M[0][j] + M[1][i] * M[1][j] + M[2][i] * M[2][j];
+  out[0] = Sg[0][0]; out[1] = Sg[0][1]; out[2] = Sg[0][2];
+  out[3] = Sg[1][1]; out[4] = Sg[1][2]; out[5] = Sg[2][2];
+}
+
+/* T rows used by both cov2D forward and backward (DGR/cuda_rasterizer/forward.cu:93-102,
+ * backward.cu:175-190): T = W * NDC2Screen with W = viewmatrix^T-upper-3x3, so
+ * Trow[i][k] = vm[4k+i] * s_i, s = (W/2, H/2, 1). In glm notation Trow[i][k] == T[i][k]. */
+static void build_T(const float* vm, int W, int H, float T[3][3]) {
+  float s[3] = {(float)(W / 2.0), (float)(H / 2.0), 1.0f};
+  for (int i = 0; i < 3; i++)
+    for (int k = 0; k < 3; k++) T[i][k] = vm[4 * k + i] * s[i];
+}
+
+static void sym_from6(const float c[6], float V[3][3]) {
+  V[0][0] = c[0]; V[0][1] = c[1]; V[0][2] = c[2];
+  V[1][0] = c[1]; V[1][1] = c[3]; V[1][2] = c[4];
+  V[2][0] = c[2]; V[2][1] = c[4]; V[2][2] = c[5];
+}
+
+/* DGR/cuda_rasterizer/forward.cu:74-112 computeCov2D: cov = T^T Vrk^T T (glm), upper-left 2x2.
+ * cov(i,j) = T[i] . Vrk . T[j]; left-associated as glm evaluates (T^T Vrk^T) first. */
+static void cov2d(const float T[3][3], const float cov3D[6], float* cxx, float* cxy, float* cyy) {
+  float V[3][3], A[2][3];
+  sym_from6(cov3D, V);
+  for (int i = 0; i < 2; i++)
+    for (int l = 0; l < 3; l++)
+      A[i][l] = T[i][0] * V[0][l] + T[i][1] * V[1][l] + T[i][2] * V[2][l];
+  *cxx = A[0][0] * T[0][0] + A[0][1] * T[0][1] + A[0][2] * T[0][2];
+  *cxy = A[1][0] * T[0][0] + A[1][1] * T[0][1] + A[1][2] * T[0][2]; /* glm cov[0][1] */
+  *cyy = A[1][0] * T[1][0] + A[1][1] * T[1][1] + A[1][2] * T[1][2];
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* Forward phase 1: FORWARD::preprocessCUDA + InclusiveSum                                     */
+/* DGR/cuda_rasterizer/forward.cu:154-283, rasterizer_impl.cu:250-284                          */
+/* ------------------------------------------------------------------------------------------- */
+int eogs_rast_forward_prepare(
+    int P, int H, int W,
+    const float* means3D, const float* scales, const float* rotations,
+    const float* cov3D_precomp, const float* opacities, float scale_modifier,
+    const float* viewmatrix, const float* projmatrix, unsigned flags,
+    int* radii, void* geom, size_t geom_bytes,
+    int64_t* num_rendered, void* stream) {
+  (void)projmatrix; (void)stream;
+  g_err[0] = 0;
+  if (P < 0 || H <= 0 || W <= 0 || !num_rendered) return fail(EOGS_ERR_INVALID_ARG, "forward_prepare: bad sizes");
+  *num_rendered = 0;
+  if (P == 0) return EOGS_OK;
+  if (!means3D || !opacities || !viewmatrix || !radii || !geom)
+    return fail(EOGS_ERR_INVALID_ARG, "forward_prepare: NULL input");
+  int have_sr = scales && rotations, have_cov = cov3D_precomp != NULL;
+  if (have_sr == have_cov || (!!scales != !!rotations))
+    return fail(EOGS_ERR_INVALID_ARG, "forward_prepare: provide exactly one of scale/rotation pair or precomputed 3D covariance");
+  if (geom_bytes < geom_layout(NULL, P, NULL)) return fail(EOGS_ERR_WORKSPACE, "forward_prepare: geom workspace too small");
+  Geom g;
+  geom_layout((char*)geom, P, &g);
+  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+  const int aa = (flags & EOGS_FLAG_ANTIALIASING) != 0;
+  float T[3][3];
+  build_T(viewmatrix, W, H, T);
+  int too_high = 0;
+
+  for (int idx = 0; idx < P; idx++) {
+    radii[idx] = 0;
+    g.radii[idx] = 0;
+    g.tiles_touched[idx] = 0;
+    /* in_frustum is a no-op that always lets the point through (auxiliary.h:151-176). */
+    const float* p = means3D + 3 * (size_t)idx;
+    /* transformPoint4x3 (auxiliary.h:70-78) */
+    float pv[3];
+    for (int i = 0; i < 3; i++)
+      pv[i] = viewmatrix[i] * p[0] + viewmatrix[4 + i] * p[1] + viewmatrix[8 + i] * p[2] + viewmatrix[12 + i];
+
+    const float* c3;
+    if (have_cov) {
+      c3 = cov3D_precomp + 6 * (size_t)idx;
+      memcpy(g.cov3D + 6 * (size_t)idx, c3, 6 * 4); /* backward reads one array either way */
+    } else {
+      cov3d_from_scale_rot(scales + 3 * (size_t)idx, scale_modifier, rotations + 4 * (size_t)idx, g.cov3D + 6 * (size_t)idx);
+      c3 = g.cov3D + 6 * (size_t)idx;
+    }
+    float cx, cy, cz; /* cov.x, cov.y, cov.z */
+    cov2d(T, c3, &cx, &cy, &cz);
+
+    const float h_var = 0.3f;
+    const float det_cov = cx * cz - cy * cy;
+    cx += h_var;
+    cz += h_var;
+    const float det_cov_plus_h_cov = cx * cz - cy * cy;
+    float h_convolution_scaling = 1.0f;
+    if (aa) h_convolution_scaling = sqrtf(fmaxf(0.000025f, det_cov / det_cov_plus_h_cov));
+    const float det = det_cov_plus_h_cov;
+    if (det == 0.0f) continue;
+    float det_inv = 1.f / det;
+    float conic[3] = {cz * det_inv, -cy * det_inv, cx * det_inv};
+
+    float mid = 0.5f * (cx + cz);
+    float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+    float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+    float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+    float px = ndc2pix(pv[0], W), py = ndc2pix(pv[1], H);
+    int x0, y0, x1, y1;
+    get_rect(px, py, (int)my_radius, gx, gy, &x0, &y0, &x1, &y1);
+    if ((x1 - x0) * (y1 - y0) == 0) continue;
+
+    /* depth = 200 - altitude, double then narrowed (forward.cu:267); the reference traps if < 0. */
+    float depth = (float)(200.0 - pv[2]);
+    g.depths[idx] = depth;
+    if (depth < 0) too_high = 1;
+    radii[idx] = (int)my_radius;
+    g.radii[idx] = (int)my_radius;
+    g.means2D[2 * (size_t)idx] = px;
+    g.means2D[2 * (size_t)idx + 1] = py;
+    float* co = g.conic_opacity + 4 * (size_t)idx;
+    co[0] = conic[0]; co[1] = conic[1]; co[2] = conic[2];
+    co[3] = opacities[idx] * h_convolution_scaling;
+    g.tiles_touched[idx] = (uint32_t)((y1 - y0) * (x1 - x0));
+  }
+  if (too_high) return fail(EOGS_ERR_ALTITUDE, "Point is too high: altitude > 200");
+
+  /* InclusiveSum (rasterizer_impl.cu:280) */
+  uint64_t run = 0;
+  for (int i = 0; i < P; i++) {
+    run += g.tiles_touched[i];
+    g.point_offsets[i] = (uint32_t)run;
+  }
+  if (run >= ((uint64_t)1 << 31)) return fail(EOGS_ERR_OVERFLOW, "num_rendered overflows 31 bits");
+  *num_rendered = (int64_t)run;
+  return EOGS_OK;
+}
+
+/* stable merge sort of (key,value) pairs by key — the contract of cub::DeviceRadixSort::SortPairs
+ * (rasterizer_impl.cu:306-311): ascending, stable. Tile ids occupy bits [32, 32+bit), so sorting on
+ * the full 64-bit key equals sorting on bits [0, 32+bit). */
+static void merge_sort_pairs(uint64_t* k, uint32_t* v, uint64_t* kt, uint32_t* vt, size_t n) {
+  for (size_t w = 1; w < n; w *= 2) {
+    for (size_t lo = 0; lo < n; lo += 2 * w) {
+      size_t mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
+      size_t i = lo, j = mid, o = lo;
+      while (i < mid && j < hi) {
+        if (k[j] < k[i]) { kt[o] = k[j]; vt[o++] = v[j++]; }
+        else { kt[o] = k[i]; vt[o++] = v[i++]; }
+      }
+      while (i < mid) { kt[o] = k[i]; vt[o++] = v[i++]; }
+      while (j < hi) { kt[o] = k[j]; vt[o++] = v[j++]; }
+    }
+    memcpy(k, kt, n * 8);
+    memcpy(v, vt, n * 4);
+  }
+}
+
+
+/* ------------------------------------------------------------------------------------------- */
+/* Forward phase 2: duplicateWithKeys, sort, identifyTileRanges, FORWARD::renderCUDA           */
+/* DGR/cuda_rasterizer/rasterizer_impl.cu:70-138,290-340; forward.cu:288-411                    */
+/* ------------------------------------------------------------------------------------------- */
+int eogs_rast_forward_render(
+    int P, int H, int W, int64_t R,
+    const float* colors, const float* bg, unsigned flags,
+    void* geom, size_t geom_bytes, void* binning, size_t binning_bytes,
+    void* image, size_t image_bytes,
+    float* out_color, float* out_invdepth, void* stream) {
+  (void)flags; (void)stream;
+  g_err[0] = 0;
+  if (P < 0 || H <= 0 || W <= 0 || R < 0 || !out_color || !bg || !image)
+    return fail(EOGS_ERR_INVALID_ARG, "forward_render: bad argument");
+  if (P > 0 && !colors) return fail(EOGS_ERR_NO_COLORS, "For non-RGB, provide precomputed Gaussian colors!");
+  if (image_bytes < image_layout(NULL, H, W, NULL)) return fail(EOGS_ERR_WORKSPACE, "forward_render: image workspace too small");
+  if (P > 0 && (!geom || geom_bytes < geom_layout(NULL, P, NULL))) return fail(EOGS_ERR_WORKSPACE, "forward_render: geom workspace too small");
+  if (R > 0 && (!binning || binning_bytes < binning_layout(NULL, R, NULL)))
+    return fail(EOGS_ERR_WORKSPACE, "forward_render: binning workspace too small");
+  Geom g; Binning b; Image im;
+  memset(&g, 0, sizeof g); memset(&b, 0, sizeof b);
+  if (P > 0) geom_layout((char*)geom, P, &g);
+  if (R > 0) binning_layout((char*)binning, R, &b);
+  image_layout((char*)image, H, W, &im);
+  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+  const size_t HW = (size_t)H * W;
+
+  /* duplicateWithKeys (rasterizer_impl.cu:70-111): key = tile << 32 | depth bits, row-major emission. */
+  for (int idx = 0; idx < P && R > 0; idx++) {
+    if (!(g.radii[idx] > 0)) continue;
+    uint32_t off = idx == 0 ? 0 : g.point_offsets[idx - 1];
+    int x0, y0, x1, y1;
+    get_rect(g.means2D[2 * (size_t)idx], g.means2D[2 * (size_t)idx + 1], g.radii[idx], gx, gy, &x0, &y0, &x1, &y1);
+    uint32_t dbits;
+    memcpy(&dbits, &g.depths[idx], 4);
+    for (int y = y0; y < y1; y++)
+      for (int x = x0; x < x1; x++) {
+        uint64_t key = (uint64_t)(y * gx + x);
+        key <<= 32;
+        key |= dbits;
+        b.keys[off] = key;
+        b.values[off] = (uint32_t)idx;
+        off++;
+      }
+  }
+  if (R > 0) merge_sort_pairs(b.keys, b.values, b.keys_tmp, b.values_tmp, (size_t)R);
+
+  /* cudaMemset + identifyTileRanges (rasterizer_impl.cu:313-320,116-138) */
+  memset(im.ranges, 0, (size_t)gx * gy * 8);
+  for (int64_t i = 0; i < R; i++) {
+    uint32_t cur = (uint32_t)(b.keys[i] >> 32);
+    if (i == 0) im.ranges[2 * cur] = 0;
+    else {
+      uint32_t prev = (uint32_t)(b.keys[i - 1] >> 32);
+      if (cur != prev) { im.ranges[2 * prev + 1] = (uint32_t)i; im.ranges[2 * cur] = (uint32_t)i; }
+    }
+    if (i == R - 1) im.ranges[2 * cur + 1] = (uint32_t)R;
+  }
+
+  /* FORWARD::renderCUDA (forward.cu:288-411), one pixel at a time; the block-level early exit
+   * (:340-342) only skips work for pixels that are all `done`, so it has no effect on results. */
+  for (int py = 0; py < H; py++)
+    for (int px = 0; px < W; px++) {
+      const uint32_t tile = (uint32_t)((py / TILE) * gx + (px / TILE));
+      const uint32_t r0 = im.ranges[2 * tile], r1 = im.ranges[2 * tile + 1];
+      const size_t pix_id = (size_t)W * py + px;
+      const float pixfx = (float)px, pixfy = (float)py;
+      float T = 1.0f;
+      uint32_t contributor = 0, last_contributor = 0;
+      float Cc[C_] = {0};
+      float expected_invdepth = 0.0f;
+      for (uint32_t k = r0; k < r1; k++) {
+        contributor++;
+        const uint32_t id = b.values[k];
+        const float dx = g.means2D[2 * (size_t)id] - pixfx, dy = g.means2D[2 * (size_t)id + 1] - pixfy;
+        const float* co = g.conic_opacity + 4 * (size_t)id;
+        const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+        if (power > 0.0f) continue;
+        const float alpha = fminf(0.99f, co[3] * expf(power));
+        if (alpha < 1.0f / 255.0f) continue;
+        const float test_T = T * (1 - alpha);
+        if (test_T < 0.0001f) break; /* done = true: this Gaussian is not blended */
+        for (int ch = 0; ch < C_; ch++) Cc[ch] += colors[(size_t)id * C_ + ch] * alpha * T;
+        expected_invdepth += (1 / g.depths[id]) * alpha * T;
+        T = test_T;
+        last_contributor = contributor;
+      }
+      im.final_T[pix_id] = T;
+      im.n_contrib[pix_id] = last_contributor;
+      for (int ch = 0; ch < C_; ch++) out_color[ch * HW + pix_id] = Cc[ch] + T * bg[ch];
+      if (out_invdepth) out_invdepth[pix_id] = expected_invdepth;
+    }
+  return EOGS_OK;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* Backward: BACKWARD::renderCUDA, computeCov2DCUDA, BACKWARD::preprocessCUDA + computeCov3D   */
+/* DGR/cuda_rasterizer/backward.cu:457-643, 147-327, 399-454, 331-394                          */
+/* ------------------------------------------------------------------------------------------- */
+int eogs_rast_backward(
+    int P, int H, int W, int64_t R,
+    const float* bg, const float* means3D, const int* radii, const float* colors,
+    const float* opacities, const float* scales, const float* rotations,
+    float scale_modifier, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, unsigned flags,
+    const float* out_color, const float* out_invdepth,
+    const float* dL_dout_color, const float* dL_dout_invdepth,
+    const void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes,
+    const void* image, size_t image_bytes,
+    float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity,
+    float* dL_dmeans3D, float* dL_dcov3D, float* dL_dscales, float* dL_drotations,
+    float* dL_dT_sum, float* dL_dvm_mean, void* stream) {
+  (void)out_color; (void)out_invdepth; (void)stream;
+  g_err[0] = 0;
+  if (P < 0 || H <= 0 || W <= 0 || R < 0) return fail(EOGS_ERR_INVALID_ARG, "backward: bad sizes");
+  if (dL_dT_sum) memset(dL_dT_sum, 0, 6 * 4);
+  if (dL_dvm_mean) memset(dL_dvm_mean, 0, 12 * 4);
+  if (P == 0) return EOGS_OK;
+  if (!bg || !means3D || !radii || !colors || !opacities || !viewmatrix || !projmatrix || !dL_dout_color ||
+      !geom || !image || !dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !dL_dcov3D)
+    return fail(EOGS_ERR_INVALID_ARG, "backward: NULL argument");
+  const int have_sr = scales && rotations;
+  if (have_sr == (cov3D_precomp != NULL)) return fail(EOGS_ERR_INVALID_ARG, "backward: scale/rotation xor cov3D_precomp");
+  if (have_sr && (!dL_dscales || !dL_drotations)) return fail(EOGS_ERR_INVALID_ARG, "backward: NULL scale/rotation gradient");
+  if (geom_bytes < geom_layout(NULL, P, NULL) || image_bytes < image_layout(NULL, H, W, NULL) ||
+      (R > 0 && (!binning || binning_bytes < binning_layout(NULL, R, NULL))))
+    return fail(EOGS_ERR_WORKSPACE, "backward: workspace too small");
+  Geom g; Binning b; Image im;
+  memset(&b, 0, sizeof b);
+  geom_layout((char*)geom, P, &g);
+  if (R > 0) binning_layout((char*)binning, R, &b);
+  image_layout((char*)image, H, W, &im);
+  const int gx = (W + TILE - 1) / TILE;
+  const size_t HW = (size_t)H * W, n = (size_t)P;
+  const int aa = (flags & EOGS_FLAG_ANTIALIASING) != 0;
+
+  /* double accumulators for the atomically-summed outputs (see header) */
+  double* acc_mean2D = (double*)calloc(n * 2, 8);
+  double* acc_conic = (double*)calloc(n * 3, 8); /* x, y, w */
+  double* acc_opac = (double*)calloc(n, 8);
+  double* acc_color = (double*)calloc(n * C_, 8);
+  double* acc_invd = (double*)calloc(n, 8); /* dL_dinvdepths: computed, consumed by nobody (backward.cu:306-307 commented) */
+  if (!acc_mean2D || !acc_conic || !acc_opac || !acc_color || !acc_invd) {
+    free(acc_mean2D); free(acc_conic); free(acc_opac); free(acc_color); free(acc_invd);
+    return fail(EOGS_ERR_DEVICE, "backward: out of host memory");
+  }
+
+  /* ---- BACKWARD::renderCUDA (backward.cu:457-643), back to front per pixel ---- */
+  const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
+  for (int py = 0; py < H; py++)
+    for (int px = 0; px < W; px++) {
+      const uint32_t tile = (uint32_t)((py / TILE) * gx + (px / TILE));
+      const uint32_t r0 = im.ranges[2 * tile], r1 = im.ranges[2 * tile + 1];
+      const size_t pix_id = (size_t)W * py + px;
+      const float pixfx = (float)px, pixfy = (float)py;
+      const float T_final = im.final_T[pix_id];
+      float T = T_final;
+      uint32_t contributor = r1 - r0;
+      const uint32_t last_contributor = im.n_contrib[pix_id];
+      float accum_rec[C_] = {0}, dL_dpixel[C_], last_color[C_] = {0};
+      float dL_invdepth = 0, accum_invdepth_rec = 0, last_invdepth = 0, last_alpha = 0;
+      for (int ch = 0; ch < C_; ch++) dL_dpixel[ch] = dL_dout_color[ch * HW + pix_id];
+      if (dL_dout_invdepth) dL_invdepth = dL_dout_invdepth[pix_id];
+      float bg_dot_dpixel = 0;
+      for (int ch = 0; ch < C_; ch++) bg_dot_dpixel += bg[ch] * dL_dpixel[ch];
+
+      for (uint32_t k = r1; k-- > r0;) {
+        contributor--;
+        if (contributor >= last_contributor) continue;
+        const uint32_t id = b.values[k];
+        const float dx = g.means2D[2 * (size_t)id] - pixfx, dy = g.means2D[2 * (size_t)id + 1] - pixfy;
+        const float* co = g.conic_opacity + 4 * (size_t)id;
+        const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+        if (power > 0.0f) continue;
+        const float G = expf(power);
+        const float alpha = fminf(0.99f, co[3] * G);
+        if (alpha < 1.0f / 255.0f) continue;
+
+        T = T / (1.f - alpha);
+        const float dchannel_dcolor = alpha * T;
+        float dL_dalpha = 0.0f;
+        for (int ch = 0; ch < C_; ch++) {
+          const float c = colors[(size_t)id * C_ + ch];
+          accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+          last_color[ch] = c;
+          const float dL_dchannel = dL_dpixel[ch];
+          dL_dalpha += (c - accum_rec[ch]) * dL_dchannel;
+          acc_color[(size_t)id * C_ + ch] += (double)(dchannel_dcolor * dL_dchannel);
+        }
+        if (dL_dout_invdepth) {
+          const float invd = 1.f / g.depths[id];
+          accum_invdepth_rec = last_alpha * last_invdepth + (1.f - last_alpha) * accum_invdepth_rec;
+          last_invdepth = invd;
+          dL_dalpha += (invd - accum_invdepth_rec) * dL_invdepth;
+          acc_invd[id] += (double)(dchannel_dcolor * dL_invdepth);
+        }
+        dL_dalpha *= T;
+        last_alpha = alpha;
+        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+
+        const float dL_dG = co[3] * dL_dalpha;
+        const float gdx = G * dx, gdy = G * dy;
+        const float dG_ddelx = -gdx * co[0] - gdy * co[1];
+        const float dG_ddely = -gdy * co[2] - gdx * co[1];
+        acc_mean2D[2 * (size_t)id] += (double)(dL_dG * dG_ddelx * ddelx_dx);
+        acc_mean2D[2 * (size_t)id + 1] += (double)(dL_dG * dG_ddely * ddely_dy);
+        acc_conic[3 * (size_t)id] += (double)(-0.5f * gdx * dx * dL_dG);
+        acc_conic[3 * (size_t)id + 1] += (double)(-0.5f * gdx * dy * dL_dG);
+        acc_conic[3 * (size_t)id + 2] += (double)(-0.5f * gdy * dy * dL_dG);
+        acc_opac[id] += (double)(G * dL_dalpha);
+      }
+    }
+
+  /* outputs zero-initialised like rasterize_points.cu:163-174 */
+  memset(dL_dmeans2D, 0, n * 3 * 4);
+  memset(dL_dmeans3D, 0, n * 3 * 4);
+  memset(dL_dcov3D, 0, n * 6 * 4);
+  if (dL_dscales) memset(dL_dscales, 0, n * 3 * 4);
+  if (dL_drotations) memset(dL_drotations, 0, n * 4 * 4);
+  for (size_t i = 0; i < n; i++) {
+    dL_dmeans2D[3 * i] = (float)acc_mean2D[2 * i];
+    dL_dmeans2D[3 * i + 1] = (float)acc_mean2D[2 * i + 1];
+    dL_dopacity[i] = (float)acc_opac[i];
+    for (int ch = 0; ch < C_; ch++) dL_dcolors[i * C_ + ch] = (float)acc_color[i * C_ + ch];
+  }
+
+  float T[3][3];
+  build_T(viewmatrix, W, H, T);
+  double dT_sum[6] = {0}, vm_mean[12] = {0};
+
+  for (int idx = 0; idx < P; idx++) {
+    if (!(radii[idx] > 0)) continue;
+    const size_t i = (size_t)idx;
+    /* ---- computeCov2DCUDA (backward.cu:147-327) ---- */
+    const float* c3 = g.cov3D + 6 * i;
+    const float dLc[3] = {(float)acc_conic[3 * i], (float)acc_conic[3 * i + 1], (float)acc_conic[3 * i + 2]};
+    float V[3][3];
+    sym_from6(c3, V);
+    float c_xx, c_xy, c_yy;
+    cov2d(T, c3, &c_xx, &c_xy, &c_yy);
+    const float h_var = 0.3f;
+    float d_inside_root = 0.f;
+    if (aa) {
+      const float det_cov = c_xx * c_yy - c_xy * c_xy;
+      c_xx += h_var;
+      c_yy += h_var;
+      const float det_cov_plus_h_cov = c_xx * c_yy - c_xy * c_xy;
+      const float hcs = sqrtf(fmaxf(0.000025f, det_cov / det_cov_plus_h_cov));
+      const float dL_dopacity_v = dL_dopacity[i];
+      const float d_hcs = dL_dopacity_v * opacities[i];
+      dL_dopacity[i] = dL_dopacity_v * hcs;
+      d_inside_root = (det_cov / det_cov_plus_h_cov) <= 0.000025f ? 0.f : d_hcs / (2 * hcs);
+    } else {
+      c_xx += h_var;
+      c_yy += h_var;
+    }
+    float dL_dc_xx = 0, dL_dc_xy = 0, dL_dc_yy = 0;
+    if (aa) {
+      const float x = c_xx, y = c_yy, z = c_xy, w = h_var;
+      const float sqv = w * w + w * (x + y) + x * y - z * z;
+      const float denom_f = d_inside_root / (sqv * sqv);
+      dL_dc_xx = w * (w * y + y * y + z * z) * denom_f;
+      dL_dc_yy = w * (w * x + x * x + z * z) * denom_f;
+      dL_dc_xy = -2.f * w * z * (w + x + y) * denom_f;
+    }
+    const float denom = c_xx * c_yy - c_xy * c_xy;
+    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+    float* dcov = dL_dcov3D + 6 * i;
+    if (denom2inv != 0) {
+      dL_dc_xx += denom2inv * (-c_yy * c_yy * dLc[0] + 2 * c_xy * c_yy * dLc[1] + (denom - c_xx * c_yy) * dLc[2]);
+      dL_dc_yy += denom2inv * (-c_xx * c_xx * dLc[2] + 2 * c_xx * c_xy * dLc[1] + (denom - c_xx * c_yy) * dLc[0]);
+      dL_dc_xy += denom2inv * 2 * (c_xy * c_yy * dLc[0] - (denom + 2 * c_xy * c_xy) * dLc[1] + c_xx * c_xy * dLc[2]);
+      dcov[0] = (T[0][0] * T[0][0] * dL_dc_xx + T[0][0] * T[1][0] * dL_dc_xy + T[1][0] * T[1][0] * dL_dc_yy);
+      dcov[3] = (T[0][1] * T[0][1] * dL_dc_xx + T[0][1] * T[1][1] * dL_dc_xy + T[1][1] * T[1][1] * dL_dc_yy);
+      dcov[5] = (T[0][2] * T[0][2] * dL_dc_xx + T[0][2] * T[1][2] * dL_dc_xy + T[1][2] * T[1][2] * dL_dc_yy);
+      dcov[1] = 2 * T[0][0] * T[0][1] * dL_dc_xx + (T[0][0] * T[1][1] + T[0][1] * T[1][0]) * dL_dc_xy + 2 * T[1][0] * T[1][1] * dL_dc_yy;
+      dcov[2] = 2 * T[0][0] * T[0][2] * dL_dc_xx + (T[0][0] * T[1][2] + T[0][2] * T[1][0]) * dL_dc_xy + 2 * T[1][0] * T[1][2] * dL_dc_yy;
+      dcov[4] = 2 * T[0][2] * T[0][1] * dL_dc_xx + (T[0][1] * T[1][2] + T[0][2] * T[1][1]) * dL_dc_xy + 2 * T[1][1] * T[1][2] * dL_dc_yy;
+    } else {
+      for (int k = 0; k < 6; k++) dcov[k] = 0;
+    }
+    /* dL/dT (2x3), backward.cu:276-287.  Vrk[a][b] is symmetric so glm's [col][row] order is immaterial. */
+    float TV[2][3];
+    for (int r = 0; r < 2; r++)
+      for (int k = 0; k < 3; k++) TV[r][k] = T[r][0] * V[k][0] + T[r][1] * V[k][1] + T[r][2] * V[k][2];
+    const float dLdT[6] = {
+        2 * TV[0][0] * dL_dc_xx + TV[1][0] * dL_dc_xy,
+        2 * TV[0][1] * dL_dc_xx + TV[1][1] * dL_dc_xy,
+        2 * TV[0][2] * dL_dc_xx + TV[1][2] * dL_dc_xy,
+        2 * TV[1][0] * dL_dc_yy + TV[0][0] * dL_dc_xy,
+        2 * TV[1][1] * dL_dc_yy + TV[0][1] * dL_dc_xy,
+        2 * TV[1][2] * dL_dc_yy + TV[0][2] * dL_dc_xy};
+    /* The reference stores these at dL_dT[idx+k] (backward.cu:320-325), which races between
+     * neighbouring threads; the intended layout is 6*idx+k and only its sum over idx is consumed
+     * (__init__.py:179-190). We produce that sum. */
+    for (int k = 0; k < 6; k++) dT_sum[k] += (double)dLdT[k];
+
+    /* ---- BACKWARD::preprocessCUDA (backward.cu:399-454): dL_dmeans = 0 (cov2D kernel, :313-317) + A^T g ---- */
+    const float gxn = dL_dmeans2D[3 * i], gyn = dL_dmeans2D[3 * i + 1];
+    dL_dmeans3D[3 * i + 0] = projmatrix[0] * gxn + projmatrix[1] * gyn;
+    dL_dmeans3D[3 * i + 1] = projmatrix[4] * gxn + projmatrix[5] * gyn;
+    dL_dmeans3D[3 * i + 2] = projmatrix[8] * gxn + projmatrix[9] * gyn;
+
+    /* ---- computeCov3D backward (backward.cu:331-394) ---- */
+    if (have_sr) {
+      const float* q = rotations + 4 * i;
+      const float r = q[0], x = q[1], y = q[2], z = q[3];
+      float Rm[3][3];
+      quat_to_Rm(q, Rm);
+      const float s[3] = {scale_modifier * scales[3 * i], scale_modifier * scales[3 * i + 1], scale_modifier * scales[3 * i + 2]};
+      float M[3][3];
+      for (int a = 0; a < 3; a++)
+        for (int c = 0; c < 3; c++) M[a][c] = s[a] * Rm[a][c];
+      float dS[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
+                        {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
+                        {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
+      /* dL_dM = 2 * M * dL_dSigma (glm) -> math: dM = 2 * M_math * dS  */
+      float dM[3][3];
+      for (int a = 0; a < 3; a++)
+        for (int c = 0; c < 3; c++)
+          dM[a][c] = (2.0f * M[a][0]) * dS[0][c] + (2.0f * M[a][1]) * dS[1][c] + (2.0f * M[a][2]) * dS[2][c];
+      /* glm: Rt = transpose(R), dL_dMt = transpose(dL_dM); Rt[k] (glm column k of R^T) = math row k of R_math;
+       * dL_dMt[k] = math row k of dM. dL_dscale_k = dot(Rm[k,:], dM[k,:]). */
+      float* ds = dL_dscales + 3 * i;
+      for (int k = 0; k < 3; k++) ds[k] = Rm[k][0] * dM[k][0] + Rm[k][1] * dM[k][1] + Rm[k][2] * dM[k][2];
+      /* dL_dMt[k] *= s_k; then dL_dMt[a][b] (glm col a, row b) = s_a * dM[a][b] */
+      float D[3][3];
+      for (int a = 0; a < 3; a++)
+        for (int c = 0; c < 3; c++) D[a][c] = dM[a][c] * s[a];
+      float* dq = dL_drotations + 4 * i;
+      dq[0] = 2 * z * (D[0][1] - D[1][0]) + 2 * y * (D[2][0] - D[0][2]) + 2 * x * (D[1][2] - D[2][1]);
+      dq[1] = 2 * y * (D[1][0] + D[0][1]) + 2 * z * (D[2][0] + D[0][2]) + 2 * r * (D[1][2] - D[2][1]) - 4 * x * (D[2][2] + D[1][1]);
+      dq[2] = 2 * x * (D[1][0] + D[0][1]) + 2 * r * (D[2][0] - D[0][2]) + 2 * z * (D[1][2] + D[2][1]) - 4 * y * (D[2][2] + D[0][0]);
+      dq[3] = 2 * r * (D[0][1] - D[1][0]) + 2 * x * (D[2][0] + D[0][2]) + 2 * y * (D[1][2] + D[2][1]) - 4 * z * (D[1][1] + D[0][0]);
+    }
+  }
+  /* wrapper-side reductions (__init__.py:193-201) over ALL Gaussians (invisible ones contribute zeros) */
+  for (size_t i = 0; i < n; i++) {
+    const float* m = means3D + 3 * i;
+    const float* gm = dL_dmeans2D + 3 * i;
+    for (int a = 0; a < 3; a++)
+      for (int c = 0; c < 3; c++) vm_mean[3 * a + c] += (double)m[a] * (double)gm[c];
+    for (int c = 0; c < 3; c++) vm_mean[9 + c] += (double)gm[c];
+  }
+  if (dL_dT_sum) for (int k = 0; k < 6; k++) dL_dT_sum[k] = (float)dT_sum[k];
+  if (dL_dvm_mean) for (int k = 0; k < 12; k++) dL_dvm_mean[k] = (float)vm_mean[k];
+
+  free(acc_mean2D); free(acc_conic); free(acc_opac); free(acc_color); free(acc_invd);
+  return EOGS_OK;
+}
+
+/* checkFrustum (rasterizer_impl.cu:54-66): in_frustum's culling is commented out and the function
+ * falls off its end (auxiliary.h:151-176); the intended value is "visible". */
+int eogs_rast_mark_visible(int P, const float* means3D, const float* viewmatrix,
+                           const float* projmatrix, uint8_t* present, void* stream) {
+  (void)means3D; (void)viewmatrix; (void)projmatrix; (void)stream;
+  g_err[0] = 0;
+  if (P < 0 || (P > 0 && !present)) return fail(EOGS_ERR_INVALID_ARG, "mark_visible: bad argument");
+  for (int i = 0; i < P; i++) present[i] = 1;
+  return EOGS_OK;
+}

@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture
+def oracle_backend(monkeypatch):
+    """Routes the host wrapper (eogs2_amd.rasterizer) to the CPU oracle library.
+
+    Test-only injection: lets the autograd wiring, argument marshalling and the
+    data-parallel shim be exercised on CPU tensors. The product never does this —
+    `eogs2_amd._lib.get()` only ever loads the HIP library.
+    """
+    import oracle
+    from eogs2_amd import _lib
+
+    abi = oracle.abi()
+    monkeypatch.setattr(_lib, "get", lambda: abi)
+    return abi

