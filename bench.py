@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py — rasterizer fwd+bwd throughput at BASELINE.json's headline configuration.
+
+A "step" = one forward + backward pass of the drop-in rasterizer for ONE training view (the unit the
+reference's training loop repeats, GS/train_pan.py:278,469) over synthetic inputs already resident in
+HBM: 1,048,576 Gaussians rendered to 1024x1024, 5 channels. With N>1 GPUs each rank renders its own
+view of the same Gaussians (view-sharded data parallelism) and a step additionally
+all-reduces the 56 B/Gaussian parameter-gradient buffer over RCCL. value = views/s over the whole job.
+
+Extra objects in the JSON line:
+  roofline      — dominant kernel (render_bwd): algorithmic bytes (52 B/pair + 32 B/pixel)
+                  / its mean HIP-event duration on the launch stream, vs the 8 TB/s HBM peak
+  pipeline      — the whole fwd+bwd: (432 P + 268 R + 64 HW) bytes / step time, same peak
+  kernels_ms    — mean device ms per kernel group (HIP events inside the library)
+  cpu_baseline  — the pure-PyTorch dense alpha-blend (oracle/torch_dense.py, fwd+bwd through autograd) on a
+                  bounded 1/64-area crop of the same workload, all host cores; rank 0, N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--gaussians", type=int, default=1 << 20)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--opacity", default="init", help="init (0.01, gs_config/train.yaml:55) | trained | float")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(P_full, S_full):
+    """Dense pure-PyTorch alpha-blend fwd+bwd on a 1/64-area crop with the same pixel density and footprint."""
+    from eogs2_amd.synthetic import make_scene
+    from oracle.torch_dense import render_dense
+
+    frac = 64
+    P, S = P_full // frac, S_full // 8
+    # same sigma in pixels as the full workload: s0 ~ P^(-1/3), pixels per unit ~ S
+    mult = (S_full / S) * (P / P_full) ** (1.0 / 3.0)
+    sc = make_scene(P, S, S, seed=0, opacity="init", scale_mult=mult)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+
+    def once():
+        leaves = [sc[k].clone().requires_grad_(True) for k in ("means3D", "opacities", "colors", "scales", "rotations")]
+        c, _, _ = render_dense(leaves[0], leaves[1], leaves[2], sc["bg"], sc["viewmatrix"], S, S, scales=leaves[3],
+                               rotations=leaves[4], block=32)
+        (c * sc["dL_dcolor"]).sum().backward()
+
+    once()
+    ts = []
+    t_end = time.perf_counter() + 20.0
+    while len(ts) < 5 and (time.perf_counter() < t_end or not ts):
+        t0 = time.perf_counter()
+        once()
+        ts.append(time.perf_counter() - t0)
+    t = sorted(ts)[len(ts) // 2]
+    return {
+        "value": 1.0 / (t * frac), "unit": "views/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"1/{frac}-area crop of the workload ({P} Gaussians / {S}x{S}, same pixel density and footprint), "
+                  f"dense PyTorch fwd+bwd via autograd, median of {len(ts)} = {t * 1e3:.0f} ms, scaled x{frac}",
+    }
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from eogs2_amd import GaussianRasterizer, _lib
+    from eogs2_amd.parallel import GradBucket
+    from eogs2_amd.synthetic import make_camera, make_scene, settings_for
+
+    abi = _lib.get()
+    P, H, W = a.gaussians, a.size, a.size
+    try:
+        opacity = float(a.opacity)
+    except ValueError:
+        opacity = a.opacity
+    sc = make_scene(P, H, W, seed=0, opacity=opacity, device=dev)  # same Gaussians on every rank
+    vm = make_camera(H, W, seed=rank, device=dev)                  # one view per rank
+    sc["viewmatrix"] = vm
+    rs = settings_for(sc, H, W)
+    params = {k: sc[k].clone().requires_grad_(True) for k in ("means3D", "colors", "opacities", "scales", "rotations")}
+    means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
+    dL = sc["dL_dcolor"]
+    bucket = GradBucket([params["means3D"], params["colors"], params["opacities"], params["scales"], params["rotations"]],
+                        cols=[slice(0, 3), slice(0, 3), slice(0, 1), slice(0, 3), slice(0, 4)])
+    rast = GaussianRasterizer(rs)
+
+    def step():
+        for p in params.values():
+            p.grad = None
+        means2D.grad = None
+        color, radii, _ = rast(params["means3D"], means2D, params["opacities"], colors_precomp=params["colors"],
+                               scales=params["scales"], rotations=params["rotations"])
+        (color * dL).sum().backward()
+        if world > 1:
+            bucket.all_reduce()
+        return color
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    abi.profile_reset()
+    abi.profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    abi.profile_enable(0)
+    prof = abi.profile()
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # num_rendered of this rank's view, straight from the API's own bookkeeping
+    color = step()
+    torch.cuda.synchronize()
+    R = int(color.grad_fn.num_rendered) if hasattr(color.grad_fn, "num_rendered") else -1
+
+    if rank == 0:
+        ms_step = dt / a.steps * 1e3
+        kern = {k: (ms / max(n, 1)) for k, (ms, n) in prof.items()}
+        dom = max(kern, key=kern.get) if kern else None
+        npx = H * W
+        alg = {
+            "render_bwd": 52 * R + 32 * npx,
+            "render_fwd": 52 * R + 32 * npx,
+            "binning": 12 * R + 24 * R * 2 + 8 * R,
+            "preprocess_fwd": 104 * P,
+            "depth_sort": 4 * 16 * P,
+            "gaussian_bwd": 300 * P,
+        }
+        roof = None
+        if dom:
+            ach = alg[dom] / (kern[dom] * 1e-3) / 1e9
+            roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg[dom],
+                    "kernel_ms": kern[dom]}
+        pipe_bytes = 432 * P + 268 * R + 64 * npx
+        pipe = {"algorithmic_bytes": pipe_bytes, "achieved": pipe_bytes / (ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": pipe_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "ideal_sort_frac": (432 * P + 148 * R + 64 * npx) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        line = {
+            "metric": "rasterizer fwd+bwd throughput @1M Gaussians/1024^2 (train iters/s with 1 render/iter)",
+            "value": world * a.steps / dt, "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{P} Gaussians x {H}x{W} x 5 channels, opacity={a.opacity}, 1 view per GPU, "
+                                   f"fwd+bwd" + (" + RCCL grad all-reduce (56 B/Gaussian)" if world > 1 else ""),
+                       "gaussians": P, "height": H, "width": W, "num_rendered": R, "parallelism": f"view-dp{world}"},
+            "roofline": roof, "pipeline": pipe, "kernels_ms": kern,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(P, H)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

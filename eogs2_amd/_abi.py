@@ -54,6 +54,10 @@ SIGNATURES = {
         + [_p],  # stream
     ),
     "eogs_rast_mark_visible": (_i, [_i, _p, _p, _p, _p, _p]),
+    "eogs_rast_profile_enable": (_i, [_i]),
+    "eogs_rast_profile_reset": (_i, []),
+    "eogs_rast_profile_slots": (_i, []),
+    "eogs_rast_profile_get": (_i, [_i, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_char_p)]),
 }
 
 
@@ -86,3 +90,12 @@ class RastABI:
 
     def __getattr__(self, name):
         return getattr(self.cdll, "eogs_rast_" + name)
+
+    def profile(self):
+        """{group name: (total device ms, launches)} accumulated since the last profile_reset()."""
+        out = {}
+        for i in range(self.cdll.eogs_rast_profile_slots()):
+            ms, n, nm = C.c_double(), _i64(), C.c_char_p()
+            self.check(self.cdll.eogs_rast_profile_get(i, C.byref(ms), C.byref(n), C.byref(nm)))
+            out[nm.value.decode()] = (ms.value, n.value)
+        return out

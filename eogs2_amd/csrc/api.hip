@@ -32,6 +32,43 @@ int check_launch(hipStream_t s, bool debug, const char* what) {
   }
   return EOGS_OK;
 }
+// ---- optional per-kernel-group timing with hipEvents on the launch stream ----
+enum { PS_PREPROCESS, PS_DEPTH_SORT, PS_BINNING, PS_RENDER_FWD, PS_RENDER_BWD, PS_GAUSS_BWD, PS_COUNT };
+const char* const kSlotNames[PS_COUNT] = {"preprocess_fwd", "depth_sort", "binning", "render_fwd", "render_bwd", "gaussian_bwd"};
+struct Pending { int slot; hipEvent_t a, b; };
+thread_local bool g_prof_on = false;
+thread_local double g_prof_ms[PS_COUNT];
+thread_local int64_t g_prof_n[PS_COUNT];
+thread_local Pending g_pending[4096];
+thread_local int g_npending = 0;
+
+void prof_drain() {
+  for (int i = 0; i < g_npending; i++) {
+    float ms = 0.f;
+    if (hipEventSynchronize(g_pending[i].b) == hipSuccess && hipEventElapsedTime(&ms, g_pending[i].a, g_pending[i].b) == hipSuccess) {
+      g_prof_ms[g_pending[i].slot] += ms;
+      g_prof_n[g_pending[i].slot] += 1;
+    }
+    (void)hipEventDestroy(g_pending[i].a);
+    (void)hipEventDestroy(g_pending[i].b);
+  }
+  g_npending = 0;
+}
+struct ProfScope {
+  hipStream_t s; int idx = -1;
+  ProfScope(int slot, hipStream_t st) : s(st) {
+    if (!g_prof_on) return;
+    if (g_npending == 4096) prof_drain();
+    Pending& p = g_pending[g_npending];
+    p.slot = slot;
+    if (hipEventCreate(&p.a) != hipSuccess) return;
+    if (hipEventCreate(&p.b) != hipSuccess) { (void)hipEventDestroy(p.a); return; }
+    idx = g_npending++;
+    (void)hipEventRecord(p.a, s);
+  }
+  ~ProfScope() { if (idx >= 0) (void)hipEventRecord(g_pending[idx].b, s); }
+};
+
 #define LAUNCH_TRY(s, dbg, what)              \
   do {                                        \
     int rc_ = check_launch((s), (dbg), what); \
@@ -90,11 +127,11 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
   HIP_TRY(hipMemsetAsync(g.misc, 0, MISC_WORDS * sizeof(uint32_t), s));
   FwdPrepArgs a{P, H, W, means3D, scales, rotations, cov3D_precomp, opacities, viewmatrix, scale_modifier,
                 (flags & EOGS_FLAG_ANTIALIASING) != 0, radii};
-  launch_preprocess_fwd(a, g, s);
+  { ProfScope ps(PS_PREPROCESS, s); launch_preprocess_fwd(a, g, s); }
   LAUNCH_TRY(s, debug, "preprocess_fwd");
   HIP_TRY(hipMemcpyAsync(g_pinned, g.misc, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   // the depth sort does not depend on num_rendered: it runs while the host waits for the readback
-  launch_depth_sort(g, P, s);
+  { ProfScope ps(PS_DEPTH_SORT, s); launch_depth_sort(g, P, s); }
   LAUNCH_TRY(s, debug, "depth_sort");
   HIP_TRY(hipStreamSynchronize(s));
   if (g_pinned[MISC_ERR] & 1u) return fail(EOGS_ERR_ALTITUDE, "Point is too high: altitude > 200");
@@ -132,9 +169,9 @@ int eogs_rast_forward_render(int P, int H, int W, int64_t R, const float* colors
     if ((size_t)(bb - (char*)binning) + b.bytes - 256 > binning_bytes)
       return fail(EOGS_ERR_WORKSPACE, "forward_render: binning workspace too small");
   }
-  launch_binning(g, b, im, P, H, W, R, s);
+  { ProfScope ps(PS_BINNING, s); launch_binning(g, b, im, P, H, W, R, s); }
   LAUNCH_TRY(s, debug, "binning");
-  launch_render_fwd(g, b, im, H, W, colors, bg, out_color, out_invdepth, s);
+  { ProfScope ps(PS_RENDER_FWD, s); launch_render_fwd(g, b, im, H, W, colors, bg, out_color, out_invdepth, s); }
   LAUNCH_TRY(s, debug, "render_fwd");
   return EOGS_OK;
 }
@@ -181,14 +218,14 @@ int eogs_rast_backward(int P, int H, int W, int64_t R, const float* bg, const fl
     return fail(EOGS_ERR_WORKSPACE, "backward: workspace too small");
 
   if (R > 0) {
-    launch_render_bwd(g, b, im, H, W, colors, out_color, out_invdepth, dL_dout_color, dL_dout_invdepth, s);
+    { ProfScope ps(PS_RENDER_BWD, s); launch_render_bwd(g, b, im, H, W, colors, out_color, out_invdepth, dL_dout_color, dL_dout_invdepth, s); }
     LAUNCH_TRY(s, debug, "render_bwd");
   }
   GaussBwdArgs a{P, H, W, means3D, have_sr ? scales : nullptr, have_sr ? rotations : nullptr, cov3D_precomp, opacities,
                  viewmatrix, projmatrix, radii, scale_modifier, (flags & EOGS_FLAG_ANTIALIASING) != 0,
                  dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, have_sr ? dL_dscales : nullptr,
                  have_sr ? dL_drotations : nullptr, dL_dT_sum, dL_dvm_mean};
-  launch_gaussian_bwd(a, g, b, s);
+  { ProfScope ps(PS_GAUSS_BWD, s); launch_gaussian_bwd(a, g, b, s); }
   LAUNCH_TRY(s, debug, "gaussian_bwd");
   return EOGS_OK;
 }
@@ -200,6 +237,26 @@ int eogs_rast_mark_visible(int P, const float* means3D, const float* viewmatrix,
   g_err[0] = 0;
   if (P < 0 || (P > 0 && !present)) return fail(EOGS_ERR_INVALID_ARG, "mark_visible: bad argument");
   if (P > 0) HIP_TRY(hipMemsetAsync(present, 1, (size_t)P, (hipStream_t)stream));
+  return EOGS_OK;
+}
+
+int eogs_rast_profile_enable(int on) {
+  if (!on) prof_drain();
+  g_prof_on = on != 0;
+  return EOGS_OK;
+}
+int eogs_rast_profile_reset(void) {
+  prof_drain();
+  for (int i = 0; i < PS_COUNT; i++) { g_prof_ms[i] = 0.0; g_prof_n[i] = 0; }
+  return EOGS_OK;
+}
+int eogs_rast_profile_slots(void) { return PS_COUNT; }
+int eogs_rast_profile_get(int slot, double* total_ms, int64_t* launches, const char** name) {
+  if (slot < 0 || slot >= PS_COUNT || !total_ms || !launches || !name) return fail(EOGS_ERR_INVALID_ARG, "profile_get: bad argument");
+  prof_drain();
+  *total_ms = g_prof_ms[slot];
+  *launches = g_prof_n[slot];
+  *name = kSlotNames[slot];
   return EOGS_OK;
 }
 

@@ -1,0 +1,72 @@
+"""View-sharded data parallelism for the rasterizer hot path.
+
+The reference is single-GPU (one view per optimizer step, GS/train_pan.py:252-257). Renders of different
+cameras are independent given the same Gaussians, so rank r renders view r with replicated parameters and
+the only exchange step is a SUM all-reduce of the Gaussian parameter gradients: 56 B/Gaussian
+(xyz 12 + f_dc 12 + opacity 4 + scaling 12 + rotation 16) in ONE contiguous bucket, i.e. one RCCL collective
+per step (`torch.distributed` backend "nccl" is RCCL on ROCm; over xGMI RCCL picks ring/tree/direct itself).
+Densification statistics (GS/train_pan.py:683-690) are kept replica-identical with three tiny all-reduces.
+
+One process per GPU; works unchanged on the gloo backend (CPU tests, world_size 2).
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradBucket:
+    """Packs selected gradient columns of several [P, k] parameters into one [P, K] fp32 buffer,
+    all-reduces it once, and scatters the result back into the .grad tensors."""
+
+    def __init__(self, params, cols=None):
+        self.params = list(params)
+        self.cols = list(cols) if cols is not None else [slice(0, p.shape[1]) for p in self.params]
+        P = self.params[0].shape[0]
+        assert all(p.shape[0] == P for p in self.params)
+        self.widths = [len(range(*c.indices(p.shape[1]))) for p, c in zip(self.params, self.cols)]
+        self.flat = torch.zeros(P, sum(self.widths), dtype=torch.float32, device=self.params[0].device)
+
+    @property
+    def bytes_per_gaussian(self):
+        return 4 * sum(self.widths)
+
+    def pack(self):
+        o = 0
+        for p, c, w in zip(self.params, self.cols, self.widths):
+            if p.grad is None:
+                self.flat[:, o:o + w].zero_()
+            else:
+                self.flat[:, o:o + w].copy_(p.grad[:, c])
+            o += w
+
+    def unpack(self):
+        o = 0
+        for p, c, w in zip(self.params, self.cols, self.widths):
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            p.grad[:, c].copy_(self.flat[:, o:o + w])
+            o += w
+
+    def all_reduce(self, group=None, average=False):
+        self.pack()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            if average:
+                self.flat.div_(dist.get_world_size(group))
+        self.unpack()
+
+
+def all_reduce_densification_stats(xyz_gradient_accum, denom, max_radii2D, group=None):
+    """Sum / sum / max across replicas so prune, clone and split decisions stay identical on every rank
+    (GS/scene/gaussian_model.py:719-723, GS/train_pan.py:679-690)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    dist.all_reduce(xyz_gradient_accum, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(denom, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(max_radii2D, op=dist.ReduceOp.MAX, group=group)
+
+
+def shard_views(num_views, rank=None, world=None):
+    """Round-robin view indices of this rank (independent views, no data-path collective)."""
+    rank = dist.get_rank() if rank is None else rank
+    world = dist.get_world_size() if world is None else world
+    return list(range(rank, num_views, world))

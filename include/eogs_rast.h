@@ -127,6 +127,17 @@ int eogs_rast_backward(
 int eogs_rast_mark_visible(int P, const float* means3D, const float* viewmatrix,
                            const float* projmatrix, uint8_t* present, void* stream);
 
+/* ---- Diagnostics (no reference counterpart; the reference has no profiler) ----
+ * When enabled, every kernel group launched by the calls above is bracketed by a pair of hipEvents recorded
+ * on the caller's stream. eogs_rast_profile_get() waits for the recorded events and returns, for slot
+ * 0..eogs_rast_profile_slots()-1, the accumulated device time, the number of bracketed launches and the
+ * group's name ("preprocess_fwd", "depth_sort", "binning", "render_fwd", "render_bwd", "gaussian_bwd").
+ * The oracle implements them as no-ops (0 slots). Per calling thread. */
+int eogs_rast_profile_enable(int on);
+int eogs_rast_profile_reset(void);
+int eogs_rast_profile_slots(void);
+int eogs_rast_profile_get(int slot, double* total_ms, int64_t* launches, const char** name);
+
 #ifdef __cplusplus
 }
 #endif

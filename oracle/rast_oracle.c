@@ -689,3 +689,12 @@ int eogs_rast_mark_visible(int P, const float* means3D, const float* viewmatrix,
   for (int i = 0; i < P; i++) present[i] = 1;
   return EOGS_OK;
 }
+
+/* diagnostics: no-ops in the oracle */
+int eogs_rast_profile_enable(int on) { (void)on; return EOGS_OK; }
+int eogs_rast_profile_reset(void) { return EOGS_OK; }
+int eogs_rast_profile_slots(void) { return 0; }
+int eogs_rast_profile_get(int slot, double* total_ms, int64_t* launches, const char** name) {
+  (void)slot; (void)total_ms; (void)launches; (void)name;
+  return fail(EOGS_ERR_INVALID_ARG, "profile_get: the oracle has no profile slots");
+}
