@@ -52,7 +52,9 @@ def cpu_baseline(P_full, S_full):
     # same sigma in pixels as the full workload: s0 ~ P^(-1/3), pixels per unit ~ S
     mult = (S_full / S) * (P / P_full) ** (1.0 / 3.0)
     sc = make_scene(P, S, S, seed=0, opacity="init", scale_mult=mult)
-    cores = os.cpu_count() or 1
+    # many small dense ops: more than ~16 intra-op threads only adds fork/join overhead (256 threads on the
+    # GPU box ran 250x slower than 8); `cores` in the JSON is what was actually used
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
 
     def once():
@@ -64,7 +66,7 @@ def cpu_baseline(P_full, S_full):
     once()
     ts = []
     t_end = time.perf_counter() + 20.0
-    while len(ts) < 5 and (time.perf_counter() < t_end or not ts):
+    while len(ts) < 15 and (time.perf_counter() < t_end or not ts):
         t0 = time.perf_counter()
         once()
         ts.append(time.perf_counter() - t0)

@@ -4,6 +4,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -36,13 +39,15 @@ int check_launch(hipStream_t s, bool debug, const char* what) {
 enum { PS_PREPROCESS, PS_DEPTH_SORT, PS_BINNING, PS_RENDER_FWD, PS_RENDER_BWD, PS_GAUSS_BWD, PS_COUNT };
 const char* const kSlotNames[PS_COUNT] = {"preprocess_fwd", "depth_sort", "binning", "render_fwd", "render_bwd", "gaussian_bwd"};
 struct Pending { int slot; hipEvent_t a, b; };
-thread_local bool g_prof_on = false;
-thread_local double g_prof_ms[PS_COUNT];
-thread_local int64_t g_prof_n[PS_COUNT];
-thread_local Pending g_pending[4096];
-thread_local int g_npending = 0;
+// process-wide (autograd runs backward on its own thread), guarded by g_prof_mu
+std::mutex g_prof_mu;
+std::atomic<bool> g_prof_on{false};
+double g_prof_ms[PS_COUNT];
+int64_t g_prof_n[PS_COUNT];
+Pending g_pending[4096];
+int g_npending = 0;
 
-void prof_drain() {
+void prof_drain() {  // caller holds g_prof_mu
   for (int i = 0; i < g_npending; i++) {
     float ms = 0.f;
     if (hipEventSynchronize(g_pending[i].b) == hipSuccess && hipEventElapsedTime(&ms, g_pending[i].a, g_pending[i].b) == hipSuccess) {
@@ -57,7 +62,8 @@ void prof_drain() {
 struct ProfScope {
   hipStream_t s; int idx = -1;
   ProfScope(int slot, hipStream_t st) : s(st) {
-    if (!g_prof_on) return;
+    if (!g_prof_on.load(std::memory_order_relaxed)) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     if (g_npending == 4096) prof_drain();
     Pending& p = g_pending[g_npending];
     p.slot = slot;
@@ -66,7 +72,11 @@ struct ProfScope {
     idx = g_npending++;
     (void)hipEventRecord(p.a, s);
   }
-  ~ProfScope() { if (idx >= 0) (void)hipEventRecord(g_pending[idx].b, s); }
+  ~ProfScope() {
+    if (idx < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    (void)hipEventRecord(g_pending[idx].b, s);
+  }
 };
 
 #define LAUNCH_TRY(s, dbg, what)              \
@@ -241,11 +251,13 @@ int eogs_rast_mark_visible(int P, const float* means3D, const float* viewmatrix,
 }
 
 int eogs_rast_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   if (!on) prof_drain();
   g_prof_on = on != 0;
   return EOGS_OK;
 }
 int eogs_rast_profile_reset(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   prof_drain();
   for (int i = 0; i < PS_COUNT; i++) { g_prof_ms[i] = 0.0; g_prof_n[i] = 0; }
   return EOGS_OK;
@@ -253,6 +265,7 @@ int eogs_rast_profile_reset(void) {
 int eogs_rast_profile_slots(void) { return PS_COUNT; }
 int eogs_rast_profile_get(int slot, double* total_ms, int64_t* launches, const char** name) {
   if (slot < 0 || slot >= PS_COUNT || !total_ms || !launches || !name) return fail(EOGS_ERR_INVALID_ARG, "profile_get: bad argument");
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   prof_drain();
   *total_ms = g_prof_ms[slot];
   *launches = g_prof_n[slot];

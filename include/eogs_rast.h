@@ -132,7 +132,7 @@ int eogs_rast_mark_visible(int P, const float* means3D, const float* viewmatrix,
  * on the caller's stream. eogs_rast_profile_get() waits for the recorded events and returns, for slot
  * 0..eogs_rast_profile_slots()-1, the accumulated device time, the number of bracketed launches and the
  * group's name ("preprocess_fwd", "depth_sort", "binning", "render_fwd", "render_bwd", "gaussian_bwd").
- * The oracle implements them as no-ops (0 slots). Per calling thread. */
+ * The oracle implements them as no-ops (0 slots). Process-wide (backward may run on another thread). */
 int eogs_rast_profile_enable(int on);
 int eogs_rast_profile_reset(void);
 int eogs_rast_profile_slots(void);
