@@ -58,6 +58,7 @@ SIGNATURES = {
     "eogs_rast_profile_reset": (_i, []),
     "eogs_rast_profile_slots": (_i, []),
     "eogs_rast_profile_get": (_i, [_i, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_char_p)]),
+    "eogs_rast_selftest": (_i, [_p, C.POINTER(_u), _p]),
 }
 
 

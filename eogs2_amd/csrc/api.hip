@@ -273,4 +273,15 @@ int eogs_rast_profile_get(int slot, double* total_ms, int64_t* launches, const c
   return EOGS_OK;
 }
 
+int eogs_rast_selftest(void* scratch, unsigned* failed, void* stream) {
+  g_err[0] = 0;
+  if (!scratch || !failed) return fail(EOGS_ERR_INVALID_ARG, "selftest: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(scratch, 0, 4, s));
+  launch_selftest((uint32_t*)scratch, s);
+  LAUNCH_TRY(s, true, "selftest");
+  HIP_TRY(hipMemcpy(failed, scratch, 4, hipMemcpyDeviceToHost));
+  return EOGS_OK;
+}
+
 }  // extern "C"

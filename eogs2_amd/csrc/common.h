@@ -169,3 +169,4 @@ struct GaussBwdArgs {
   float *dL_dT_sum, *dL_dvm_mean;
 };
 void launch_gaussian_bwd(const GaussBwdArgs& a, const GeomWS& g, const BinWS& b, hipStream_t s);
+void launch_selftest(uint32_t* out, hipStream_t s);

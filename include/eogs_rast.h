@@ -137,6 +137,9 @@ int eogs_rast_profile_enable(int on);
 int eogs_rast_profile_reset(void);
 int eogs_rast_profile_slots(void);
 int eogs_rast_profile_get(int slot, double* total_ms, int64_t* launches, const char** name);
+/* Runs the library's wave64 primitive self-test (DPP reduction, readlane broadcast) on `stream` and returns,
+ * after synchronising, a bit mask of failing primitives in *failed (0 = all good). scratch: >= 4 device bytes. */
+int eogs_rast_selftest(void* scratch, unsigned* failed, void* stream);
 
 #ifdef __cplusplus
 }

@@ -698,3 +698,8 @@ int eogs_rast_profile_get(int slot, double* total_ms, int64_t* launches, const c
   (void)slot; (void)total_ms; (void)launches; (void)name;
   return fail(EOGS_ERR_INVALID_ARG, "profile_get: the oracle has no profile slots");
 }
+int eogs_rast_selftest(void* scratch, unsigned* failed, void* stream) {
+  (void)scratch; (void)stream;
+  if (failed) *failed = 0;
+  return EOGS_OK;
+}

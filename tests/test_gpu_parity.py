@@ -25,6 +25,19 @@ def dev():
     return torch.device("cuda:0")
 
 
+def test_wave64_primitives_selftest(dev):
+    import ctypes
+
+    from eogs2_amd import _lib
+
+    abi = _lib.get()
+    scratch = torch.zeros(4, dtype=torch.int32, device=dev)
+    failed = ctypes.c_uint(99)
+    abi.check(abi.selftest(ctypes.c_void_p(scratch.data_ptr()), ctypes.byref(failed),
+                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    assert failed.value == 0, f"wave64 primitive self-test failed: mask {failed.value:#x}"
+
+
 def _compare(out, ref, name, means3D=None):
     assert np.array_equal(out["out_radii"].cpu().numpy(), np.asarray(ref["out_radii"])), f"{name}: radii differ"
     for k, v in out.items():
