@@ -53,7 +53,9 @@ def _compare(out, ref, name, means3D=None):
             err = float((v.cpu().double() - r.double()).abs().max()) / scale
             assert err <= 1e-4, f"{name}:{k}: {err:.3e} of the magnitude sum"
             continue
-        assert_close(v, r, f"{name}:{k}")
+        from util import GRAD_RTOL, RTOL
+
+        assert_close(v, r, f"{name}:{k}", rtol=GRAD_RTOL.get(name, RTOL) if k.startswith("g_") else RTOL)
 
 
 @pytest.mark.parametrize("name", GOLDEN)
