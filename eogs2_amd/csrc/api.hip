@@ -119,8 +119,8 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
   if (P < 0 || H <= 0 || W <= 0 || !num_rendered) return fail(EOGS_ERR_INVALID_ARG, "forward_prepare: bad sizes");
   *num_rendered = 0;
   if (P == 0) return EOGS_OK;
-  if (((W + TILE - 1) / TILE) > 65535 || ((H + TILE - 1) / TILE) > 65535)
-    return fail(EOGS_ERR_INVALID_ARG, "forward_prepare: image too large for 16-bit tile coordinates");
+  if (((W + TILE - 1) / TILE) > 32767 || ((H + TILE - 1) / TILE) > 32767)
+    return fail(EOGS_ERR_INVALID_ARG, "forward_prepare: image too large for 16-bit internal tile coordinates");
   if (!means3D || !opacities || !viewmatrix || !radii || !geom) return fail(EOGS_ERR_INVALID_ARG, "forward_prepare: NULL input");
   const bool have_sr = scales && rotations, have_cov = cov3D_precomp != nullptr;
   if (have_sr == have_cov || (!!scales != !!rotations))

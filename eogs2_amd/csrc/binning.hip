@@ -6,8 +6,12 @@
 //
 //   1. depth sort of the P Gaussians: stable LSD radix on the 32 depth bits, payload = Gaussian id (8 B/item,
 //      4 passes over P items instead of 6 passes over R pairs of 12 B);
-//   2. expand in depth order: pair slot = exclusive scan of tiles_touched over the depth-sorted Gaussians; a
-//      load-balanced workgroup expansion writes (tile id, Gaussian id) with contiguous lanes;
+//   2. expand in depth order: pair slot = exclusive scan of the per-Gaussian tile counts over the depth-sorted
+//      Gaussians; a load-balanced workgroup expansion writes (tile id, pair slot) with contiguous lanes.
+//      Lists are built per INTERNAL 8x8 tile (one wave64 of pixels) and only for the internal tiles of the
+//      reference's 16-px tile rect in which the Gaussian can reach alpha >= 1/255 (exact hit mask computed
+//      in preprocess): a subset of the reference's candidates that contains every (pixel, Gaussian) pair
+//      the reference blends, so rendering results are unchanged;
 //   3. stable LSD radix on the tile id only (ceil(log2 T) bits, 1-2 passes, 8 B/pair): stability keeps the
 //      depth order inside every tile;
 //   4. tile ranges from the sorted tile ids.
@@ -200,18 +204,23 @@ __global__ __launch_bounds__(BLK) void expand_scan_kernel(uint32_t* __restrict__
   if (threadIdx.x == 0) blocksum[nblk] = carry;
 }
 
-// ---- expand step C: load-balanced emission of (tile id, Gaussian id) in depth order ----
+// ---- expand step C: load-balanced emission of (internal tile id, pair slot) in depth order ----
+// q-th listed internal tile of a Gaussian: the q-th set bit of its hit mask, or (mask == 0) the q-th tile of its
+// clipped rect in row-major order.
 __global__ __launch_bounds__(BLK) void expand_kernel(const uint32_t* __restrict__ sorted_ids,
                                                      const uint32_t* __restrict__ tiles,
                                                      const uint2* __restrict__ rect,
-                                                     const uint32_t* __restrict__ blocksum, uint32_t P, uint32_t gx,
-                                                     uint32_t* __restrict__ slot_base, uint32_t* __restrict__ tkey,
-                                                     uint32_t* __restrict__ tval) {
+                                                     const unsigned long long* __restrict__ mask,
+                                                     const uint32_t* __restrict__ blocksum, uint32_t P, uint32_t gsx,
+                                                     uint32_t gsy, uint32_t* __restrict__ slot_base,
+                                                     uint32_t* __restrict__ tkey, uint32_t* __restrict__ tval,
+                                                     uint32_t* __restrict__ gid) {
   constexpr int N = BLK * EXPAND_ITEMS;
   __shared__ uint32_t s_lo[N + 1];  // exclusive pair offset of each Gaussian of the chunk
   __shared__ uint32_t s_id[N];
-  __shared__ uint32_t s_x0w[N];     // x0 | width << 16
-  __shared__ uint32_t s_y0[N];
+  __shared__ uint32_t s_org[N];     // sx0 | sy0 << 16 (internal tile coordinates of the rect origin)
+  __shared__ uint32_t s_wd[N];      // sw (mask row width) | wc (clipped width) << 16
+  __shared__ unsigned long long s_mask[N];
   __shared__ uint32_t s_w[4];
   const int t = threadIdx.x;
   const uint32_t base = blockIdx.x * (uint32_t)N;
@@ -221,18 +230,25 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint32_t* __restrict_
     const uint32_t j = i * BLK + t, k = base + j;
     uint32_t id = 0, c = 0;
     uint2 r = make_uint2(0, 0);
+    unsigned long long m = 0ull;
     if (k < P) {
       id = sorted_ids[k];
       c = tiles[id];
-      if (c) r = rect[id];
+      if (c) {
+        r = rect[id];
+        m = mask[id];
+      }
     }
     uint32_t tot;
     const uint32_t ex = block_excl_scan(c, s_w, tot);
     s_lo[j] = carry + ex;
     s_id[j] = id;
-    const uint32_t x0 = r.x & 0xFFFFu, x1 = r.x >> 16;
-    s_x0w[j] = x0 | ((x1 - x0) << 16);
-    s_y0[j] = r.y & 0xFFFFu;
+    const uint32_t x0 = r.x & 0xFFFFu, x1 = r.x >> 16, y0 = r.y & 0xFFFFu;
+    const uint32_t sx0 = 2 * x0, sw = 2 * (x1 - x0);
+    const uint32_t sx1 = 2 * x1 < gsx ? 2 * x1 : gsx;
+    s_org[j] = sx0 | ((2 * y0) << 16);
+    s_wd[j] = sw | ((sx1 - sx0) << 16);
+    s_mask[j] = m;
     if (k < P && c) slot_base[id] = gbase + carry + ex;
     carry += tot;
   }
@@ -246,11 +262,24 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint32_t* __restrict_
       const uint32_t mid = (lo + hi) >> 1;
       if (s_lo[mid] <= sidx) lo = mid; else hi = mid;
     }
-    const uint32_t q = sidx - s_lo[lo];
-    const uint32_t x0 = s_x0w[lo] & 0xFFFFu, wdt = s_x0w[lo] >> 16;
-    const uint32_t row = q / wdt, col = q - row * wdt;
-    tkey[gbase + sidx] = (s_y0[lo] + row) * gx + x0 + col;
-    tval[gbase + sidx] = s_id[lo];
+    uint32_t q = sidx - s_lo[lo];
+    const uint32_t sx0 = s_org[lo] & 0xFFFFu, sy0 = s_org[lo] >> 16;
+    unsigned long long m = s_mask[lo];
+    uint32_t row, col;
+    if (m) {
+      for (; q; q--) m &= m - 1ull;  // drop the q lowest set bits
+      const uint32_t bit = (uint32_t)__builtin_ctzll(m), sw = s_wd[lo] & 0xFFFFu;
+      row = bit / sw;
+      col = bit - row * sw;
+    } else {
+      const uint32_t wc = s_wd[lo] >> 16;
+      row = q / wc;
+      col = q - row * wc;
+    }
+    const uint32_t slot = gbase + sidx;
+    tkey[slot] = (sy0 + row) * gsx + sx0 + col;
+    tval[slot] = slot;  // the sort carries the pair slot; gid[] maps it back to the Gaussian
+    gid[slot] = s_id[lo];
   }
 }
 
@@ -272,13 +301,13 @@ __global__ __launch_bounds__(BLK) void tile_ranges_kernel(const uint32_t* __rest
 }
 
 void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, hipStream_t s) {
-  const uint32_t gx = (uint32_t)((W + TILE - 1) / TILE), gy = (uint32_t)((H + TILE - 1) / TILE);
-  (void)hipMemsetAsync(im.ranges, 0, (size_t)gx * gy * sizeof(uint2), s);
+  const uint32_t gsx = (uint32_t)((W + SUB - 1) / SUB), gsy = (uint32_t)((H + SUB - 1) / SUB);
+  (void)hipMemsetAsync(im.ranges, 0, (size_t)gsx * gsy * sizeof(uint2), s);
   if (R <= 0) return;
   hipLaunchKernelGGL(expand_count_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.svalA, g.tiles, (uint32_t)P, g.blocksum);
   hipLaunchKernelGGL(expand_scan_kernel, dim3(1), dim3(BLK), 0, s, g.blocksum, g.nblkE);
-  hipLaunchKernelGGL(expand_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.svalA, g.tiles, g.rect, g.blocksum, (uint32_t)P, gx,
-                     g.slot_base, b.tkeyA, b.tvalA);
+  hipLaunchKernelGGL(expand_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.svalA, g.tiles, g.rect, g.mask, g.blocksum, (uint32_t)P,
+                     gsx, gsy, g.slot_base, b.tkeyA, b.tvalA, b.gid);
   uint32_t *ka = b.tkeyA, *kb = b.tkeyB, *va = b.tvalA, *vb = b.tvalB;
   int shift = 0;
   for (int pass = 0; pass < b.passes; pass++) {

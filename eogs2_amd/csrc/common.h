@@ -7,7 +7,9 @@
 #include "eogs_rast.h"
 
 #define NCH EOGS_RAST_CHANNELS  // 5 feature channels
-#define TILE EOGS_RAST_TILE     // 16x16 pixel tiles
+#define TILE EOGS_RAST_TILE     // 16x16 pixel tiles: the reference's binning granularity (tile rect, radii)
+#define SUB 8                   // internal tile = 8x8 pixels = one wave64; lists are built per internal tile
+#define MASK_MAX_SUBTILES 64    // Gaussians whose 16-px rect spans <= 64 internal tiles carry an exact hit mask
 #define BLK 256                 // threads per workgroup everywhere (4 wave64)
 #define NFEAT 6                 // staged per-Gaussian features: 5 colours + 1/depth
 #define REC 12                  // floats per (tile,Gaussian) gradient record (48 B, 11 used)
@@ -39,8 +41,10 @@ struct GeomWS {
   float2* means2D;      // pixel centre
   float* depth;         // 200 - altitude
   float4* conic_o;      // conic (a,b,c) + effective opacity
-  uint2* rect;          // x0 | x1<<16 , y0 | y1<<16 (tile units)
-  uint32_t* tiles;      // tiles touched (0 = culled)
+  uint2* rect;          // x0 | x1<<16 , y0 | y1<<16 (16-px tile units, the reference's getRect)
+  unsigned long long* mask;  // bit (sy-2*y0)*2*(x1-x0) + (sx-2*x0): internal tile (sx,sy) can reach alpha >= 1/255;
+                        // 0 = no mask: every internal tile of the rect (clipped to the image) is listed
+  uint32_t* tiles;      // number of internal tiles listed for this Gaussian (0 = none)
   uint32_t* slot_base;  // first pair slot of this Gaussian in depth-expanded order
   uint32_t* skeyA;      // depth-sort ping-pong (keys = depth bits, vals = Gaussian id)
   uint32_t* skeyB;
@@ -63,6 +67,7 @@ static inline GeomWS geom_layout(char* base, int P) {
   o = ws_carve(base, o, g.depth, n);
   o = ws_carve(base, o, g.conic_o, n);
   o = ws_carve(base, o, g.rect, n);
+  o = ws_carve(base, o, g.mask, n);
   o = ws_carve(base, o, g.tiles, n);
   o = ws_carve(base, o, g.slot_base, n);
   o = ws_carve(base, o, g.skeyA, n);
@@ -81,8 +86,9 @@ static inline GeomWS geom_layout(char* base, int P) {
 struct BinWS {
   uint32_t* tkeyA;  // tile ids, ping-pong
   uint32_t* tkeyB;
-  uint32_t* tvalA;  // Gaussian ids, ping-pong
+  uint32_t* tvalA;  // pair slots (position in depth-expanded order), ping-pong
   uint32_t* tvalB;
+  uint32_t* gid;    // Gaussian id of each pair slot
   uint32_t* hist;   // [nbins][nblkR]
   uint32_t* dtotal; // [256]
   float* records;   // backward scratch: REC floats per pair slot
@@ -102,7 +108,7 @@ static inline int ceil_log2_u32(uint32_t n) {  // smallest b with (1<<b) >= n
 static inline BinWS bin_layout(char* base, int H, int W, int64_t R) {
   BinWS b;
   size_t n = (size_t)R, o = 0;
-  uint32_t T = (uint32_t)((W + TILE - 1) / TILE) * (uint32_t)((H + TILE - 1) / TILE);
+  uint32_t T = (uint32_t)((W + SUB - 1) / SUB) * (uint32_t)((H + SUB - 1) / SUB);
   b.tile_bits = ceil_log2_u32(T) < 1 ? 1 : ceil_log2_u32(T);
   b.passes = (b.tile_bits + 7) / 8;
   b.bits_per_pass = (b.tile_bits + b.passes - 1) / b.passes;
@@ -111,6 +117,7 @@ static inline BinWS bin_layout(char* base, int H, int W, int64_t R) {
   o = ws_carve(base, o, b.tkeyB, n);
   o = ws_carve(base, o, b.tvalA, n);
   o = ws_carve(base, o, b.tvalB, n);
+  o = ws_carve(base, o, b.gid, n);
   o = ws_carve(base, o, b.hist, (size_t)256 * (b.nblkR ? b.nblkR : 1));
   o = ws_carve(base, o, b.dtotal, 256);
   o = ws_carve(base, o, b.records, n * REC);
@@ -122,7 +129,7 @@ static inline BinWS bin_layout(char* base, int H, int W, int64_t R) {
 
 // Image workspace: O(H*W) + O(tiles).
 struct ImgWS {
-  uint2* ranges;       // per tile [start,end) into point_list
+  uint2* ranges;       // per internal (8x8) tile [start,end) into point_list
   float* final_T;      // transmittance after the last blended Gaussian
   uint32_t* n_contrib; // 1 + list index of the last blended Gaussian
   size_t bytes;
@@ -131,7 +138,7 @@ struct ImgWS {
 static inline ImgWS img_layout(char* base, int H, int W) {
   ImgWS im;
   size_t n = (size_t)H * W, o = 0;
-  size_t T = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+  size_t T = (size_t)((W + SUB - 1) / SUB) * ((H + SUB - 1) / SUB);
   o = ws_carve(base, o, im.ranges, T);
   o = ws_carve(base, o, im.final_T, n);
   o = ws_carve(base, o, im.n_contrib, n);

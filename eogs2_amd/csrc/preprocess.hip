@@ -81,6 +81,26 @@ __device__ inline void stage_rows3(const float* __restrict__ src, size_t row0, i
   }
 }
 
+// Can this Gaussian reach alpha >= 1/255 anywhere in the pixel block [x0,x1] x [y0,y1]?
+// alpha = o exp(-q/2), q(d) = a dx^2 + 2 b dx dy + c dy^2 (d = centre - pixel), so alpha >= 1/255 <=> q <= tau,
+// tau = 2 ln(255 o). The minimum of the convex q over the block is 0 if the centre is inside, otherwise it lies on
+// the edges that face the centre: minimise q along x = clamp(gx) and along y = clamp(gy), the free coordinate
+// clamped to the block. The continuous block contains the pixel centres, so q_min(block) <= q(pixel): dropping the
+// block when q_min > tau (plus a margin far above the fp32 rounding of the renderer's `power`) never drops a pixel
+// that would blend this Gaussian (forward.cu:374-376 skips alpha < 1/255). NaNs fail the comparison -> kept.
+__device__ inline bool block_hit(float gx, float gy, float a, float b, float c, float tau_m, float x0, float y0,
+                                 float x1, float y1) {
+  const float cx = fminf(fmaxf(gx, x0), x1), cy = fminf(fmaxf(gy, y0), y1);
+  const float dxe = gx - cx, dye = gy - cy;
+  const float py = fminf(fmaxf(gy + b * dxe / c, y0), y1);  // edge x = cx, free y
+  const float dy1 = gy - py;
+  const float q1 = a * dxe * dxe + 2.f * b * dxe * dy1 + c * dy1 * dy1;
+  const float pxs = fminf(fmaxf(gx + b * dye / a, x0), x1);  // edge y = cy, free x
+  const float dx2 = gx - pxs;
+  const float q2 = a * dx2 * dx2 + 2.f * b * dx2 * dye + c * dye * dye;
+  return !(fminf(q1, q2) > tau_m);
+}
+
 __device__ inline float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -95,8 +115,9 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
     const float* __restrict__ cov3D_precomp, const float* __restrict__ opacities, const float* __restrict__ vm,
     float scale_modifier, int antialiasing,
     int* __restrict__ radii, float2* __restrict__ means2D, float* __restrict__ depth_out,
-    float4* __restrict__ conic_o, uint2* __restrict__ rect, uint32_t* __restrict__ tiles,
-    uint32_t* __restrict__ skey, uint32_t* __restrict__ sval, uint32_t* __restrict__ misc) {
+    float4* __restrict__ conic_o, uint2* __restrict__ rect, unsigned long long* __restrict__ mask_out,
+    uint32_t* __restrict__ tiles, uint32_t* __restrict__ skey, uint32_t* __restrict__ sval,
+    uint32_t* __restrict__ misc) {
   __shared__ float s_m[3 * BLK];
   __shared__ float s_s[3 * BLK];
   __shared__ uint32_t s_cnt[BLK / 64];
@@ -159,17 +180,38 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
       const int area = (x1 - x0) * (y1 - y0);
       if (area != 0) {
         radius = r;
-        my_tiles = (uint32_t)area;
         const float d = (float)(200.0 - (double)pv[2]);  // forward.cu:267
         if (d < 0) atomicOr(&misc[MISC_ERR], 1u);
-        means2D[idx] = make_float2(px, py);
-        depth_out[idx] = d;
-        conic_o[idx] = make_float4(cz * det_inv, -cy * det_inv, cx * det_inv, opacities[idx] * hcs);
-        rect[idx] = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16));
-        skey[idx] = __float_as_uint(d);
+        const float ca = cz * det_inv, cb = -cy * det_inv, cc = cx * det_inv, op = opacities[idx] * hcs;
+        // internal 8x8 tiles inside the reference's 16-px tile rect, clipped to the image
+        const int gsx = (W + SUB - 1) / SUB, gsy = (H + SUB - 1) / SUB;
+        const int sx0 = 2 * x0, sy0 = 2 * y0, sw = 2 * (x1 - x0), sh = 2 * (y1 - y0);
+        const int sx1 = 2 * x1 < gsx ? 2 * x1 : gsx, sy1 = 2 * y1 < gsy ? 2 * y1 : gsy;
+        unsigned long long m = 0ull;
+        if (sw * sh <= MASK_MAX_SUBTILES) {
+          const float tau = 2.f * __logf(255.f * op);
+          const float tau_m = tau + 1e-3f * (1.f + fabsf(tau));
+          for (int sy = sy0; sy < sy1; sy++)
+            for (int sx = sx0; sx < sx1; sx++) {
+              const float bx = (float)(sx * SUB), by = (float)(sy * SUB);
+              if (block_hit(px, py, ca, cb, cc, tau_m, bx, by, bx + (SUB - 1), by + (SUB - 1)))
+                m |= 1ull << ((sy - sy0) * sw + (sx - sx0));
+            }
+          my_tiles = (uint32_t)__popcll(m);
+        } else {
+          my_tiles = (uint32_t)((sx1 - sx0) * (sy1 - sy0));
+        }
+        if (my_tiles) {
+          means2D[idx] = make_float2(px, py);
+          depth_out[idx] = d;
+          conic_o[idx] = make_float4(ca, cb, cc, op);
+          rect[idx] = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16));
+          mask_out[idx] = m;
+          skey[idx] = __float_as_uint(d);
+        }
       }
     }
-    if (my_tiles == 0) skey[idx] = 0xFFFFFFFFu;  // culled Gaussians sort last and emit nothing
+    if (my_tiles == 0) skey[idx] = 0xFFFFFFFFu;  // Gaussians that reach no pixel sort last and emit nothing
     radii[idx] = radius;
     tiles[idx] = my_tiles;
     sval[idx] = (uint32_t)idx;
@@ -191,7 +233,7 @@ void launch_preprocess_fwd(const FwdPrepArgs& a, const GeomWS& g, hipStream_t s)
   const uint32_t nblk = ceil_div_u32((uint64_t)a.P, BLK);
   hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nblk), dim3(BLK), 0, s, a.P, a.H, a.W, gx, gy, a.means3D, a.scales,
                      a.rotations, a.cov3D_precomp, a.opacities, a.viewmatrix, a.scale_modifier, (int)a.antialiasing,
-                     a.radii, g.means2D, g.depth, g.conic_o, g.rect, g.tiles, g.skeyA, g.svalA, g.misc);
+                     a.radii, g.means2D, g.depth, g.conic_o, g.rect, g.mask, g.tiles, g.skeyA, g.svalA, g.misc);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -1,18 +1,15 @@
-// render.hip — per-tile alpha blending, forward and backward.
+// render.hip — alpha blending per internal 8x8 tile, forward and backward.
 //
 // Work decomposition (both directions)
-//   * one 256-thread workgroup (4 wave64) per 16x16 tile; wave w owns the 8x8 pixel block (w&1, w>>1);
-//   * the tile's depth-ordered Gaussian list is staged through LDS in batches of 256 candidates, one
-//     candidate per lane: {xy, conic+opacity, 5 colours, 1/depth} = 48 B, gathered ONCE per tile (the
-//     reference re-fetches colours from global per contributing pixel, DGR/cuda_rasterizer/forward.cu:386);
-//   * wave64 ballot compaction: every wave takes the batch 64 candidates at a time (one per lane, read from
-//     LDS conflict-free), tests the candidate's alpha >= 1/255 ellipse against ITS 8x8 block with an exact
-//     continuous minimisation of the conic over the block (conservative margin), and ballots. Only the
-//     survivors are visited, in list order, by a scalar bit loop; a survivor's parameters are broadcast from
-//     the owning lane with v_readlane into SGPRs, so the hot loop has no memory latency at all.
-//     A culled candidate would have been skipped by every pixel of the block (alpha < 1/255, forward.cu:375),
-//     so results are identical to visiting every list entry; with the reference's init opacity 0.01 the
-//     alpha >= 1/255 footprint is 1.37 sigma against the 3 sigma tile rect, i.e. ~5x fewer visits.
+//   * ONE wave64 per internal 8x8 tile, lane = pixel. Waves are fully independent: no LDS, no barriers, no
+//     cross-wave merge. A 256-thread workgroup is just four tiles; workgroups are dealt to the 8 XCDs so that
+//     each XCD (own L2) walks one contiguous band of tiles and neighbouring tiles share their Gaussians in L2.
+//   * the tile's list (built by binning.hip) holds exactly the Gaussians that can reach alpha >= 1/255 inside
+//     the tile, in (depth, index) order. The wave takes it 64 entries at a time: lane i gathers entry i
+//     ({xy, conic+opacity, 5 colours, 1/depth} = 48 B) into registers, the NEXT chunk's gather is issued before
+//     the current chunk is consumed (software pipeline), and each entry's parameters are then broadcast from
+//     the owning lane with v_readlane into SGPRs — the hot loop touches no memory (the reference re-fetches
+//     colours from global per contributing pixel, DGR/cuda_rasterizer/forward.cu:386).
 //
 // Forward semantics: DGR/cuda_rasterizer/forward.cu:288-411.
 // Backward semantics: DGR/cuda_rasterizer/backward.cu:457-643, restructured:
@@ -22,10 +19,10 @@
 //     the reference's dL/dalpha_j = T_j (g.c_j - g.accum_rec_j) - T_final/(1-alpha_j) bg.g   (:586-620)
 //     equals  T_j (g.c_j) - (D_final - D_j) / (1 - alpha_j): one dot product per pair instead of a
 //     5-channel recurrence.
-//   * no global atomics: the 12 atomicAdd per contributing (pixel,Gaussian) of the reference (:598-640) are
-//     replaced by a DPP wave reduction, a per-tile LDS accumulation and ONE 48-byte record per (tile,Gaussian)
-//     pair written with plain stores; gaussian_bwd_kernel sums each Gaussian's records in fixed order
-//     (bitwise reproducible gradients).
+//   * no atomics: the 12 atomicAdd per contributing (pixel,Gaussian) of the reference (:598-640) become a DPP
+//     wave reduction and ONE 48-byte record per (tile,Gaussian) pair, written with plain stores by the only
+//     wave that owns the pair; gaussian_bwd_kernel sums each Gaussian's records in fixed order (bitwise
+//     reproducible gradients).
 #include "common.h"
 
 #pragma clang fp contract(fast)
@@ -36,6 +33,7 @@ namespace {
 __device__ inline float rl(float v, int lane) {  // broadcast lane `lane` (wave-uniform) to an SGPR
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
+__device__ inline uint32_t rlu(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
 
 template <int CTRL, int ROW_MASK>
 __device__ inline float dpp_add(float v) {
@@ -61,301 +59,229 @@ __device__ inline uint32_t wave_max_u32(uint32_t v) {
   return v;
 }
 
-struct PixelMap {
-  int px, py;
-  bool inside;
-  uint32_t pix_id;
+// XCD-aware tile of this wave: workgroup b runs on XCD b % 8 (round-robin dispatch; speed only, never
+// correctness), so XCD x gets the contiguous run of tile groups [x*per, (x+1)*per). gridDim.x is a multiple of 8.
+__device__ inline int tile_of_wave() {
+  const int per = gridDim.x >> 3;
+  const int grp = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  return grp * (BLK / 64) + (threadIdx.x >> 6);
+}
+
+// One list entry held by a lane.
+struct Cand {
+  float2 xy;
+  float4 co;
+  float ft[NFEAT];
+  uint32_t slot;
 };
-__device__ inline PixelMap pixel_of_thread(int tile, int gx, int W, int H) {
-  const int t = threadIdx.x, w = t >> 6, l = t & 63;
-  const int tx = tile % gx, ty = tile / gx;
-  PixelMap m;
-  m.px = tx * TILE + (w & 1) * 8 + (l & 7);
-  m.py = ty * TILE + (w >> 1) * 8 + (l >> 3);
-  m.inside = m.px < W && m.py < H;
-  m.pix_id = (uint32_t)m.py * (uint32_t)W + (uint32_t)m.px;
-  return m;
-}
 
-// Gather one Gaussian per lane into the staging arrays.
-__device__ inline void stage_gaussian(uint32_t id, int t, const float2* __restrict__ means2D,
-                                      const float4* __restrict__ conic_o, const float* __restrict__ depth,
-                                      const float* __restrict__ colors, float2* s_xy, float4* s_co, float* s_ft) {
-  s_xy[t] = means2D[id];
-  s_co[t] = conic_o[id];
-  const float* c = colors + (size_t)id * NCH;
+__device__ inline Cand load_cand(uint32_t k, uint32_t end, const uint32_t* __restrict__ point_list,
+                                 const uint32_t* __restrict__ gid, const float2* __restrict__ means2D,
+                                 const float4* __restrict__ conic_o, const float* __restrict__ depth,
+                                 const float* __restrict__ colors) {
+  Cand c;
+  c.xy = make_float2(0.f, 0.f);
+  c.co = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int ch = 0; ch < NCH; ch++) s_ft[t * NFEAT + ch] = c[ch];
-  s_ft[t * NFEAT + NCH] = 1.f / depth[id];
-}
-
-// Can this Gaussian reach alpha >= 1/255 anywhere in the pixel block [x0,x1] x [y0,y1]?
-// alpha = o exp(-q/2) with q(d) = a dx^2 + 2 b dx dy + c dy^2 (d = centre - pixel), so alpha >= 1/255 <=> q <= tau,
-// tau = 2 ln(255 o). The minimum of the convex q over the block is 0 if the centre is inside, otherwise it lies on
-// the edges that face the centre: minimise q along x = clamp(gx) and along y = clamp(gy) with the free coordinate
-// clamped to the block. The continuous block contains the pixel centres, so q_min(block) <= q(pixel): culling when
-// q_min > tau (plus a margin far above fp32 rounding of `power`) never drops a contributing Gaussian.
-// NaNs (degenerate conics) fail the comparison and are kept.
-__device__ inline bool block_hit(float gx, float gy, float a, float b, float c, float o, float x0, float y0, float x1,
-                                 float y1) {
-  const float cx = fminf(fmaxf(gx, x0), x1), cy = fminf(fmaxf(gy, y0), y1);
-  const float dxe = gx - cx, dye = gy - cy;
-  // edge x = cx: free y
-  const float py = fminf(fmaxf(gy + b * dxe / c, y0), y1);
-  const float dy1 = gy - py;
-  const float q1 = a * dxe * dxe + 2.f * b * dxe * dy1 + c * dy1 * dy1;
-  // edge y = cy: free x
-  const float pxs = fminf(fmaxf(gx + b * dye / a, x0), x1);
-  const float dx2 = gx - pxs;
-  const float q2 = a * dx2 * dx2 + 2.f * b * dx2 * dye + c * dye * dye;
-  const float qmin = fminf(q1, q2);
-  const float tau = 2.f * __logf(255.f * o);
-  return !(qmin > tau + 1e-3f * (1.f + fabsf(tau)));
+  for (int q = 0; q < NFEAT; q++) c.ft[q] = 0.f;
+  c.slot = 0;
+  if (k < end) {
+    c.slot = point_list[k];
+    const uint32_t id = gid[c.slot];
+    c.xy = means2D[id];
+    c.co = conic_o[id];
+    const float* f = colors + (size_t)id * NCH;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) c.ft[ch] = f[ch];
+    c.ft[NCH] = 1.f / depth[id];
+  }
+  return c;
 }
 
 }  // namespace
 
 __global__ __launch_bounds__(BLK) void render_fwd_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx,
-    const float2* __restrict__ means2D, const float4* __restrict__ conic_o, const float* __restrict__ depth,
-    const float* __restrict__ colors, const float* __restrict__ bg, float* __restrict__ final_T,
-    uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_invdepth) {
-  __shared__ float2 s_xy[BLK];
-  __shared__ float4 s_co[BLK];
-  __shared__ float s_ft[BLK * NFEAT];
-  const int t = threadIdx.x, w = t >> 6, lane = t & 63;
-  const int tile = blockIdx.x;
-  const PixelMap pm = pixel_of_thread(tile, gx, W, H);
-  const float pxf = (float)pm.px, pyf = (float)pm.py;
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ gid,
+    int W, int H, int gsx, int ntiles, const float2* __restrict__ means2D, const float4* __restrict__ conic_o,
+    const float* __restrict__ depth, const float* __restrict__ colors, const float* __restrict__ bg,
+    float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
+    float* __restrict__ out_invdepth) {
+  const int lane = threadIdx.x & 63;
+  const int tile = tile_of_wave();
+  if (tile >= ntiles) return;  // wave-uniform; waves never synchronise with each other
+  const int px = (tile % gsx) * SUB + (lane & 7), py = (tile / gsx) * SUB + (lane >> 3);
+  const bool inside = px < W && py < H;
+  const uint32_t pix_id = (uint32_t)py * (uint32_t)W + (uint32_t)px;
+  const float pxf = (float)px, pyf = (float)py;
   const uint2 range = ranges[tile];
-  // this wave's 8x8 block in pixel coordinates (wave-uniform)
-  const float bx0 = (float)((tile % gx) * TILE + (w & 1) * 8), by0 = (float)((tile / gx) * TILE + (w >> 1) * 8);
-  const float bx1 = bx0 + 7.f, by1 = by0 + 7.f;
 
   float T = 1.0f;
   uint32_t last_contributor = 0;
   float C[NCH] = {0.f, 0.f, 0.f, 0.f, 0.f};
   float invd = 0.f;
-  bool done = !pm.inside;
+  bool done = !inside;
 
-  for (uint32_t b0 = range.x; b0 < range.y; b0 += BLK) {
-    if (__syncthreads_and(done)) break;  // also fences LDS reuse
-    const uint32_t k = b0 + t;
-    if (k < range.y) stage_gaussian(point_list[k], t, means2D, conic_o, depth, colors, s_xy, s_co, s_ft);
-    __syncthreads();
-    const int nb = (int)((range.y - b0) < (uint32_t)BLK ? (range.y - b0) : (uint32_t)BLK);
-    const uint32_t jbase = b0 - range.x;
-    for (int cb = 0; cb < nb; cb += 64) {
-      if (__ballot(!done) == 0ull) break;  // every pixel of this wave has terminated
-      const int ci = cb + lane;
-      const bool cand = ci < nb;
-      const float2 cxy = s_xy[cand ? ci : 0];
-      const float4 cco = s_co[cand ? ci : 0];
-      unsigned long long mask = __ballot(cand && block_hit(cxy.x, cxy.y, cco.x, cco.y, cco.z, cco.w, bx0, by0, bx1, by1));
-      if (mask == 0ull) continue;
-      float cf[NFEAT];
+  Cand cur = load_cand(range.x + lane, range.y, point_list, gid, means2D, conic_o, depth, colors);
+  for (uint32_t c0 = range.x; c0 < range.y; c0 += 64) {
+    const Cand nxt = load_cand(c0 + 64 + lane, range.y, point_list, gid, means2D, conic_o, depth, colors);
+    if (__ballot(!done) == 0ull) break;  // every pixel of the tile has terminated
+    const int n = (int)((range.y - c0) < 64u ? (range.y - c0) : 64u);
+    const uint32_t jbase = c0 - range.x;
+    for (int j = 0; j < n; j++) {
+      const float gxs = rl(cur.xy.x, j), gys = rl(cur.xy.y, j);
+      const float ca = rl(cur.co.x, j), cb = rl(cur.co.y, j), cc = rl(cur.co.z, j), op = rl(cur.co.w, j);
+      const float dx = gxs - pxf, dy = gys - pyf;
+      const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
+      const float alpha = fminf(0.99f, op * __expf(power));
+      bool valid = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+      const float test_T = T * (1.f - alpha);
+      const bool term = valid && test_T < 0.0001f;  // this Gaussian is NOT blended; the pixel is finished
+      done = done || term;
+      valid = valid && !term;
+      if (__ballot(valid) == 0ull) continue;
+      const float wgt = valid ? alpha * T : 0.f;
 #pragma unroll
-      for (int q = 0; q < NFEAT; q++) cf[q] = s_ft[(cand ? ci : 0) * NFEAT + q];
-      while (mask) {
-        const int j = __builtin_ctzll(mask);
-        mask &= mask - 1ull;
-        const float gxs = rl(cxy.x, j), gys = rl(cxy.y, j);
-        const float ca = rl(cco.x, j), cbb = rl(cco.y, j), cc = rl(cco.z, j), op = rl(cco.w, j);
-        const float dx = gxs - pxf, dy = gys - pyf;
-        const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cbb * dx * dy;
-        const float alpha = fminf(0.99f, op * __expf(power));
-        bool valid = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-        const float test_T = T * (1.f - alpha);
-        const bool term = valid && test_T < 0.0001f;  // this Gaussian is NOT blended; the pixel is finished
-        done = done || term;
-        valid = valid && !term;
-        if (__ballot(valid) == 0ull) continue;
-        const float wgt = valid ? alpha * T : 0.f;
-#pragma unroll
-        for (int ch = 0; ch < NCH; ch++) C[ch] += rl(cf[ch], j) * wgt;
-        invd += rl(cf[NCH], j) * wgt;
-        T = valid ? test_T : T;
-        last_contributor = valid ? jbase + (uint32_t)(cb + j) + 1u : last_contributor;
-      }
+      for (int ch = 0; ch < NCH; ch++) C[ch] += rl(cur.ft[ch], j) * wgt;
+      invd += rl(cur.ft[NCH], j) * wgt;
+      T = valid ? test_T : T;
+      last_contributor = valid ? jbase + (uint32_t)j + 1u : last_contributor;
     }
+    cur = nxt;
   }
-  if (pm.inside) {
+  if (inside) {
     const size_t HW = (size_t)H * W;
-    final_T[pm.pix_id] = T;
-    n_contrib[pm.pix_id] = last_contributor;
+    final_T[pix_id] = T;
+    n_contrib[pix_id] = last_contributor;
 #pragma unroll
-    for (int ch = 0; ch < NCH; ch++) out_color[ch * HW + pm.pix_id] = C[ch] + T * bg[ch];
-    if (out_invdepth) out_invdepth[pm.pix_id] = invd;
+    for (int ch = 0; ch < NCH; ch++) out_color[ch * HW + pix_id] = C[ch] + T * bg[ch];
+    if (out_invdepth) out_invdepth[pix_id] = invd;
   }
+}
+
+static inline uint32_t render_grid(int ntiles) {
+  const uint32_t groups = ceil_div_u32((uint64_t)ntiles, BLK / 64);
+  return ((groups + 7u) / 8u) * 8u;  // multiple of 8 for the XCD band mapping
 }
 
 void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, int W, const float* colors,
                        const float* bg, float* out_color, float* out_invdepth, hipStream_t s) {
-  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-  hipLaunchKernelGGL(render_fwd_kernel, dim3(gx * gy), dim3(BLK), 0, s, im.ranges, b.point_list, W, H, gx, g.means2D,
-                     g.conic_o, g.depth, colors, bg, im.final_T, im.n_contrib, out_color, out_invdepth);
+  const int gsx = (W + SUB - 1) / SUB, gsy = (H + SUB - 1) / SUB, ntiles = gsx * gsy;
+  hipLaunchKernelGGL(render_fwd_kernel, dim3(render_grid(ntiles)), dim3(BLK), 0, s, im.ranges, b.point_list, b.gid, W, H,
+                     gsx, ntiles, g.means2D, g.conic_o, g.depth, colors, bg, im.final_T, im.n_contrib, out_color,
+                     out_invdepth);
 }
 
 // ------------------------------------------------------------------------------------------------------
 // Backward
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLK) void render_bwd_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx,
-    const float2* __restrict__ means2D, const float4* __restrict__ conic_o, const float* __restrict__ depth,
-    const float* __restrict__ colors, const uint2* __restrict__ rect, const uint32_t* __restrict__ slot_base,
-    const uint32_t* __restrict__ n_contrib, const float* __restrict__ out_color,
-    const float* __restrict__ out_invdepth, const float* __restrict__ dL_dpix, const float* __restrict__ dL_dinv,
-    float* __restrict__ records) {
-  __shared__ float2 s_xy[BLK];
-  __shared__ float4 s_co[BLK];
-  __shared__ float s_ft[BLK * NFEAT];
-  __shared__ uint32_t s_id[BLK];
-  __shared__ float s_acc[BLK / 64][BLK][REC];  // per-wave partial sums of the current batch
-  __shared__ uint32_t s_wmax[BLK / 64];
-  const int t = threadIdx.x, w = t >> 6, lane = t & 63;
-  const int tile = blockIdx.x;
-  const int tx = tile % gx, ty = tile / gx;
-  const PixelMap pm = pixel_of_thread(tile, gx, W, H);
-  const float pxf = (float)pm.px, pyf = (float)pm.py;
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ gid,
+    int W, int H, int gsx, int ntiles, const float2* __restrict__ means2D, const float4* __restrict__ conic_o,
+    const float* __restrict__ depth, const float* __restrict__ colors, const uint32_t* __restrict__ n_contrib,
+    const float* __restrict__ out_color, const float* __restrict__ out_invdepth, const float* __restrict__ dL_dpix,
+    const float* __restrict__ dL_dinv, float* __restrict__ records) {
+  const int lane = threadIdx.x & 63;
+  const int tile = tile_of_wave();
+  if (tile >= ntiles) return;
+  const int px = (tile % gsx) * SUB + (lane & 7), py = (tile / gsx) * SUB + (lane >> 3);
+  const bool inside = px < W && py < H;
+  const uint32_t pix_id = (uint32_t)py * (uint32_t)W + (uint32_t)px;
+  const float pxf = (float)px, pyf = (float)py;
   const uint2 range = ranges[tile];
   const size_t HW = (size_t)H * W;
   const bool have_inv = dL_dinv != nullptr;
-  const float bx0 = (float)(tx * TILE + (w & 1) * 8), by0 = (float)(ty * TILE + (w >> 1) * 8);
-  const float bx1 = bx0 + 7.f, by1 = by0 + 7.f;
 
   float g[NCH] = {0.f, 0.f, 0.f, 0.f, 0.f};
   float ginv = 0.f, Dfinal = 0.f;
   uint32_t ncontrib = 0;
-  if (pm.inside) {
-    ncontrib = n_contrib[pm.pix_id];
+  if (inside) {
+    ncontrib = n_contrib[pix_id];
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) {
-      g[ch] = dL_dpix[ch * HW + pm.pix_id];
-      Dfinal += g[ch] * out_color[ch * HW + pm.pix_id];
+      g[ch] = dL_dpix[ch * HW + pix_id];
+      Dfinal += g[ch] * out_color[ch * HW + pix_id];
     }
     if (have_inv) {
-      ginv = dL_dinv[pm.pix_id];
-      Dfinal += ginv * out_invdepth[pm.pix_id];
+      ginv = dL_dinv[pix_id];
+      Dfinal += ginv * out_invdepth[pix_id];
     }
   }
-  // Gaussians past the last contributor of every pixel of this wave / tile cannot receive gradient
-  const uint32_t wave_last = wave_max_u32(ncontrib);
-  if (lane == 0) s_wmax[w] = wave_last;
-  __syncthreads();
-  const uint32_t m01 = s_wmax[0] > s_wmax[1] ? s_wmax[0] : s_wmax[1];
-  const uint32_t m23 = s_wmax[2] > s_wmax[3] ? s_wmax[2] : s_wmax[3];
-  const uint32_t tile_last = m01 > m23 ? m01 : m23;
-  const uint32_t list_end = range.x + tile_last < range.y ? range.x + tile_last : range.y;
+  // list entries past the last contributor of every pixel of the tile receive no gradient
+  const uint32_t tile_last = wave_max_u32(ncontrib);
 
   const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
   float T = 1.0f, Dacc = 0.f;
 
-  for (uint32_t b0 = range.x; b0 < list_end; b0 += BLK) {
-    __syncthreads();  // previous batch's flush has read s_id / s_acc
-    const uint32_t k = b0 + t;
-    const int nb = (int)((list_end - b0) < (uint32_t)BLK ? (list_end - b0) : (uint32_t)BLK);
-    if (k < list_end) {
-      const uint32_t id = point_list[k];
-      s_id[t] = id;
-      stage_gaussian(id, t, means2D, conic_o, depth, colors, s_xy, s_co, s_ft);
-    }
-#pragma unroll
-    for (int ww = 0; ww < BLK / 64; ww++)
-#pragma unroll
-      for (int c = 0; c < REC; c++) s_acc[ww][t][c] = 0.f;
-    __syncthreads();
+  Cand cur = load_cand(range.x + lane, range.y, point_list, gid, means2D, conic_o, depth, colors);
+  for (uint32_t c0 = range.x; c0 < range.y; c0 += 64) {
+    const Cand nxt = load_cand(c0 + 64 + lane, range.y, point_list, gid, means2D, conic_o, depth, colors);
+    const int n = (int)((range.y - c0) < 64u ? (range.y - c0) : 64u);
+    const uint32_t jbase = c0 - range.x;
+    int jn = n;  // entries of this chunk that can still matter
+    if (tile_last < jbase + (uint32_t)n) jn = tile_last > jbase ? (int)(tile_last - jbase) : 0;
+    unsigned long long written = 0ull;
+    for (int j = 0; j < jn; j++) {
+      const float gxs = rl(cur.xy.x, j), gys = rl(cur.xy.y, j);
+      const float ca = rl(cur.co.x, j), cb = rl(cur.co.y, j), cc = rl(cur.co.z, j), op = rl(cur.co.w, j);
+      const float dx = gxs - pxf, dy = gys - pyf;
+      const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
+      const float G = __expf(power);
+      const float alpha = fminf(0.99f, op * G);
+      const bool valid = (jbase + (uint32_t)j < ncontrib) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+      if (__ballot(valid) == 0ull) continue;  // wave-uniform skip
 
-    const uint32_t jbase = b0 - range.x;  // list index of the batch's first entry
-    int jend = nb;                        // candidates at list index >= wave_last cannot matter to this wave
-    if (wave_last < jbase + (uint32_t)nb) jend = wave_last > jbase ? (int)(wave_last - jbase) : 0;
-    for (int cb = 0; cb < jend; cb += 64) {
-      const int ci = cb + lane;
-      const bool cand = ci < jend;
-      const float2 cxy = s_xy[cand ? ci : 0];
-      const float4 cco = s_co[cand ? ci : 0];
-      unsigned long long mask = __ballot(cand && block_hit(cxy.x, cxy.y, cco.x, cco.y, cco.z, cco.w, bx0, by0, bx1, by1));
-      if (mask == 0ull) continue;
-      float cf[NFEAT];
+      float gc = 0.f;
 #pragma unroll
-      for (int q = 0; q < NFEAT; q++) cf[q] = s_ft[(cand ? ci : 0) * NFEAT + q];
-      while (mask) {
-        const int j = __builtin_ctzll(mask);
-        mask &= mask - 1ull;
-        const float gxs = rl(cxy.x, j), gys = rl(cxy.y, j);
-        const float ca = rl(cco.x, j), cbb = rl(cco.y, j), cc = rl(cco.z, j), op = rl(cco.w, j);
-        const float dx = gxs - pxf, dy = gys - pyf;
-        const float power = -0.5f * (ca * dx * dx + cc * dy * dy) - cbb * dx * dy;
-        const float G = __expf(power);
-        const float alpha = fminf(0.99f, op * G);
-        const bool valid = (jbase + (uint32_t)(cb + j) < ncontrib) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-        if (__ballot(valid) == 0ull) continue;  // wave-uniform skip
-
-        float gc = 0.f;
+      for (int ch = 0; ch < NCH; ch++) gc += g[ch] * rl(cur.ft[ch], j);
+      if (have_inv) gc += ginv * rl(cur.ft[NCH], j);
+      const float wgt = valid ? alpha * T : 0.f;
+      Dacc += gc * wgt;
+      const float one_m = 1.f - alpha;
+      const float dL_dalpha = valid ? T * gc - (Dfinal - Dacc) * __frcp_rn(one_m) : 0.f;
+      T = valid ? T * one_m : T;
+      const float dL_dG = op * dL_dalpha;  // no zeroing when alpha was clamped (backward.cu:624)
+      const float Gs = valid ? G : 0.f;    // exp() may overflow on lanes that skip this Gaussian
+      const float gdx = Gs * dx, gdy = Gs * dy;
+      const float dG_ddelx = -gdx * ca - gdy * cb;
+      const float dG_ddely = -gdy * cc - gdx * cb;
+      float c[REC];
+      c[0] = dL_dG * dG_ddelx * ddelx_dx;
+      c[1] = dL_dG * dG_ddely * ddely_dy;
+      c[2] = -0.5f * gdx * dx * dL_dG;
+      c[3] = -0.5f * gdx * dy * dL_dG;
+      c[4] = -0.5f * gdy * dy * dL_dG;
+      c[5] = Gs * dL_dalpha;
 #pragma unroll
-        for (int ch = 0; ch < NCH; ch++) gc += g[ch] * rl(cf[ch], j);
-        if (have_inv) gc += ginv * rl(cf[NCH], j);
-        const float wgt = valid ? alpha * T : 0.f;
-        Dacc += gc * wgt;
-        const float one_m = 1.f - alpha;
-        const float dL_dalpha = valid ? T * gc - (Dfinal - Dacc) * __frcp_rn(one_m) : 0.f;
-        T = valid ? T * one_m : T;
-        const float dL_dG = op * dL_dalpha;  // no zeroing when alpha was clamped (backward.cu:624)
-        const float Gs = valid ? G : 0.f;    // exp() may overflow on lanes that skip this Gaussian
-        const float gdx = Gs * dx, gdy = Gs * dy;
-        const float dG_ddelx = -gdx * ca - gdy * cbb;
-        const float dG_ddely = -gdy * cc - gdx * cbb;
-        float c[REC - 1];
-        c[0] = dL_dG * dG_ddelx * ddelx_dx;
-        c[1] = dL_dG * dG_ddely * ddely_dy;
-        c[2] = -0.5f * gdx * dx * dL_dG;
-        c[3] = -0.5f * gdx * dy * dL_dG;
-        c[4] = -0.5f * gdy * dy * dL_dG;
-        c[5] = Gs * dL_dalpha;
+      for (int ch = 0; ch < NCH; ch++) c[6 + ch] = wgt * g[ch];
 #pragma unroll
-        for (int ch = 0; ch < NCH; ch++) c[6 + ch] = wgt * g[ch];
-        float* acc = &s_acc[w][cb + j][0];
-#pragma unroll
-        for (int q = 0; q < REC - 1; q++) {
-          const float v = wave_sum_lane63(c[q]);
-          if (lane == 63) acc[q] = v;
-        }
+      for (int q = 0; q < REC - 1; q++) c[q] = wave_sum_lane63(c[q]);
+      c[REC - 1] = 0.f;
+      const uint32_t slot = rlu(cur.slot, j);
+      if (lane == 63) {
+        float4* dst = reinterpret_cast<float4*>(records + (size_t)slot * REC);
+        dst[0] = make_float4(c[0], c[1], c[2], c[3]);
+        dst[1] = make_float4(c[4], c[5], c[6], c[7]);
+        dst[2] = make_float4(c[8], c[9], c[10], 0.f);
       }
+      written |= 1ull << j;
     }
-    __syncthreads();
-    // flush: one 48-byte record per (tile, Gaussian) pair, fixed wave order
-    if (t < nb) {
-      float r[REC];
-#pragma unroll
-      for (int q = 0; q < REC; q++) r[q] = ((s_acc[0][t][q] + s_acc[1][t][q]) + s_acc[2][t][q]) + s_acc[3][t][q];
-      const uint32_t id = s_id[t];
-      const uint2 rc = rect[id];
-      const uint32_t x0 = rc.x & 0xFFFFu, x1 = rc.x >> 16, y0 = rc.y & 0xFFFFu;
-      const uint32_t slot = slot_base[id] + ((uint32_t)ty - y0) * (x1 - x0) + ((uint32_t)tx - x0);
-      float4* dst = reinterpret_cast<float4*>(records + (size_t)slot * REC);
-      dst[0] = make_float4(r[0], r[1], r[2], r[3]);
-      dst[1] = make_float4(r[4], r[5], r[6], r[7]);
-      dst[2] = make_float4(r[8], r[9], r[10], 0.f);
+    // every pair owns a record: entries that reached no pixel get zeros
+    if (lane < n && !((written >> lane) & 1ull)) {
+      float4* dst = reinterpret_cast<float4*>(records + (size_t)cur.slot * REC);
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      dst[0] = z; dst[1] = z; dst[2] = z;
     }
-  }
-  // list entries beyond the last contributor of the whole tile still own a record: zero it
-  for (uint32_t k = list_end + t; k < range.y; k += BLK) {
-    const uint32_t id = point_list[k];
-    const uint2 rc = rect[id];
-    const uint32_t x0 = rc.x & 0xFFFFu, x1 = rc.x >> 16, y0 = rc.y & 0xFFFFu;
-    const uint32_t slot = slot_base[id] + ((uint32_t)ty - y0) * (x1 - x0) + ((uint32_t)tx - x0);
-    float4* dst = reinterpret_cast<float4*>(records + (size_t)slot * REC);
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    dst[0] = z; dst[1] = z; dst[2] = z;
+    cur = nxt;
   }
 }
 
 void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, int W, const float* colors,
                        const float* out_color, const float* out_invdepth, const float* dL_dcolor,
                        const float* dL_dinvdepth, hipStream_t s) {
-  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-  hipLaunchKernelGGL(render_bwd_kernel, dim3(gx * gy), dim3(BLK), 0, s, im.ranges, b.point_list, W, H, gx, g.means2D,
-                     g.conic_o, g.depth, colors, g.rect, g.slot_base, im.n_contrib, out_color, out_invdepth, dL_dcolor,
-                     dL_dinvdepth, b.records);
+  const int gsx = (W + SUB - 1) / SUB, gsy = (H + SUB - 1) / SUB, ntiles = gsx * gsy;
+  hipLaunchKernelGGL(render_bwd_kernel, dim3(render_grid(ntiles)), dim3(BLK), 0, s, im.ranges, b.point_list, b.gid, W, H,
+                     gsx, ntiles, g.means2D, g.conic_o, g.depth, colors, im.n_contrib, out_color, out_invdepth,
+                     dL_dcolor, dL_dinvdepth, b.records);
 }
 
 // ---- self test of the wave64 primitives (diagnostics; returns mismatching lanes in out[0]) ----
