@@ -35,12 +35,42 @@ __device__ inline float rl(float v, int lane) {  // broadcast lane `lane` (wave-
 }
 __device__ inline uint32_t rlu(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
 
+// ---- wave64 sum of 11 values at once: 6 DPP steps x 11 registers = 66 v_add_f32_dpp ----
+// GFX9 DPP reduction: row_shr 1/2/4/8 (bound_ctrl: out-of-row sources read 0) build each 16-lane row's inclusive
+// scan (lane 15 of a row = row sum); row_bcast:15 (rows 1,3) adds the previous row's sum; row_bcast:31 (rows 2,3)
+// adds lane 31's. The totals are valid in LANE 63 ONLY. Written as inline asm because hipcc materialises
+// "old = 0" moves around the masked steps (3 instructions per step). An asm statement is opaque to the hazard
+// recogniser: a DPP read of a VGPR written by the previous VALU instruction needs 2 wait states, so each block
+// starts with s_nop 1; inside a block the 11 chains are independent and every register is re-read 11
+// instructions after it was written.
+#define DPP_STEP11(CTRL)                                                                                         \
+  asm volatile("s_nop 1\n\t"                                                                                     \
+               "v_add_f32_dpp %0, %0, %0 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %1, %1, %1 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %2, %2, %2 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %3, %3, %3 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %4, %4, %4 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %5, %5, %5 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %6, %6, %6 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %7, %7, %7 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %8, %8, %8 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %9, %9, %9 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %10, %10, %10 " CTRL                                                                \
+               : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), \
+                 "+v"(c[8]), "+v"(c[9]), "+v"(c[10]))
+__device__ inline void wave_sum11_lane63(float (&c)[REC]) {
+  DPP_STEP11("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+  DPP_STEP11("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+  DPP_STEP11("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+  DPP_STEP11("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+  DPP_STEP11("row_bcast:15 row_mask:0xa bank_mask:0xf");
+  DPP_STEP11("row_bcast:31 row_mask:0xc bank_mask:0xf");
+}
+// compiler-scheduled single-value form (self test reference)
 template <int CTRL, int ROW_MASK>
 __device__ inline float dpp_add(float v) {
   return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
 }
-// Sum over the 64 lanes; the total is valid in lane 63 only. GFX9 DPP: row_shr 1/2/4/8 build each row's
-// inclusive scan (lane 15 of a row = row sum), row_bcast15 adds it into the next row, row_bcast31 into rows 2-3.
 __device__ inline float wave_sum_lane63(float v) {
   v = dpp_add<0x111, 0xf>(v);
   v = dpp_add<0x112, 0xf>(v);
@@ -64,7 +94,8 @@ __device__ inline uint32_t wave_max_u32(uint32_t v) {
 __device__ inline int tile_of_wave() {
   const int per = gridDim.x >> 3;
   const int grp = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  return grp * (BLK / 64) + (threadIdx.x >> 6);
+  // the wave index is uniform across the wave: tell the compiler, so tile, list range and loop control live in SGPRs
+  return grp * (BLK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 }
 
 // One list entry held by a lane.
@@ -207,7 +238,7 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
     }
   }
   // list entries past the last contributor of every pixel of the tile receive no gradient
-  const uint32_t tile_last = wave_max_u32(ncontrib);
+  const uint32_t tile_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(ncontrib));
 
   const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
   float T = 1.0f, Dacc = 0.f;
@@ -237,7 +268,7 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
       const float wgt = valid ? alpha * T : 0.f;
       Dacc += gc * wgt;
       const float one_m = 1.f - alpha;
-      const float dL_dalpha = valid ? T * gc - (Dfinal - Dacc) * __frcp_rn(one_m) : 0.f;
+      const float dL_dalpha = valid ? T * gc - (Dfinal - Dacc) * __builtin_amdgcn_rcpf(one_m) : 0.f;
       T = valid ? T * one_m : T;
       const float dL_dG = op * dL_dalpha;  // no zeroing when alpha was clamped (backward.cu:624)
       const float Gs = valid ? G : 0.f;    // exp() may overflow on lanes that skip this Gaussian
@@ -253,9 +284,8 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
       c[5] = Gs * dL_dalpha;
 #pragma unroll
       for (int ch = 0; ch < NCH; ch++) c[6 + ch] = wgt * g[ch];
-#pragma unroll
-      for (int q = 0; q < REC - 1; q++) c[q] = wave_sum_lane63(c[q]);
       c[REC - 1] = 0.f;
+      wave_sum11_lane63(c);
       const uint32_t slot = rlu(cur.slot, j);
       if (lane == 63) {
         float4* dst = reinterpret_cast<float4*>(records + (size_t)slot * REC);
@@ -295,6 +325,17 @@ __global__ void selftest_kernel(uint32_t* out) {
   const float b = rl(v, 17);
   uint32_t bad = 0;
   if (lane == 63 && got != ref) bad |= 1u;
+  float c[REC];
+#pragma unroll
+  for (int q = 0; q < REC; q++) c[q] = v * (float)(q + 1) + (float)q * 0.25f;  // freshly written VGPRs (hazard case)
+  wave_sum11_lane63(c);
+#pragma unroll
+  for (int q = 0; q < REC - 1; q++) {
+    float r = v * (float)(q + 1) + (float)q * 0.25f;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) r += __shfl_xor(r, o, 64);
+    if (lane == 63 && c[q] != r) bad |= 4u;
+  }
   if (b != (float)((17 * 37 + 11) % 101) - 50.f) bad |= 2u;
   if (bad) atomicOr(out, bad);
 }
