@@ -1,12 +1,15 @@
-set -x
-mkdir -p gpurun_out/prof
+# usage: bash tools/prof.sh <tag>   (on the GPU box, from the repo root)
+TAG=${1:-run}
+mkdir -p gpurun_out/prof_$TAG
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/prof_$TAG
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 B="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof/stats -- $B > $R/gpurun_out/prof/stats.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS --output-format csv -d $R/gpurun_out/prof/pmc_sq -- $B > $R/gpurun_out/prof/pmc_sq.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof/pmc_fetch -- $B > $R/gpurun_out/prof/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof/pmc_write -- $B > $R/gpurun_out/prof/pmc_write.log 2>&1
-cd $R/gpurun_out/prof && find . -name "*.csv" | head -30 && du -sh .
-# keep only compact files
-find . -name "*agent_info*" -delete
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B > $O/stats.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $O/pmc_sq -- $B > $O/pmc_sq.log 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU SQ_WAVE_CYCLES --output-format csv -d $O/pmc_sq2 -- $B > $O/pmc_sq2.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $B > $O/pmc_write.log 2>&1
+find $O -name "*agent_info*" -delete
+find $O -name "*.csv" | head -20
+tail -3 $O/pmc_sq2.log

@@ -1,0 +1,20 @@
+"""Condenses a gpurun_out/prof_<tag> directory (tools/prof.sh) into profiles/<name>/ : kernel_stats.csv +
+pmc_mean_per_dispatch.json (mean counter value per dispatch, per kernel)."""
+import collections, csv, glob, json, os, re, shutil, sys
+
+src, dst = sys.argv[1], sys.argv[2]
+os.makedirs(dst, exist_ok=True)
+short = lambda n: re.sub(r"\(.*", "", n).replace("void ", "")[:60]
+for f in glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")):
+    shutil.copy(f, os.path.join(dst, "kernel_stats.csv"))
+out = {}
+for f in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        out.setdefault(k, {}).update({c: sum(x) / len(x) for c, x in v.items()})
+json.dump(out, open(os.path.join(dst, "pmc_mean_per_dispatch.json"), "w"), indent=1, sort_keys=True)
+for k in ("render_bwd_kernel", "render_fwd_kernel"):
+    if k in out:
+        print(k, {c: f"{v:.3g}" for c, v in sorted(out[k].items())})
