@@ -11,7 +11,7 @@ OUT = os.path.join(_HERE, "libeogs_rast_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fno-slp-vectorize",  # SLP packs independent DPP reduction chains into v_pk_* ops, which cannot carry DPP
-         "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include")]
+         "-Wall", "-Werror=unused-value", "-Wno-unused-function", "-I", os.path.join(ROOT, "include")]
 
 
 def sources():

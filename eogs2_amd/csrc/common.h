@@ -8,7 +8,8 @@
 
 #define NCH EOGS_RAST_CHANNELS  // 5 feature channels
 #define TILE EOGS_RAST_TILE     // 16x16 pixel tiles: the reference's binning granularity (tile rect, radii)
-#define SUB 8                   // internal tile = 8x8 pixels = one wave64; lists are built per internal tile
+#define SUBX 16                  // internal tile = 16x8 pixels = one wave64 with two horizontally adjacent pixels per
+#define SUBY 8                   // lane (packed fp32 math); lists are built per internal tile
 #define MASK_MAX_SUBTILES 64    // Gaussians whose 16-px rect spans <= 64 internal tiles carry an exact hit mask
 #define BLK 256                 // threads per workgroup everywhere (4 wave64)
 #define NFEAT 6                 // staged per-Gaussian features: 5 colours + 1/depth
@@ -42,7 +43,7 @@ struct GeomWS {
   float* depth;         // 200 - altitude
   float4* conic_o;      // conic (a,b,c) + effective opacity
   uint2* rect;          // x0 | x1<<16 , y0 | y1<<16 (16-px tile units, the reference's getRect)
-  unsigned long long* mask;  // bit (sy-2*y0)*2*(x1-x0) + (sx-2*x0): internal tile (sx,sy) can reach alpha >= 1/255;
+  unsigned long long* mask;  // bit (sy-2*y0)*(x1-x0) + (sx-x0): internal tile (sx,sy) can reach alpha >= 1/255;
                         // 0 = no mask: every internal tile of the rect (clipped to the image) is listed
   uint32_t* tiles;      // number of internal tiles listed for this Gaussian (0 = none)
   uint32_t* slot_base;  // first pair slot of this Gaussian in depth-expanded order
@@ -108,7 +109,7 @@ static inline int ceil_log2_u32(uint32_t n) {  // smallest b with (1<<b) >= n
 static inline BinWS bin_layout(char* base, int H, int W, int64_t R) {
   BinWS b;
   size_t n = (size_t)R, o = 0;
-  uint32_t T = (uint32_t)((W + SUB - 1) / SUB) * (uint32_t)((H + SUB - 1) / SUB);
+  uint32_t T = (uint32_t)((W + SUBX - 1) / SUBX) * (uint32_t)((H + SUBY - 1) / SUBY);
   b.tile_bits = ceil_log2_u32(T) < 1 ? 1 : ceil_log2_u32(T);
   b.passes = (b.tile_bits + 7) / 8;
   b.bits_per_pass = (b.tile_bits + b.passes - 1) / b.passes;
@@ -129,7 +130,7 @@ static inline BinWS bin_layout(char* base, int H, int W, int64_t R) {
 
 // Image workspace: O(H*W) + O(tiles).
 struct ImgWS {
-  uint2* ranges;       // per internal (8x8) tile [start,end) into point_list
+  uint2* ranges;       // per internal (16x8) tile [start,end) into point_list
   float* final_T;      // transmittance after the last blended Gaussian
   uint32_t* n_contrib; // 1 + list index of the last blended Gaussian
   size_t bytes;
@@ -138,7 +139,7 @@ struct ImgWS {
 static inline ImgWS img_layout(char* base, int H, int W) {
   ImgWS im;
   size_t n = (size_t)H * W, o = 0;
-  size_t T = (size_t)((W + SUB - 1) / SUB) * ((H + SUB - 1) / SUB);
+  size_t T = (size_t)((W + SUBX - 1) / SUBX) * ((H + SUBY - 1) / SUBY);
   o = ws_carve(base, o, im.ranges, T);
   o = ws_carve(base, o, im.final_T, n);
   o = ws_carve(base, o, im.n_contrib, n);

@@ -183,18 +183,19 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
         const float d = (float)(200.0 - (double)pv[2]);  // forward.cu:267
         if (d < 0) atomicOr(&misc[MISC_ERR], 1u);
         const float ca = cz * det_inv, cb = -cy * det_inv, cc = cx * det_inv, op = opacities[idx] * hcs;
-        // internal 8x8 tiles inside the reference's 16-px tile rect, clipped to the image
-        const int gsx = (W + SUB - 1) / SUB, gsy = (H + SUB - 1) / SUB;
-        const int sx0 = 2 * x0, sy0 = 2 * y0, sw = 2 * (x1 - x0), sh = 2 * (y1 - y0);
-        const int sx1 = 2 * x1 < gsx ? 2 * x1 : gsx, sy1 = 2 * y1 < gsy ? 2 * y1 : gsy;
+        // internal 16x8 tiles inside the reference's 16-px tile rect (same columns, two rows per 16-px tile row),
+        // clipped to the image
+        const int gsy = (H + SUBY - 1) / SUBY;
+        const int sx0 = x0, sy0 = 2 * y0, sw = x1 - x0, sh = 2 * (y1 - y0);
+        const int sx1 = x1, sy1 = 2 * y1 < gsy ? 2 * y1 : gsy;
         unsigned long long m = 0ull;
         if (sw * sh <= MASK_MAX_SUBTILES) {
           const float tau = 2.f * __logf(255.f * op);
           const float tau_m = tau + 1e-3f * (1.f + fabsf(tau));
           for (int sy = sy0; sy < sy1; sy++)
             for (int sx = sx0; sx < sx1; sx++) {
-              const float bx = (float)(sx * SUB), by = (float)(sy * SUB);
-              if (block_hit(px, py, ca, cb, cc, tau_m, bx, by, bx + (SUB - 1), by + (SUB - 1)))
+              const float bx = (float)(sx * SUBX), by = (float)(sy * SUBY);
+              if (block_hit(px, py, ca, cb, cc, tau_m, bx, by, bx + (SUBX - 1), by + (SUBY - 1)))
                 m |= 1ull << ((sy - sy0) * sw + (sx - sx0));
             }
           my_tiles = (uint32_t)__popcll(m);
