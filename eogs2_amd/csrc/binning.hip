@@ -8,7 +8,7 @@
 //      4 passes over P items instead of 6 passes over R pairs of 12 B);
 //   2. expand in depth order: pair slot = exclusive scan of the per-Gaussian tile counts over the depth-sorted
 //      Gaussians; a load-balanced workgroup expansion writes (tile id, pair slot) with contiguous lanes.
-//      Lists are built per INTERNAL 16x8 tile (one wave64, two pixels per lane) and only for the internal tiles of the
+//      Lists are built per INTERNAL tile (SUBX x SUBY pixels = one wave64) and only for the internal tiles of the
 //      reference's 16-px tile rect in which the Gaussian can reach alpha >= 1/255 (exact hit mask computed
 //      in preprocess): a subset of the reference's candidates that contains every (pixel, Gaussian) pair
 //      the reference blends, so rendering results are unchanged;
@@ -244,10 +244,10 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint32_t* __restrict_
     s_lo[j] = carry + ex;
     s_id[j] = id;
     const uint32_t x0 = r.x & 0xFFFFu, x1 = r.x >> 16, y0 = r.y & 0xFFFFu;
-    // internal 16x8 tiles: same columns as the 16-px tiles, two rows per 16-px tile row
-    const uint32_t sx0 = x0, sw = x1 - x0;
-    s_org[j] = sx0 | ((2 * y0) << 16);
-    s_wd[j] = sw | (sw << 16);
+    const uint32_t sx0 = FX * x0, sw = FX * (x1 - x0);
+    const uint32_t sx1 = FX * x1 < gsx ? FX * x1 : gsx;
+    s_org[j] = sx0 | ((FY * y0) << 16);
+    s_wd[j] = sw | ((sx1 - sx0) << 16);
     s_mask[j] = m;
     if (k < P && c) slot_base[id] = gbase + carry + ex;
     carry += tot;

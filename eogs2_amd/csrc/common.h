@@ -8,8 +8,11 @@
 
 #define NCH EOGS_RAST_CHANNELS  // 5 feature channels
 #define TILE EOGS_RAST_TILE     // 16x16 pixel tiles: the reference's binning granularity (tile rect, radii)
-#define SUBX 16                  // internal tile = 16x8 pixels = one wave64 with two horizontally adjacent pixels per
-#define SUBY 8                   // lane (packed fp32 math); lists are built per internal tile
+#define SUBX 8                  // internal tile = SUBX x SUBY pixels = one wave64 (PPL pixels per lane, side by side);
+#define SUBY 8                  // lists are built per internal tile. SUBX, SUBY divide TILE.
+#define PPL (SUBX * SUBY / 64)  // pixels per lane
+#define FX (TILE / SUBX)        // internal tiles per 16-px tile, horizontally / vertically
+#define FY (TILE / SUBY)
 #define MASK_MAX_SUBTILES 64    // Gaussians whose 16-px rect spans <= 64 internal tiles carry an exact hit mask
 #define BLK 256                 // threads per workgroup everywhere (4 wave64)
 #define NFEAT 6                 // staged per-Gaussian features: 5 colours + 1/depth
@@ -43,7 +46,7 @@ struct GeomWS {
   float* depth;         // 200 - altitude
   float4* conic_o;      // conic (a,b,c) + effective opacity
   uint2* rect;          // x0 | x1<<16 , y0 | y1<<16 (16-px tile units, the reference's getRect)
-  unsigned long long* mask;  // bit (sy-2*y0)*(x1-x0) + (sx-x0): internal tile (sx,sy) can reach alpha >= 1/255;
+  unsigned long long* mask;  // bit (sy-FY*y0)*FX*(x1-x0) + (sx-FX*x0): internal tile (sx,sy) can reach alpha >= 1/255;
                         // 0 = no mask: every internal tile of the rect (clipped to the image) is listed
   uint32_t* tiles;      // number of internal tiles listed for this Gaussian (0 = none)
   uint32_t* slot_base;  // first pair slot of this Gaussian in depth-expanded order
@@ -130,7 +133,7 @@ static inline BinWS bin_layout(char* base, int H, int W, int64_t R) {
 
 // Image workspace: O(H*W) + O(tiles).
 struct ImgWS {
-  uint2* ranges;       // per internal (16x8) tile [start,end) into point_list
+  uint2* ranges;       // per internal tile [start,end) into point_list
   float* final_T;      // transmittance after the last blended Gaussian
   uint32_t* n_contrib; // 1 + list index of the last blended Gaussian
   size_t bytes;

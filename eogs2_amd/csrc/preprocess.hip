@@ -183,11 +183,10 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
         const float d = (float)(200.0 - (double)pv[2]);  // forward.cu:267
         if (d < 0) atomicOr(&misc[MISC_ERR], 1u);
         const float ca = cz * det_inv, cb = -cy * det_inv, cc = cx * det_inv, op = opacities[idx] * hcs;
-        // internal 16x8 tiles inside the reference's 16-px tile rect (same columns, two rows per 16-px tile row),
-        // clipped to the image
-        const int gsy = (H + SUBY - 1) / SUBY;
-        const int sx0 = x0, sy0 = 2 * y0, sw = x1 - x0, sh = 2 * (y1 - y0);
-        const int sx1 = x1, sy1 = 2 * y1 < gsy ? 2 * y1 : gsy;
+        // internal SUBX x SUBY tiles inside the reference's 16-px tile rect, clipped to the image
+        const int gsx = (W + SUBX - 1) / SUBX, gsy = (H + SUBY - 1) / SUBY;
+        const int sx0 = FX * x0, sy0 = FY * y0, sw = FX * (x1 - x0), sh = FY * (y1 - y0);
+        const int sx1 = FX * x1 < gsx ? FX * x1 : gsx, sy1 = FY * y1 < gsy ? FY * y1 : gsy;
         unsigned long long m = 0ull;
         if (sw * sh <= MASK_MAX_SUBTILES) {
           const float tau = 2.f * __logf(255.f * op);

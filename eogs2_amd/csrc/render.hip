@@ -1,21 +1,21 @@
-// render.hip — alpha blending per internal 16x8 tile, forward and backward.
+// render.hip — alpha blending per internal 8x8 tile, forward and backward.
 //
 // Work decomposition (both directions)
-//   * ONE wave64 per internal 16x8 tile; lane l owns the two horizontally adjacent pixels
-//     (2*(l&7), 2*(l&7)+1) of tile row l>>3 and evaluates them with PACKED fp32 (v_pk_fma/mul/add_f32): plain
-//     fp32 VALU issues a wave64 instruction in 4 cycles on gfx950 (measured: SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU),
-//     packed fp32 does two pixels in the same 4 cycles, and every per-Gaussian cost (parameter broadcast, wave
-//     reduction) is paid once per 128 pixels. Waves are fully independent: no LDS, no barriers, no cross-wave
-//     merge. A 256-thread workgroup is just four tiles; workgroups are dealt to the 8 XCDs so that each XCD (own
-//     L2) walks one contiguous band of tiles and neighbouring tiles share their Gaussians in L2.
+//   * ONE wave64 per internal 8x8 tile, lane = pixel. Waves are fully independent: no barriers, no cross-wave
+//     merge; each wave owns a private slab of LDS. A 256-thread workgroup is just four tiles; workgroups are dealt
+//     to the 8 XCDs so that each XCD (own L2) walks one contiguous band of tiles and neighbouring tiles share
+//     their Gaussians in L2.
 //   * the tile's list (built by binning.hip) holds exactly the Gaussians that can reach alpha >= 1/255 inside
 //     the tile, in (depth, index) order. The wave takes it 64 entries at a time: lane i gathers entry i
-//     ({xy, conic+opacity, 5 colours, 1/depth} = 48 B) into registers, the NEXT chunk's gather is issued before
-//     the current chunk is consumed (software pipeline), and each entry's parameters are then broadcast from
-//     the owning lane with v_readlane into SGPRs — the hot loop touches no memory (the reference re-fetches
-//     colours from global per contributing pixel, DGR/cuda_rasterizer/forward.cu:386).
+//     ({xy, conic+opacity, 5 colours, 1/depth} = 48 B) from HBM/L2 (the gather of the NEXT chunk is in flight
+//     while the current one is consumed), parks it in the wave's LDS slab, and the hot loop reads each entry back
+//     at a wave-uniform address (LDS broadcast) one entry ahead of its use. Operands therefore arrive in VGPRs:
+//     on gfx950 a VALU op with VGPR operands issues in ~2.4 cycles per wave64, with an SGPR operand in ~4.2, a
+//     v_readlane with a variable lane in ~8 and v_pk_fma_f32 in ~10 (tools/ubench.hip), so LDS-broadcast beats both
+//     the readlane broadcast and packed math here. (The reference re-fetches colours from global memory per
+//     contributing pixel, DGR/cuda_rasterizer/forward.cu:386.)
 //   * the conic is pre-scaled by log2(e) at gather time, so alpha = o * 2^p with p = (A dx - B dy) dx + C dy^2,
-//     A = -a log2e / 2, B = b log2e, C = -c log2e / 2: two packed FMAs and one v_exp_f32 per pixel.
+//     A = -a log2e / 2, B = b log2e, C = -c log2e / 2: three FMAs and one v_exp_f32 per pixel.
 //
 // Forward semantics: DGR/cuda_rasterizer/forward.cu:288-411.
 // Backward semantics: DGR/cuda_rasterizer/backward.cu:457-643, restructured:
@@ -25,72 +25,28 @@
 //     the reference's dL/dalpha_j = T_j (g.c_j - g.accum_rec_j) - T_final/(1-alpha_j) bg.g   (:586-620)
 //     equals  T_j (g.c_j) - (D_final - D_j) / (1 - alpha_j): one dot product per pair instead of a
 //     5-channel recurrence.
-//   * per (tile, Gaussian) the position/conic/opacity gradients are linear in six moments of v = G dL/dalpha:
-//       M = sum_pixels v * {1, dx, dy, dx^2, dx dy, dy^2}
-//     (:624-640: dL/dmean2D = o (W/2, H/2) * (-(a M_dx + b M_dy), -(c M_dy + b M_dx)), dL/dconic = -o/2 (M_dxdx,
-//     M_dxdy, M_dydy), dL/dopacity = M_1), so a lane adds its two pixels, the wave reduces 6 moments + 5 colour
-//     sums with DPP, and lane 63 applies the per-Gaussian factors once.
-//   * no atomics: the 12 atomicAdd per contributing (pixel,Gaussian) of the reference (:598-640) become that
-//     DPP reduction and ONE 48-byte record per (tile,Gaussian) pair, written with plain stores by the only wave
-//     that owns the pair; gaussian_bwd_kernel sums each Gaussian's records in fixed order (bitwise
-//     reproducible gradients).
+//   * the 12 atomicAdd per contributing (pixel,Gaussian) of the reference (:598-640) are replaced by a
+//     transposition through LDS: the pixel-parallel pass only produces two numbers per (pixel, Gaussian),
+//     u = alpha T and v = G dL/dalpha; every 16 surviving Gaussians the wave switches to lanes = (Gaussian,
+//     16-pixel row) and accumulates the six moments of v and the five colour sums of u serially in registers
+//     (see transpose_round). No cross-lane reduction tree, no atomics, and ONE 48-byte record per
+//     (tile,Gaussian) pair written with plain stores by the only wave that owns the pair; gaussian_bwd_kernel
+//     sums each Gaussian's records in fixed order (bitwise reproducible gradients).
 #include "common.h"
 
 #pragma clang fp contract(fast)
 
+static_assert(SUBX == 8 && SUBY == 8 && PPL == 1, "render kernels are written for 8x8 internal tiles, one pixel per lane");
+
 namespace {
 
-// ---- wave64 helpers ----
-__device__ inline float rl(float v, int lane) {  // broadcast lane `lane` (wave-uniform) to an SGPR
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-__device__ inline uint32_t rlu(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+#define ENT 12   // floats per staged list entry: gx gy A B | C op f0 f1 | f2 f3 f4 1/depth
+#define KSURV 16 // survivors per transposition round (backward)
+#define UVS 65   // row stride (floats) of the u/v matrices: 65 = 1 mod 32 keeps both access patterns conflict-free
 
-// ---- wave64 sum of 11 values at once: 6 DPP steps x 11 registers = 66 v_add_f32_dpp ----
-// GFX9 DPP reduction: row_shr 1/2/4/8 (bound_ctrl: out-of-row sources read 0) build each 16-lane row's inclusive
-// scan (lane 15 of a row = row sum); row_bcast:15 (rows 1,3) adds the previous row's sum; row_bcast:31 (rows 2,3)
-// adds lane 31's. The totals are valid in LANE 63 ONLY. Written as inline asm because hipcc materialises
-// "old = 0" moves around the masked steps (3 instructions per step). An asm statement is opaque to the hazard
-// recogniser: a DPP read of a VGPR written by the previous VALU instruction needs 2 wait states, so each block
-// starts with s_nop 1; inside a block the 11 chains are independent and every register is re-read 11
-// instructions after it was written.
-#define DPP_STEP11(CTRL)                                                                                         \
-  asm volatile("s_nop 1\n\t"                                                                                     \
-               "v_add_f32_dpp %0, %0, %0 " CTRL "\n\t"                                                            \
-               "v_add_f32_dpp %1, %1, %1 " CTRL "\n\t"                                                            \
-               "v_add_f32_dpp %2, %2, %2 " CTRL "\n\t"                                                            \
-               "v_add_f32_dpp %3, %3, %3 " CTRL "\n\t"                                                            \
-               "v_add_f32_dpp %4, %4, %4 " CTRL "\n\t"                                                            \
-               "v_add_f32_dpp %5, %5, %5 " CTRL "\n\t"                                                            \
-               "v_add_f32_dpp %6, %6, %6 " CTRL "\n\t"                                                            \
-               "v_add_f32_dpp %7, %7, %7 " CTRL "\n\t"                                                            \
-               "v_add_f32_dpp %8, %8, %8 " CTRL "\n\t"                                                            \
-               "v_add_f32_dpp %9, %9, %9 " CTRL "\n\t"                                                            \
-               "v_add_f32_dpp %10, %10, %10 " CTRL                                                                \
-               : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), \
-                 "+v"(c[8]), "+v"(c[9]), "+v"(c[10]))
-__device__ inline void wave_sum11_lane63(float (&c)[REC]) {
-  DPP_STEP11("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1");
-  DPP_STEP11("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1");
-  DPP_STEP11("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1");
-  DPP_STEP11("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1");
-  DPP_STEP11("row_bcast:15 row_mask:0xa bank_mask:0xf");
-  DPP_STEP11("row_bcast:31 row_mask:0xc bank_mask:0xf");
-}
-// compiler-scheduled single-value form (self test reference)
-template <int CTRL, int ROW_MASK>
-__device__ inline float dpp_add(float v) {
-  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
-}
-__device__ inline float wave_sum_lane63(float v) {
-  v = dpp_add<0x111, 0xf>(v);
-  v = dpp_add<0x112, 0xf>(v);
-  v = dpp_add<0x114, 0xf>(v);
-  v = dpp_add<0x118, 0xf>(v);
-  v = dpp_add<0x142, 0xa>(v);
-  v = dpp_add<0x143, 0xc>(v);
-  return v;
-}
+// ---- wave64 helpers ----
 __device__ inline uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
@@ -98,6 +54,13 @@ __device__ inline uint32_t wave_max_u32(uint32_t v) {
     v = n > v ? n : v;
   }
   return v;
+}
+// LDS produced and consumed by the SAME wave: the hardware executes a wave's LDS instructions in order, so only
+// the compiler must be kept from reordering them.
+__device__ inline void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // XCD-aware tile of this wave: workgroup b runs on XCD b % 8 (round-robin dispatch; speed only, never
@@ -109,18 +72,12 @@ __device__ inline int tile_of_wave() {
   return grp * (BLK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 }
 
-typedef float f2 __attribute__((ext_vector_type(2)));
-#define LOG2E 1.4426950408889634f
-#define LN2 0.6931471805599453f
-
-__device__ inline f2 splat(float v) { return f2{v, v}; }
-__device__ inline f2 exp2_2(f2 p) { return f2{__builtin_amdgcn_exp2f(p.x), __builtin_amdgcn_exp2f(p.y)}; }
-__device__ inline f2 sel(bool c0, bool c1, f2 a, f2 b) { return f2{c0 ? a.x : b.x, c1 ? a.y : b.y}; }
-
-// One list entry held by a lane (conic pre-scaled by log2 e, see header).
+// One list entry as gathered by a lane (conic pre-scaled by log2 e: alpha = o 2^p, p = (A dx - B dy) dx + C dy^2,
+// A = -a log2e/2, B = b log2e, C = -c log2e/2).
 struct Cand {
-  float gx, gy, A, B, C, op;
-  float ft[NFEAT];
+  float4 q0;  // gx gy A B
+  float4 q1;  // C op f0 f1
+  float4 q2;  // f2 f3 f4 1/depth
   uint32_t slot;
 };
 
@@ -129,40 +86,37 @@ __device__ inline Cand load_cand(uint32_t k, uint32_t end, const uint32_t* __res
                                  const float4* __restrict__ conic_o, const float* __restrict__ depth,
                                  const float* __restrict__ colors) {
   Cand c;
-  c.gx = c.gy = c.A = c.B = c.C = c.op = 0.f;
-#pragma unroll
-  for (int q = 0; q < NFEAT; q++) c.ft[q] = 0.f;
+  c.q0 = c.q1 = c.q2 = make_float4(0.f, 0.f, 0.f, 0.f);
   c.slot = 0;
   if (k < end) {
     c.slot = point_list[k];
     const uint32_t id = gid[c.slot];
     const float2 xy = means2D[id];
     const float4 co = conic_o[id];
-    c.gx = xy.x; c.gy = xy.y;
-    c.A = co.x * (-0.5f * LOG2E); c.B = co.y * LOG2E; c.C = co.z * (-0.5f * LOG2E); c.op = co.w;
     const float* f = colors + (size_t)id * NCH;
-#pragma unroll
-    for (int ch = 0; ch < NCH; ch++) c.ft[ch] = f[ch];
-    c.ft[NCH] = 1.f / depth[id];
+    c.q0 = make_float4(xy.x, xy.y, co.x * (-0.5f * LOG2E), co.y * LOG2E);
+    c.q1 = make_float4(co.z * (-0.5f * LOG2E), co.w, f[0], f[1]);
+    c.q2 = make_float4(f[2], f[3], f[4], 1.f / depth[id]);
   }
   return c;
 }
 
-// the two pixels of a lane
-struct Pix {
-  int px0, py;
-  bool in0, in1;
-  uint32_t id0;
+// lane i parks its entry in the wave's LDS slab; afterwards any lane can read any entry at a wave-uniform address
+// (LDS broadcast, no bank conflicts) and gets the values in VGPRs: VALU ops on VGPR operands issue in ~2.4 cycles,
+// the same ops on SGPR operands (v_readlane broadcast) in ~4.2, and a v_readlane with a variable lane costs ~8
+// (measured, tools/ubench.hip).
+__device__ inline void park(float* slab, int lane, const Cand& c) {
+  float4* d = reinterpret_cast<float4*>(slab + lane * ENT);
+  d[0] = c.q0; d[1] = c.q1; d[2] = c.q2;
+}
+struct Ent {
+  float4 q0, q1, q2;
 };
-__device__ inline Pix pixels_of_lane(int tile, int gsx, int W, int H) {
-  const int lane = threadIdx.x & 63;
-  Pix p;
-  p.px0 = (tile % gsx) * SUBX + 2 * (lane & 7);
-  p.py = (tile / gsx) * SUBY + (lane >> 3);
-  p.in0 = p.px0 < W && p.py < H;
-  p.in1 = p.px0 + 1 < W && p.py < H;
-  p.id0 = (uint32_t)p.py * (uint32_t)W + (uint32_t)p.px0;
-  return p;
+__device__ inline Ent fetch(const float* slab, int j) {
+  const float4* s = reinterpret_cast<const float4*>(slab + j * ENT);
+  Ent e;
+  e.q0 = s[0]; e.q1 = s[1]; e.q2 = s[2];
+  return e;
 }
 
 }  // namespace
@@ -173,68 +127,60 @@ __global__ __launch_bounds__(BLK) void render_fwd_kernel(
     const float* __restrict__ depth, const float* __restrict__ colors, const float* __restrict__ bg,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
     float* __restrict__ out_invdepth) {
+  __shared__ __attribute__((aligned(16))) float s_slab[BLK / 64][64 * ENT];
   const int lane = threadIdx.x & 63;
   const int tile = tile_of_wave();
   if (tile >= ntiles) return;  // wave-uniform; waves never synchronise with each other
-  const Pix pm = pixels_of_lane(tile, gsx, W, H);
-  const f2 pxf = f2{(float)pm.px0, (float)(pm.px0 + 1)};
-  const float pyf = (float)pm.py;
+  float* slab = s_slab[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+  const int px = (tile % gsx) * SUBX + (lane & 7), py = (tile / gsx) * SUBY + (lane >> 3);
+  const bool inside = px < W && py < H;
+  const uint32_t pix_id = (uint32_t)py * (uint32_t)W + (uint32_t)px;
+  const float pxf = (float)px, pyf = (float)py;
   const uint2 range = ranges[tile];
 
-  f2 T = splat(1.0f);
-  uint32_t last0 = 0, last1 = 0;
-  f2 C[NCH];
-#pragma unroll
-  for (int ch = 0; ch < NCH; ch++) C[ch] = splat(0.f);
-  f2 invd = splat(0.f);
-  bool done0 = !pm.in0, done1 = !pm.in1;
+  float T = 1.0f;
+  uint32_t last_contributor = 0;
+  float C[NCH] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  float invd = 0.f;
+  bool done = !inside;
 
-  Cand cur = load_cand(range.x + lane, range.y, point_list, gid, means2D, conic_o, depth, colors);
+  Cand nxt = load_cand(range.x + lane, range.y, point_list, gid, means2D, conic_o, depth, colors);
   for (uint32_t c0 = range.x; c0 < range.y; c0 += 64) {
-    const Cand nxt = load_cand(c0 + 64 + lane, range.y, point_list, gid, means2D, conic_o, depth, colors);
-    if (__ballot(!(done0 && done1)) == 0ull) break;  // every pixel of the tile has terminated
+    wave_lds_sync();  // previous chunk's reads are done
+    park(slab, lane, nxt);
+    nxt = load_cand(c0 + 64 + lane, range.y, point_list, gid, means2D, conic_o, depth, colors);  // in flight during this chunk
+    wave_lds_sync();
+    if (__ballot(!done) == 0ull) break;  // every pixel of the tile has terminated
     const int n = (int)((range.y - c0) < 64u ? (range.y - c0) : 64u);
     const uint32_t jbase = c0 - range.x;
+    Ent cur = fetch(slab, 0);
     for (int j = 0; j < n; j++) {
-      const float gxs = rl(cur.gx, j), gys = rl(cur.gy, j);
-      const float A = rl(cur.A, j), B = rl(cur.B, j), Cq = rl(cur.C, j), op = rl(cur.op, j);
-      const f2 dx = gxs - pxf;
-      const float dy = gys - pyf;
-      const float e1 = B * dy, e0 = Cq * dy * dy;
-      const f2 p = (A * dx - e1) * dx + e0;  // log2 of the Gaussian falloff
-      const f2 alpha = __builtin_elementwise_min(op * exp2_2(p), splat(0.99f));
-      bool v0 = !done0 && !(p.x > 0.0f) && !(alpha.x < 1.0f / 255.0f);
-      bool v1 = !done1 && !(p.y > 0.0f) && !(alpha.y < 1.0f / 255.0f);
-      const f2 test_T = T * (1.f - alpha);
-      const bool t0 = v0 && test_T.x < 0.0001f, t1 = v1 && test_T.y < 0.0001f;  // not blended; pixel finished
-      done0 = done0 || t0; done1 = done1 || t1;
-      v0 = v0 && !t0; v1 = v1 && !t1;
-      if (__ballot(v0 || v1) == 0ull) continue;
-      const f2 wgt = sel(v0, v1, alpha * T, splat(0.f));
-#pragma unroll
-      for (int ch = 0; ch < NCH; ch++) C[ch] += rl(cur.ft[ch], j) * wgt;
-      invd += rl(cur.ft[NCH], j) * wgt;
-      T = sel(v0, v1, test_T, T);
-      const uint32_t idx = jbase + (uint32_t)j + 1u;
-      last0 = v0 ? idx : last0;
-      last1 = v1 ? idx : last1;
+      const Ent e = cur;
+      cur = fetch(slab, j + 1 < n ? j + 1 : j);  // software pipeline: next entry's broadcast read
+      const float dx = e.q0.x - pxf, dy = e.q0.y - pyf;
+      const float p = (e.q0.z * dx - e.q0.w * dy) * dx + e.q1.x * dy * dy;
+      const float alpha = fminf(e.q1.y * __builtin_amdgcn_exp2f(p), 0.99f);
+      bool valid = !done && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);
+      const float test_T = T * (1.f - alpha);
+      const bool term = valid && test_T < 0.0001f;  // this Gaussian is NOT blended; the pixel is finished
+      done = done || term;
+      valid = valid && !term;
+      if (__ballot(valid) == 0ull) continue;
+      const float wgt = valid ? alpha * T : 0.f;
+      C[0] += e.q1.z * wgt; C[1] += e.q1.w * wgt;
+      C[2] += e.q2.x * wgt; C[3] += e.q2.y * wgt; C[4] += e.q2.z * wgt;
+      invd += e.q2.w * wgt;
+      T = valid ? test_T : T;
+      last_contributor = valid ? jbase + (uint32_t)j + 1u : last_contributor;
     }
-    cur = nxt;
   }
-  const size_t HW = (size_t)H * W;
-  if (pm.in0) {
-    final_T[pm.id0] = T.x;
-    n_contrib[pm.id0] = last0;
+  if (inside) {
+    const size_t HW = (size_t)H * W;
+    final_T[pix_id] = T;
+    n_contrib[pix_id] = last_contributor;
 #pragma unroll
-    for (int ch = 0; ch < NCH; ch++) out_color[ch * HW + pm.id0] = C[ch].x + T.x * bg[ch];
-    if (out_invdepth) out_invdepth[pm.id0] = invd.x;
-  }
-  if (pm.in1) {
-    final_T[pm.id0 + 1] = T.y;
-    n_contrib[pm.id0 + 1] = last1;
-#pragma unroll
-    for (int ch = 0; ch < NCH; ch++) out_color[ch * HW + pm.id0 + 1] = C[ch].y + T.y * bg[ch];
-    if (out_invdepth) out_invdepth[pm.id0 + 1] = invd.y;
+    for (int ch = 0; ch < NCH; ch++) out_color[ch * HW + pix_id] = C[ch] + T * bg[ch];
+    if (out_invdepth) out_invdepth[pix_id] = invd;
   }
 }
 
@@ -254,127 +200,177 @@ void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, 
 // ------------------------------------------------------------------------------------------------------
 // Backward
 // ------------------------------------------------------------------------------------------------------
+namespace {
+
+// Transposition round: the wave has parked, for up to KSURV surviving entries k, the per-pixel pairs
+//   u[k][p] = alpha T (weight of the colour gradient),  v[k][p] = G dL/dalpha
+// in LDS. Now lane (k = lane & 15, r = lane >> 4) owns survivor k and the 16 pixels 16r .. 16r+15 and accumulates
+//   M = sum_p v {1, dx, dy, dx^2, dx dy, dy^2}   and   sum_p u g_p[ch]
+// in registers with plain FMAs on VGPR operands; the four pixel-rows are then combined with two xor-shuffles and the
+// lanes r == 0 turn the moments into the record (backward.cu:624-640):
+//   dL/dmean2D = o (W/2, H/2) * (-(a M_dx + b M_dy), -(c M_dy + b M_dx)),  dL/dconic = -o/2 (M_dxdx, M_dxdy, M_dydy),
+//   dL/dopacity = M_1,  dL/dcolour = sum u g.
+__device__ inline void transpose_round(int nsurv, int lane, const float* slab, const float* s_u, const float* s_v,
+                                       const float* s_pix, const uint32_t* s_kj, const uint32_t* s_slot, float bx0,
+                                       float by0, float kx, float ky, float* __restrict__ records) {
+  const int k = lane & 15, r = lane >> 4;
+  const bool live = k < nsurv;
+  const uint32_t jk = live ? s_kj[k] : 0u;
+  const float4 q0 = *reinterpret_cast<const float4*>(slab + jk * ENT);      // gx gy A B
+  const float2 q1 = *reinterpret_cast<const float2*>(slab + jk * ENT + 4);  // C op
+  const float gxr = q0.x - bx0;                // centre relative to the tile origin
+  const float dy0 = q0.y - (by0 + 2.f * r);    // this lane's two pixel rows: 2r and 2r+1
+  const float dy1 = dy0 - 1.f;
+  float M0 = 0.f, Mx = 0.f, My = 0.f, Mxx = 0.f, Mxy = 0.f, Myy = 0.f;
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f, c4 = 0.f;
+  const float* urow = s_u + k * UVS + 16 * r;
+  const float* vrow = s_v + k * UVS + 16 * r;
+  const float* prow = s_pix + (16 * r) * 8 + 4 * r;  // 8 floats per pixel, +4 floats per lane-row against bank conflicts
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    const float u = urow[i], v = vrow[i];
+    const float4 ga = *reinterpret_cast<const float4*>(prow + i * 8);
+    const float gb = prow[i * 8 + 4];
+    const float dx = gxr - (float)(i & 7);
+    const float dy = (i < 8) ? dy0 : dy1;
+    const float t1 = v * dx, t2 = v * dy;
+    M0 += v; Mx += t1; My += t2;
+    Mxx += t1 * dx; Mxy += t1 * dy; Myy += t2 * dy;
+    c0 += u * ga.x; c1 += u * ga.y; c2 += u * ga.z; c3 += u * ga.w; c4 += u * gb;
+  }
+  float acc[11] = {M0, Mx, My, Mxx, Mxy, Myy, c0, c1, c2, c3, c4};
+#pragma unroll
+  for (int q = 0; q < 11; q++) {
+    acc[q] += __shfl_xor(acc[q], 16, 64);
+    acc[q] += __shfl_xor(acc[q], 32, 64);
+  }
+  if (live && r == 0) {
+    const float A = q0.z, B = q0.w, Cq = q1.x, op = q1.y;
+    const float m2x = op * kx * (2.f * A * acc[1] - B * acc[2]);   // -a = 2A/log2e, -b = -B/log2e
+    const float m2y = op * ky * (2.f * Cq * acc[2] - B * acc[1]);  // -c = 2C/log2e
+    const float ho = -0.5f * op;
+    float4* dst = reinterpret_cast<float4*>(records + (size_t)s_slot[jk] * REC);
+    dst[0] = make_float4(m2x, m2y, ho * acc[3], ho * acc[4]);
+    dst[1] = make_float4(ho * acc[5], acc[0], acc[6], acc[7]);
+    dst[2] = make_float4(acc[8], acc[9], acc[10], 0.f);
+  }
+}
+
+}  // namespace
+
 __global__ __launch_bounds__(BLK) void render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ gid,
     int W, int H, int gsx, int ntiles, const float2* __restrict__ means2D, const float4* __restrict__ conic_o,
     const float* __restrict__ depth, const float* __restrict__ colors, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ out_color, const float* __restrict__ out_invdepth, const float* __restrict__ dL_dpix,
     const float* __restrict__ dL_dinv, float* __restrict__ records) {
+  __shared__ __attribute__((aligned(16))) float s_slab[BLK / 64][64 * ENT];
+  __shared__ __attribute__((aligned(16))) float s_u[BLK / 64][KSURV * UVS];
+  __shared__ __attribute__((aligned(16))) float s_v[BLK / 64][KSURV * UVS];
+  __shared__ __attribute__((aligned(16))) float s_pix[BLK / 64][64 * 8 + 16];
+  __shared__ uint32_t s_kj[BLK / 64][KSURV];
+  __shared__ uint32_t s_slot[BLK / 64][64];
   const int lane = threadIdx.x & 63;
   const int tile = tile_of_wave();
   if (tile >= ntiles) return;
-  const Pix pm = pixels_of_lane(tile, gsx, W, H);
-  const f2 pxf = f2{(float)pm.px0, (float)(pm.px0 + 1)};
-  const float pyf = (float)pm.py;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float* slab = s_slab[w];
+  float* su = s_u[w];
+  float* sv = s_v[w];
+  float* spix = s_pix[w];
+  uint32_t* skj = s_kj[w];
+  uint32_t* sslot = s_slot[w];
+  const int tx0 = (tile % gsx) * SUBX, ty0 = (tile / gsx) * SUBY;
+  const int px = tx0 + (lane & 7), py = ty0 + (lane >> 3);
+  const bool inside = px < W && py < H;
+  const uint32_t pix_id = (uint32_t)py * (uint32_t)W + (uint32_t)px;
+  const float pxf = (float)px, pyf = (float)py;
   const uint2 range = ranges[tile];
   const size_t HW = (size_t)H * W;
   const bool have_inv = dL_dinv != nullptr;
 
-  f2 g[NCH];
-  f2 ginv = splat(0.f), Dfinal = splat(0.f);
-  uint32_t nc0 = 0, nc1 = 0;
-#pragma unroll
-  for (int ch = 0; ch < NCH; ch++) g[ch] = splat(0.f);
-  if (pm.in0) {
-    nc0 = n_contrib[pm.id0];
+  float g[NCH] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  float ginv = 0.f, Dfinal = 0.f;
+  uint32_t ncontrib = 0;
+  if (inside) {
+    ncontrib = n_contrib[pix_id];
 #pragma unroll
     for (int ch = 0; ch < NCH; ch++) {
-      g[ch].x = dL_dpix[ch * HW + pm.id0];
-      Dfinal.x += g[ch].x * out_color[ch * HW + pm.id0];
+      g[ch] = dL_dpix[ch * HW + pix_id];
+      Dfinal += g[ch] * out_color[ch * HW + pix_id];
     }
     if (have_inv) {
-      ginv.x = dL_dinv[pm.id0];
-      Dfinal.x += ginv.x * out_invdepth[pm.id0];
+      ginv = dL_dinv[pix_id];
+      Dfinal += ginv * out_invdepth[pix_id];
     }
   }
-  if (pm.in1) {
-    nc1 = n_contrib[pm.id0 + 1];
-#pragma unroll
-    for (int ch = 0; ch < NCH; ch++) {
-      g[ch].y = dL_dpix[ch * HW + pm.id0 + 1];
-      Dfinal.y += g[ch].y * out_color[ch * HW + pm.id0 + 1];
-    }
-    if (have_inv) {
-      ginv.y = dL_dinv[pm.id0 + 1];
-      Dfinal.y += ginv.y * out_invdepth[pm.id0 + 1];
-    }
+  {  // pixel gradients for the transposition rounds: 8 floats per pixel, rows of 16 pixels offset by 4 floats
+    float* d = spix + lane * 8 + 4 * (lane >> 4);
+    *reinterpret_cast<float4*>(d) = make_float4(g[0], g[1], g[2], g[3]);
+    d[4] = g[4];
   }
   // list entries past the last contributor of every pixel of the tile receive no gradient
-  const uint32_t tile_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(nc0 > nc1 ? nc0 : nc1));
+  const uint32_t tile_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(ncontrib));
+  const float kx = LN2 * 0.5f * W, ky = LN2 * 0.5f * H;  // d(pixel)/d(ndc) times the ln2 of the log2-domain conic
+  const float bx0 = (float)tx0, by0 = (float)ty0;
+  float T = 1.0f, Dacc = 0.f;
 
-  const float kx = LN2 * 0.5f * W, ky = LN2 * 0.5f * H;  // d(pixel)/d(ndc) and the ln2 of the log2-domain conic
-  f2 T = splat(1.0f), Dacc = splat(0.f);
-
-  Cand cur = load_cand(range.x + lane, range.y, point_list, gid, means2D, conic_o, depth, colors);
+  Cand nxt = load_cand(range.x + lane, range.y, point_list, gid, means2D, conic_o, depth, colors);
   for (uint32_t c0 = range.x; c0 < range.y; c0 += 64) {
-    const Cand nxt = load_cand(c0 + 64 + lane, range.y, point_list, gid, means2D, conic_o, depth, colors);
+    wave_lds_sync();
+    park(slab, lane, nxt);
+    sslot[lane] = nxt.slot;
+    const uint32_t my_slot = nxt.slot;
+    nxt = load_cand(c0 + 64 + lane, range.y, point_list, gid, means2D, conic_o, depth, colors);
+    wave_lds_sync();
     const int n = (int)((range.y - c0) < 64u ? (range.y - c0) : 64u);
     const uint32_t jbase = c0 - range.x;
     int jn = n;  // entries of this chunk that can still matter
     if (tile_last < jbase + (uint32_t)n) jn = tile_last > jbase ? (int)(tile_last - jbase) : 0;
-    unsigned long long written = 0ull;
+    unsigned long long survivors = 0ull;
+    int k = 0;
+    Ent cur = fetch(slab, 0);
     for (int j = 0; j < jn; j++) {
-      const float gxs = rl(cur.gx, j), gys = rl(cur.gy, j);
-      const float A = rl(cur.A, j), B = rl(cur.B, j), Cq = rl(cur.C, j), op = rl(cur.op, j);
-      const f2 dx = gxs - pxf;
-      const float dy = gys - pyf;
-      const float e1 = B * dy, e0 = Cq * dy * dy;
-      const f2 p = (A * dx - e1) * dx + e0;
-      const f2 G = exp2_2(p);
-      const f2 alpha = __builtin_elementwise_min(op * G, splat(0.99f));
-      const uint32_t li = jbase + (uint32_t)j;
-      const bool v0 = (li < nc0) && !(p.x > 0.0f) && !(alpha.x < 1.0f / 255.0f);
-      const bool v1 = (li < nc1) && !(p.y > 0.0f) && !(alpha.y < 1.0f / 255.0f);
-      if (__ballot(v0 || v1) == 0ull) continue;  // wave-uniform skip
+      const Ent e = cur;
+      cur = fetch(slab, j + 1 < jn ? j + 1 : j);
+      const float dx = e.q0.x - pxf, dy = e.q0.y - pyf;
+      const float p = (e.q0.z * dx - e.q0.w * dy) * dx + e.q1.x * dy * dy;
+      const float G = __builtin_amdgcn_exp2f(p);
+      const float alpha = fminf(e.q1.y * G, 0.99f);
+      const bool valid = (jbase + (uint32_t)j < ncontrib) && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);
+      if (__ballot(valid) == 0ull) continue;  // wave-uniform skip: this entry reaches no pixel of the tile
 
-      f2 gc = g[0] * rl(cur.ft[0], j);
-#pragma unroll
-      for (int ch = 1; ch < NCH; ch++) gc += g[ch] * rl(cur.ft[ch], j);
-      if (have_inv) gc += ginv * rl(cur.ft[NCH], j);
-      const f2 wgt = sel(v0, v1, alpha * T, splat(0.f));
+      float gc = g[0] * e.q1.z + g[1] * e.q1.w + g[2] * e.q2.x + g[3] * e.q2.y + g[4] * e.q2.z;
+      if (have_inv) gc += ginv * e.q2.w;
+      const float wgt = valid ? alpha * T : 0.f;
       Dacc += gc * wgt;
-      const f2 one_m = 1.f - alpha;
-      const f2 rc = f2{__builtin_amdgcn_rcpf(one_m.x), __builtin_amdgcn_rcpf(one_m.y)};
-      const f2 dLda = sel(v0, v1, T * gc - (Dfinal - Dacc) * rc, splat(0.f));
-      T = sel(v0, v1, T * one_m, T);
-      // v = G dL/dalpha (exp2 may overflow on pixels that skip this Gaussian: select, do not multiply by 0);
+      const float one_m = 1.f - alpha;
+      const float dLda = T * gc - (Dfinal - Dacc) * __builtin_amdgcn_rcpf(one_m);
+      T = valid ? T * one_m : T;
+      // v = G dL/dalpha; select instead of multiplying by 0 (exp2 may overflow on pixels that skip this Gaussian);
       // no zeroing when alpha was clamped (backward.cu:624)
-      const f2 v = sel(v0, v1, G * dLda, splat(0.f));
-      const f2 vdx = v * dx, vdxdx = vdx * dx;
-      float c[REC];
-      c[0] = v.x + v.y;          // M_1
-      c[1] = vdx.x + vdx.y;      // M_dx
-      c[2] = dy * c[0];          // M_dy
-      c[3] = vdxdx.x + vdxdx.y;  // M_dxdx
-      c[4] = dy * c[1];          // M_dxdy
-      c[5] = dy * c[2];          // M_dydy
-#pragma unroll
-      for (int ch = 0; ch < NCH; ch++) {
-        const f2 wg = wgt * g[ch];
-        c[6 + ch] = wg.x + wg.y;
+      const float v = valid ? G * dLda : 0.f;
+      su[k * UVS + lane] = wgt;
+      sv[k * UVS + lane] = v;
+      if (lane == 0) skj[k] = (uint32_t)j;
+      survivors |= 1ull << j;
+      if (++k == KSURV) {
+        wave_lds_sync();
+        transpose_round(KSURV, lane, slab, su, sv, spix, skj, sslot, bx0, by0, kx, ky, records);
+        wave_lds_sync();
+        k = 0;
       }
-      c[REC - 1] = 0.f;
-      wave_sum11_lane63(c);
-      const uint32_t slot = rlu(cur.slot, j);
-      if (lane == 63) {
-        // -a = 2A/log2e, -b = -B/log2e, -c = 2C/log2e
-        const float m2x = op * kx * (2.f * A * c[1] - B * c[2]);
-        const float m2y = op * ky * (2.f * Cq * c[2] - B * c[1]);
-        const float ho = -0.5f * op;
-        float4* dst = reinterpret_cast<float4*>(records + (size_t)slot * REC);
-        dst[0] = make_float4(m2x, m2y, ho * c[3], ho * c[4]);
-        dst[1] = make_float4(ho * c[5], c[0], c[6], c[7]);
-        dst[2] = make_float4(c[8], c[9], c[10], 0.f);
-      }
-      written |= 1ull << j;
+    }
+    if (k) {
+      wave_lds_sync();
+      transpose_round(k, lane, slab, su, sv, spix, skj, sslot, bx0, by0, kx, ky, records);
     }
     // every pair owns a record: entries that reached no pixel get zeros
-    if (lane < n && !((written >> lane) & 1ull)) {
-      float4* dst = reinterpret_cast<float4*>(records + (size_t)cur.slot * REC);
+    if (lane < n && !((survivors >> lane) & 1ull)) {
+      float4* dst = reinterpret_cast<float4*>(records + (size_t)my_slot * REC);
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       dst[0] = z; dst[1] = z; dst[2] = z;
     }
-    cur = nxt;
   }
 }
 
@@ -387,29 +383,18 @@ void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, 
                      dL_dcolor, dL_dinvdepth, b.records);
 }
 
-// ---- self test of the wave64 primitives (diagnostics; returns mismatching lanes in out[0]) ----
+// ---- self test of the wave64 primitives (diagnostics) ----
 __global__ void selftest_kernel(uint32_t* out) {
   const int lane = threadIdx.x & 63;
   const float v = (float)((lane * 37 + 11) % 101) - 50.f;
-  float ref = v;
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) ref += __shfl_xor(ref, o, 64);
-  const float got = wave_sum_lane63(v);
-  const float b = rl(v, 17);
+  float a = v;
+  a += __shfl_xor(a, 16, 64);
+  a += __shfl_xor(a, 32, 64);
+  float ref = 0.f;
+  for (int r = 0; r < 4; r++) ref += (float)((((lane & 15) + 16 * r) * 37 + 11) % 101) - 50.f;
   uint32_t bad = 0;
-  if (lane == 63 && got != ref) bad |= 1u;
-  float c[REC];
-#pragma unroll
-  for (int q = 0; q < REC; q++) c[q] = v * (float)(q + 1) + (float)q * 0.25f;  // freshly written VGPRs (hazard case)
-  wave_sum11_lane63(c);
-#pragma unroll
-  for (int q = 0; q < REC - 1; q++) {
-    float r = v * (float)(q + 1) + (float)q * 0.25f;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) r += __shfl_xor(r, o, 64);
-    if (lane == 63 && c[q] != r) bad |= 4u;
-  }
-  if (b != (float)((17 * 37 + 11) % 101) - 50.f) bad |= 2u;
+  if (a != ref) bad |= 1u;
+  if (wave_max_u32((uint32_t)lane * 3u) != 189u) bad |= 2u;
   if (bad) atomicOr(out, bad);
 }
 void launch_selftest(uint32_t* out, hipStream_t s) { hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(256), 0, s, out); }
