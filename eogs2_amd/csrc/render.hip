@@ -27,8 +27,8 @@
 //     5-channel recurrence.
 //   * the 12 atomicAdd per contributing (pixel,Gaussian) of the reference (:598-640) are replaced by a
 //     transposition through LDS: the pixel-parallel pass only produces two numbers per (pixel, Gaussian),
-//     u = alpha T and v = G dL/dalpha; every 16 surviving Gaussians the wave switches to lanes = (Gaussian,
-//     16-pixel row) and accumulates the six moments of v and the five colour sums of u serially in registers
+//     u = alpha T and v = G dL/dalpha; every 8 surviving Gaussians the wave switches to lanes = (Gaussian,
+//     pixel row) and accumulates the six moments of v and the five colour sums of u serially in registers
 //     (see transpose_round). No cross-lane reduction tree, no atomics, and ONE 48-byte record per
 //     (tile,Gaussian) pair written with plain stores by the only wave that owns the pair; gaussian_bwd_kernel
 //     sums each Gaussian's records in fixed order (bitwise reproducible gradients).
@@ -43,7 +43,7 @@ namespace {
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
 #define ENT 12   // floats per staged list entry: gx gy A B | C op f0 f1 | f2 f3 f4 1/depth
-#define KSURV 16 // survivors per transposition round (backward)
+#define KSURV 8  // survivors per transposition round (backward)
 #define UVS 65   // row stride (floats) of the u/v matrices: 65 = 1 mod 32 keeps both access patterns conflict-free
 
 // ---- wave64 helpers ----
@@ -202,49 +202,48 @@ void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, 
 // ------------------------------------------------------------------------------------------------------
 namespace {
 
-// Transposition round: the wave has parked, for up to KSURV surviving entries k, the per-pixel pairs
+// Transposition round: the wave has parked, for up to KSURV = 8 surviving entries k, the per-pixel pairs
 //   u[k][p] = alpha T (weight of the colour gradient),  v[k][p] = G dL/dalpha
-// in LDS. Now lane (k = lane & 15, r = lane >> 4) owns survivor k and the 16 pixels 16r .. 16r+15 and accumulates
-//   M = sum_p v {1, dx, dy, dx^2, dx dy, dy^2}   and   sum_p u g_p[ch]
-// in registers with plain FMAs on VGPR operands; the four pixel-rows are then combined with two xor-shuffles and the
-// lanes r == 0 turn the moments into the record (backward.cu:624-640):
+// in LDS. Now lane (k = lane & 7, o = lane >> 3) owns survivor k and pixel row o of the tile (8 pixels, constant
+// dy) and accumulates  sum v, sum v dx, sum v dx^2  and  sum u g_p[ch]  serially in registers with plain FMAs on
+// VGPR operands; the y-moments follow from the constant dy. The eight rows are then combined with three
+// xor-shuffles and the lanes of row 0 turn the moments M = sum_p v {1, dx, dy, dx^2, dx dy, dy^2} into the record
+// (backward.cu:624-640):
 //   dL/dmean2D = o (W/2, H/2) * (-(a M_dx + b M_dy), -(c M_dy + b M_dx)),  dL/dconic = -o/2 (M_dxdx, M_dxdy, M_dydy),
 //   dL/dopacity = M_1,  dL/dcolour = sum u g.
 __device__ inline void transpose_round(int nsurv, int lane, const float* slab, const float* s_u, const float* s_v,
                                        const float* s_pix, const uint32_t* s_kj, const uint32_t* s_slot, float bx0,
                                        float by0, float kx, float ky, float* __restrict__ records) {
-  const int k = lane & 15, r = lane >> 4;
+  const int k = lane & 7, o = lane >> 3;
   const bool live = k < nsurv;
   const uint32_t jk = live ? s_kj[k] : 0u;
   const float4 q0 = *reinterpret_cast<const float4*>(slab + jk * ENT);      // gx gy A B
   const float2 q1 = *reinterpret_cast<const float2*>(slab + jk * ENT + 4);  // C op
-  const float gxr = q0.x - bx0;                // centre relative to the tile origin
-  const float dy0 = q0.y - (by0 + 2.f * r);    // this lane's two pixel rows: 2r and 2r+1
-  const float dy1 = dy0 - 1.f;
-  float M0 = 0.f, Mx = 0.f, My = 0.f, Mxx = 0.f, Mxy = 0.f, Myy = 0.f;
+  const float gxr = q0.x - bx0;            // centre relative to the tile origin
+  const float dy = q0.y - (by0 + (float)o);
+  float S0 = 0.f, Sx = 0.f, Sxx = 0.f;
   float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f, c4 = 0.f;
-  const float* urow = s_u + k * UVS + 16 * r;
-  const float* vrow = s_v + k * UVS + 16 * r;
-  const float* prow = s_pix + (16 * r) * 8 + 4 * r;  // 8 floats per pixel, +4 floats per lane-row against bank conflicts
+  const float* urow = s_u + k * UVS + 8 * o;
+  const float* vrow = s_v + k * UVS + 8 * o;
+  const float* prow = s_pix + (8 * o) * 8 + 4 * o;  // 8 floats per pixel, +4 floats per pixel row against bank conflicts
 #pragma unroll
-  for (int i = 0; i < 16; i++) {
+  for (int i = 0; i < 8; i++) {
     const float u = urow[i], v = vrow[i];
     const float4 ga = *reinterpret_cast<const float4*>(prow + i * 8);
     const float gb = prow[i * 8 + 4];
-    const float dx = gxr - (float)(i & 7);
-    const float dy = (i < 8) ? dy0 : dy1;
-    const float t1 = v * dx, t2 = v * dy;
-    M0 += v; Mx += t1; My += t2;
-    Mxx += t1 * dx; Mxy += t1 * dy; Myy += t2 * dy;
+    const float dx = gxr - (float)i;
+    const float t1 = v * dx;
+    S0 += v; Sx += t1; Sxx += t1 * dx;
     c0 += u * ga.x; c1 += u * ga.y; c2 += u * ga.z; c3 += u * ga.w; c4 += u * gb;
   }
-  float acc[11] = {M0, Mx, My, Mxx, Mxy, Myy, c0, c1, c2, c3, c4};
+  float acc[11] = {S0, Sx, dy * S0, Sxx, dy * Sx, dy * dy * S0, c0, c1, c2, c3, c4};
 #pragma unroll
   for (int q = 0; q < 11; q++) {
+    acc[q] += __shfl_xor(acc[q], 8, 64);
     acc[q] += __shfl_xor(acc[q], 16, 64);
     acc[q] += __shfl_xor(acc[q], 32, 64);
   }
-  if (live && r == 0) {
+  if (live && o == 0) {
     const float A = q0.z, B = q0.w, Cq = q1.x, op = q1.y;
     const float m2x = op * kx * (2.f * A * acc[1] - B * acc[2]);   // -a = 2A/log2e, -b = -B/log2e
     const float m2y = op * ky * (2.f * Cq * acc[2] - B * acc[1]);  // -c = 2C/log2e
@@ -267,7 +266,7 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
   __shared__ __attribute__((aligned(16))) float s_slab[BLK / 64][64 * ENT];
   __shared__ __attribute__((aligned(16))) float s_u[BLK / 64][KSURV * UVS];
   __shared__ __attribute__((aligned(16))) float s_v[BLK / 64][KSURV * UVS];
-  __shared__ __attribute__((aligned(16))) float s_pix[BLK / 64][64 * 8 + 16];
+  __shared__ __attribute__((aligned(16))) float s_pix[BLK / 64][64 * 8 + 32];
   __shared__ uint32_t s_kj[BLK / 64][KSURV];
   __shared__ uint32_t s_slot[BLK / 64][64];
   const int lane = threadIdx.x & 63;
@@ -304,8 +303,8 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
       Dfinal += ginv * out_invdepth[pix_id];
     }
   }
-  {  // pixel gradients for the transposition rounds: 8 floats per pixel, rows of 16 pixels offset by 4 floats
-    float* d = spix + lane * 8 + 4 * (lane >> 4);
+  {  // pixel gradients for the transposition rounds: 8 floats per pixel, each pixel row offset by 4 more floats
+    float* d = spix + lane * 8 + 4 * (lane >> 3);
     *reinterpret_cast<float4*>(d) = make_float4(g[0], g[1], g[2], g[3]);
     d[4] = g[4];
   }
@@ -388,10 +387,11 @@ __global__ void selftest_kernel(uint32_t* out) {
   const int lane = threadIdx.x & 63;
   const float v = (float)((lane * 37 + 11) % 101) - 50.f;
   float a = v;
+  a += __shfl_xor(a, 8, 64);
   a += __shfl_xor(a, 16, 64);
   a += __shfl_xor(a, 32, 64);
   float ref = 0.f;
-  for (int r = 0; r < 4; r++) ref += (float)((((lane & 15) + 16 * r) * 37 + 11) % 101) - 50.f;
+  for (int r = 0; r < 8; r++) ref += (float)((((lane & 7) + 8 * r) * 37 + 11) % 101) - 50.f;
   uint32_t bad = 0;
   if (a != ref) bad |= 1u;
   if (wave_max_u32((uint32_t)lane * 3u) != 189u) bad |= 2u;

@@ -74,6 +74,8 @@ SEEDED = [
     (3000, 64, 64, 12, 0.7, 8.0, False, False),      # long lists (>256/tile), early termination
     (20000, 256, 256, 13, "trained", 1.0, False, False),
     (777, 33, 47, 14, "trained", 4.0, False, True),    # ragged image, ragged P
+    (400, 200, 168, 15, "trained", 14.0, False, False),  # tile rects > 64 internal tiles: unmasked listing path
+    (1, 64, 64, 16, 0.9, 30.0, False, False),            # one Gaussian covering every tile
 ]
 
 
