@@ -96,6 +96,7 @@ struct BinWS {
   uint32_t* hist;   // [nbins][nblkR]
   uint32_t* dtotal; // [256]
   float* records;   // backward scratch: REC floats per pair slot
+  uint8_t* live;    // backward scratch: 1 = the pair's record was written (dead pairs are never touched)
   uint32_t nblkR;
   int tile_bits, passes, bits_per_pass;
   uint32_t* point_list;  // = tval buffer holding the sorted result
@@ -125,6 +126,7 @@ static inline BinWS bin_layout(char* base, int H, int W, int64_t R) {
   o = ws_carve(base, o, b.hist, (size_t)256 * (b.nblkR ? b.nblkR : 1));
   o = ws_carve(base, o, b.dtotal, 256);
   o = ws_carve(base, o, b.records, n * REC);
+  o = ws_carve(base, o, b.live, n);
   b.point_list = (b.passes & 1) ? b.tvalB : b.tvalA;
   b.sorted_keys = (b.passes & 1) ? b.tkeyB : b.tkeyA;
   b.bytes = ws_align(o) + 256;
@@ -167,7 +169,7 @@ void launch_depth_sort(const GeomWS& g, int P, hipStream_t s);
 void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, hipStream_t s);
 void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, int W, const float* colors,
                        const float* bg, float* out_color, float* out_invdepth, hipStream_t s);
-void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, int W, const float* colors,
+void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, int W, int64_t R, const float* colors,
                        const float* out_color, const float* out_invdepth, const float* dL_dcolor,
                        const float* dL_dinvdepth, hipStream_t s);
 struct GaussBwdArgs {

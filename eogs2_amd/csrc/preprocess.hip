@@ -245,6 +245,7 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
     const float* __restrict__ cov3D_precomp, const float* __restrict__ opacities, const float* __restrict__ vm,
     const float* __restrict__ proj, const int* __restrict__ radii, float scale_modifier, int antialiasing,
     const uint32_t* __restrict__ tiles, const uint32_t* __restrict__ slot_base, const float* __restrict__ records,
+    const uint8_t* __restrict__ live,
     float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscales,
     float* __restrict__ dL_drotations, float* __restrict__ dL_dT_sum, float* __restrict__ dL_dvm_mean) {
@@ -271,8 +272,10 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
     if (visible) {
       // fixed-order sum of this Gaussian's (tile,Gaussian) records: deterministic, no atomics
       const uint32_t n = tiles[idx];
-      const float4* r4 = reinterpret_cast<const float4*>(records + (size_t)slot_base[idx] * REC);
+      const size_t s0 = slot_base[idx];
+      const float4* r4 = reinterpret_cast<const float4*>(records + s0 * REC);
       for (uint32_t q = 0; q < n; q++) {
+        if (!live[s0 + q]) continue;  // pair behind every pixel's last contributor: no record was written
         const float4 a = r4[3 * q], b = r4[3 * q + 1], c = r4[3 * q + 2];
         acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
         acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
@@ -454,6 +457,6 @@ void launch_gaussian_bwd(const GaussBwdArgs& a, const GeomWS& g, const BinWS& b,
   const uint32_t nblk = ceil_div_u32((uint64_t)a.P, BLK);
   hipLaunchKernelGGL(gaussian_bwd_kernel, dim3(nblk), dim3(BLK), 0, s, a.P, a.H, a.W, a.means3D, a.scales, a.rotations,
                      a.cov3D_precomp, a.opacities, a.viewmatrix, a.projmatrix, a.radii, a.scale_modifier,
-                     (int)a.antialiasing, g.tiles, g.slot_base, b.records, a.dL_dmeans2D, a.dL_dcolors, a.dL_dopacity,
+                     (int)a.antialiasing, g.tiles, g.slot_base, b.records, b.live, a.dL_dmeans2D, a.dL_dcolors, a.dL_dopacity,
                      a.dL_dmeans3D, a.dL_dcov3D, a.dL_dscales, a.dL_drotations, a.dL_dT_sum, a.dL_dvm_mean);
 }

@@ -30,8 +30,9 @@
 //     u = alpha T and v = G dL/dalpha; every 8 surviving Gaussians the wave switches to lanes = (Gaussian,
 //     pixel row) and accumulates the six moments of v and the five colour sums of u serially in registers
 //     (see transpose_round). No cross-lane reduction tree, no atomics, and ONE 48-byte record per
-//     (tile,Gaussian) pair written with plain stores by the only wave that owns the pair; gaussian_bwd_kernel
-//     sums each Gaussian's records in fixed order (bitwise reproducible gradients).
+//     (tile,Gaussian) pair written with plain stores by the only wave that owns the pair (plus a 1-byte live flag:
+//     pairs behind every pixel's last contributor are never gathered nor written); gaussian_bwd_kernel sums each
+//     Gaussian's live records in fixed order (bitwise reproducible gradients).
 #include "common.h"
 
 #pragma clang fp contract(fast)
@@ -213,7 +214,8 @@ namespace {
 //   dL/dopacity = M_1,  dL/dcolour = sum u g.
 __device__ inline void transpose_round(int nsurv, int lane, const float* slab, const float* s_u, const float* s_v,
                                        const float* s_pix, const uint32_t* s_kj, const uint32_t* s_slot, float bx0,
-                                       float by0, float kx, float ky, float* __restrict__ records) {
+                                       float by0, float kx, float ky, float* __restrict__ records,
+                                       uint8_t* __restrict__ live_flag) {
   const int k = lane & 7, o = lane >> 3;
   const bool live = k < nsurv;
   const uint32_t jk = live ? s_kj[k] : 0u;
@@ -248,10 +250,12 @@ __device__ inline void transpose_round(int nsurv, int lane, const float* slab, c
     const float m2x = op * kx * (2.f * A * acc[1] - B * acc[2]);   // -a = 2A/log2e, -b = -B/log2e
     const float m2y = op * ky * (2.f * Cq * acc[2] - B * acc[1]);  // -c = 2C/log2e
     const float ho = -0.5f * op;
-    float4* dst = reinterpret_cast<float4*>(records + (size_t)s_slot[jk] * REC);
+    const uint32_t slot = s_slot[jk];
+    float4* dst = reinterpret_cast<float4*>(records + (size_t)slot * REC);
     dst[0] = make_float4(m2x, m2y, ho * acc[3], ho * acc[4]);
     dst[1] = make_float4(ho * acc[5], acc[0], acc[6], acc[7]);
     dst[2] = make_float4(acc[8], acc[9], acc[10], 0.f);
+    live_flag[slot] = 1;  // pairs that never get here keep the 0 of the memset and are skipped by gaussian_bwd
   }
 }
 
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
     int W, int H, int gsx, int ntiles, const float2* __restrict__ means2D, const float4* __restrict__ conic_o,
     const float* __restrict__ depth, const float* __restrict__ colors, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ out_color, const float* __restrict__ out_invdepth, const float* __restrict__ dL_dpix,
-    const float* __restrict__ dL_dinv, float* __restrict__ records) {
+    const float* __restrict__ dL_dinv, float* __restrict__ records, uint8_t* __restrict__ live_flag) {
   __shared__ __attribute__((aligned(16))) float s_slab[BLK / 64][64 * ENT];
   __shared__ __attribute__((aligned(16))) float s_u[BLK / 64][KSURV * UVS];
   __shared__ __attribute__((aligned(16))) float s_v[BLK / 64][KSURV * UVS];
@@ -314,19 +318,17 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
   const float bx0 = (float)tx0, by0 = (float)ty0;
   float T = 1.0f, Dacc = 0.f;
 
-  Cand nxt = load_cand(range.x + lane, range.y, point_list, gid, means2D, conic_o, depth, colors);
-  for (uint32_t c0 = range.x; c0 < range.y; c0 += 64) {
+  // the list is only walked up to the last contributor: pairs behind it are dead (never gathered, never written)
+  const uint32_t end = range.x + tile_last < range.y ? range.x + tile_last : range.y;
+  Cand nxt = load_cand(range.x + lane, end, point_list, gid, means2D, conic_o, depth, colors);
+  for (uint32_t c0 = range.x; c0 < end; c0 += 64) {
     wave_lds_sync();
     park(slab, lane, nxt);
     sslot[lane] = nxt.slot;
-    const uint32_t my_slot = nxt.slot;
-    nxt = load_cand(c0 + 64 + lane, range.y, point_list, gid, means2D, conic_o, depth, colors);
+    nxt = load_cand(c0 + 64 + lane, end, point_list, gid, means2D, conic_o, depth, colors);
     wave_lds_sync();
-    const int n = (int)((range.y - c0) < 64u ? (range.y - c0) : 64u);
+    const int jn = (int)((end - c0) < 64u ? (end - c0) : 64u);
     const uint32_t jbase = c0 - range.x;
-    int jn = n;  // entries of this chunk that can still matter
-    if (tile_last < jbase + (uint32_t)n) jn = tile_last > jbase ? (int)(tile_last - jbase) : 0;
-    unsigned long long survivors = 0ull;
     int k = 0;
     Ent cur = fetch(slab, 0);
     for (int j = 0; j < jn; j++) {
@@ -352,34 +354,28 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
       su[k * UVS + lane] = wgt;
       sv[k * UVS + lane] = v;
       if (lane == 0) skj[k] = (uint32_t)j;
-      survivors |= 1ull << j;
       if (++k == KSURV) {
         wave_lds_sync();
-        transpose_round(KSURV, lane, slab, su, sv, spix, skj, sslot, bx0, by0, kx, ky, records);
+        transpose_round(KSURV, lane, slab, su, sv, spix, skj, sslot, bx0, by0, kx, ky, records, live_flag);
         wave_lds_sync();
         k = 0;
       }
     }
     if (k) {
       wave_lds_sync();
-      transpose_round(k, lane, slab, su, sv, spix, skj, sslot, bx0, by0, kx, ky, records);
-    }
-    // every pair owns a record: entries that reached no pixel get zeros
-    if (lane < n && !((survivors >> lane) & 1ull)) {
-      float4* dst = reinterpret_cast<float4*>(records + (size_t)my_slot * REC);
-      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      dst[0] = z; dst[1] = z; dst[2] = z;
+      transpose_round(k, lane, slab, su, sv, spix, skj, sslot, bx0, by0, kx, ky, records, live_flag);
     }
   }
 }
 
-void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, int W, const float* colors,
+void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, int W, int64_t R, const float* colors,
                        const float* out_color, const float* out_invdepth, const float* dL_dcolor,
                        const float* dL_dinvdepth, hipStream_t s) {
   const int gsx = (W + SUBX - 1) / SUBX, gsy = (H + SUBY - 1) / SUBY, ntiles = gsx * gsy;
+  (void)hipMemsetAsync(b.live, 0, (size_t)R, s);
   hipLaunchKernelGGL(render_bwd_kernel, dim3(render_grid(ntiles)), dim3(BLK), 0, s, im.ranges, b.point_list, b.gid, W, H,
                      gsx, ntiles, g.means2D, g.conic_o, g.depth, colors, im.n_contrib, out_color, out_invdepth,
-                     dL_dcolor, dL_dinvdepth, b.records);
+                     dL_dcolor, dL_dinvdepth, b.records, b.live);
 }
 
 // ---- self test of the wave64 primitives (diagnostics) ----
