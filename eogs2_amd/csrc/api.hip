@@ -179,7 +179,7 @@ int eogs_rast_forward_render(int P, int H, int W, int64_t R, const float* colors
     if ((size_t)(bb - (char*)binning) + b.bytes - 256 > binning_bytes)
       return fail(EOGS_ERR_WORKSPACE, "forward_render: binning workspace too small");
   }
-  { ProfScope ps(PS_BINNING, s); launch_binning(g, b, im, P, H, W, R, s); }
+  { ProfScope ps(PS_BINNING, s); launch_binning(g, b, im, P, H, W, R, colors, s); }
   LAUNCH_TRY(s, debug, "binning");
   { ProfScope ps(PS_RENDER_FWD, s); launch_render_fwd(g, b, im, H, W, colors, bg, out_color, out_invdepth, s); }
   LAUNCH_TRY(s, debug, "render_fwd");

@@ -283,6 +283,19 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint32_t* __restrict_
   }
 }
 
+// ---- colours into the per-Gaussian render record (floats 6..10 of the 64-byte line) ----
+__global__ __launch_bounds__(BLK) void pack_colors_kernel(const float* __restrict__ colors,
+                                                          const uint32_t* __restrict__ tiles, uint32_t P,
+                                                          float4* __restrict__ packed) {
+  const uint32_t i = blockIdx.x * BLK + threadIdx.x;
+  if (i >= P || tiles[i] == 0) return;
+  const float* c = colors + (size_t)i * NCH;
+  float* dst = reinterpret_cast<float*>(packed + 4 * (size_t)i);
+  const float c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4];
+  *reinterpret_cast<float2*>(dst + 6) = make_float2(c0, c1);
+  dst[8] = c2; dst[9] = c3; dst[10] = c4;
+}
+
 // ---- tile ranges from the sorted tile ids (identifyTileRanges, rasterizer_impl.cu:116-138) ----
 __global__ __launch_bounds__(BLK) void tile_ranges_kernel(const uint32_t* __restrict__ skeys, uint32_t R,
                                                           uint2* __restrict__ ranges) {
@@ -300,10 +313,13 @@ __global__ __launch_bounds__(BLK) void tile_ranges_kernel(const uint32_t* __rest
   if (i == R - 1) ranges[cur].y = R;
 }
 
-void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, hipStream_t s) {
+void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R,
+                    const float* colors, hipStream_t s) {
   const uint32_t gsx = (uint32_t)((W + SUBX - 1) / SUBX), gsy = (uint32_t)((H + SUBY - 1) / SUBY);
   (void)hipMemsetAsync(im.ranges, 0, (size_t)gsx * gsy * sizeof(uint2), s);
   if (R <= 0) return;
+  hipLaunchKernelGGL(pack_colors_kernel, dim3(ceil_div_u32((uint64_t)P, BLK)), dim3(BLK), 0, s, colors, g.tiles, (uint32_t)P,
+                     g.packed);
   hipLaunchKernelGGL(expand_count_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.svalA, g.tiles, (uint32_t)P, g.blocksum);
   hipLaunchKernelGGL(expand_scan_kernel, dim3(1), dim3(BLK), 0, s, g.blocksum, g.nblkE);
   hipLaunchKernelGGL(expand_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.svalA, g.tiles, g.rect, g.mask, g.blocksum, (uint32_t)P,

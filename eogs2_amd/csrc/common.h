@@ -42,9 +42,9 @@ static inline uint32_t ceil_div_u32(uint64_t a, uint64_t b) { return (uint32_t)(
 
 // Geometry workspace: everything that is O(P). SoA, every array 256-B aligned.
 struct GeomWS {
-  float2* means2D;      // pixel centre
-  float* depth;         // 200 - altitude
-  float4* conic_o;      // conic (a,b,c) + effective opacity
+  float4* packed;       // 4 x float4 = one 64-byte line per Gaussian, everything the render kernels gather:
+                        //   {gx, gy, A, B} {C, opacity, f0, f1} {f2, f3, f4, 1/depth} {pad}
+                        //   with the conic pre-scaled by log2 e: A = -a log2e/2, B = b log2e, C = -c log2e/2
   uint2* rect;          // x0 | x1<<16 , y0 | y1<<16 (16-px tile units, the reference's getRect)
   unsigned long long* mask;  // bit (sy-FY*y0)*FX*(x1-x0) + (sx-FX*x0): internal tile (sx,sy) can reach alpha >= 1/255;
                         // 0 = no mask: every internal tile of the rect (clipped to the image) is listed
@@ -67,9 +67,7 @@ static inline GeomWS geom_layout(char* base, int P) {
   size_t n = (size_t)P, o = 0;
   g.nblkP = ceil_div_u32(n, BLK * SORTP_ITEMS);
   g.nblkE = ceil_div_u32(n, BLK * EXPAND_ITEMS);
-  o = ws_carve(base, o, g.means2D, n);
-  o = ws_carve(base, o, g.depth, n);
-  o = ws_carve(base, o, g.conic_o, n);
+  o = ws_carve(base, o, g.packed, n * 4);
   o = ws_carve(base, o, g.rect, n);
   o = ws_carve(base, o, g.mask, n);
   o = ws_carve(base, o, g.tiles, n);
@@ -166,7 +164,8 @@ struct FwdPrepArgs {
 };
 void launch_preprocess_fwd(const FwdPrepArgs& a, const GeomWS& g, hipStream_t s);
 void launch_depth_sort(const GeomWS& g, int P, hipStream_t s);
-void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, hipStream_t s);
+void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R,
+                    const float* colors, hipStream_t s);
 void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, int W, const float* colors,
                        const float* bg, float* out_color, float* out_invdepth, hipStream_t s);
 void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, int W, int64_t R, const float* colors,

@@ -114,8 +114,7 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
     const float* __restrict__ means3D, const float* __restrict__ scales, const float* __restrict__ rotations,
     const float* __restrict__ cov3D_precomp, const float* __restrict__ opacities, const float* __restrict__ vm,
     float scale_modifier, int antialiasing,
-    int* __restrict__ radii, float2* __restrict__ means2D, float* __restrict__ depth_out,
-    float4* __restrict__ conic_o, uint2* __restrict__ rect, unsigned long long* __restrict__ mask_out,
+    int* __restrict__ radii, float4* __restrict__ packed, uint2* __restrict__ rect, unsigned long long* __restrict__ mask_out,
     uint32_t* __restrict__ tiles, uint32_t* __restrict__ skey, uint32_t* __restrict__ sval,
     uint32_t* __restrict__ misc) {
   __shared__ float s_m[3 * BLK];
@@ -202,9 +201,11 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
           my_tiles = (uint32_t)((sx1 - sx0) * (sy1 - sy0));
         }
         if (my_tiles) {
-          means2D[idx] = make_float2(px, py);
-          depth_out[idx] = d;
-          conic_o[idx] = make_float4(ca, cb, cc, op);
+          // render record (one 64-byte line); the colour slots are filled by pack_colors_kernel
+          const float L2E = 1.4426950408889634f;
+          packed[4 * idx + 0] = make_float4(px, py, ca * (-0.5f * L2E), cb * L2E);
+          packed[4 * idx + 1] = make_float4(cc * (-0.5f * L2E), op, 0.f, 0.f);
+          packed[4 * idx + 2] = make_float4(0.f, 0.f, 0.f, 1.f / d);
           rect[idx] = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16));
           mask_out[idx] = m;
           skey[idx] = __float_as_uint(d);
@@ -233,7 +234,7 @@ void launch_preprocess_fwd(const FwdPrepArgs& a, const GeomWS& g, hipStream_t s)
   const uint32_t nblk = ceil_div_u32((uint64_t)a.P, BLK);
   hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nblk), dim3(BLK), 0, s, a.P, a.H, a.W, gx, gy, a.means3D, a.scales,
                      a.rotations, a.cov3D_precomp, a.opacities, a.viewmatrix, a.scale_modifier, (int)a.antialiasing,
-                     a.radii, g.means2D, g.depth, g.conic_o, g.rect, g.mask, g.tiles, g.skeyA, g.svalA, g.misc);
+                     a.radii, g.packed, g.rect, g.mask, g.tiles, g.skeyA, g.svalA, g.misc);
 }
 
 // ------------------------------------------------------------------------------------------------------

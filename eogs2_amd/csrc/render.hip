@@ -41,7 +41,6 @@ static_assert(SUBX == 8 && SUBY == 8 && PPL == 1, "render kernels are written fo
 
 namespace {
 
-#define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
 #define ENT 12   // floats per staged list entry: gx gy A B | C op f0 f1 | f2 f3 f4 1/depth
 #define KSURV 8  // survivors per transposition round (backward)
@@ -73,8 +72,8 @@ __device__ inline int tile_of_wave() {
   return grp * (BLK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 }
 
-// One list entry as gathered by a lane (conic pre-scaled by log2 e: alpha = o 2^p, p = (A dx - B dy) dx + C dy^2,
-// A = -a log2e/2, B = b log2e, C = -c log2e/2).
+// One list entry as gathered by a lane: the Gaussian's 64-byte render record written by preprocess_fwd_kernel and
+// pack_colors_kernel (conic pre-scaled by log2 e: alpha = o 2^p, p = (A dx - B dy) dx + C dy^2).
 struct Cand {
   float4 q0;  // gx gy A B
   float4 q1;  // C op f0 f1
@@ -83,21 +82,14 @@ struct Cand {
 };
 
 __device__ inline Cand load_cand(uint32_t k, uint32_t end, const uint32_t* __restrict__ point_list,
-                                 const uint32_t* __restrict__ gid, const float2* __restrict__ means2D,
-                                 const float4* __restrict__ conic_o, const float* __restrict__ depth,
-                                 const float* __restrict__ colors) {
+                                 const uint32_t* __restrict__ gid, const float4* __restrict__ packed) {
   Cand c;
   c.q0 = c.q1 = c.q2 = make_float4(0.f, 0.f, 0.f, 0.f);
   c.slot = 0;
   if (k < end) {
     c.slot = point_list[k];
-    const uint32_t id = gid[c.slot];
-    const float2 xy = means2D[id];
-    const float4 co = conic_o[id];
-    const float* f = colors + (size_t)id * NCH;
-    c.q0 = make_float4(xy.x, xy.y, co.x * (-0.5f * LOG2E), co.y * LOG2E);
-    c.q1 = make_float4(co.z * (-0.5f * LOG2E), co.w, f[0], f[1]);
-    c.q2 = make_float4(f[2], f[3], f[4], 1.f / depth[id]);
+    const float4* r = packed + 4 * (size_t)gid[c.slot];  // one 64-byte line per list entry
+    c.q0 = r[0]; c.q1 = r[1]; c.q2 = r[2];
   }
   return c;
 }
@@ -124,8 +116,7 @@ __device__ inline Ent fetch(const float* slab, int j) {
 
 __global__ __launch_bounds__(BLK) void render_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ gid,
-    int W, int H, int gsx, int ntiles, const float2* __restrict__ means2D, const float4* __restrict__ conic_o,
-    const float* __restrict__ depth, const float* __restrict__ colors, const float* __restrict__ bg,
+    int W, int H, int gsx, int ntiles, const float4* __restrict__ packed, const float* __restrict__ bg,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
     float* __restrict__ out_invdepth) {
   __shared__ __attribute__((aligned(16))) float s_slab[BLK / 64][64 * ENT];
@@ -145,11 +136,11 @@ __global__ __launch_bounds__(BLK) void render_fwd_kernel(
   float invd = 0.f;
   bool done = !inside;
 
-  Cand nxt = load_cand(range.x + lane, range.y, point_list, gid, means2D, conic_o, depth, colors);
+  Cand nxt = load_cand(range.x + lane, range.y, point_list, gid, packed);
   for (uint32_t c0 = range.x; c0 < range.y; c0 += 64) {
     wave_lds_sync();  // previous chunk's reads are done
     park(slab, lane, nxt);
-    nxt = load_cand(c0 + 64 + lane, range.y, point_list, gid, means2D, conic_o, depth, colors);  // in flight during this chunk
+    nxt = load_cand(c0 + 64 + lane, range.y, point_list, gid, packed);  // in flight during this chunk
     wave_lds_sync();
     if (__ballot(!done) == 0ull) break;  // every pixel of the tile has terminated
     const int n = (int)((range.y - c0) < 64u ? (range.y - c0) : 64u);
@@ -194,8 +185,7 @@ void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, 
                        const float* bg, float* out_color, float* out_invdepth, hipStream_t s) {
   const int gsx = (W + SUBX - 1) / SUBX, gsy = (H + SUBY - 1) / SUBY, ntiles = gsx * gsy;
   hipLaunchKernelGGL(render_fwd_kernel, dim3(render_grid(ntiles)), dim3(BLK), 0, s, im.ranges, b.point_list, b.gid, W, H,
-                     gsx, ntiles, g.means2D, g.conic_o, g.depth, colors, bg, im.final_T, im.n_contrib, out_color,
-                     out_invdepth);
+                     gsx, ntiles, g.packed, bg, im.final_T, im.n_contrib, out_color, out_invdepth);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -263,8 +253,7 @@ __device__ inline void transpose_round(int nsurv, int lane, const float* slab, c
 
 __global__ __launch_bounds__(BLK) void render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ gid,
-    int W, int H, int gsx, int ntiles, const float2* __restrict__ means2D, const float4* __restrict__ conic_o,
-    const float* __restrict__ depth, const float* __restrict__ colors, const uint32_t* __restrict__ n_contrib,
+    int W, int H, int gsx, int ntiles, const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ out_color, const float* __restrict__ out_invdepth, const float* __restrict__ dL_dpix,
     const float* __restrict__ dL_dinv, float* __restrict__ records, uint8_t* __restrict__ live_flag) {
   __shared__ __attribute__((aligned(16))) float s_slab[BLK / 64][64 * ENT];
@@ -320,12 +309,12 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
 
   // the list is only walked up to the last contributor: pairs behind it are dead (never gathered, never written)
   const uint32_t end = range.x + tile_last < range.y ? range.x + tile_last : range.y;
-  Cand nxt = load_cand(range.x + lane, end, point_list, gid, means2D, conic_o, depth, colors);
+  Cand nxt = load_cand(range.x + lane, end, point_list, gid, packed);
   for (uint32_t c0 = range.x; c0 < end; c0 += 64) {
     wave_lds_sync();
     park(slab, lane, nxt);
     sslot[lane] = nxt.slot;
-    nxt = load_cand(c0 + 64 + lane, end, point_list, gid, means2D, conic_o, depth, colors);
+    nxt = load_cand(c0 + 64 + lane, end, point_list, gid, packed);
     wave_lds_sync();
     const int jn = (int)((end - c0) < 64u ? (end - c0) : 64u);
     const uint32_t jbase = c0 - range.x;
@@ -374,8 +363,8 @@ void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, 
   const int gsx = (W + SUBX - 1) / SUBX, gsy = (H + SUBY - 1) / SUBY, ntiles = gsx * gsy;
   (void)hipMemsetAsync(b.live, 0, (size_t)R, s);
   hipLaunchKernelGGL(render_bwd_kernel, dim3(render_grid(ntiles)), dim3(BLK), 0, s, im.ranges, b.point_list, b.gid, W, H,
-                     gsx, ntiles, g.means2D, g.conic_o, g.depth, colors, im.n_contrib, out_color, out_invdepth,
-                     dL_dcolor, dL_dinvdepth, b.records, b.live);
+                     gsx, ntiles, g.packed, im.n_contrib, out_color, out_invdepth, dL_dcolor, dL_dinvdepth, b.records,
+                     b.live);
 }
 
 // ---- self test of the wave64 primitives (diagnostics) ----
