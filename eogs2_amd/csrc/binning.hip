@@ -85,9 +85,13 @@ __global__ __launch_bounds__(BLK) void radix_rowscan_kernel(uint32_t* __restrict
 }
 
 // ---- radix pass, kernel 3: stable scatter ----
-// Round i handles keys [base + i*256, base + (i+1)*256): lane order == key order, so ranking by
-// (rounds, waves, lanes) is stable. Per round: wave-level match by ballot on the digit bits, per-wave digit
-// counts in LDS, prefix over earlier waves, running per-digit count over earlier rounds.
+// Wave w of the workgroup owns the contiguous segment [base + w*64*ITEMS, base + (w+1)*64*ITEMS) and takes it 64 keys
+// at a time (lane order == key order), so ranking needs NO workgroup barrier: per chunk a wave-level match by ballot
+// on the digit bits gives the rank among equal digits inside the chunk, a wave-private LDS counter row gives the
+// count of that digit in the wave's earlier chunks. One barrier later the workgroup knows, per digit, its start in the
+// workgroup's sorted order and each wave's offset inside the digit; keys and payloads are then placed in LDS in
+// sorted order and streamed out so that consecutive lanes write consecutive addresses inside each digit run.
+// Stable: (wave segment, chunk, lane) order is index order.
 template <int ITEMS>
 __global__ __launch_bounds__(BLK) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                             const uint32_t* __restrict__ vals_in,
@@ -95,60 +99,80 @@ __global__ __launch_bounds__(BLK) void radix_scatter_kernel(const uint32_t* __re
                                                             uint32_t* __restrict__ vals_out, uint32_t n, int shift,
                                                             int nbits, const uint32_t* __restrict__ hist,
                                                             uint32_t nblk, const uint32_t* __restrict__ dtotal) {
-  __shared__ uint32_t s_gbase[256];    // global output base of each digit for this workgroup
-  __shared__ uint32_t s_run[256];      // keys of each digit seen in earlier rounds
-  __shared__ uint32_t s_cnt[4][256];   // per-wave digit counts of the current round
+  constexpr int NW = BLK / 64, SEG = 64 * ITEMS, TILE_KEYS = BLK * ITEMS;
+  __shared__ uint32_t s_gbase[256];     // global output position of this workgroup's first key of each digit
+  __shared__ uint32_t s_dstart[256];    // start of each digit in the workgroup's sorted order
+  __shared__ uint32_t s_wcnt[NW][256];  // per-wave digit counts -> per-wave offset inside the digit
+  __shared__ uint32_t s_key[TILE_KEYS];
+  __shared__ uint32_t s_val[TILE_KEYS];
   __shared__ uint32_t s_w[4];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const uint32_t mask = (1u << nbits) - 1u;
-
-  // digit base = exclusive scan of digit totals + this workgroup's offset inside the digit
-  {
-    const uint32_t tot = (uint32_t)t <= mask ? dtotal[t] : 0u;
-    uint32_t all;
-    const uint32_t ex = block_excl_scan(tot, s_w, all);
-    s_gbase[t] = (uint32_t)t <= mask ? ex + hist[(size_t)t * nblk + blockIdx.x] : 0u;
-    s_run[t] = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) s_cnt[k][t] = 0;
-  }
+  for (int k = 0; k < NW; k++) s_wcnt[k][t] = 0;
   __syncthreads();
 
-  const uint32_t base = blockIdx.x * (uint32_t)(BLK * ITEMS);
+  const uint32_t base = blockIdx.x * (uint32_t)TILE_KEYS + (uint32_t)w * SEG;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  uint32_t key[ITEMS], val[ITEMS], lrank[ITEMS];
+#pragma unroll
   for (int i = 0; i < ITEMS; i++) {
-    const uint32_t k = base + i * BLK + t;
-    const bool live = k < n;
-    uint32_t key = 0, val = 0, d = 0;
-    if (live) {
-      key = keys_in[k];
-      val = vals_in[k];
-      d = (key >> shift) & mask;
-    }
-    // lanes of this wave holding the same digit
+    const uint32_t k = base + i * 64 + lane;
+    key[i] = k < n ? keys_in[k] : 0xFFFFFFFFu;
+    val[i] = k < n ? vals_in[k] : 0u;
+  }
+#pragma unroll
+  for (int i = 0; i < ITEMS; i++) {
+    const bool live = base + i * 64 + lane < n;
+    const uint32_t d = (key[i] >> shift) & mask;
     unsigned long long peers = __ballot(live);
     for (int b = 0; b < nbits; b++) {
       const unsigned long long m = __ballot((d >> b) & 1u);
       peers &= ((d >> b) & 1u) ? m : ~m;
     }
-    const uint32_t rank_in_wave = (uint32_t)__popcll(peers & lt_mask);
-    if (live && rank_in_wave == 0) s_cnt[w][d] = (uint32_t)__popcll(peers);  // one leader per digit per wave
-    __syncthreads();
-    if (live) {
-      uint32_t pre = s_run[d];
-      if (w > 0) pre += s_cnt[0][d];
-      if (w > 1) pre += s_cnt[1][d];
-      if (w > 2) pre += s_cnt[2][d];
-      const uint32_t pos = s_gbase[d] + pre + rank_in_wave;
-      keys_out[pos] = key;
-      vals_out[pos] = val;
+    const uint32_t r = (uint32_t)__popcll(peers & lt_mask);
+    uint32_t before = 0;
+    if (live) before = s_wcnt[w][d];  // this wave's earlier chunks (LDS ops of one wave execute in order)
+    __builtin_amdgcn_wave_barrier();
+    if (live && r == 0) s_wcnt[w][d] = before + (uint32_t)__popcll(peers);  // one leader per digit
+    __builtin_amdgcn_wave_barrier();
+    lrank[i] = before + r;
+  }
+  __syncthreads();
+  {  // thread t owns digit t
+    uint32_t c[NW], tot = 0;
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+      c[k] = s_wcnt[k][t];
+      s_wcnt[k][t] = tot;  // offset of wave k inside digit t
+      tot += c[k];
     }
-    __syncthreads();
-    {  // thread t owns digit t: fold this round into the running count and clear the per-wave slots
-      s_run[t] += s_cnt[0][t] + s_cnt[1][t] + s_cnt[2][t] + s_cnt[3][t];
-      s_cnt[0][t] = 0; s_cnt[1][t] = 0; s_cnt[2][t] = 0; s_cnt[3][t] = 0;
+    uint32_t all;
+    const uint32_t ex = block_excl_scan(tot, s_w, all);
+    s_dstart[t] = ex;
+    const uint32_t gtot = (uint32_t)t <= mask ? dtotal[t] : 0u;
+    const uint32_t gex = block_excl_scan(gtot, s_w, all);
+    s_gbase[t] = (uint32_t)t <= mask ? gex + hist[(size_t)t * nblk + blockIdx.x] : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < ITEMS; i++) {
+    if (base + i * 64 + lane < n) {
+      const uint32_t d = (key[i] >> shift) & mask;
+      const uint32_t pos = s_dstart[d] + s_wcnt[w][d] + lrank[i];
+      s_key[pos] = key[i];
+      s_val[pos] = val[i];
     }
-    __syncthreads();
+  }
+  __syncthreads();
+  const uint32_t tile0 = blockIdx.x * (uint32_t)TILE_KEYS;
+  const uint32_t nvalid = n - tile0 < (uint32_t)TILE_KEYS ? n - tile0 : (uint32_t)TILE_KEYS;
+  for (uint32_t idx = t; idx < nvalid; idx += BLK) {
+    const uint32_t k = s_key[idx];
+    const uint32_t d = (k >> shift) & mask;
+    const uint32_t pos = s_gbase[d] + (idx - s_dstart[d]);
+    keys_out[pos] = k;
+    vals_out[pos] = s_val[idx];
   }
 }
 
