@@ -145,10 +145,8 @@ __global__ __launch_bounds__(BLK) void render_fwd_kernel(
     if (__ballot(!done) == 0ull) break;  // every pixel of the tile has terminated
     const int n = (int)((range.y - c0) < 64u ? (range.y - c0) : 64u);
     const uint32_t jbase = c0 - range.x;
-    Ent cur = fetch(slab, 0);
-    for (int j = 0; j < n; j++) {
-      const Ent e = cur;
-      cur = fetch(slab, j + 1 < n ? j + 1 : j);  // software pipeline: next entry's broadcast read
+    // one list entry against this lane's pixel; returns nothing, all state is captured by reference
+    auto blend = [&](const Ent& e, int j) {
       const float dx = e.q0.x - pxf, dy = e.q0.y - pyf;
       const float p = (e.q0.z * dx - e.q0.w * dy) * dx + e.q1.x * dy * dy;
       const float alpha = fminf(e.q1.y * __builtin_amdgcn_exp2f(p), 0.99f);
@@ -157,14 +155,25 @@ __global__ __launch_bounds__(BLK) void render_fwd_kernel(
       const bool term = valid && test_T < 0.0001f;  // this Gaussian is NOT blended; the pixel is finished
       done = done || term;
       valid = valid && !term;
-      if (__ballot(valid) == 0ull) continue;
+      if (__ballot(valid) == 0ull) return;
       const float wgt = valid ? alpha * T : 0.f;
       C[0] += e.q1.z * wgt; C[1] += e.q1.w * wgt;
       C[2] += e.q2.x * wgt; C[3] += e.q2.y * wgt; C[4] += e.q2.z * wgt;
       invd += e.q2.w * wgt;
       T = valid ? test_T : T;
       last_contributor = valid ? jbase + (uint32_t)j + 1u : last_contributor;
+    };
+    // software pipeline over two register sets: each entry's broadcast read is issued one entry ahead of its use
+    // and lands directly in the set that has just been consumed (no register rotation)
+    Ent ea = fetch(slab, 0);
+    int j = 0;
+    for (; j + 1 < n; j += 2) {
+      const Ent eb = fetch(slab, j + 1);
+      blend(ea, j);
+      ea = fetch(slab, j + 2 < n ? j + 2 : j + 1);
+      blend(eb, j + 1);
     }
+    if (j < n) blend(ea, j);
   }
   if (inside) {
     const size_t HW = (size_t)H * W;
@@ -319,16 +328,13 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
     const int jn = (int)((end - c0) < 64u ? (end - c0) : 64u);
     const uint32_t jbase = c0 - range.x;
     int k = 0;
-    Ent cur = fetch(slab, 0);
-    for (int j = 0; j < jn; j++) {
-      const Ent e = cur;
-      cur = fetch(slab, j + 1 < jn ? j + 1 : j);
+    auto grad = [&](const Ent& e, int j) {
       const float dx = e.q0.x - pxf, dy = e.q0.y - pyf;
       const float p = (e.q0.z * dx - e.q0.w * dy) * dx + e.q1.x * dy * dy;
       const float G = __builtin_amdgcn_exp2f(p);
       const float alpha = fminf(e.q1.y * G, 0.99f);
       const bool valid = (jbase + (uint32_t)j < ncontrib) && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);
-      if (__ballot(valid) == 0ull) continue;  // wave-uniform skip: this entry reaches no pixel of the tile
+      if (__ballot(valid) == 0ull) return;  // wave-uniform skip: this entry reaches no pixel of the tile
 
       float gc = g[0] * e.q1.z + g[1] * e.q1.w + g[2] * e.q2.x + g[3] * e.q2.y + g[4] * e.q2.z;
       if (have_inv) gc += ginv * e.q2.w;
@@ -349,7 +355,16 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
         wave_lds_sync();
         k = 0;
       }
+    };
+    Ent ea = fetch(slab, 0);
+    int j = 0;
+    for (; j + 1 < jn; j += 2) {
+      const Ent eb = fetch(slab, j + 1);
+      grad(ea, j);
+      ea = fetch(slab, j + 2 < jn ? j + 2 : j + 1);
+      grad(eb, j + 1);
     }
+    if (j < jn) grad(ea, j);
     if (k) {
       wave_lds_sync();
       transpose_round(k, lane, slab, su, sv, spix, skj, sslot, bx0, by0, kx, ky, records, live_flag);
