@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--opacity", default="init", help="init (0.01, gs_config/train.yaml:55) | trained | float")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) and run the gradient all-reduce even with one rank (self-test)")
     return ap.parse_args()
 
 
@@ -88,11 +90,14 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from eogs2_amd import GaussianRasterizer, _lib
     from eogs2_amd.parallel import GradBucket
@@ -122,12 +127,12 @@ def main():
         color, radii, _ = rast(params["means3D"], means2D, params["opacities"], colors_precomp=params["colors"],
                                scales=params["scales"], rotations=params["rotations"])
         (color * dL).sum().backward()
-        if world > 1:
+        if use_dist:
             bucket.all_reduce()
         return color
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -143,7 +148,7 @@ def main():
     dt = time.perf_counter() - t0
     abi.profile_enable(0)
     prof = abi.profile()
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -182,14 +187,14 @@ def main():
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{P} Gaussians x {H}x{W} x 5 channels, opacity={a.opacity}, 1 view per GPU, "
-                                   f"fwd+bwd" + (" + RCCL grad all-reduce (56 B/Gaussian)" if world > 1 else ""),
+                                   f"fwd+bwd" + (" + RCCL grad all-reduce (56 B/Gaussian)" if use_dist else ""),
                        "gaussians": P, "height": H, "width": W, "num_rendered": R, "parallelism": f"view-dp{world}"},
             "roofline": roof, "pipeline": pipe, "kernels_ms": kern,
         }
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(P, H)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -88,14 +88,15 @@ __device__ inline void stage_rows3(const float* __restrict__ src, size_t row0, i
 // clamped to the block. The continuous block contains the pixel centres, so q_min(block) <= q(pixel): dropping the
 // block when q_min > tau (plus a margin far above the fp32 rounding of the renderer's `power`) never drops a pixel
 // that would blend this Gaussian (forward.cu:374-376 skips alpha < 1/255). NaNs fail the comparison -> kept.
-__device__ inline bool block_hit(float gx, float gy, float a, float b, float c, float tau_m, float x0, float y0,
-                                 float x1, float y1) {
+// b_c = b/c and b_a = b/a are per-Gaussian constants (the unclamped minimiser on an edge).
+__device__ inline bool block_hit(float gx, float gy, float a, float b, float c, float b_c, float b_a, float tau_m,
+                                 float x0, float y0, float x1, float y1) {
   const float cx = fminf(fmaxf(gx, x0), x1), cy = fminf(fmaxf(gy, y0), y1);
   const float dxe = gx - cx, dye = gy - cy;
-  const float py = fminf(fmaxf(gy + b * dxe / c, y0), y1);  // edge x = cx, free y
+  const float py = fminf(fmaxf(gy + b_c * dxe, y0), y1);  // edge x = cx, free y
   const float dy1 = gy - py;
   const float q1 = a * dxe * dxe + 2.f * b * dxe * dy1 + c * dy1 * dy1;
-  const float pxs = fminf(fmaxf(gx + b * dye / a, x0), x1);  // edge y = cy, free x
+  const float pxs = fminf(fmaxf(gx + b_a * dye, x0), x1);  // edge y = cy, free x
   const float dx2 = gx - pxs;
   const float q2 = a * dx2 * dx2 + 2.f * b * dx2 * dye + c * dye * dye;
   return !(fminf(q1, q2) > tau_m);
@@ -190,10 +191,11 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
         if (sw * sh <= MASK_MAX_SUBTILES) {
           const float tau = 2.f * __logf(255.f * op);
           const float tau_m = tau + 1e-3f * (1.f + fabsf(tau));
+          const float b_c = cb / cc, b_a = cb / ca;
           for (int sy = sy0; sy < sy1; sy++)
             for (int sx = sx0; sx < sx1; sx++) {
               const float bx = (float)(sx * SUBX), by = (float)(sy * SUBY);
-              if (block_hit(px, py, ca, cb, cc, tau_m, bx, by, bx + (SUBX - 1), by + (SUBY - 1)))
+              if (block_hit(px, py, ca, cb, cc, b_c, b_a, tau_m, bx, by, bx + (SUBX - 1), by + (SUBY - 1)))
                 m |= 1ull << ((sy - sy0) * sw + (sx - sx0));
             }
           my_tiles = (uint32_t)__popcll(m);

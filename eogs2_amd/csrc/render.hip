@@ -212,12 +212,12 @@ namespace {
 //   dL/dmean2D = o (W/2, H/2) * (-(a M_dx + b M_dy), -(c M_dy + b M_dx)),  dL/dconic = -o/2 (M_dxdx, M_dxdy, M_dydy),
 //   dL/dopacity = M_1,  dL/dcolour = sum u g.
 __device__ inline void transpose_round(int nsurv, int lane, const float* slab, const float* s_u, const float* s_v,
-                                       const float* s_pix, const uint32_t* s_kj, const uint32_t* s_slot, float bx0,
+                                       const float* s_pix, unsigned long long kj_packed, const uint32_t* s_slot, float bx0,
                                        float by0, float kx, float ky, float* __restrict__ records,
                                        uint8_t* __restrict__ live_flag) {
   const int k = lane & 7, o = lane >> 3;
   const bool live = k < nsurv;
-  const uint32_t jk = live ? s_kj[k] : 0u;
+  const uint32_t jk = live ? (uint32_t)(kj_packed >> (8 * k)) & 63u : 0u;  // 8 bits per survivor, wave-uniform word
   const float4 q0 = *reinterpret_cast<const float4*>(slab + jk * ENT);      // gx gy A B
   const float2 q1 = *reinterpret_cast<const float2*>(slab + jk * ENT + 4);  // C op
   const float gxr = q0.x - bx0;            // centre relative to the tile origin
@@ -269,7 +269,6 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
   __shared__ __attribute__((aligned(16))) float s_u[BLK / 64][KSURV * UVS];
   __shared__ __attribute__((aligned(16))) float s_v[BLK / 64][KSURV * UVS];
   __shared__ __attribute__((aligned(16))) float s_pix[BLK / 64][64 * 8 + 32];
-  __shared__ uint32_t s_kj[BLK / 64][KSURV];
   __shared__ uint32_t s_slot[BLK / 64][64];
   const int lane = threadIdx.x & 63;
   const int tile = tile_of_wave();
@@ -279,7 +278,6 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
   float* su = s_u[w];
   float* sv = s_v[w];
   float* spix = s_pix[w];
-  uint32_t* skj = s_kj[w];
   uint32_t* sslot = s_slot[w];
   const int tx0 = (tile % gsx) * SUBX, ty0 = (tile / gsx) * SUBY;
   const int px = tx0 + (lane & 7), py = ty0 + (lane >> 3);
@@ -328,6 +326,7 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
     const int jn = (int)((end - c0) < 64u ? (end - c0) : 64u);
     const uint32_t jbase = c0 - range.x;
     int k = 0;
+    unsigned long long kj = 0ull;  // list positions (within the chunk) of the survivors of the current round
     auto grad = [&](const Ent& e, int j) {
       const float dx = e.q0.x - pxf, dy = e.q0.y - pyf;
       const float p = (e.q0.z * dx - e.q0.w * dy) * dx + e.q1.x * dy * dy;
@@ -338,22 +337,24 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
 
       float gc = g[0] * e.q1.z + g[1] * e.q1.w + g[2] * e.q2.x + g[3] * e.q2.y + g[4] * e.q2.z;
       if (have_inv) gc += ginv * e.q2.w;
-      const float wgt = valid ? alpha * T : 0.f;
+      // pixels that skip this Gaussian behave as alpha = 0, G = 0 (selects, not multiplications: exp2 may have
+      // overflowed there): wgt = 0, T unchanged, v = 0. No zeroing when alpha was clamped (backward.cu:624).
+      const float a_eff = valid ? alpha : 0.f;
+      const float G_eff = valid ? G : 0.f;
+      const float wgt = a_eff * T;
       Dacc += gc * wgt;
-      const float one_m = 1.f - alpha;
+      const float one_m = 1.f - a_eff;
       const float dLda = T * gc - (Dfinal - Dacc) * __builtin_amdgcn_rcpf(one_m);
-      T = valid ? T * one_m : T;
-      // v = G dL/dalpha; select instead of multiplying by 0 (exp2 may overflow on pixels that skip this Gaussian);
-      // no zeroing when alpha was clamped (backward.cu:624)
-      const float v = valid ? G * dLda : 0.f;
+      T = T * one_m;
       su[k * UVS + lane] = wgt;
-      sv[k * UVS + lane] = v;
-      if (lane == 0) skj[k] = (uint32_t)j;
+      sv[k * UVS + lane] = G_eff * dLda;  // v = G dL/dalpha
+      kj |= (unsigned long long)j << (8 * k);
       if (++k == KSURV) {
         wave_lds_sync();
-        transpose_round(KSURV, lane, slab, su, sv, spix, skj, sslot, bx0, by0, kx, ky, records, live_flag);
+        transpose_round(KSURV, lane, slab, su, sv, spix, kj, sslot, bx0, by0, kx, ky, records, live_flag);
         wave_lds_sync();
         k = 0;
+        kj = 0ull;
       }
     };
     Ent ea = fetch(slab, 0);
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
     if (j < jn) grad(ea, j);
     if (k) {
       wave_lds_sync();
-      transpose_round(k, lane, slab, su, sv, spix, skj, sslot, bx0, by0, kx, ky, records, live_flag);
+      transpose_round(k, lane, slab, su, sv, spix, kj, sslot, bx0, by0, kx, ky, records, live_flag);
     }
   }
 }

@@ -48,7 +48,7 @@ class GradBucket:
 
     def all_reduce(self, group=None, average=False):
         self.pack()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.is_available() and dist.is_initialized():
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             if average:
                 self.flat.div_(dist.get_world_size(group))
