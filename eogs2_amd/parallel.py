@@ -29,21 +29,31 @@ class GradBucket:
     def bytes_per_gaussian(self):
         return 4 * sum(self.widths)
 
+    def _full(self, i):
+        return self.widths[i] == self.params[i].shape[1]
+
     def pack(self):
-        o = 0
-        for p, c, w in zip(self.params, self.cols, self.widths):
-            if p.grad is None:
-                self.flat[:, o:o + w].zero_()
-            else:
-                self.flat[:, o:o + w].copy_(p.grad[:, c])
-            o += w
+        """One fused concatenation kernel: grads (or zeros) -> the contiguous [P, K] bucket."""
+        parts = []
+        for p, c in zip(self.params, self.cols):
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            parts.append(g[:, c])
+        if any(pt.data_ptr() == self.flat.data_ptr() for pt in parts):
+            # grads are already views of the bucket (second call without a new backward): nothing to pack
+            return
+        torch.cat(parts, dim=1, out=self.flat)
 
     def unpack(self):
+        """Parameters whose every column is in the bucket get a VIEW of it as .grad (no copy); partially bucketed
+        ones (colors_precomp: only the f_dc columns are parameters) get their columns copied back."""
         o = 0
-        for p, c, w in zip(self.params, self.cols, self.widths):
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
-            p.grad[:, c].copy_(self.flat[:, o:o + w])
+        for i, (p, c, w) in enumerate(zip(self.params, self.cols, self.widths)):
+            if self._full(i):
+                p.grad = self.flat[:, o:o + w]
+            else:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+                p.grad[:, c].copy_(self.flat[:, o:o + w])
             o += w
 
     def all_reduce(self, group=None, average=False):
