@@ -137,7 +137,7 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
   HIP_TRY(hipMemsetAsync(g.misc, 0, MISC_WORDS * sizeof(uint32_t), s));
   FwdPrepArgs a{P, H, W, means3D, scales, rotations, cov3D_precomp, opacities, viewmatrix, scale_modifier,
                 (flags & EOGS_FLAG_ANTIALIASING) != 0, radii};
-  { ProfScope ps(PS_PREPROCESS, s); launch_preprocess_fwd(a, g, s); }
+  { ProfScope ps(PS_PREPROCESS, s); launch_preprocess_fwd(a, g, s); launch_scan_pblock(g, P, s); }
   LAUNCH_TRY(s, debug, "preprocess_fwd");
   HIP_TRY(hipMemcpyAsync(g_pinned, g.misc, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   // the depth sort does not depend on num_rendered: it runs while the host waits for the readback

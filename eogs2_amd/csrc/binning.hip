@@ -196,24 +196,21 @@ void launch_depth_sort(const GeomWS& g, int P, hipStream_t s) {
   }
 }
 
-// ---- expand step A: pair count of each chunk of 1024 depth-sorted Gaussians ----
+// ---- expand step A: pair count of each chunk of 256 depth-sorted Gaussians (+ zeroes the tile ranges) ----
 __global__ __launch_bounds__(BLK) void expand_count_kernel(const uint32_t* __restrict__ sorted_ids,
                                                            const uint32_t* __restrict__ tiles, uint32_t P,
-                                                           uint32_t* __restrict__ blocksum) {
+                                                           uint32_t* __restrict__ blocksum, uint2* __restrict__ ranges,
+                                                           uint32_t ntiles) {
   __shared__ uint32_t s_w[4];
-  const uint32_t base = blockIdx.x * (uint32_t)(BLK * EXPAND_ITEMS);
-  uint32_t v = 0;
-#pragma unroll
-  for (int i = 0; i < EXPAND_ITEMS; i++) {
-    const uint32_t k = base + i * BLK + threadIdx.x;
-    if (k < P) v += tiles[sorted_ids[k]];
-  }
+  for (uint32_t i = blockIdx.x * BLK + threadIdx.x; i < ntiles; i += gridDim.x * BLK) ranges[i] = make_uint2(0u, 0u);
+  const uint32_t k = blockIdx.x * BLK + threadIdx.x;
+  const uint32_t v = k < P ? tiles[sorted_ids[k]] : 0u;
   uint32_t tot;
   (void)block_excl_scan(v, s_w, tot);
   if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
 }
 
-// ---- expand step B: exclusive scan of the chunk counts (single workgroup; nblk <= a few thousand) ----
+// ---- expand step B: exclusive scan of the chunk counts (single workgroup) ----
 __global__ __launch_bounds__(BLK) void expand_scan_kernel(uint32_t* __restrict__ blocksum, uint32_t nblk) {
   __shared__ uint32_t s_w[4];
   uint32_t carry = 0;
@@ -228,82 +225,85 @@ __global__ __launch_bounds__(BLK) void expand_scan_kernel(uint32_t* __restrict__
   if (threadIdx.x == 0) blocksum[nblk] = carry;
 }
 
-// ---- expand step C: load-balanced emission of (internal tile id, pair slot) in depth order ----
-// q-th listed internal tile of a Gaussian: the q-th set bit of its hit mask, or (mask == 0) the q-th tile of its
-// clipped rect in row-major order.
+// ---- expand step C: emission of (internal tile id, record slot) in depth order ----
+// One lane per depth-sorted Gaussian. The q-th listed tile of a Gaussian is the q-th set bit of its hit mask
+// (walked incrementally: ctz, clear lowest bit) or, for unmasked Gaussians, the q-th tile of its clipped rect.
+// Output position = depth-order offset (exclusive scan of the counts); payload = record slot in Gaussian-id order.
+// Gaussians with more than 32 tiles are emitted by the whole wave, one after the other.
+struct ExpandItem {
+  uint32_t id, c, pos0, rbase, sx0, sy0, sw, wc;
+  unsigned long long m;
+};
+__device__ inline uint32_t tile_of(const ExpandItem& it, uint32_t bit_or_q, uint32_t gsx) {
+  const uint32_t wdt = it.m ? it.sw : it.wc;
+  const uint32_t row = bit_or_q / wdt, col = bit_or_q - row * wdt;
+  return (it.sy0 + row) * gsx + it.sx0 + col;
+}
 __global__ __launch_bounds__(BLK) void expand_kernel(const uint32_t* __restrict__ sorted_ids,
                                                      const uint32_t* __restrict__ tiles,
                                                      const uint2* __restrict__ rect,
                                                      const unsigned long long* __restrict__ mask,
+                                                     const uint32_t* __restrict__ lpre,
+                                                     const uint32_t* __restrict__ pblock,
                                                      const uint32_t* __restrict__ blocksum, uint32_t P, uint32_t gsx,
-                                                     uint32_t gsy, uint32_t* __restrict__ slot_base,
-                                                     uint32_t* __restrict__ tkey, uint32_t* __restrict__ tval,
-                                                     uint32_t* __restrict__ gid) {
-  constexpr int N = BLK * EXPAND_ITEMS;
-  __shared__ uint32_t s_lo[N + 1];  // exclusive pair offset of each Gaussian of the chunk
-  __shared__ uint32_t s_id[N];
-  __shared__ uint32_t s_org[N];     // sx0 | sy0 << 16 (internal tile coordinates of the rect origin)
-  __shared__ uint32_t s_wd[N];      // sw (mask row width) | wc (clipped width) << 16
-  __shared__ unsigned long long s_mask[N];
+                                                     uint32_t gsy, uint32_t* __restrict__ tkey,
+                                                     uint32_t* __restrict__ tval, uint32_t* __restrict__ gid) {
   __shared__ uint32_t s_w[4];
-  const int t = threadIdx.x;
-  const uint32_t base = blockIdx.x * (uint32_t)N;
-  const uint32_t gbase = blocksum[blockIdx.x];
-  uint32_t carry = 0;
-  for (int i = 0; i < EXPAND_ITEMS; i++) {
-    const uint32_t j = i * BLK + t, k = base + j;
-    uint32_t id = 0, c = 0;
-    uint2 r = make_uint2(0, 0);
-    unsigned long long m = 0ull;
-    if (k < P) {
-      id = sorted_ids[k];
-      c = tiles[id];
-      if (c) {
-        r = rect[id];
-        m = mask[id];
-      }
-    }
-    uint32_t tot;
-    const uint32_t ex = block_excl_scan(c, s_w, tot);
-    s_lo[j] = carry + ex;
-    s_id[j] = id;
-    const uint32_t x0 = r.x & 0xFFFFu, x1 = r.x >> 16, y0 = r.y & 0xFFFFu;
-    const uint32_t sx0 = FX * x0, sw = FX * (x1 - x0);
-    const uint32_t sx1 = FX * x1 < gsx ? FX * x1 : gsx;
-    s_org[j] = sx0 | ((FY * y0) << 16);
-    s_wd[j] = sw | ((sx1 - sx0) << 16);
-    s_mask[j] = m;
-    if (k < P && c) slot_base[id] = gbase + carry + ex;
-    carry += tot;
+  const int lane = threadIdx.x & 63;
+  const uint32_t k = blockIdx.x * BLK + threadIdx.x;
+  ExpandItem it;
+  it.id = 0; it.c = 0; it.m = 0ull; it.sx0 = it.sy0 = 0; it.sw = it.wc = 1; it.rbase = 0;
+  if (k < P) {
+    it.id = sorted_ids[k];
+    it.c = tiles[it.id];
   }
-  if (t == 0) s_lo[N] = carry;
-  __syncthreads();
-  const uint32_t total = carry;
-  for (uint32_t sidx = t; sidx < total; sidx += BLK) {
-    // largest j in [0,N) with s_lo[j] <= sidx (its count is > 0 because s_lo[j+1] > sidx)
-    uint32_t lo = 0, hi = N;  // invariant: s_lo[lo] <= sidx < s_lo[hi]
-    while (hi - lo > 1) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (s_lo[mid] <= sidx) lo = mid; else hi = mid;
+  uint32_t tot;
+  it.pos0 = blocksum[blockIdx.x] + block_excl_scan(it.c, s_w, tot);
+  if (it.c) {
+    const uint2 r = rect[it.id];
+    const uint32_t x0 = r.x & 0xFFFFu, x1 = r.x >> 16, y0 = r.y & 0xFFFFu;
+    it.m = mask[it.id];
+    it.sx0 = FX * x0; it.sy0 = FY * y0; it.sw = FX * (x1 - x0);
+    const uint32_t sx1 = FX * x1 < gsx ? FX * x1 : gsx;
+    it.wc = sx1 - it.sx0;
+    it.rbase = pblock[it.id / BLK] + lpre[it.id];
+  }
+  // small Gaussians: every lane emits its own pairs
+  if (it.c && it.c <= 32u) {
+    unsigned long long m = it.m;
+    for (uint32_t q = 0; q < it.c; q++) {
+      uint32_t sel = q;
+      if (it.m) {
+        sel = (uint32_t)__builtin_ctzll(m);
+        m &= m - 1ull;
+      }
+      tkey[it.pos0 + q] = tile_of(it, sel, gsx);
+      tval[it.pos0 + q] = it.rbase + q;
+      gid[it.rbase + q] = it.id;
     }
-    uint32_t q = sidx - s_lo[lo];
-    const uint32_t sx0 = s_org[lo] & 0xFFFFu, sy0 = s_org[lo] >> 16;
-    unsigned long long m = s_mask[lo];
-    uint32_t row, col;
-    if (m) {
-      for (; q; q--) m &= m - 1ull;  // drop the q lowest set bits
-      const uint32_t bit = (uint32_t)__builtin_ctzll(m), sw = s_wd[lo] & 0xFFFFu;
-      row = bit / sw;
-      col = bit - row * sw;
-    } else {
-      const uint32_t wc = s_wd[lo] >> 16;
-      row = q / wc;
-      col = q - row * wc;
+  }
+  // large Gaussians: the wave emits them cooperatively, 64 pairs per step
+  unsigned long long big = __ballot(it.c > 32u);
+  while (big) {
+    const int src = __builtin_ctzll(big);
+    big &= big - 1ull;
+    ExpandItem g;
+    g.id = __shfl(it.id, src, 64); g.c = __shfl(it.c, src, 64); g.pos0 = __shfl(it.pos0, src, 64);
+    g.rbase = __shfl(it.rbase, src, 64); g.sx0 = __shfl(it.sx0, src, 64); g.sy0 = __shfl(it.sy0, src, 64);
+    g.sw = __shfl(it.sw, src, 64); g.wc = __shfl(it.wc, src, 64);
+    const uint32_t mlo = __shfl((uint32_t)it.m, src, 64), mhi = __shfl((uint32_t)(it.m >> 32), src, 64);
+    g.m = ((unsigned long long)mhi << 32) | mlo;
+    for (uint32_t q = lane; q < g.c; q += 64) {
+      uint32_t sel = q;
+      if (g.m) {  // masked => c <= 64: drop the q lowest set bits
+        unsigned long long m = g.m;
+        for (uint32_t d = 0; d < q; d++) m &= m - 1ull;
+        sel = (uint32_t)__builtin_ctzll(m);
+      }
+      tkey[g.pos0 + q] = tile_of(g, sel, gsx);
+      tval[g.pos0 + q] = g.rbase + q;
+      gid[g.rbase + q] = g.id;
     }
-    const uint32_t slot = gbase + sidx;
-    tkey[slot] = (sy0 + row) * gsx + sx0 + col;
-    tval[slot] = slot;  // the sort carries the pair slot; gid[] maps it back to the Gaussian
-    gid[slot] = s_id[lo];
   }
 }
 
@@ -321,10 +321,13 @@ __global__ __launch_bounds__(BLK) void pack_colors_kernel(const float* __restric
 }
 
 // ---- tile ranges from the sorted tile ids (identifyTileRanges, rasterizer_impl.cu:116-138) ----
+// Also clears the backward's per-record live flags: which records get written depends only on forward state (lists and
+// n_contrib), so one clear per forward serves every backward over this workspace.
 __global__ __launch_bounds__(BLK) void tile_ranges_kernel(const uint32_t* __restrict__ skeys, uint32_t R,
-                                                          uint2* __restrict__ ranges) {
+                                                          uint2* __restrict__ ranges, uint8_t* __restrict__ live) {
   const uint32_t i = blockIdx.x * BLK + threadIdx.x;
   if (i >= R) return;
+  live[i] = 0;
   const uint32_t cur = skeys[i];
   if (i == 0) ranges[cur].x = 0;
   else {
@@ -340,14 +343,17 @@ __global__ __launch_bounds__(BLK) void tile_ranges_kernel(const uint32_t* __rest
 void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R,
                     const float* colors, hipStream_t s) {
   const uint32_t gsx = (uint32_t)((W + SUBX - 1) / SUBX), gsy = (uint32_t)((H + SUBY - 1) / SUBY);
-  (void)hipMemsetAsync(im.ranges, 0, (size_t)gsx * gsy * sizeof(uint2), s);
-  if (R <= 0) return;
+  if (R <= 0) {
+    (void)hipMemsetAsync(im.ranges, 0, (size_t)gsx * gsy * sizeof(uint2), s);
+    return;
+  }
   hipLaunchKernelGGL(pack_colors_kernel, dim3(ceil_div_u32((uint64_t)P, BLK)), dim3(BLK), 0, s, colors, g.tiles, (uint32_t)P,
                      g.packed);
-  hipLaunchKernelGGL(expand_count_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.svalA, g.tiles, (uint32_t)P, g.blocksum);
+  hipLaunchKernelGGL(expand_count_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.svalA, g.tiles, (uint32_t)P, g.blocksum,
+                     im.ranges, gsx * gsy);
   hipLaunchKernelGGL(expand_scan_kernel, dim3(1), dim3(BLK), 0, s, g.blocksum, g.nblkE);
-  hipLaunchKernelGGL(expand_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.svalA, g.tiles, g.rect, g.mask, g.blocksum, (uint32_t)P,
-                     gsx, gsy, g.slot_base, b.tkeyA, b.tvalA, b.gid);
+  hipLaunchKernelGGL(expand_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.svalA, g.tiles, g.rect, g.mask, g.lpre, g.pblock,
+                     g.blocksum, (uint32_t)P, gsx, gsy, b.tkeyA, b.tvalA, b.gid);
   uint32_t *ka = b.tkeyA, *kb = b.tkeyB, *va = b.tvalA, *vb = b.tvalB;
   int shift = 0;
   for (int pass = 0; pass < b.passes; pass++) {
@@ -358,5 +364,5 @@ void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int
     uint32_t* tv = va; va = vb; vb = tv;
   }
   hipLaunchKernelGGL(tile_ranges_kernel, dim3(ceil_div_u32((uint64_t)R, BLK)), dim3(BLK), 0, s, b.sorted_keys,
-                     (uint32_t)R, im.ranges);
+                     (uint32_t)R, im.ranges, b.live);
 }

@@ -27,7 +27,7 @@
 // ---- radix sort geometry ----
 #define SORTP_ITEMS 8    // depth sort of P Gaussians: 2048 keys per workgroup
 #define SORTR_ITEMS 16   // tile sort of R pairs: 4096 keys per workgroup
-#define EXPAND_ITEMS 4   // expand: 1024 depth-sorted Gaussians per workgroup
+#define EXPAND_ITEMS 1   // expand: 256 depth-sorted Gaussians per workgroup
 
 static inline size_t ws_align(size_t x) { return (x + 255u) & ~(size_t)255u; }
 
@@ -49,7 +49,10 @@ struct GeomWS {
   unsigned long long* mask;  // bit (sy-FY*y0)*FX*(x1-x0) + (sx-FX*x0): internal tile (sx,sy) can reach alpha >= 1/255;
                         // 0 = no mask: every internal tile of the rect (clipped to the image) is listed
   uint32_t* tiles;      // number of internal tiles listed for this Gaussian (0 = none)
-  uint32_t* slot_base;  // first pair slot of this Gaussian in depth-expanded order
+  uint32_t* lpre;       // exclusive prefix of `tiles` inside the Gaussian's preprocess workgroup (256 Gaussians)
+  uint32_t* pblock;     // per preprocess workgroup: total, then (scan_pblock_kernel) exclusive prefix over workgroups.
+                        // record slot of (Gaussian i, its q-th tile) = pblock[i/256] + lpre[i] + q: records are laid out
+                        // in Gaussian-id order, so gaussian_bwd streams them
   uint32_t* skeyA;      // depth-sort ping-pong (keys = depth bits, vals = Gaussian id)
   uint32_t* skeyB;
   uint32_t* svalA;
@@ -71,7 +74,8 @@ static inline GeomWS geom_layout(char* base, int P) {
   o = ws_carve(base, o, g.rect, n);
   o = ws_carve(base, o, g.mask, n);
   o = ws_carve(base, o, g.tiles, n);
-  o = ws_carve(base, o, g.slot_base, n);
+  o = ws_carve(base, o, g.lpre, n);
+  o = ws_carve(base, o, g.pblock, (size_t)ceil_div_u32(n, BLK) + 1);
   o = ws_carve(base, o, g.skeyA, n);
   o = ws_carve(base, o, g.skeyB, n);
   o = ws_carve(base, o, g.svalA, n);
@@ -88,12 +92,12 @@ static inline GeomWS geom_layout(char* base, int P) {
 struct BinWS {
   uint32_t* tkeyA;  // tile ids, ping-pong
   uint32_t* tkeyB;
-  uint32_t* tvalA;  // pair slots (position in depth-expanded order), ping-pong
+  uint32_t* tvalA;  // record slots (Gaussian-id order), ping-pong
   uint32_t* tvalB;
-  uint32_t* gid;    // Gaussian id of each pair slot
+  uint32_t* gid;    // Gaussian id of each record slot
   uint32_t* hist;   // [nbins][nblkR]
   uint32_t* dtotal; // [256]
-  float* records;   // backward scratch: REC floats per pair slot
+  float* records;   // backward scratch: REC floats per record slot (Gaussian-id order, see GeomWS::pblock)
   uint8_t* live;    // backward scratch: 1 = the pair's record was written (dead pairs are never touched)
   uint32_t nblkR;
   int tile_bits, passes, bits_per_pass;
@@ -164,6 +168,7 @@ struct FwdPrepArgs {
 };
 void launch_preprocess_fwd(const FwdPrepArgs& a, const GeomWS& g, hipStream_t s);
 void launch_depth_sort(const GeomWS& g, int P, hipStream_t s);
+void launch_scan_pblock(const GeomWS& g, int P, hipStream_t s);
 void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R,
                     const float* colors, hipStream_t s);
 void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, int W, const float* colors,

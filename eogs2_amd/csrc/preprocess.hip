@@ -116,8 +116,8 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
     const float* __restrict__ cov3D_precomp, const float* __restrict__ opacities, const float* __restrict__ vm,
     float scale_modifier, int antialiasing,
     int* __restrict__ radii, float4* __restrict__ packed, uint2* __restrict__ rect, unsigned long long* __restrict__ mask_out,
-    uint32_t* __restrict__ tiles, uint32_t* __restrict__ skey, uint32_t* __restrict__ sval,
-    uint32_t* __restrict__ misc) {
+    uint32_t* __restrict__ tiles, uint32_t* __restrict__ lpre, uint32_t* __restrict__ pblock,
+    uint32_t* __restrict__ skey, uint32_t* __restrict__ sval, uint32_t* __restrict__ misc) {
   __shared__ float s_m[3 * BLK];
   __shared__ float s_s[3 * BLK];
   __shared__ uint32_t s_cnt[BLK / 64];
@@ -219,16 +219,55 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
     tiles[idx] = my_tiles;
     sval[idx] = (uint32_t)idx;
   }
-  // num_rendered: one 64-bit atomic per workgroup
-  uint32_t v = my_tiles;
+  // exclusive prefix of the tile counts inside the workgroup (record slots in Gaussian-id order) and the
+  // workgroup total; num_rendered: one 64-bit atomic per workgroup
+  uint32_t inc = my_tiles;
+  const int lane = t & 63;
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  if ((t & 63) == 0) s_cnt[t >> 6] = v;
-  __syncthreads();
-  if (t == 0) {
-    unsigned long long tot = (unsigned long long)s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-    if (tot) atomicAdd(reinterpret_cast<unsigned long long*>(misc + MISC_TOTAL_LO), tot);
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t nb = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += nb;
   }
+  if (lane == 63) s_cnt[t >> 6] = inc;
+  __syncthreads();
+  const uint32_t w0 = s_cnt[0], w1 = s_cnt[1], w2 = s_cnt[2], w3 = s_cnt[3];
+  const int w = t >> 6;
+  const uint32_t pre = (w > 0 ? w0 : 0u) + (w > 1 ? w1 : 0u) + (w > 2 ? w2 : 0u);
+  if (t < rows) lpre[idx] = pre + inc - my_tiles;
+  if (t == 0) {
+    const uint32_t tot = w0 + w1 + w2 + w3;
+    pblock[blockIdx.x] = tot;
+    if (tot) atomicAdd(reinterpret_cast<unsigned long long*>(misc + MISC_TOTAL_LO), (unsigned long long)tot);
+  }
+}
+
+// exclusive scan of the per-workgroup totals (single workgroup; P/256 entries)
+__global__ __launch_bounds__(BLK) void scan_pblock_kernel(uint32_t* __restrict__ pblock, uint32_t nblk) {
+  __shared__ uint32_t s_w[4];
+  uint32_t carry = 0;
+  for (uint32_t b0 = 0; b0 < nblk; b0 += BLK) {
+    const uint32_t i = b0 + threadIdx.x;
+    const uint32_t v = i < nblk ? pblock[i] : 0u;
+    uint32_t inc = v;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t nb = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += nb;
+    }
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    const uint32_t w0 = s_w[0], w1 = s_w[1], w2 = s_w[2], w3 = s_w[3];
+    const uint32_t pre = (w > 0 ? w0 : 0u) + (w > 1 ? w1 : 0u) + (w > 2 ? w2 : 0u);
+    __syncthreads();
+    if (i < nblk) pblock[i] = carry + pre + inc - v;
+    carry += w0 + w1 + w2 + w3;
+  }
+  if (threadIdx.x == 0) pblock[nblk] = carry;
+}
+
+void launch_scan_pblock(const GeomWS& g, int P, hipStream_t s) {
+  hipLaunchKernelGGL(scan_pblock_kernel, dim3(1), dim3(BLK), 0, s, g.pblock, ceil_div_u32((uint64_t)P, BLK));
 }
 
 void launch_preprocess_fwd(const FwdPrepArgs& a, const GeomWS& g, hipStream_t s) {
@@ -236,7 +275,7 @@ void launch_preprocess_fwd(const FwdPrepArgs& a, const GeomWS& g, hipStream_t s)
   const uint32_t nblk = ceil_div_u32((uint64_t)a.P, BLK);
   hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nblk), dim3(BLK), 0, s, a.P, a.H, a.W, gx, gy, a.means3D, a.scales,
                      a.rotations, a.cov3D_precomp, a.opacities, a.viewmatrix, a.scale_modifier, (int)a.antialiasing,
-                     a.radii, g.packed, g.rect, g.mask, g.tiles, g.skeyA, g.svalA, g.misc);
+                     a.radii, g.packed, g.rect, g.mask, g.tiles, g.lpre, g.pblock, g.skeyA, g.svalA, g.misc);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -247,7 +286,8 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
     const float* __restrict__ means3D, const float* __restrict__ scales, const float* __restrict__ rotations,
     const float* __restrict__ cov3D_precomp, const float* __restrict__ opacities, const float* __restrict__ vm,
     const float* __restrict__ proj, const int* __restrict__ radii, float scale_modifier, int antialiasing,
-    const uint32_t* __restrict__ tiles, const uint32_t* __restrict__ slot_base, const float* __restrict__ records,
+    const uint32_t* __restrict__ tiles, const uint32_t* __restrict__ lpre, const uint32_t* __restrict__ pblock,
+    const float* __restrict__ records,
     const uint8_t* __restrict__ live,
     float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscales,
@@ -275,7 +315,7 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
     if (visible) {
       // fixed-order sum of this Gaussian's (tile,Gaussian) records: deterministic, no atomics
       const uint32_t n = tiles[idx];
-      const size_t s0 = slot_base[idx];
+      const size_t s0 = (size_t)pblock[blockIdx.x] + lpre[idx];  // Gaussian-id order: a wave reads one contiguous region
       const float4* r4 = reinterpret_cast<const float4*>(records + s0 * REC);
       for (uint32_t q = 0; q < n; q++) {
         if (!live[s0 + q]) continue;  // pair behind every pixel's last contributor: no record was written
@@ -460,6 +500,6 @@ void launch_gaussian_bwd(const GaussBwdArgs& a, const GeomWS& g, const BinWS& b,
   const uint32_t nblk = ceil_div_u32((uint64_t)a.P, BLK);
   hipLaunchKernelGGL(gaussian_bwd_kernel, dim3(nblk), dim3(BLK), 0, s, a.P, a.H, a.W, a.means3D, a.scales, a.rotations,
                      a.cov3D_precomp, a.opacities, a.viewmatrix, a.projmatrix, a.radii, a.scale_modifier,
-                     (int)a.antialiasing, g.tiles, g.slot_base, b.records, b.live, a.dL_dmeans2D, a.dL_dcolors, a.dL_dopacity,
+                     (int)a.antialiasing, g.tiles, g.lpre, g.pblock, b.records, b.live, a.dL_dmeans2D, a.dL_dcolors, a.dL_dopacity,
                      a.dL_dmeans3D, a.dL_dcov3D, a.dL_dscales, a.dL_drotations, a.dL_dT_sum, a.dL_dvm_mean);
 }

@@ -377,7 +377,7 @@ void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, 
                        const float* out_color, const float* out_invdepth, const float* dL_dcolor,
                        const float* dL_dinvdepth, hipStream_t s) {
   const int gsx = (W + SUBX - 1) / SUBX, gsy = (H + SUBY - 1) / SUBY, ntiles = gsx * gsy;
-  (void)hipMemsetAsync(b.live, 0, (size_t)R, s);
+  (void)R;  // live flags are cleared once per forward (tile_ranges_kernel)
   hipLaunchKernelGGL(render_bwd_kernel, dim3(render_grid(ntiles)), dim3(BLK), 0, s, im.ranges, b.point_list, b.gid, W, H,
                      gsx, ntiles, g.packed, im.n_contrib, out_color, out_invdepth, dL_dcolor, dL_dinvdepth, b.records,
                      b.live);
