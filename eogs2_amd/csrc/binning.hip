@@ -92,11 +92,11 @@ __global__ __launch_bounds__(BLK) void radix_rowscan_kernel(uint32_t* __restrict
 // workgroup's sorted order and each wave's offset inside the digit; keys and payloads are then placed in LDS in
 // sorted order and streamed out so that consecutive lanes write consecutive addresses inside each digit run.
 // Stable: (wave segment, chunk, lane) order is index order.
-template <int ITEMS>
+template <int ITEMS, typename VT>
 __global__ __launch_bounds__(BLK) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
-                                                            const uint32_t* __restrict__ vals_in,
+                                                            const VT* __restrict__ vals_in,
                                                             uint32_t* __restrict__ keys_out,
-                                                            uint32_t* __restrict__ vals_out, uint32_t n, int shift,
+                                                            VT* __restrict__ vals_out, uint32_t n, int shift,
                                                             int nbits, const uint32_t* __restrict__ hist,
                                                             uint32_t nblk, const uint32_t* __restrict__ dtotal) {
   constexpr int NW = BLK / 64, SEG = 64 * ITEMS, TILE_KEYS = BLK * ITEMS;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(BLK) void radix_scatter_kernel(const uint32_t* __re
   __shared__ uint32_t s_dstart[256];    // start of each digit in the workgroup's sorted order
   __shared__ uint32_t s_wcnt[NW][256];  // per-wave digit counts -> per-wave offset inside the digit
   __shared__ uint32_t s_key[TILE_KEYS];
-  __shared__ uint32_t s_val[TILE_KEYS];
+  __shared__ VT s_val[TILE_KEYS];
   __shared__ uint32_t s_w[4];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const uint32_t mask = (1u << nbits) - 1u;
@@ -114,12 +114,13 @@ __global__ __launch_bounds__(BLK) void radix_scatter_kernel(const uint32_t* __re
 
   const uint32_t base = blockIdx.x * (uint32_t)TILE_KEYS + (uint32_t)w * SEG;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  uint32_t key[ITEMS], val[ITEMS], lrank[ITEMS];
+  uint32_t key[ITEMS], lrank[ITEMS];
+  VT val[ITEMS];
 #pragma unroll
   for (int i = 0; i < ITEMS; i++) {
     const uint32_t k = base + i * 64 + lane;
     key[i] = k < n ? keys_in[k] : 0xFFFFFFFFu;
-    val[i] = k < n ? vals_in[k] : 0u;
+    if (k < n) val[i] = vals_in[k];
   }
 #pragma unroll
   for (int i = 0; i < ITEMS; i++) {
@@ -176,13 +177,13 @@ __global__ __launch_bounds__(BLK) void radix_scatter_kernel(const uint32_t* __re
   }
 }
 
-template <int ITEMS>
-static void radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, uint32_t n, int shift,
+template <int ITEMS, typename VT>
+static void radix_pass(const uint32_t* kin, const VT* vin, uint32_t* kout, VT* vout, uint32_t n, int shift,
                        int nbits, uint32_t* hist, uint32_t nblk, uint32_t* dtotal, hipStream_t s) {
   const uint32_t mask = (1u << nbits) - 1u;
   hipLaunchKernelGGL((radix_hist_kernel<ITEMS>), dim3(nblk), dim3(BLK), 0, s, kin, n, shift, mask, hist, nblk);
   hipLaunchKernelGGL(radix_rowscan_kernel, dim3(mask + 1), dim3(BLK), 0, s, hist, nblk, dtotal);
-  hipLaunchKernelGGL((radix_scatter_kernel<ITEMS>), dim3(nblk), dim3(BLK), 0, s, kin, vin, kout, vout, n, shift, nbits,
+  hipLaunchKernelGGL((radix_scatter_kernel<ITEMS, VT>), dim3(nblk), dim3(BLK), 0, s, kin, vin, kout, vout, n, shift, nbits,
                      hist, nblk, dtotal);
 }
 
@@ -190,7 +191,7 @@ static void radix_pass(const uint32_t* kin, const uint32_t* vin, uint32_t* kout,
 void launch_depth_sort(const GeomWS& g, int P, hipStream_t s) {
   uint32_t *ka = g.skeyA, *kb = g.skeyB, *va = g.svalA, *vb = g.svalB;
   for (int pass = 0; pass < 4; pass++) {
-    radix_pass<SORTP_ITEMS>(ka, va, kb, vb, (uint32_t)P, 8 * pass, 8, g.hist, g.nblkP, g.dtotal, s);
+    radix_pass<SORTP_ITEMS, uint32_t>(ka, va, kb, vb, (uint32_t)P, 8 * pass, 8, g.hist, g.nblkP, g.dtotal, s);
     uint32_t* tk = ka; ka = kb; kb = tk;
     uint32_t* tv = va; va = vb; vb = tv;
   }
@@ -228,7 +229,8 @@ __global__ __launch_bounds__(BLK) void expand_scan_kernel(uint32_t* __restrict__
 // ---- expand step C: emission of (internal tile id, record slot) in depth order ----
 // One lane per depth-sorted Gaussian. The q-th listed tile of a Gaussian is the q-th set bit of its hit mask
 // (walked incrementally: ctz, clear lowest bit) or, for unmasked Gaussians, the q-th tile of its clipped rect.
-// Output position = depth-order offset (exclusive scan of the counts); payload = record slot in Gaussian-id order.
+// Output position = depth-order offset (exclusive scan of the counts); payload = {Gaussian id, record slot in
+// Gaussian-id order}, carried through the tile sort so the render kernels read both with one coalesced load.
 // Gaussians with more than 32 tiles are emitted by the whole wave, one after the other.
 struct ExpandItem {
   uint32_t id, c, pos0, rbase, sx0, sy0, sw, wc;
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint32_t* __restrict_
                                                      const uint32_t* __restrict__ pblock,
                                                      const uint32_t* __restrict__ blocksum, uint32_t P, uint32_t gsx,
                                                      uint32_t gsy, uint32_t* __restrict__ tkey,
-                                                     uint32_t* __restrict__ tval, uint32_t* __restrict__ gid) {
+                                                     uint2* __restrict__ tval) {
   __shared__ uint32_t s_w[4];
   const int lane = threadIdx.x & 63;
   const uint32_t k = blockIdx.x * BLK + threadIdx.x;
@@ -278,8 +280,7 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint32_t* __restrict_
         m &= m - 1ull;
       }
       tkey[it.pos0 + q] = tile_of(it, sel, gsx);
-      tval[it.pos0 + q] = it.rbase + q;
-      gid[it.rbase + q] = it.id;
+      tval[it.pos0 + q] = make_uint2(it.id, it.rbase + q);
     }
   }
   // large Gaussians: the wave emits them cooperatively, 64 pairs per step
@@ -301,8 +302,7 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint32_t* __restrict_
         sel = (uint32_t)__builtin_ctzll(m);
       }
       tkey[g.pos0 + q] = tile_of(g, sel, gsx);
-      tval[g.pos0 + q] = g.rbase + q;
-      gid[g.rbase + q] = g.id;
+      tval[g.pos0 + q] = make_uint2(g.id, g.rbase + q);
     }
   }
 }
@@ -353,15 +353,16 @@ void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int
                      im.ranges, gsx * gsy);
   hipLaunchKernelGGL(expand_scan_kernel, dim3(1), dim3(BLK), 0, s, g.blocksum, g.nblkE);
   hipLaunchKernelGGL(expand_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.svalA, g.tiles, g.rect, g.mask, g.lpre, g.pblock,
-                     g.blocksum, (uint32_t)P, gsx, gsy, b.tkeyA, b.tvalA, b.gid);
-  uint32_t *ka = b.tkeyA, *kb = b.tkeyB, *va = b.tvalA, *vb = b.tvalB;
+                     g.blocksum, (uint32_t)P, gsx, gsy, b.tkeyA, b.tvalA);
+  uint32_t *ka = b.tkeyA, *kb = b.tkeyB;
+  uint2 *va = b.tvalA, *vb = b.tvalB;
   int shift = 0;
   for (int pass = 0; pass < b.passes; pass++) {
     const int nbits = (b.tile_bits - shift) < b.bits_per_pass ? (b.tile_bits - shift) : b.bits_per_pass;
-    radix_pass<SORTR_ITEMS>(ka, va, kb, vb, (uint32_t)R, shift, nbits, b.hist, b.nblkR, b.dtotal, s);
+    radix_pass<SORTR_ITEMS, uint2>(ka, va, kb, vb, (uint32_t)R, shift, nbits, b.hist, b.nblkR, b.dtotal, s);
     shift += nbits;
     uint32_t* tk = ka; ka = kb; kb = tk;
-    uint32_t* tv = va; va = vb; vb = tv;
+    uint2* tv = va; va = vb; vb = tv;
   }
   hipLaunchKernelGGL(tile_ranges_kernel, dim3(ceil_div_u32((uint64_t)R, BLK)), dim3(BLK), 0, s, b.sorted_keys,
                      (uint32_t)R, im.ranges, b.live);

@@ -26,7 +26,7 @@
 
 // ---- radix sort geometry ----
 #define SORTP_ITEMS 8    // depth sort of P Gaussians: 2048 keys per workgroup
-#define SORTR_ITEMS 16   // tile sort of R pairs: 4096 keys per workgroup
+#define SORTR_ITEMS 8    // tile sort of R pairs: 2048 keys per workgroup (12-byte items: key + {id, slot})
 #define EXPAND_ITEMS 1   // expand: 256 depth-sorted Gaussians per workgroup
 
 static inline size_t ws_align(size_t x) { return (x + 255u) & ~(size_t)255u; }
@@ -92,16 +92,15 @@ static inline GeomWS geom_layout(char* base, int P) {
 struct BinWS {
   uint32_t* tkeyA;  // tile ids, ping-pong
   uint32_t* tkeyB;
-  uint32_t* tvalA;  // record slots (Gaussian-id order), ping-pong
-  uint32_t* tvalB;
-  uint32_t* gid;    // Gaussian id of each record slot
+  uint2* tvalA;     // payload {Gaussian id, record slot (Gaussian-id order)}, ping-pong
+  uint2* tvalB;
   uint32_t* hist;   // [nbins][nblkR]
   uint32_t* dtotal; // [256]
   float* records;   // backward scratch: REC floats per record slot (Gaussian-id order, see GeomWS::pblock)
   uint8_t* live;    // backward scratch: 1 = the pair's record was written (dead pairs are never touched)
   uint32_t nblkR;
   int tile_bits, passes, bits_per_pass;
-  uint32_t* point_list;  // = tval buffer holding the sorted result
+  uint2* point_list;     // = tval buffer holding the sorted result: per list entry {Gaussian id, record slot}
   uint32_t* sorted_keys; // = tkey buffer holding the sorted result
   size_t bytes;
 };
@@ -124,7 +123,6 @@ static inline BinWS bin_layout(char* base, int H, int W, int64_t R) {
   o = ws_carve(base, o, b.tkeyB, n);
   o = ws_carve(base, o, b.tvalA, n);
   o = ws_carve(base, o, b.tvalB, n);
-  o = ws_carve(base, o, b.gid, n);
   o = ws_carve(base, o, b.hist, (size_t)256 * (b.nblkR ? b.nblkR : 1));
   o = ws_carve(base, o, b.dtotal, 256);
   o = ws_carve(base, o, b.records, n * REC);

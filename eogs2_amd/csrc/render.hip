@@ -81,14 +81,15 @@ struct Cand {
   uint32_t slot;
 };
 
-__device__ inline Cand load_cand(uint32_t k, uint32_t end, const uint32_t* __restrict__ point_list,
-                                 const uint32_t* __restrict__ gid, const float4* __restrict__ packed) {
+__device__ inline Cand load_cand(uint32_t k, uint32_t end, const uint2* __restrict__ point_list,
+                                 const float4* __restrict__ packed) {
   Cand c;
   c.q0 = c.q1 = c.q2 = make_float4(0.f, 0.f, 0.f, 0.f);
   c.slot = 0;
   if (k < end) {
-    c.slot = point_list[k];
-    const float4* r = packed + 4 * (size_t)gid[c.slot];  // one 64-byte line per list entry
+    const uint2 e = point_list[k];  // {Gaussian id, record slot}: one coalesced 8-byte load per lane
+    c.slot = e.y;
+    const float4* r = packed + 4 * (size_t)e.x;  // one 64-byte line per list entry
     c.q0 = r[0]; c.q1 = r[1]; c.q2 = r[2];
   }
   return c;
@@ -115,8 +116,7 @@ __device__ inline Ent fetch(const float* slab, int j) {
 }  // namespace
 
 __global__ __launch_bounds__(BLK) void render_fwd_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ gid,
-    int W, int H, int gsx, int ntiles, const float4* __restrict__ packed, const float* __restrict__ bg,
+    const uint2* __restrict__ ranges, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, const float4* __restrict__ packed, const float* __restrict__ bg,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
     float* __restrict__ out_invdepth) {
   __shared__ __attribute__((aligned(16))) float s_slab[BLK / 64][64 * ENT];
@@ -136,11 +136,11 @@ __global__ __launch_bounds__(BLK) void render_fwd_kernel(
   float invd = 0.f;
   bool done = !inside;
 
-  Cand nxt = load_cand(range.x + lane, range.y, point_list, gid, packed);
+  Cand nxt = load_cand(range.x + lane, range.y, point_list, packed);
   for (uint32_t c0 = range.x; c0 < range.y; c0 += 64) {
     wave_lds_sync();  // previous chunk's reads are done
     park(slab, lane, nxt);
-    nxt = load_cand(c0 + 64 + lane, range.y, point_list, gid, packed);  // in flight during this chunk
+    nxt = load_cand(c0 + 64 + lane, range.y, point_list, packed);  // in flight during this chunk
     wave_lds_sync();
     if (__ballot(!done) == 0ull) break;  // every pixel of the tile has terminated
     const int n = (int)((range.y - c0) < 64u ? (range.y - c0) : 64u);
@@ -193,7 +193,7 @@ static inline uint32_t render_grid(int ntiles) {
 void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, int W, const float* colors,
                        const float* bg, float* out_color, float* out_invdepth, hipStream_t s) {
   const int gsx = (W + SUBX - 1) / SUBX, gsy = (H + SUBY - 1) / SUBY, ntiles = gsx * gsy;
-  hipLaunchKernelGGL(render_fwd_kernel, dim3(render_grid(ntiles)), dim3(BLK), 0, s, im.ranges, b.point_list, b.gid, W, H,
+  hipLaunchKernelGGL(render_fwd_kernel, dim3(render_grid(ntiles)), dim3(BLK), 0, s, im.ranges, b.point_list, W, H,
                      gsx, ntiles, g.packed, bg, im.final_T, im.n_contrib, out_color, out_invdepth);
 }
 
@@ -261,8 +261,7 @@ __device__ inline void transpose_round(int nsurv, int lane, const float* slab, c
 }  // namespace
 
 __global__ __launch_bounds__(BLK) void render_bwd_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ gid,
-    int W, int H, int gsx, int ntiles, const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib,
+    const uint2* __restrict__ ranges, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ out_color, const float* __restrict__ out_invdepth, const float* __restrict__ dL_dpix,
     const float* __restrict__ dL_dinv, float* __restrict__ records, uint8_t* __restrict__ live_flag) {
   __shared__ __attribute__((aligned(16))) float s_slab[BLK / 64][64 * ENT];
@@ -316,12 +315,12 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
 
   // the list is only walked up to the last contributor: pairs behind it are dead (never gathered, never written)
   const uint32_t end = range.x + tile_last < range.y ? range.x + tile_last : range.y;
-  Cand nxt = load_cand(range.x + lane, end, point_list, gid, packed);
+  Cand nxt = load_cand(range.x + lane, end, point_list, packed);
   for (uint32_t c0 = range.x; c0 < end; c0 += 64) {
     wave_lds_sync();
     park(slab, lane, nxt);
     sslot[lane] = nxt.slot;
-    nxt = load_cand(c0 + 64 + lane, end, point_list, gid, packed);
+    nxt = load_cand(c0 + 64 + lane, end, point_list, packed);
     wave_lds_sync();
     const int jn = (int)((end - c0) < 64u ? (end - c0) : 64u);
     const uint32_t jbase = c0 - range.x;
@@ -378,7 +377,7 @@ void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, 
                        const float* dL_dinvdepth, hipStream_t s) {
   const int gsx = (W + SUBX - 1) / SUBX, gsy = (H + SUBY - 1) / SUBY, ntiles = gsx * gsy;
   (void)R;  // live flags are cleared once per forward (tile_ranges_kernel)
-  hipLaunchKernelGGL(render_bwd_kernel, dim3(render_grid(ntiles)), dim3(BLK), 0, s, im.ranges, b.point_list, b.gid, W, H,
+  hipLaunchKernelGGL(render_bwd_kernel, dim3(render_grid(ntiles)), dim3(BLK), 0, s, im.ranges, b.point_list, W, H,
                      gsx, ntiles, g.packed, im.n_contrib, out_color, out_invdepth, dL_dcolor, dL_dinvdepth, b.records,
                      b.live);
 }
