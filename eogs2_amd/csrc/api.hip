@@ -111,8 +111,9 @@ int eogs_rast_binning_bytes(int P, int H, int W, int64_t R, size_t* bytes) {
 }
 
 int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const float* scales, const float* rotations,
-                              const float* cov3D_precomp, const float* opacities, float scale_modifier,
-                              const float* viewmatrix, const float* projmatrix, unsigned flags, int* radii, void* geom,
+                              const float* cov3D_precomp, const float* opacities, const float* colors,
+                              float scale_modifier, const float* viewmatrix, const float* projmatrix, unsigned flags,
+                              int* radii, void* geom,
                               size_t geom_bytes, int64_t* num_rendered, void* stream) {
   (void)projmatrix;
   g_err[0] = 0;
@@ -122,6 +123,7 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
   if (((W + TILE - 1) / TILE) > 32767 || ((H + TILE - 1) / TILE) > 32767)
     return fail(EOGS_ERR_INVALID_ARG, "forward_prepare: image too large for 16-bit internal tile coordinates");
   if (!means3D || !opacities || !viewmatrix || !radii || !geom) return fail(EOGS_ERR_INVALID_ARG, "forward_prepare: NULL input");
+  if (!colors) return fail(EOGS_ERR_NO_COLORS, "For non-RGB, provide precomputed Gaussian colors!");
   const bool have_sr = scales && rotations, have_cov = cov3D_precomp != nullptr;
   if (have_sr == have_cov || (!!scales != !!rotations))
     return fail(EOGS_ERR_INVALID_ARG,
@@ -135,7 +137,7 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
   if (!g_pinned) HIP_TRY(hipHostMalloc((void**)&g_pinned, MISC_WORDS * sizeof(uint32_t), hipHostMallocDefault));
 
   HIP_TRY(hipMemsetAsync(g.misc, 0, MISC_WORDS * sizeof(uint32_t), s));
-  FwdPrepArgs a{P, H, W, means3D, scales, rotations, cov3D_precomp, opacities, viewmatrix, scale_modifier,
+  FwdPrepArgs a{P, H, W, means3D, scales, rotations, cov3D_precomp, opacities, colors, viewmatrix, scale_modifier,
                 (flags & EOGS_FLAG_ANTIALIASING) != 0, radii};
   { ProfScope ps(PS_PREPROCESS, s); launch_preprocess_fwd(a, g, s); launch_scan_pblock(g, P, s); }
   LAUNCH_TRY(s, debug, "preprocess_fwd");
@@ -151,13 +153,12 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
   return EOGS_OK;
 }
 
-int eogs_rast_forward_render(int P, int H, int W, int64_t R, const float* colors, const float* bg, unsigned flags,
+int eogs_rast_forward_render(int P, int H, int W, int64_t R, const float* bg, unsigned flags,
                              void* geom, size_t geom_bytes, void* binning, size_t binning_bytes, void* image,
                              size_t image_bytes, float* out_color, float* out_invdepth, void* stream) {
   g_err[0] = 0;
   if (P < 0 || H <= 0 || W <= 0 || R < 0 || !out_color || !bg || !image)
     return fail(EOGS_ERR_INVALID_ARG, "forward_render: bad argument");
-  if (P > 0 && !colors) return fail(EOGS_ERR_NO_COLORS, "For non-RGB, provide precomputed Gaussian colors!");
   if (R > 0 && (P == 0 || !geom || !binning)) return fail(EOGS_ERR_INVALID_ARG, "forward_render: NULL workspace");
   hipStream_t s = (hipStream_t)stream;
   const bool debug = flags & EOGS_FLAG_DEBUG;
@@ -179,9 +180,9 @@ int eogs_rast_forward_render(int P, int H, int W, int64_t R, const float* colors
     if ((size_t)(bb - (char*)binning) + b.bytes - 256 > binning_bytes)
       return fail(EOGS_ERR_WORKSPACE, "forward_render: binning workspace too small");
   }
-  { ProfScope ps(PS_BINNING, s); launch_binning(g, b, im, P, H, W, R, colors, s); }
+  { ProfScope ps(PS_BINNING, s); launch_binning(g, b, im, P, H, W, R, s); }
   LAUNCH_TRY(s, debug, "binning");
-  { ProfScope ps(PS_RENDER_FWD, s); launch_render_fwd(g, b, im, H, W, colors, bg, out_color, out_invdepth, s); }
+  { ProfScope ps(PS_RENDER_FWD, s); launch_render_fwd(g, b, im, H, W, bg, out_color, out_invdepth, s); }
   LAUNCH_TRY(s, debug, "render_fwd");
   return EOGS_OK;
 }

@@ -232,6 +232,7 @@ __global__ __launch_bounds__(BLK) void expand_scan_kernel(uint32_t* __restrict__
 // Output position = depth-order offset (exclusive scan of the counts); payload = {Gaussian id, record slot in
 // Gaussian-id order}, carried through the tile sort so the render kernels read both with one coalesced load.
 // Gaussians with more than 32 tiles are emitted by the whole wave, one after the other.
+#define EXPAND_STAGE 3072  // pairs a workgroup of 256 Gaussians can stage in LDS (36 KB)
 struct ExpandItem {
   uint32_t id, c, pos0, rbase, sx0, sy0, sw, wc;
   unsigned long long m;
@@ -251,6 +252,8 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint32_t* __restrict_
                                                      uint32_t gsy, uint32_t* __restrict__ tkey,
                                                      uint2* __restrict__ tval) {
   __shared__ uint32_t s_w[4];
+  __shared__ uint32_t s_tk[EXPAND_STAGE];
+  __shared__ uint2 s_tv[EXPAND_STAGE];
   const int lane = threadIdx.x & 63;
   const uint32_t k = blockIdx.x * BLK + threadIdx.x;
   ExpandItem it;
@@ -269,6 +272,32 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint32_t* __restrict_
     const uint32_t sx1 = FX * x1 < gsx ? FX * x1 : gsx;
     it.wc = sx1 - it.sx0;
     it.rbase = pblock[it.id / BLK] + lpre[it.id];
+  }
+  // Workgroups whose pairs fit the LDS stage (the common case: ~4 pairs per Gaussian) place them there at their
+  // workgroup-local position and stream them out with consecutive lanes writing consecutive addresses.
+  const uint32_t wg0 = blocksum[blockIdx.x];
+  // workgroup-uniform; Gaussians with many tiles go through the wave-cooperative path below instead
+  const bool staged = !__syncthreads_or(it.c > 64u) && tot <= (uint32_t)EXPAND_STAGE;
+  if (staged) {
+    if (it.c) {
+      unsigned long long m = it.m;
+      const uint32_t l0 = it.pos0 - wg0;
+      for (uint32_t q = 0; q < it.c; q++) {
+        uint32_t sel = q;
+        if (it.m) {
+          sel = (uint32_t)__builtin_ctzll(m);
+          m &= m - 1ull;
+        }
+        s_tk[l0 + q] = tile_of(it, sel, gsx);
+        s_tv[l0 + q] = make_uint2(it.id, it.rbase + q);
+      }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < tot; i += BLK) {
+      tkey[wg0 + i] = s_tk[i];
+      tval[wg0 + i] = s_tv[i];
+    }
+    return;
   }
   // small Gaussians: every lane emits its own pairs
   if (it.c && it.c <= 32u) {
@@ -307,19 +336,6 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint32_t* __restrict_
   }
 }
 
-// ---- colours into the per-Gaussian render record (floats 6..10 of the 64-byte line) ----
-__global__ __launch_bounds__(BLK) void pack_colors_kernel(const float* __restrict__ colors,
-                                                          const uint32_t* __restrict__ tiles, uint32_t P,
-                                                          float4* __restrict__ packed) {
-  const uint32_t i = blockIdx.x * BLK + threadIdx.x;
-  if (i >= P || tiles[i] == 0) return;
-  const float* c = colors + (size_t)i * NCH;
-  float* dst = reinterpret_cast<float*>(packed + 4 * (size_t)i);
-  const float c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3], c4 = c[4];
-  *reinterpret_cast<float2*>(dst + 6) = make_float2(c0, c1);
-  dst[8] = c2; dst[9] = c3; dst[10] = c4;
-}
-
 // ---- tile ranges from the sorted tile ids (identifyTileRanges, rasterizer_impl.cu:116-138) ----
 // Also clears the backward's per-record live flags: which records get written depends only on forward state (lists and
 // n_contrib), so one clear per forward serves every backward over this workspace.
@@ -340,15 +356,12 @@ __global__ __launch_bounds__(BLK) void tile_ranges_kernel(const uint32_t* __rest
   if (i == R - 1) ranges[cur].y = R;
 }
 
-void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R,
-                    const float* colors, hipStream_t s) {
+void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, hipStream_t s) {
   const uint32_t gsx = (uint32_t)((W + SUBX - 1) / SUBX), gsy = (uint32_t)((H + SUBY - 1) / SUBY);
   if (R <= 0) {
     (void)hipMemsetAsync(im.ranges, 0, (size_t)gsx * gsy * sizeof(uint2), s);
     return;
   }
-  hipLaunchKernelGGL(pack_colors_kernel, dim3(ceil_div_u32((uint64_t)P, BLK)), dim3(BLK), 0, s, colors, g.tiles, (uint32_t)P,
-                     g.packed);
   hipLaunchKernelGGL(expand_count_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.svalA, g.tiles, (uint32_t)P, g.blocksum,
                      im.ranges, gsx * gsy);
   hipLaunchKernelGGL(expand_scan_kernel, dim3(1), dim3(BLK), 0, s, g.blocksum, g.nblkE);

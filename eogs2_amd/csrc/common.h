@@ -159,7 +159,7 @@ static inline char* ws_base(const void* p) {  // round the caller's pointer up t
 // ---- launch entry points implemented in the .hip files (host functions) ----
 struct FwdPrepArgs {
   int P, H, W;
-  const float *means3D, *scales, *rotations, *cov3D_precomp, *opacities, *viewmatrix;
+  const float *means3D, *scales, *rotations, *cov3D_precomp, *opacities, *colors, *viewmatrix;
   float scale_modifier;
   bool antialiasing;
   int* radii;
@@ -167,9 +167,8 @@ struct FwdPrepArgs {
 void launch_preprocess_fwd(const FwdPrepArgs& a, const GeomWS& g, hipStream_t s);
 void launch_depth_sort(const GeomWS& g, int P, hipStream_t s);
 void launch_scan_pblock(const GeomWS& g, int P, hipStream_t s);
-void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R,
-                    const float* colors, hipStream_t s);
-void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, int W, const float* colors,
+void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, hipStream_t s);
+void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, int W,
                        const float* bg, float* out_color, float* out_invdepth, hipStream_t s);
 void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, int W, int64_t R, const float* colors,
                        const float* out_color, const float* out_invdepth, const float* dL_dcolor,

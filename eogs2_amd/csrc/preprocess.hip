@@ -113,8 +113,8 @@ __device__ inline float wave_sum(float v) {
 __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
     int P, int H, int W, int gx, int gy,
     const float* __restrict__ means3D, const float* __restrict__ scales, const float* __restrict__ rotations,
-    const float* __restrict__ cov3D_precomp, const float* __restrict__ opacities, const float* __restrict__ vm,
-    float scale_modifier, int antialiasing,
+    const float* __restrict__ cov3D_precomp, const float* __restrict__ opacities, const float* __restrict__ colors,
+    const float* __restrict__ vm, float scale_modifier, int antialiasing,
     int* __restrict__ radii, float4* __restrict__ packed, uint2* __restrict__ rect, unsigned long long* __restrict__ mask_out,
     uint32_t* __restrict__ tiles, uint32_t* __restrict__ lpre, uint32_t* __restrict__ pblock,
     uint32_t* __restrict__ skey, uint32_t* __restrict__ sval, uint32_t* __restrict__ misc) {
@@ -203,11 +203,13 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
           my_tiles = (uint32_t)((sx1 - sx0) * (sy1 - sy0));
         }
         if (my_tiles) {
-          // render record (one 64-byte line); the colour slots are filled by pack_colors_kernel
+          // render record: one whole 64-byte line per Gaussian
           const float L2E = 1.4426950408889634f;
+          const float* f = colors + NCH * idx;
           packed[4 * idx + 0] = make_float4(px, py, ca * (-0.5f * L2E), cb * L2E);
-          packed[4 * idx + 1] = make_float4(cc * (-0.5f * L2E), op, 0.f, 0.f);
-          packed[4 * idx + 2] = make_float4(0.f, 0.f, 0.f, 1.f / d);
+          packed[4 * idx + 1] = make_float4(cc * (-0.5f * L2E), op, f[0], f[1]);
+          packed[4 * idx + 2] = make_float4(f[2], f[3], f[4], 1.f / d);
+          packed[4 * idx + 3] = make_float4(0.f, 0.f, 0.f, 0.f);
           rect[idx] = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16));
           mask_out[idx] = m;
           skey[idx] = __float_as_uint(d);
@@ -274,7 +276,7 @@ void launch_preprocess_fwd(const FwdPrepArgs& a, const GeomWS& g, hipStream_t s)
   const int gx = (a.W + TILE - 1) / TILE, gy = (a.H + TILE - 1) / TILE;
   const uint32_t nblk = ceil_div_u32((uint64_t)a.P, BLK);
   hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nblk), dim3(BLK), 0, s, a.P, a.H, a.W, gx, gy, a.means3D, a.scales,
-                     a.rotations, a.cov3D_precomp, a.opacities, a.viewmatrix, a.scale_modifier, (int)a.antialiasing,
+                     a.rotations, a.cov3D_precomp, a.opacities, a.colors, a.viewmatrix, a.scale_modifier, (int)a.antialiasing,
                      a.radii, g.packed, g.rect, g.mask, g.tiles, g.lpre, g.pblock, g.skeyA, g.svalA, g.misc);
 }
 

@@ -72,8 +72,8 @@ __device__ inline int tile_of_wave() {
   return grp * (BLK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 }
 
-// One list entry as gathered by a lane: the Gaussian's 64-byte render record written by preprocess_fwd_kernel and
-// pack_colors_kernel (conic pre-scaled by log2 e: alpha = o 2^p, p = (A dx - B dy) dx + C dy^2).
+// One list entry as gathered by a lane: the Gaussian's 64-byte render record written by preprocess_fwd_kernel
+// (conic pre-scaled by log2 e: alpha = o 2^p, p = (A dx - B dy) dx + C dy^2).
 struct Cand {
   float4 q0;  // gx gy A B
   float4 q1;  // C op f0 f1
@@ -190,7 +190,7 @@ static inline uint32_t render_grid(int ntiles) {
   return ((groups + 7u) / 8u) * 8u;  // multiple of 8 for the XCD band mapping
 }
 
-void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, int W, const float* colors,
+void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, int W,
                        const float* bg, float* out_color, float* out_invdepth, hipStream_t s) {
   const int gsx = (W + SUBX - 1) / SUBX, gsy = (H + SUBY - 1) / SUBY, ntiles = gsx * gsy;
   hipLaunchKernelGGL(render_fwd_kernel, dim3(render_grid(ntiles)), dim3(BLK), 0, s, im.ranges, b.point_list, W, H,

@@ -181,7 +181,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 R = ctypes.c_int64()
                 abi.check(
                     abi.forward_prepare(
-                        P, H, W, _ptr(m3), _ptr(sc), _ptr(rot), _ptr(cov), _ptr(opa),
+                        P, H, W, _ptr(m3), _ptr(sc), _ptr(rot), _ptr(cov), _ptr(opa), _ptr(col),
                         float(rs.scale_modifier), _ptr(vm), _ptr(pm), flags,
                         _ptr(radii), _ptr(geom), geom.numel(), ctypes.byref(R), cx.stream,
                     )
@@ -191,7 +191,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 binning = torch.empty((nbytes.value,), dtype=torch.uint8, device=dev)
                 abi.check(
                     abi.forward_render(
-                        P, H, W, num_rendered, _ptr(col), _ptr(bg), flags,
+                        P, H, W, num_rendered, _ptr(bg), flags,
                         _ptr(geom), geom.numel(), _ptr(binning), binning.numel(), _ptr(img), img.numel(),
                         _ptr(color), _ptr(invdepths), cx.stream,
                     )

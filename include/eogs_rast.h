@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EOGS_RAST_ABI_VERSION 1
+#define EOGS_RAST_ABI_VERSION 2
 #define EOGS_RAST_CHANNELS 5 /* DGR/cuda_rasterizer/config.h:15 NUM_CHANNELS */
 #define EOGS_RAST_TILE 16    /* DGR/cuda_rasterizer/config.h:16-17 BLOCK_X/BLOCK_Y */
 
@@ -68,12 +68,14 @@ int eogs_rast_binning_bytes(int P, int H, int W, int64_t num_rendered, size_t* b
  * (DGR/cuda_rasterizer/rasterizer_impl.cu:198-288: FORWARD::preprocess, InclusiveSum,
  * and the blocking 4-byte D2H of num_rendered at :284 — this call synchronises
  * `stream` once for the same reason: the binning workspace size depends on it).
- * Exactly one of (scales, rotations) / cov3D_precomp must be non-NULL.
+ * Exactly one of (scales, rotations) / cov3D_precomp must be non-NULL. `colors` (colors_precomp, f32[P,5]) is
+ * required when P > 0 (EOGS_ERR_NO_COLORS otherwise, DGR/cuda_rasterizer/rasterizer_impl.cu:244-247): the
+ * per-Gaussian render record is written once, whole, by the preprocess kernel.
  * Writes radii[P] and *num_rendered (host). */
 int eogs_rast_forward_prepare(
     int P, int H, int W,
     const float* means3D, const float* scales, const float* rotations,
-    const float* cov3D_precomp, const float* opacities, float scale_modifier,
+    const float* cov3D_precomp, const float* opacities, const float* colors, float scale_modifier,
     const float* viewmatrix, const float* projmatrix, unsigned flags,
     int* radii, void* geom, size_t geom_bytes,
     int64_t* num_rendered, void* stream);
@@ -84,7 +86,7 @@ int eogs_rast_forward_prepare(
  * out_invdepth may be NULL. Asynchronous on `stream`. */
 int eogs_rast_forward_render(
     int P, int H, int W, int64_t num_rendered,
-    const float* colors, const float* bg, unsigned flags,
+    const float* bg, unsigned flags,
     void* geom, size_t geom_bytes, void* binning, size_t binning_bytes,
     void* image, size_t image_bytes,
     float* out_color, float* out_invdepth, void* stream);

@@ -64,6 +64,7 @@ typedef struct {
   uint32_t* tiles_touched; /* [P] */
   uint32_t* point_offsets; /* [P] inclusive scan */
   int* radii;              /* [P] internal copy (GeometryState::internal_radii, rasterizer_impl.h:38) */
+  float* colors;           /* [P,5] copy of colors_precomp handed to forward_prepare */
 } Geom;
 
 typedef struct {
@@ -95,6 +96,7 @@ static size_t geom_layout(char* base, int P, Geom* g) {
   o = carve(base, o, (void**)&d.tiles_touched, n * 4);
   o = carve(base, o, (void**)&d.point_offsets, n * 4);
   o = carve(base, o, (void**)&d.radii, n * 4);
+  o = carve(base, o, (void**)&d.colors, n * C_ * 4);
   if (g) *g = d;
   return align_up(o) + 128;
 }
@@ -215,7 +217,7 @@ static void cov2d(const float T[3][3], const float cov3D[6], float* cxx, float* 
 int eogs_rast_forward_prepare(
     int P, int H, int W,
     const float* means3D, const float* scales, const float* rotations,
-    const float* cov3D_precomp, const float* opacities, float scale_modifier,
+    const float* cov3D_precomp, const float* opacities, const float* colors, float scale_modifier,
     const float* viewmatrix, const float* projmatrix, unsigned flags,
     int* radii, void* geom, size_t geom_bytes,
     int64_t* num_rendered, void* stream) {
@@ -224,6 +226,7 @@ int eogs_rast_forward_prepare(
   if (P < 0 || H <= 0 || W <= 0 || !num_rendered) return fail(EOGS_ERR_INVALID_ARG, "forward_prepare: bad sizes");
   *num_rendered = 0;
   if (P == 0) return EOGS_OK;
+  if (!colors) return fail(EOGS_ERR_NO_COLORS, "For non-RGB, provide precomputed Gaussian colors!");
   if (!means3D || !opacities || !viewmatrix || !radii || !geom)
     return fail(EOGS_ERR_INVALID_ARG, "forward_prepare: NULL input");
   int have_sr = scales && rotations, have_cov = cov3D_precomp != NULL;
@@ -232,6 +235,7 @@ int eogs_rast_forward_prepare(
   if (geom_bytes < geom_layout(NULL, P, NULL)) return fail(EOGS_ERR_WORKSPACE, "forward_prepare: geom workspace too small");
   Geom g;
   geom_layout((char*)geom, P, &g);
+  memcpy(g.colors, colors, (size_t)P * C_ * 4);
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   const int aa = (flags & EOGS_FLAG_ANTIALIASING) != 0;
   float T[3][3];
@@ -334,7 +338,7 @@ static void merge_sort_pairs(uint64_t* k, uint32_t* v, uint64_t* kt, uint32_t* v
 /* ------------------------------------------------------------------------------------------- */
 int eogs_rast_forward_render(
     int P, int H, int W, int64_t R,
-    const float* colors, const float* bg, unsigned flags,
+    const float* bg, unsigned flags,
     void* geom, size_t geom_bytes, void* binning, size_t binning_bytes,
     void* image, size_t image_bytes,
     float* out_color, float* out_invdepth, void* stream) {
@@ -342,7 +346,6 @@ int eogs_rast_forward_render(
   g_err[0] = 0;
   if (P < 0 || H <= 0 || W <= 0 || R < 0 || !out_color || !bg || !image)
     return fail(EOGS_ERR_INVALID_ARG, "forward_render: bad argument");
-  if (P > 0 && !colors) return fail(EOGS_ERR_NO_COLORS, "For non-RGB, provide precomputed Gaussian colors!");
   if (image_bytes < image_layout(NULL, H, W, NULL)) return fail(EOGS_ERR_WORKSPACE, "forward_render: image workspace too small");
   if (P > 0 && (!geom || geom_bytes < geom_layout(NULL, P, NULL))) return fail(EOGS_ERR_WORKSPACE, "forward_render: geom workspace too small");
   if (R > 0 && (!binning || binning_bytes < binning_layout(NULL, R, NULL)))
@@ -354,6 +357,7 @@ int eogs_rast_forward_render(
   image_layout((char*)image, H, W, &im);
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   const size_t HW = (size_t)H * W;
+  const float* colors = g.colors;
 
   /* duplicateWithKeys (rasterizer_impl.cu:70-111): key = tile << 32 | depth bits, row-major emission. */
   for (int idx = 0; idx < P && R > 0; idx++) {
