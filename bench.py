@@ -44,6 +44,26 @@ def parse():
     return ap.parse_args()
 
 
+def measured_traffic(kernel, a):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/prof.sh: FETCH_SIZE and
+    WRITE_SIZE collected in separate --pmc runs of this same command). gfx950 correction per MI355X_MICROARCH.md:
+    FETCH_SIZE counts 128-byte requests as 64 bytes -> doubled; both counters are in KiB. None when no profile of
+    the default workload is committed (PMC counters cannot be read from inside this process)."""
+    import glob
+
+    if a.gaussians != (1 << 20) or a.size != 1024 or a.opacity != "init":
+        return None, None
+    for d in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_v*", "pmc_mean_per_dispatch.json")), reverse=True):
+        try:
+            pm = json.load(open(d))
+        except Exception:
+            continue
+        for name, c in pm.items():
+            if name.startswith(kernel + "_kernel") and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                return int((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024), os.path.relpath(d, ROOT)
+    return None, None
+
+
 def cpu_baseline(P_full, S_full):
     """Dense pure-PyTorch alpha-blend fwd+bwd on a 1/64-area crop with the same pixel density and footprint."""
     from eogs2_amd.synthetic import make_scene
@@ -126,7 +146,7 @@ def main():
         means2D.grad = None
         color, radii, _ = rast(params["means3D"], means2D, params["opacities"], colors_precomp=params["colors"],
                                scales=params["scales"], rotations=params["rotations"])
-        (color * dL).sum().backward()
+        torch.autograd.backward([color], [dL])  # the loss gradient dL/dcolor is an input of the path
         if use_dist:
             bucket.all_reduce()
         return color
@@ -174,9 +194,10 @@ def main():
         roof = None
         if dom:
             ach = alg[dom] / (kern[dom] * 1e-3) / 1e9
+            traffic, tsrc = measured_traffic(dom, a)
             roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": alg[dom],
-                    "kernel_ms": kern[dom]}
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                    "algorithmic_bytes": alg[dom], "kernel_ms": kern[dom]}
         pipe_bytes = 432 * P + 268 * R + 64 * npx
         pipe = {"algorithmic_bytes": pipe_bytes, "achieved": pipe_bytes / (ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": pipe_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
