@@ -199,13 +199,21 @@ void launch_depth_sort(const GeomWS& g, int P, hipStream_t s) {
 
 // ---- expand step A: pair count of each chunk of 256 depth-sorted Gaussians (+ zeroes the tile ranges) ----
 __global__ __launch_bounds__(BLK) void expand_count_kernel(const uint32_t* __restrict__ sorted_ids,
-                                                           const uint32_t* __restrict__ tiles, uint32_t P,
-                                                           uint32_t* __restrict__ blocksum, uint2* __restrict__ ranges,
-                                                           uint32_t ntiles) {
+                                                           const uint4* __restrict__ binfo, uint32_t P,
+                                                           uint4* __restrict__ sinfo, uint32_t* __restrict__ blocksum,
+                                                           uint2* __restrict__ ranges, uint32_t ntiles) {
   __shared__ uint32_t s_w[4];
   for (uint32_t i = blockIdx.x * BLK + threadIdx.x; i < ntiles; i += gridDim.x * BLK) ranges[i] = make_uint2(0u, 0u);
   const uint32_t k = blockIdx.x * BLK + threadIdx.x;
-  const uint32_t v = k < P ? tiles[sorted_ids[k]] : 0u;
+  uint32_t v = 0;
+  if (k < P) {
+    // the only per-Gaussian gather of the binning stage: one 32-byte record, re-written in depth order
+    const uint32_t id = sorted_ids[k];
+    const uint4 a = binfo[2 * (size_t)id], b = binfo[2 * (size_t)id + 1];
+    sinfo[2 * (size_t)k] = a;
+    sinfo[2 * (size_t)k + 1] = b;
+    v = b.x;
+  }
   uint32_t tot;
   (void)block_excl_scan(v, s_w, tot);
   if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
@@ -242,11 +250,7 @@ __device__ inline uint32_t tile_of(const ExpandItem& it, uint32_t bit_or_q, uint
   const uint32_t row = bit_or_q / wdt, col = bit_or_q - row * wdt;
   return (it.sy0 + row) * gsx + it.sx0 + col;
 }
-__global__ __launch_bounds__(BLK) void expand_kernel(const uint32_t* __restrict__ sorted_ids,
-                                                     const uint32_t* __restrict__ tiles,
-                                                     const uint2* __restrict__ rect,
-                                                     const unsigned long long* __restrict__ mask,
-                                                     const uint32_t* __restrict__ lpre,
+__global__ __launch_bounds__(BLK) void expand_kernel(const uint4* __restrict__ sinfo,
                                                      const uint32_t* __restrict__ pblock,
                                                      const uint32_t* __restrict__ blocksum, uint32_t P, uint32_t gsx,
                                                      uint32_t gsy, uint32_t* __restrict__ tkey,
@@ -258,20 +262,22 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint32_t* __restrict_
   const uint32_t k = blockIdx.x * BLK + threadIdx.x;
   ExpandItem it;
   it.id = 0; it.c = 0; it.m = 0ull; it.sx0 = it.sy0 = 0; it.sw = it.wc = 1; it.rbase = 0;
+  uint4 ia = make_uint4(0u, 0u, 0u, 0u), ib = ia;
   if (k < P) {
-    it.id = sorted_ids[k];
-    it.c = tiles[it.id];
+    ia = sinfo[2 * (size_t)k];
+    ib = sinfo[2 * (size_t)k + 1];
+    it.c = ib.x;
+    it.id = ib.z;
   }
   uint32_t tot;
   it.pos0 = blocksum[blockIdx.x] + block_excl_scan(it.c, s_w, tot);
   if (it.c) {
-    const uint2 r = rect[it.id];
-    const uint32_t x0 = r.x & 0xFFFFu, x1 = r.x >> 16, y0 = r.y & 0xFFFFu;
-    it.m = mask[it.id];
+    const uint32_t x0 = ia.x & 0xFFFFu, x1 = ia.x >> 16, y0 = ia.y & 0xFFFFu;
+    it.m = ((unsigned long long)ia.w << 32) | ia.z;
     it.sx0 = FX * x0; it.sy0 = FY * y0; it.sw = FX * (x1 - x0);
     const uint32_t sx1 = FX * x1 < gsx ? FX * x1 : gsx;
     it.wc = sx1 - it.sx0;
-    it.rbase = pblock[it.id / BLK] + lpre[it.id];
+    it.rbase = pblock[it.id / BLK] + ib.y;  // pblock is 4 bytes per 256 Gaussians: cache resident
   }
   // Workgroups whose pairs fit the LDS stage (the common case: ~4 pairs per Gaussian) place them there at their
   // workgroup-local position and stream them out with consecutive lanes writing consecutive addresses.
@@ -362,11 +368,11 @@ void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int
     (void)hipMemsetAsync(im.ranges, 0, (size_t)gsx * gsy * sizeof(uint2), s);
     return;
   }
-  hipLaunchKernelGGL(expand_count_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.svalA, g.tiles, (uint32_t)P, g.blocksum,
-                     im.ranges, gsx * gsy);
+  hipLaunchKernelGGL(expand_count_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.svalA, g.binfo, (uint32_t)P, g.sinfo,
+                     g.blocksum, im.ranges, gsx * gsy);
   hipLaunchKernelGGL(expand_scan_kernel, dim3(1), dim3(BLK), 0, s, g.blocksum, g.nblkE);
-  hipLaunchKernelGGL(expand_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.svalA, g.tiles, g.rect, g.mask, g.lpre, g.pblock,
-                     g.blocksum, (uint32_t)P, gsx, gsy, b.tkeyA, b.tvalA);
+  hipLaunchKernelGGL(expand_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.sinfo, g.pblock, g.blocksum, (uint32_t)P, gsx, gsy,
+                     b.tkeyA, b.tvalA);
   uint32_t *ka = b.tkeyA, *kb = b.tkeyB;
   uint2 *va = b.tvalA, *vb = b.tvalB;
   int shift = 0;

@@ -45,11 +45,13 @@ struct GeomWS {
   float4* packed;       // 4 x float4 = one 64-byte line per Gaussian, everything the render kernels gather:
                         //   {gx, gy, A, B} {C, opacity, f0, f1} {f2, f3, f4, 1/depth} {pad}
                         //   with the conic pre-scaled by log2 e: A = -a log2e/2, B = b log2e, C = -c log2e/2
-  uint2* rect;          // x0 | x1<<16 , y0 | y1<<16 (16-px tile units, the reference's getRect)
-  unsigned long long* mask;  // bit (sy-FY*y0)*FX*(x1-x0) + (sx-FX*x0): internal tile (sx,sy) can reach alpha >= 1/255;
-                        // 0 = no mask: every internal tile of the rect (clipped to the image) is listed
-  uint32_t* tiles;      // number of internal tiles listed for this Gaussian (0 = none)
-  uint32_t* lpre;       // exclusive prefix of `tiles` inside the Gaussian's preprocess workgroup (256 Gaussians)
+  uint4* binfo;         // 2 x uint4 = 32 bytes per Gaussian, everything binning needs, written once by preprocess:
+                        //   [0] = {x0 | x1<<16, y0 | y1<<16 (the reference's 16-px tile rect), mask lo, mask hi}
+                        //   [1] = {tiles (internal tiles listed, 0 = none), lpre, Gaussian id (filled in sinfo), 0}
+                        //   mask bit (sy-FY*y0)*FX*(x1-x0) + (sx-FX*x0): internal tile (sx,sy) can reach alpha >= 1/255;
+                        //   mask == 0 with tiles > 0: every internal tile of the rect (clipped to the image) is listed;
+                        //   lpre = exclusive prefix of `tiles` inside the Gaussian's preprocess workgroup (256 Gaussians)
+  uint4* sinfo;         // the same records in DEPTH order (gathered once by expand_count_kernel)
   uint32_t* pblock;     // per preprocess workgroup: total, then (scan_pblock_kernel) exclusive prefix over workgroups.
                         // record slot of (Gaussian i, its q-th tile) = pblock[i/256] + lpre[i] + q: records are laid out
                         // in Gaussian-id order, so gaussian_bwd streams them
@@ -71,10 +73,8 @@ static inline GeomWS geom_layout(char* base, int P) {
   g.nblkP = ceil_div_u32(n, BLK * SORTP_ITEMS);
   g.nblkE = ceil_div_u32(n, BLK * EXPAND_ITEMS);
   o = ws_carve(base, o, g.packed, n * 4);
-  o = ws_carve(base, o, g.rect, n);
-  o = ws_carve(base, o, g.mask, n);
-  o = ws_carve(base, o, g.tiles, n);
-  o = ws_carve(base, o, g.lpre, n);
+  o = ws_carve(base, o, g.binfo, n * 2);
+  o = ws_carve(base, o, g.sinfo, n * 2);
   o = ws_carve(base, o, g.pblock, (size_t)ceil_div_u32(n, BLK) + 1);
   o = ws_carve(base, o, g.skeyA, n);
   o = ws_carve(base, o, g.skeyB, n);

@@ -115,8 +115,7 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
     const float* __restrict__ means3D, const float* __restrict__ scales, const float* __restrict__ rotations,
     const float* __restrict__ cov3D_precomp, const float* __restrict__ opacities, const float* __restrict__ colors,
     const float* __restrict__ vm, float scale_modifier, int antialiasing,
-    int* __restrict__ radii, float4* __restrict__ packed, uint2* __restrict__ rect, unsigned long long* __restrict__ mask_out,
-    uint32_t* __restrict__ tiles, uint32_t* __restrict__ lpre, uint32_t* __restrict__ pblock,
+    int* __restrict__ radii, float4* __restrict__ packed, uint4* __restrict__ binfo, uint32_t* __restrict__ pblock,
     uint32_t* __restrict__ skey, uint32_t* __restrict__ sval, uint32_t* __restrict__ misc) {
   __shared__ float s_m[3 * BLK];
   __shared__ float s_s[3 * BLK];
@@ -130,6 +129,7 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
 
   const size_t idx = row0 + t;
   uint32_t my_tiles = 0;
+  uint4 bi0 = make_uint4(0u, 0u, 0u, 0u);
   if (t < rows) {
     const float p[3] = {s_m[3 * t], s_m[3 * t + 1], s_m[3 * t + 2]};
     // transformPoint4x3 (auxiliary.h:70-78)
@@ -210,15 +210,14 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
           packed[4 * idx + 1] = make_float4(cc * (-0.5f * L2E), op, f[0], f[1]);
           packed[4 * idx + 2] = make_float4(f[2], f[3], f[4], 1.f / d);
           packed[4 * idx + 3] = make_float4(0.f, 0.f, 0.f, 0.f);
-          rect[idx] = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16));
-          mask_out[idx] = m;
+          bi0 = make_uint4((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16), (uint32_t)m,
+                           (uint32_t)(m >> 32));
           skey[idx] = __float_as_uint(d);
         }
       }
     }
     if (my_tiles == 0) skey[idx] = 0xFFFFFFFFu;  // Gaussians that reach no pixel sort last and emit nothing
     radii[idx] = radius;
-    tiles[idx] = my_tiles;
     sval[idx] = (uint32_t)idx;
   }
   // exclusive prefix of the tile counts inside the workgroup (record slots in Gaussian-id order) and the
@@ -235,7 +234,10 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
   const uint32_t w0 = s_cnt[0], w1 = s_cnt[1], w2 = s_cnt[2], w3 = s_cnt[3];
   const int w = t >> 6;
   const uint32_t pre = (w > 0 ? w0 : 0u) + (w > 1 ? w1 : 0u) + (w > 2 ? w2 : 0u);
-  if (t < rows) lpre[idx] = pre + inc - my_tiles;
+  if (t < rows) {
+    binfo[2 * idx] = bi0;
+    binfo[2 * idx + 1] = make_uint4(my_tiles, pre + inc - my_tiles, (uint32_t)idx, 0u);
+  }
   if (t == 0) {
     const uint32_t tot = w0 + w1 + w2 + w3;
     pblock[blockIdx.x] = tot;
@@ -277,7 +279,7 @@ void launch_preprocess_fwd(const FwdPrepArgs& a, const GeomWS& g, hipStream_t s)
   const uint32_t nblk = ceil_div_u32((uint64_t)a.P, BLK);
   hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nblk), dim3(BLK), 0, s, a.P, a.H, a.W, gx, gy, a.means3D, a.scales,
                      a.rotations, a.cov3D_precomp, a.opacities, a.colors, a.viewmatrix, a.scale_modifier, (int)a.antialiasing,
-                     a.radii, g.packed, g.rect, g.mask, g.tiles, g.lpre, g.pblock, g.skeyA, g.svalA, g.misc);
+                     a.radii, g.packed, g.binfo, g.pblock, g.skeyA, g.svalA, g.misc);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -288,8 +290,7 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
     const float* __restrict__ means3D, const float* __restrict__ scales, const float* __restrict__ rotations,
     const float* __restrict__ cov3D_precomp, const float* __restrict__ opacities, const float* __restrict__ vm,
     const float* __restrict__ proj, const int* __restrict__ radii, float scale_modifier, int antialiasing,
-    const uint32_t* __restrict__ tiles, const uint32_t* __restrict__ lpre, const uint32_t* __restrict__ pblock,
-    const float* __restrict__ records,
+    const uint4* __restrict__ binfo, const uint32_t* __restrict__ pblock, const float* __restrict__ records,
     const uint8_t* __restrict__ live,
     float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscales,
@@ -316,8 +317,9 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
     const bool visible = radii[idx] > 0;
     if (visible) {
       // fixed-order sum of this Gaussian's (tile,Gaussian) records: deterministic, no atomics
-      const uint32_t n = tiles[idx];
-      const size_t s0 = (size_t)pblock[blockIdx.x] + lpre[idx];  // Gaussian-id order: a wave reads one contiguous region
+      const uint4 bi1 = binfo[2 * idx + 1];
+      const uint32_t n = bi1.x;
+      const size_t s0 = (size_t)pblock[blockIdx.x] + bi1.y;  // Gaussian-id order: a wave reads one contiguous region
       const float4* r4 = reinterpret_cast<const float4*>(records + s0 * REC);
       for (uint32_t q = 0; q < n; q++) {
         if (!live[s0 + q]) continue;  // pair behind every pixel's last contributor: no record was written
@@ -502,6 +504,6 @@ void launch_gaussian_bwd(const GaussBwdArgs& a, const GeomWS& g, const BinWS& b,
   const uint32_t nblk = ceil_div_u32((uint64_t)a.P, BLK);
   hipLaunchKernelGGL(gaussian_bwd_kernel, dim3(nblk), dim3(BLK), 0, s, a.P, a.H, a.W, a.means3D, a.scales, a.rotations,
                      a.cov3D_precomp, a.opacities, a.viewmatrix, a.projmatrix, a.radii, a.scale_modifier,
-                     (int)a.antialiasing, g.tiles, g.lpre, g.pblock, b.records, b.live, a.dL_dmeans2D, a.dL_dcolors, a.dL_dopacity,
+                     (int)a.antialiasing, g.binfo, g.pblock, b.records, b.live, a.dL_dmeans2D, a.dL_dcolors, a.dL_dopacity,
                      a.dL_dmeans3D, a.dL_dcov3D, a.dL_dscales, a.dL_drotations, a.dL_dT_sum, a.dL_dvm_mean);
 }
