@@ -142,7 +142,7 @@ __global__ __launch_bounds__(BLK) void render_fwd_kernel(
     park(slab, lane, nxt);
     nxt = load_cand(c0 + 64 + lane, range.y, point_list, packed);  // in flight during this chunk
     wave_lds_sync();
-    if (__ballot(!done) == 0ull) break;  // every pixel of the tile has terminated
+    if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;  // every pixel of the tile has terminated
     const int n = (int)((range.y - c0) < 64u ? (range.y - c0) : 64u);
     const uint32_t jbase = c0 - range.x;
     // one list entry against this lane's pixel; returns nothing, all state is captured by reference
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(BLK) void render_fwd_kernel(
       const bool term = valid && test_T < 0.0001f;  // this Gaussian is NOT blended; the pixel is finished
       done = done || term;
       valid = valid && !term;
-      if (__ballot(valid) == 0ull) return;
+      if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;
       const float wgt = valid ? alpha * T : 0.f;
       C[0] += e.q1.z * wgt; C[1] += e.q1.w * wgt;
       C[2] += e.q2.x * wgt; C[3] += e.q2.y * wgt; C[4] += e.q2.z * wgt;
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
       const float G = __builtin_amdgcn_exp2f(p);
       const float alpha = fminf(e.q1.y * G, 0.99f);
       const bool valid = (jbase + (uint32_t)j < ncontrib) && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);
-      if (__ballot(valid) == 0ull) return;  // wave-uniform skip: this entry reaches no pixel of the tile
+      if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;  // wave-uniform skip: this entry reaches no pixel of the tile
 
       float gc = g[0] * e.q1.z + g[1] * e.q1.w + g[2] * e.q2.x + g[3] * e.q2.y + g[4] * e.q2.z;
       if (have_inv) gc += ginv * e.q2.w;

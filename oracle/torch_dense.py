@@ -70,9 +70,11 @@ def project(means3D, viewmatrix, H, W, means2D=None):
 def render_dense(
     means3D, opacities, colors, bg, viewmatrix, H, W,
     scales=None, rotations=None, cov3D_precomp=None, scale_modifier=1.0,
-    antialiasing=False, means2D=None, T_override=None, block=64, want_aux=False,
+    antialiasing=False, means2D=None, T_override=None, block=64, want_aux=False, crop=None,
 ):
-    """Returns (color[5,H,W], radii[P] int32, invdepth[1,H,W]) (+ dict of aux tensors)."""
+    """Returns (color[5,H,W], radii[P] int32, invdepth[1,H,W]) (+ dict of aux tensors).
+    crop=(y0, x0, h, w) (multiples of `block`... of 16 at least) renders only that window of the H x W image and
+    returns images of the window's size."""
     dev = means3D.device
     P = means3D.shape[0]
     if P == 0:
@@ -120,21 +122,24 @@ def render_dense(
         order = torch.sort(depth, stable=True).indices  # ties keep index order
         order = order[visible[order]]
 
-    out_color = torch.zeros(C, H, W, device=dev)
-    out_invd = torch.zeros(1, H, W, device=dev)
-    out_T = torch.ones(H, W, device=dev)
+    cy0, cx0, ch, cw = (0, 0, H, W) if crop is None else crop
+    assert cy0 % TILE == 0 and cx0 % TILE == 0
+    out_color = torch.zeros(C, ch, cw, device=dev)
+    out_invd = torch.zeros(1, ch, cw, device=dev)
+    out_T = torch.ones(ch, cw, device=dev)
     assert block % TILE == 0
-    for by in range(0, H, block):
-        for bx in range(0, W, block):
+    for by in range(cy0, min(cy0 + ch, H), block):
+        for bx in range(cx0, min(cx0 + cw, W), block):
             ty0, ty1 = by // TILE, min((by + block + TILE - 1) // TILE, gy)
             tx0, tx1 = bx // TILE, min((bx + block + TILE - 1) // TILE, gx)
             with torch.no_grad():
                 cand = (x0[order] < tx1) & (x1[order] > tx0) & (y0[order] < ty1) & (y1[order] > ty0)
                 ids = order[cand]
-            ys = torch.arange(by, min(by + block, H), device=dev)
-            xs = torch.arange(bx, min(bx + block, W), device=dev)
+            ys = torch.arange(by, min(by + block, H, cy0 + ch), device=dev)
+            xs = torch.arange(bx, min(bx + block, W, cx0 + cw), device=dev)
+            oy, ox = ys - cy0, xs - cx0
             if ids.numel() == 0:
-                out_color[:, ys[:, None], xs[None, :]] = bg[:, None, None].expand(C, ys.numel(), xs.numel())
+                out_color[:, oy[:, None], ox[None, :]] = bg[:, None, None].expand(C, ys.numel(), xs.numel())
                 continue
             PY, PX = torch.meshgrid(ys, xs, indexing="ij")
             pxf, pyf = PX.reshape(-1).float(), PY.reshape(-1).float()
@@ -163,9 +168,9 @@ def render_dense(
             col = colors[ids].t() @ w + bg[:, None] * T_final[None, :]
             invd = (1.0 / depth[ids]).detach()[None, :] @ w  # depth is a constant in the reference backward (backward.cu:305-307 commented out)
             shp = (ys.numel(), xs.numel())
-            out_color[:, ys[:, None], xs[None, :]] = col.view(C, *shp)
-            out_invd[:, ys[:, None], xs[None, :]] = invd.view(1, *shp)
-            out_T[ys[:, None], xs[None, :]] = T_final.detach().view(*shp)
+            out_color[:, oy[:, None], ox[None, :]] = col.view(C, *shp)
+            out_invd[:, oy[:, None], ox[None, :]] = invd.view(1, *shp)
+            out_T[oy[:, None], ox[None, :]] = T_final.detach().view(*shp)
     if want_aux:
         return out_color, radii, out_invd, {"final_T": out_T, "pix": pix, "depth": depth,
                                            "conic": torch.stack([conic_a, conic_b, conic_c], -1), "opac": opac,

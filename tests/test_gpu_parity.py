@@ -76,6 +76,8 @@ SEEDED = [
     (777, 33, 47, 14, "trained", 4.0, False, True),    # ragged image, ragged P
     (400, 200, 168, 15, "trained", 14.0, False, False),  # tile rects > 64 internal tiles: unmasked listing path
     (1, 64, 64, 16, 0.9, 30.0, False, False),            # one Gaussian covering every tile
+    (4000, 517, 1021, 17, "trained", 1.0, True, True),   # odd sizes: partial 8x8 and 16x16 tiles on both edges
+    (1500, 96, 96, 18, 0.003, 3.0, False, False),        # opacity < 1/255: visible radii, nothing ever blended
 ]
 
 
@@ -123,6 +125,33 @@ def test_depth_ties_and_overlap_order(dev):
     assert torch.equal(radii.cpu(), r2)
     assert_close(color, col2, "tie-order image")
     assert_close(invd, inv2, "tie-order invdepth")
+
+
+def test_sun_camera_size_2048(dev):
+    """2048 x 2048 (the reference's 2H x 2W sun-camera render, affine_cameras.py:366-367): 65,536 internal tiles,
+    16-bit tile keys, two 8-bit tile-sort passes. Checked against size-independent properties and a crop computed by
+    the dense renderer."""
+    from eogs2_amd import GaussianRasterizer
+    from eogs2_amd.synthetic import make_scene, settings_for
+    from oracle.torch_dense import render_dense
+
+    P, H, W = 200_000, 2048, 2048
+    sc = make_scene(P, H, W, seed=7, opacity="trained", device=dev)
+    rs = settings_for(sc, H, W)
+    leaves = {k: sc[k].clone().requires_grad_(True) for k in ["means3D", "scales", "rotations", "opacities", "colors"]}
+    color, radii, invd = GaussianRasterizer(rs)(leaves["means3D"], torch.zeros(P, 3, device=dev), leaves["opacities"],
+                                                colors_precomp=leaves["colors"], scales=leaves["scales"],
+                                                rotations=leaves["rotations"])
+    torch.autograd.backward([color], [sc["dL_dcolor"]])
+    assert torch.isfinite(color).all() and all(torch.isfinite(v.grad).all() for v in leaves.values())
+    # accumulated-opacity channel (feature 4 is the constant 1, bg[4] = 0) must stay in [0, 1]
+    assert float(color[4].min()) >= -1e-6 and float(color[4].max()) <= 1 + 1e-5
+    # a 64 x 64 crop at an 8-aligned offset, recomputed densely from the Gaussians that can reach it
+    c = {k: v.cpu() for k, v in sc.items()}
+    y0, x0, S = 1024 - 32, 1536, 64
+    full = render_dense(c["means3D"], c["opacities"], c["colors"], c["bg"], c["viewmatrix"], H, W, scales=c["scales"],
+                        rotations=c["rotations"], block=64, crop=(y0, x0, S, S))[0]
+    assert_close(color[:, y0:y0 + S, x0:x0 + S], full, "2048 crop")
 
 
 def test_backward_is_deterministic(dev):
