@@ -180,7 +180,7 @@ def main():
 
     if rank == 0:
         ms_step = dt / a.steps * 1e3
-        kern = {k: (ms / max(n, 1)) for k, (ms, n) in prof.items()}
+        kern = {k: ms / a.steps for k, (ms, n) in prof.items()}  # device ms per step of each kernel group
         dom = max(kern, key=kern.get) if kern else None
         npx = H * W
         alg = {

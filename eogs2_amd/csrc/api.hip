@@ -141,11 +141,24 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
                 (flags & EOGS_FLAG_ANTIALIASING) != 0, radii};
   { ProfScope ps(PS_PREPROCESS, s); launch_preprocess_fwd(a, g, s); launch_scan_pblock(g, P, s); }
   LAUNCH_TRY(s, debug, "preprocess_fwd");
-  HIP_TRY(hipMemcpyAsync(g_pinned, g.misc, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-  // the depth sort does not depend on num_rendered: it runs while the host waits for the readback
-  { ProfScope ps(PS_DEPTH_SORT, s); launch_depth_sort(g, P, s); }
+  HIP_TRY(hipMemcpyAsync(g_pinned, g.misc, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  // the depth sort does not depend on num_rendered: its first three passes run while the host waits for the readback
+  { ProfScope ps(PS_DEPTH_SORT, s); launch_depth_sort(g, P, 0, 3, s); }
   LAUNCH_TRY(s, debug, "depth_sort");
   HIP_TRY(hipStreamSynchronize(s));
+  {
+    // Fourth pass (bits 24..31) only if the listed Gaussians' keys differ there. EOGS altitudes span far less than
+    // a factor of two around 200 - altitude, so they normally share sign, exponent-high bits: one digit, no pass.
+    const uint32_t kmax = g_pinned[MISC_KEY_MAX], kmin = ~g_pinned[MISC_KEY_NMIN];
+    ProfScope ps(PS_DEPTH_SORT, s);
+    if (kmax != 0 && ((kmax ^ kmin) >> 24) == 0) {
+      // three passes left the order in buffer B; unlisted Gaussians (key 0xFFFFFFFF) may sit anywhere: they emit nothing
+      HIP_TRY(hipMemcpyAsync(g.svalA, g.svalB, (size_t)P * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    } else {
+      launch_depth_sort(g, P, 3, 4, s);
+    }
+  }
+  LAUNCH_TRY(s, debug, "depth_sort_tail");
   if (g_pinned[MISC_ERR] & 1u) return fail(EOGS_ERR_ALTITUDE, "Point is too high: altitude > 200");
   const uint64_t total = (uint64_t)g_pinned[MISC_TOTAL_LO] | ((uint64_t)g_pinned[MISC_TOTAL_HI] << 32);
   if (total >= ((uint64_t)1 << 31)) return fail(EOGS_ERR_OVERFLOW, "num_rendered overflows 31 bits");

@@ -187,14 +187,42 @@ static void radix_pass(const uint32_t* kin, const VT* vin, uint32_t* kout, VT* v
                      hist, nblk, dtotal);
 }
 
-// Depth sort: 4 stable passes over the 32 depth bits; result (ids in depth order) lands back in svalA.
-void launch_depth_sort(const GeomWS& g, int P, hipStream_t s) {
-  uint32_t *ka = g.skeyA, *kb = g.skeyB, *va = g.svalA, *vb = g.svalB;
-  for (int pass = 0; pass < 4; pass++) {
-    radix_pass<SORTP_ITEMS, uint32_t>(ka, va, kb, vb, (uint32_t)P, 8 * pass, 8, g.hist, g.nblkP, g.dtotal, s);
-    uint32_t* tk = ka; ka = kb; kb = tk;
-    uint32_t* tv = va; va = vb; vb = tv;
+// Depth sort: stable 8-bit passes over the depth bits, ping-ponging A -> B -> A ...; after an even number of passes
+// the ids in depth order are in svalA.
+void launch_depth_sort(const GeomWS& g, int P, int first, int last, hipStream_t s) {
+  for (int pass = first; pass < last; pass++) {
+    const bool a2b = (pass & 1) == 0;
+    radix_pass<SORTP_ITEMS, uint32_t>(a2b ? g.skeyA : g.skeyB, a2b ? g.svalA : g.svalB, a2b ? g.skeyB : g.skeyA,
+                                      a2b ? g.svalB : g.svalA, (uint32_t)P, 8 * pass, 8, g.hist, g.nblkP, g.dtotal, s);
   }
+}
+
+// ---- exclusive scan of a small array in place (single workgroup, 16 elements per thread per round);
+//      data[n] receives the total ----
+__global__ __launch_bounds__(BLK) void small_scan_kernel(uint32_t* __restrict__ data, uint32_t n) {
+  __shared__ uint32_t s_w[4];
+  uint32_t carry = 0;
+  for (uint32_t b0 = 0; b0 < n; b0 += BLK * 16) {
+    const uint32_t i0 = b0 + threadIdx.x * 16;
+    uint32_t v[16], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      v[k] = i0 + k < n ? data[i0 + k] : 0u;
+      sum += v[k];
+    }
+    uint32_t tot;
+    uint32_t run = carry + block_excl_scan(sum, s_w, tot);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      if (i0 + k < n) data[i0 + k] = run;
+      run += v[k];
+    }
+    carry += tot;
+  }
+  if (threadIdx.x == 0) data[n] = carry;
+}
+void launch_small_scan(uint32_t* data, uint32_t n, hipStream_t s) {
+  hipLaunchKernelGGL(small_scan_kernel, dim3(1), dim3(BLK), 0, s, data, n);
 }
 
 // ---- expand step A: pair count of each chunk of 256 depth-sorted Gaussians (+ zeroes the tile ranges) ----
@@ -217,21 +245,6 @@ __global__ __launch_bounds__(BLK) void expand_count_kernel(const uint32_t* __res
   uint32_t tot;
   (void)block_excl_scan(v, s_w, tot);
   if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
-}
-
-// ---- expand step B: exclusive scan of the chunk counts (single workgroup) ----
-__global__ __launch_bounds__(BLK) void expand_scan_kernel(uint32_t* __restrict__ blocksum, uint32_t nblk) {
-  __shared__ uint32_t s_w[4];
-  uint32_t carry = 0;
-  for (uint32_t b0 = 0; b0 < nblk; b0 += BLK) {
-    const uint32_t i = b0 + threadIdx.x;
-    const uint32_t v = i < nblk ? blocksum[i] : 0u;
-    uint32_t tot;
-    const uint32_t ex = block_excl_scan(v, s_w, tot);
-    if (i < nblk) blocksum[i] = carry + ex;
-    carry += tot;
-  }
-  if (threadIdx.x == 0) blocksum[nblk] = carry;
 }
 
 // ---- expand step C: emission of (internal tile id, record slot) in depth order ----
@@ -370,7 +383,7 @@ void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int
   }
   hipLaunchKernelGGL(expand_count_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.svalA, g.binfo, (uint32_t)P, g.sinfo,
                      g.blocksum, im.ranges, gsx * gsy);
-  hipLaunchKernelGGL(expand_scan_kernel, dim3(1), dim3(BLK), 0, s, g.blocksum, g.nblkE);
+  launch_small_scan(g.blocksum, g.nblkE, s);
   hipLaunchKernelGGL(expand_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.sinfo, g.pblock, g.blocksum, (uint32_t)P, gsx, gsy,
                      b.tkeyA, b.tvalA);
   uint32_t *ka = b.tkeyA, *kb = b.tkeyB;

@@ -22,6 +22,8 @@
 #define MISC_TOTAL_LO 0  // sum of tiles_touched (u64, lo/hi)
 #define MISC_TOTAL_HI 1
 #define MISC_ERR 2       // bit0: altitude > 200
+#define MISC_KEY_MAX 4   // max depth key over listed Gaussians
+#define MISC_KEY_NMIN 5  // max of ~key = ~min depth key (zero-initialised like the rest of misc)
 #define MISC_WORDS 64
 
 // ---- radix sort geometry ----
@@ -165,7 +167,9 @@ struct FwdPrepArgs {
   int* radii;
 };
 void launch_preprocess_fwd(const FwdPrepArgs& a, const GeomWS& g, hipStream_t s);
-void launch_depth_sort(const GeomWS& g, int P, hipStream_t s);
+// passes [first, last) of the 4-pass depth sort (8 bits each); pass p reads buffer A if p is even, B if odd
+void launch_depth_sort(const GeomWS& g, int P, int first, int last, hipStream_t s);
+void launch_small_scan(uint32_t* data, uint32_t n, hipStream_t s);
 void launch_scan_pblock(const GeomWS& g, int P, hipStream_t s);
 void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, hipStream_t s);
 void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, int W,

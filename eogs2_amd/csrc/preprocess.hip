@@ -128,7 +128,7 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
   __syncthreads();
 
   const size_t idx = row0 + t;
-  uint32_t my_tiles = 0;
+  uint32_t my_tiles = 0, key_bits = 0;
   uint4 bi0 = make_uint4(0u, 0u, 0u, 0u);
   if (t < rows) {
     const float p[3] = {s_m[3 * t], s_m[3 * t + 1], s_m[3 * t + 2]};
@@ -212,7 +212,8 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
           packed[4 * idx + 3] = make_float4(0.f, 0.f, 0.f, 0.f);
           bi0 = make_uint4((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16), (uint32_t)m,
                            (uint32_t)(m >> 32));
-          skey[idx] = __float_as_uint(d);
+          key_bits = __float_as_uint(d);
+          skey[idx] = key_bits;
         }
       }
     }
@@ -243,35 +244,18 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
     pblock[blockIdx.x] = tot;
     if (tot) atomicAdd(reinterpret_cast<unsigned long long*>(misc + MISC_TOTAL_LO), (unsigned long long)tot);
   }
-}
-
-// exclusive scan of the per-workgroup totals (single workgroup; P/256 entries)
-__global__ __launch_bounds__(BLK) void scan_pblock_kernel(uint32_t* __restrict__ pblock, uint32_t nblk) {
-  __shared__ uint32_t s_w[4];
-  uint32_t carry = 0;
-  for (uint32_t b0 = 0; b0 < nblk; b0 += BLK) {
-    const uint32_t i = b0 + threadIdx.x;
-    const uint32_t v = i < nblk ? pblock[i] : 0u;
-    uint32_t inc = v;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // range of the depth keys of listed Gaussians: lets the host drop sort passes whose digit is constant
+  uint32_t kmax = my_tiles ? key_bits : 0u, knmin = my_tiles ? ~key_bits : 0u;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t nb = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += nb;
-    }
-    if (lane == 63) s_w[w] = inc;
-    __syncthreads();
-    const uint32_t w0 = s_w[0], w1 = s_w[1], w2 = s_w[2], w3 = s_w[3];
-    const uint32_t pre = (w > 0 ? w0 : 0u) + (w > 1 ? w1 : 0u) + (w > 2 ? w2 : 0u);
-    __syncthreads();
-    if (i < nblk) pblock[i] = carry + pre + inc - v;
-    carry += w0 + w1 + w2 + w3;
+  for (int o = 32; o >= 1; o >>= 1) {
+    const uint32_t a = __shfl_xor(kmax, o, 64), b = __shfl_xor(knmin, o, 64);
+    kmax = a > kmax ? a : kmax;
+    knmin = b > knmin ? b : knmin;
   }
-  if (threadIdx.x == 0) pblock[nblk] = carry;
-}
-
-void launch_scan_pblock(const GeomWS& g, int P, hipStream_t s) {
-  hipLaunchKernelGGL(scan_pblock_kernel, dim3(1), dim3(BLK), 0, s, g.pblock, ceil_div_u32((uint64_t)P, BLK));
+  if (lane == 0 && kmax) {
+    atomicMax(&misc[MISC_KEY_MAX], kmax);
+    atomicMax(&misc[MISC_KEY_NMIN], knmin);
+  }
 }
 
 void launch_preprocess_fwd(const FwdPrepArgs& a, const GeomWS& g, hipStream_t s) {
@@ -280,6 +264,10 @@ void launch_preprocess_fwd(const FwdPrepArgs& a, const GeomWS& g, hipStream_t s)
   hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nblk), dim3(BLK), 0, s, a.P, a.H, a.W, gx, gy, a.means3D, a.scales,
                      a.rotations, a.cov3D_precomp, a.opacities, a.colors, a.viewmatrix, a.scale_modifier, (int)a.antialiasing,
                      a.radii, g.packed, g.binfo, g.pblock, g.skeyA, g.svalA, g.misc);
+}
+
+void launch_scan_pblock(const GeomWS& g, int P, hipStream_t s) {
+  launch_small_scan(g.pblock, ceil_div_u32((uint64_t)P, BLK), s);
 }
 
 // ------------------------------------------------------------------------------------------------------

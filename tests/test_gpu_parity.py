@@ -127,6 +127,29 @@ def test_depth_ties_and_overlap_order(dev):
     assert_close(invd, inv2, "tie-order invdepth")
 
 
+def test_wide_altitude_range_uses_all_sort_passes(dev, monkeypatch):
+    """Depth keys spanning several binades (200 - altitude from ~25 to ~305): the top byte of the key differs, so the
+    fourth depth-sort pass must run (with EOGS-like altitudes it is skipped). Compared with the oracle."""
+    import oracle
+    from eogs2_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib
+    from eogs2_amd.synthetic import make_scene
+
+    P, H, W = 6000, 128, 160
+    sc = make_scene(P, H, W, seed=31, opacity="trained", scale_mult=2.5)
+    sc["means3D"][:, 2] = sc["means3D"][:, 2] * 4.0 - 0.1  # z in [-0.3, 0.5] -> altitude in [-105, 175]
+    sc["colors"][:, 3] = (sc["means3D"] @ sc["viewmatrix"][:3, :3] + sc["viewmatrix"][3, :3])[:, 2]
+    depth = 200.0 - sc["colors"][:, 3]
+    assert float(depth.min()) < 64 and float(depth.max()) > 256
+    case = {k: v.numpy() for k, v in sc.items()}
+    case.update(H=H, W=W, antialiasing=False)
+    got = run_case(case, dev, GaussianRasterizer, GaussianRasterizationSettings)
+    hip = _lib.get()
+    monkeypatch.setattr(_lib, "get", lambda: oracle.abi())
+    ref = run_case(case, torch.device("cpu"), GaussianRasterizer, GaussianRasterizationSettings)
+    monkeypatch.setattr(_lib, "get", lambda: hip)
+    _compare(got, {k: v.cpu().numpy() for k, v in ref.items()}, "wide-altitude", case["means3D"])
+
+
 def test_sun_camera_size_2048(dev):
     """2048 x 2048 (the reference's 2H x 2W sun-camera render, affine_cameras.py:366-367): 65,536 internal tiles,
     16-bit tile keys, two 8-bit tile-sort passes. Checked against size-independent properties and a crop computed by
