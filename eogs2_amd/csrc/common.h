@@ -54,6 +54,7 @@ struct GeomWS {
                         //   mask == 0 with tiles > 0: every internal tile of the rect (clipped to the image) is listed;
                         //   lpre = exclusive prefix of `tiles` inside the Gaussian's preprocess workgroup (256 Gaussians)
   uint4* sinfo;         // the same records in DEPTH order (gathered once by expand_count_kernel)
+  uint32_t* pbkey;      // per preprocess workgroup: {max depth key, max ~key} over its listed Gaussians
   uint32_t* pblock;     // per preprocess workgroup: total, then (scan_pblock_kernel) exclusive prefix over workgroups.
                         // record slot of (Gaussian i, its q-th tile) = pblock[i/256] + lpre[i] + q: records are laid out
                         // in Gaussian-id order, so gaussian_bwd streams them
@@ -78,6 +79,7 @@ static inline GeomWS geom_layout(char* base, int P) {
   o = ws_carve(base, o, g.binfo, n * 2);
   o = ws_carve(base, o, g.sinfo, n * 2);
   o = ws_carve(base, o, g.pblock, (size_t)ceil_div_u32(n, BLK) + 1);
+  o = ws_carve(base, o, g.pbkey, (size_t)ceil_div_u32(n, BLK) * 2);
   o = ws_carve(base, o, g.skeyA, n);
   o = ws_carve(base, o, g.skeyB, n);
   o = ws_carve(base, o, g.svalA, n);

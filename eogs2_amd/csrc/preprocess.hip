@@ -116,7 +116,7 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
     const float* __restrict__ cov3D_precomp, const float* __restrict__ opacities, const float* __restrict__ colors,
     const float* __restrict__ vm, float scale_modifier, int antialiasing,
     int* __restrict__ radii, float4* __restrict__ packed, uint4* __restrict__ binfo, uint32_t* __restrict__ pblock,
-    uint32_t* __restrict__ skey, uint32_t* __restrict__ sval, uint32_t* __restrict__ misc) {
+    uint32_t* __restrict__ pbkey, uint32_t* __restrict__ skey, uint32_t* __restrict__ sval, uint32_t* __restrict__ misc) {
   __shared__ float s_m[3 * BLK];
   __shared__ float s_s[3 * BLK];
   __shared__ uint32_t s_cnt[BLK / 64];
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
     sval[idx] = (uint32_t)idx;
   }
   // exclusive prefix of the tile counts inside the workgroup (record slots in Gaussian-id order) and the
-  // workgroup total; num_rendered: one 64-bit atomic per workgroup
+  // workgroup total
   uint32_t inc = my_tiles;
   const int lane = t & 63;
 #pragma unroll
@@ -239,12 +239,10 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
     binfo[2 * idx] = bi0;
     binfo[2 * idx + 1] = make_uint4(my_tiles, pre + inc - my_tiles, (uint32_t)idx, 0u);
   }
-  if (t == 0) {
-    const uint32_t tot = w0 + w1 + w2 + w3;
-    pblock[blockIdx.x] = tot;
-    if (tot) atomicAdd(reinterpret_cast<unsigned long long*>(misc + MISC_TOTAL_LO), (unsigned long long)tot);
-  }
-  // range of the depth keys of listed Gaussians: lets the host drop sort passes whose digit is constant
+  // range of the depth keys of listed Gaussians (lets the host drop sort passes whose digit is constant) and the
+  // workgroup's pair count: plain stores, reduced by pblock_scan_kernel (same-address atomics from 16k waves cost
+  // 0.36 ms here)
+  __shared__ uint32_t s_k[2][BLK / 64];
   uint32_t kmax = my_tiles ? key_bits : 0u, knmin = my_tiles ? ~key_bits : 0u;
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
@@ -252,9 +250,81 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
     kmax = a > kmax ? a : kmax;
     knmin = b > knmin ? b : knmin;
   }
-  if (lane == 0 && kmax) {
-    atomicMax(&misc[MISC_KEY_MAX], kmax);
-    atomicMax(&misc[MISC_KEY_NMIN], knmin);
+  if (lane == 0) { s_k[0][w] = kmax; s_k[1][w] = knmin; }
+  __syncthreads();
+  if (t == 0) {
+    pblock[blockIdx.x] = w0 + w1 + w2 + w3;
+    uint32_t a = s_k[0][0], b = s_k[1][0];
+    for (int i = 1; i < BLK / 64; i++) {
+      a = s_k[0][i] > a ? s_k[0][i] : a;
+      b = s_k[1][i] > b ? s_k[1][i] : b;
+    }
+    pbkey[2 * blockIdx.x] = a;
+    pbkey[2 * blockIdx.x + 1] = b;
+  }
+}
+
+// Single workgroup: exclusive scan of the per-workgroup pair counts (-> record slots in Gaussian-id order), their
+// 64-bit total (= num_rendered) and the key range, written to misc[] for the host readback.
+__global__ __launch_bounds__(BLK) void pblock_scan_kernel(uint32_t* __restrict__ pblock, const uint32_t* __restrict__ pbkey,
+                                                          uint32_t nblk, uint32_t* __restrict__ misc) {
+  __shared__ uint32_t s_w[4];
+  __shared__ uint32_t s_k[2][BLK / 64];
+  unsigned long long carry = 0ull;
+  uint32_t kmax = 0, knmin = 0;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (uint32_t b0 = 0; b0 < nblk; b0 += BLK * 16) {
+    const uint32_t i0 = b0 + threadIdx.x * 16;
+    uint32_t v[16], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      v[k] = 0;
+      if (i0 + k < nblk) {
+        v[k] = pblock[i0 + k];
+        const uint32_t a = pbkey[2 * (i0 + k)], b = pbkey[2 * (i0 + k) + 1];
+        kmax = a > kmax ? a : kmax;
+        knmin = b > knmin ? b : knmin;
+      }
+      sum += v[k];
+    }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t nb = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += nb;
+    }
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    const uint32_t w0 = s_w[0], w1 = s_w[1], w2 = s_w[2], w3 = s_w[3];
+    const uint32_t pre = (w > 0 ? w0 : 0u) + (w > 1 ? w1 : 0u) + (w > 2 ? w2 : 0u);
+    __syncthreads();
+    uint32_t run = (uint32_t)carry + pre + inc - sum;  // slots are u32: the host rejects totals >= 2^31
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      if (i0 + k < nblk) pblock[i0 + k] = run;
+      run += v[k];
+    }
+    carry += (unsigned long long)w0 + w1 + w2 + w3;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const uint32_t a = __shfl_xor(kmax, o, 64), b = __shfl_xor(knmin, o, 64);
+    kmax = a > kmax ? a : kmax;
+    knmin = b > knmin ? b : knmin;
+  }
+  if (lane == 0) { s_k[0][w] = kmax; s_k[1][w] = knmin; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t a = s_k[0][0], b = s_k[1][0];
+    for (int i = 1; i < BLK / 64; i++) {
+      a = s_k[0][i] > a ? s_k[0][i] : a;
+      b = s_k[1][i] > b ? s_k[1][i] : b;
+    }
+    pblock[nblk] = (uint32_t)carry;
+    misc[MISC_TOTAL_LO] = (uint32_t)carry;
+    misc[MISC_TOTAL_HI] = (uint32_t)(carry >> 32);
+    misc[MISC_KEY_MAX] = a;
+    misc[MISC_KEY_NMIN] = b;
   }
 }
 
@@ -263,11 +333,11 @@ void launch_preprocess_fwd(const FwdPrepArgs& a, const GeomWS& g, hipStream_t s)
   const uint32_t nblk = ceil_div_u32((uint64_t)a.P, BLK);
   hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nblk), dim3(BLK), 0, s, a.P, a.H, a.W, gx, gy, a.means3D, a.scales,
                      a.rotations, a.cov3D_precomp, a.opacities, a.colors, a.viewmatrix, a.scale_modifier, (int)a.antialiasing,
-                     a.radii, g.packed, g.binfo, g.pblock, g.skeyA, g.svalA, g.misc);
+                     a.radii, g.packed, g.binfo, g.pblock, g.pbkey, g.skeyA, g.svalA, g.misc);
 }
 
 void launch_scan_pblock(const GeomWS& g, int P, hipStream_t s) {
-  launch_small_scan(g.pblock, ceil_div_u32((uint64_t)P, BLK), s);
+  hipLaunchKernelGGL(pblock_scan_kernel, dim3(1), dim3(BLK), 0, s, g.pblock, g.pbkey, ceil_div_u32((uint64_t)P, BLK), g.misc);
 }
 
 // ------------------------------------------------------------------------------------------------------
