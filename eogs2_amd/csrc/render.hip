@@ -44,7 +44,13 @@ namespace {
 #define LN2 0.6931471805599453f
 #define ENT 12   // floats per staged list entry: gx gy A B | C op f0 f1 | f2 f3 f4 1/depth
 #define KSURV 8  // survivors per transposition round (backward)
-#define UVS 65   // row stride (floats) of the u/v matrices: 65 = 1 mod 32 keeps both access patterns conflict-free
+// u/v matrices [survivor k][pixel p] in LDS, laid out as two half-matrices (pixels 0..31 / 32..63) with row stride 33 and
+// 268 floats between the halves: bank(k,p) = 12*(p>>5) + k + (p&31) mod 32. The pixel-parallel writes (lane = p, fixed k)
+// hit 32 consecutive banks per half-wave, and the transposed reads (lane = 8k + o reads pixel 8o + i) hit
+// {k + 8(o&3) + 12(o>>2) + i}: 32 different banks for the 32 (k,o) pairs of a half-wave.
+#define UV_HALF 268
+#define UV_SIZE (2 * UV_HALF)
+__device__ inline int uv_index(int k, int p) { return (p >> 5) * UV_HALF + k * 33 + (p & 31); }
 
 // ---- wave64 helpers ----
 __device__ inline uint32_t wave_max_u32(uint32_t v) {
@@ -202,12 +208,39 @@ void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, 
 // ------------------------------------------------------------------------------------------------------
 namespace {
 
+// Sum of 11 values over each group of 8 consecutive lanes; the group total is valid in the group's LAST lane (7, 15,
+// ..., 63). Three DPP steps, row_shr 1/2/4 (bound_ctrl: sources outside the 16-lane row read 0): after them lane l holds
+// the sum of lanes l-7..l, which for l = 8m+7 is exactly group m. Inline asm so each step is ONE v_add_f32_dpp per value
+// (hipcc materialises "old = 0" moves otherwise); an asm statement is opaque to the hazard recogniser and a DPP read of
+// a VGPR written by the previous VALU instruction needs 2 wait states, hence the leading s_nop 1; inside a block the 11
+// chains are independent and every register is re-read 11 instructions after it was written.
+#define DPP_STEP11(CTRL)                                                                                         \
+  asm volatile("s_nop 1\n\t"                                                                                     \
+               "v_add_f32_dpp %0, %0, %0 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %1, %1, %1 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %2, %2, %2 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %3, %3, %3 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %4, %4, %4 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %5, %5, %5 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %6, %6, %6 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %7, %7, %7 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %8, %8, %8 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %9, %9, %9 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %10, %10, %10 " CTRL                                                                \
+               : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), \
+                 "+v"(c[8]), "+v"(c[9]), "+v"(c[10]))
+__device__ inline void group8_sum11(float (&c)[11]) {
+  DPP_STEP11("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+  DPP_STEP11("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+  DPP_STEP11("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+}
+
 // Transposition round: the wave has parked, for up to KSURV = 8 surviving entries k, the per-pixel pairs
 //   u[k][p] = alpha T (weight of the colour gradient),  v[k][p] = G dL/dalpha
-// in LDS. Now lane (k = lane & 7, o = lane >> 3) owns survivor k and pixel row o of the tile (8 pixels, constant
+// in LDS. Now lane (k = lane >> 3, o = lane & 7) owns survivor k and pixel row o of the tile (8 pixels, constant
 // dy) and accumulates  sum v, sum v dx, sum v dx^2  and  sum u g_p[ch]  serially in registers with plain FMAs on
-// VGPR operands; the y-moments follow from the constant dy. The eight rows are then combined with three
-// xor-shuffles and the lanes of row 0 turn the moments M = sum_p v {1, dx, dy, dx^2, dx dy, dy^2} into the record
+// VGPR operands; the y-moments follow from the constant dy. A survivor's eight rows sit in eight consecutive lanes,
+// so they are combined with three in-register DPP steps (group8_sum11) and lane o = 7 turns the moments M = sum_p v {1, dx, dy, dx^2, dx dy, dy^2} into the record
 // (backward.cu:624-640):
 //   dL/dmean2D = o (W/2, H/2) * (-(a M_dx + b M_dy), -(c M_dy + b M_dx)),  dL/dconic = -o/2 (M_dxdx, M_dxdy, M_dydy),
 //   dL/dopacity = M_1,  dL/dcolour = sum u g.
@@ -215,7 +248,7 @@ __device__ inline void transpose_round(int nsurv, int lane, const float* slab, c
                                        const float* s_pix, unsigned long long kj_packed, const uint32_t* s_slot, float bx0,
                                        float by0, float kx, float ky, float* __restrict__ records,
                                        uint8_t* __restrict__ live_flag) {
-  const int k = lane & 7, o = lane >> 3;
+  const int k = lane >> 3, o = lane & 7;
   const bool live = k < nsurv;
   const uint32_t jk = live ? (uint32_t)(kj_packed >> (8 * k)) & 63u : 0u;  // 8 bits per survivor, wave-uniform word
   const float4 q0 = *reinterpret_cast<const float4*>(slab + jk * ENT);      // gx gy A B
@@ -224,8 +257,8 @@ __device__ inline void transpose_round(int nsurv, int lane, const float* slab, c
   const float dy = q0.y - (by0 + (float)o);
   float S0 = 0.f, Sx = 0.f, Sxx = 0.f;
   float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f, c4 = 0.f;
-  const float* urow = s_u + k * UVS + 8 * o;
-  const float* vrow = s_v + k * UVS + 8 * o;
+  const float* urow = s_u + uv_index(k, 8 * o);  // a pixel row (8 pixels) never straddles the two halves
+  const float* vrow = s_v + uv_index(k, 8 * o);
   const float* prow = s_pix + (8 * o) * 8 + 4 * o;  // 8 floats per pixel, +4 floats per pixel row against bank conflicts
 #pragma unroll
   for (int i = 0; i < 8; i++) {
@@ -238,13 +271,8 @@ __device__ inline void transpose_round(int nsurv, int lane, const float* slab, c
     c0 += u * ga.x; c1 += u * ga.y; c2 += u * ga.z; c3 += u * ga.w; c4 += u * gb;
   }
   float acc[11] = {S0, Sx, dy * S0, Sxx, dy * Sx, dy * dy * S0, c0, c1, c2, c3, c4};
-#pragma unroll
-  for (int q = 0; q < 11; q++) {
-    acc[q] += __shfl_xor(acc[q], 8, 64);
-    acc[q] += __shfl_xor(acc[q], 16, 64);
-    acc[q] += __shfl_xor(acc[q], 32, 64);
-  }
-  if (live && o == 0) {
+  group8_sum11(acc);
+  if (live && o == 7) {
     const float A = q0.z, B = q0.w, Cq = q1.x, op = q1.y;
     const float m2x = op * kx * (2.f * A * acc[1] - B * acc[2]);   // -a = 2A/log2e, -b = -B/log2e
     const float m2y = op * ky * (2.f * Cq * acc[2] - B * acc[1]);  // -c = 2C/log2e
@@ -265,8 +293,8 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
     const float* __restrict__ out_color, const float* __restrict__ out_invdepth, const float* __restrict__ dL_dpix,
     const float* __restrict__ dL_dinv, float* __restrict__ records, uint8_t* __restrict__ live_flag) {
   __shared__ __attribute__((aligned(16))) float s_slab[BLK / 64][64 * ENT];
-  __shared__ __attribute__((aligned(16))) float s_u[BLK / 64][KSURV * UVS];
-  __shared__ __attribute__((aligned(16))) float s_v[BLK / 64][KSURV * UVS];
+  __shared__ __attribute__((aligned(16))) float s_u[BLK / 64][UV_SIZE];
+  __shared__ __attribute__((aligned(16))) float s_v[BLK / 64][UV_SIZE];
   __shared__ __attribute__((aligned(16))) float s_pix[BLK / 64][64 * 8 + 32];
   __shared__ uint32_t s_slot[BLK / 64][64];
   const int lane = threadIdx.x & 63;
@@ -345,8 +373,8 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
       const float one_m = 1.f - a_eff;
       const float dLda = T * gc - (Dfinal - Dacc) * __builtin_amdgcn_rcpf(one_m);
       T = T * one_m;
-      su[k * UVS + lane] = wgt;
-      sv[k * UVS + lane] = G_eff * dLda;  // v = G dL/dalpha
+      su[uv_index(k, lane)] = wgt;
+      sv[uv_index(k, lane)] = G_eff * dLda;  // v = G dL/dalpha
       kj |= (unsigned long long)j << (8 * k);
       if (++k == KSURV) {
         wave_lds_sync();
@@ -385,15 +413,17 @@ void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, 
 // ---- self test of the wave64 primitives (diagnostics) ----
 __global__ void selftest_kernel(uint32_t* out) {
   const int lane = threadIdx.x & 63;
-  const float v = (float)((lane * 37 + 11) % 101) - 50.f;
-  float a = v;
-  a += __shfl_xor(a, 8, 64);
-  a += __shfl_xor(a, 16, 64);
-  a += __shfl_xor(a, 32, 64);
-  float ref = 0.f;
-  for (int r = 0; r < 8; r++) ref += (float)((((lane & 7) + 8 * r) * 37 + 11) % 101) - 50.f;
   uint32_t bad = 0;
-  if (a != ref) bad |= 1u;
+  float c[11];
+#pragma unroll
+  for (int q = 0; q < 11; q++) c[q] = (float)(((lane * 37 + 11 * q + 5) % 101) - 50);  // freshly written VGPRs (hazard case)
+  group8_sum11(c);
+#pragma unroll
+  for (int q = 0; q < 11; q++) {
+    float ref = 0.f;
+    for (int i = 0; i < 8; i++) ref += (float)(((((lane & ~7) + i) * 37 + 11 * q + 5) % 101) - 50);
+    if ((lane & 7) == 7 && c[q] != ref) bad |= 1u;
+  }
   if (wave_max_u32((uint32_t)lane * 3u) != 189u) bad |= 2u;
   if (bad) atomicOr(out, bad);
 }
