@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--opacity", default="init", help="init (0.01, gs_config/train.yaml:55) | trained | float")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-iter", action="store_true", help="skip the extra synthetic training-iteration measurement")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the gradient all-reduce even with one rank (self-test)")
     return ap.parse_args()
@@ -62,6 +63,43 @@ def measured_traffic(kernel, a):
             if name.startswith(kernel + "_kernel") and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 return int((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024), os.path.relpath(d, ROOT)
     return None, None
+
+
+def train_iteration(sc, P, H, W, dev, iters=5):
+    """Extra, reported beside the headline: one synthetic EOGS++ training iteration as the reference schedules it after
+    iteration 1000 (GS/train_pan.py:278,305-316,375-391): three renders of the same Gaussians — the view (H x W), the
+    sun camera (2H x 2W, affine_cameras.py:366-367) and a random virtual camera (H x W) — each forward + backward through
+    the drop-in, gradients accumulated, then one fused Adam step on the five parameter tensors. Losses are replaced by
+    fixed upstream gradients dL/dcolor (the image-space losses are out of scope)."""
+    from eogs2_amd import GaussianRasterizer
+    from eogs2_amd.synthetic import make_camera, settings_for
+
+    params = {k: sc[k].clone().requires_grad_(True) for k in ("means3D", "colors", "opacities", "scales", "rotations")}
+    opt = torch.optim.Adam(list(params.values()), lr=1e-4, fused=True)
+    views = []
+    for seed, (h, w) in ((11, (H, W)), (12, (2 * H, 2 * W)), (13, (H, W))):
+        s2 = dict(sc, viewmatrix=make_camera(h, w, seed=seed, device=dev))
+        g = torch.Generator().manual_seed(seed)
+        dL = (torch.randn(5, h, w, generator=g) / (h * w)).to(dev)
+        views.append((GaussianRasterizer(settings_for(s2, h, w)), torch.zeros(P, 3, device=dev), dL))
+
+    def it():
+        opt.zero_grad(set_to_none=True)
+        for rast, m2, dL in views:
+            color, _, _ = rast(params["means3D"], m2, params["opacities"], colors_precomp=params["colors"],
+                               scales=params["scales"], rotations=params["rotations"])
+            torch.autograd.backward([color], [dL])
+        opt.step()
+
+    it()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        it()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    return {"iters_per_s": 1.0 / dt, "ms_per_iter": dt * 1e3, "renders_per_iter": 3,
+            "what": f"3 renders ({H}x{W}, {2 * H}x{2 * W} sun camera, {H}x{W}) fwd+bwd + fused Adam, fixed dL/dcolor"}
 
 
 def cpu_baseline(P_full, S_full):
@@ -212,6 +250,8 @@ def main():
                        "gaussians": P, "height": H, "width": W, "num_rendered": R, "parallelism": f"view-dp{world}"},
             "roofline": roof, "pipeline": pipe, "kernels_ms": kern,
         }
+        if world == 1 and not use_dist and not a.no_train_iter:
+            line["train_iter"] = train_iteration(sc, P, H, W, dev)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(P, H)
         print(json.dumps(line), flush=True)

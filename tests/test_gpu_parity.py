@@ -241,3 +241,73 @@ def test_full_size_properties(dev):
     inv = radii == 0
     for k, v in g1.items():
         assert float(v[inv].abs().sum()) == 0.0, k
+
+
+def _small_scene(dev, P=3000, H=96, W=128, seed=5):
+    from eogs2_amd.synthetic import make_scene, settings_for
+
+    sc = make_scene(P, H, W, seed=seed, opacity="trained", scale_mult=2.0, device=dev)
+    return sc, settings_for(sc, H, W), P, H, W
+
+
+def _render(sc, rs, P, dev, leaves=None):
+    from eogs2_amd import GaussianRasterizer
+
+    x = leaves or sc
+    return GaussianRasterizer(rs)(x["means3D"], torch.zeros(P, 3, device=dev), x["opacities"], colors_precomp=x["colors"],
+                                  scales=x["scales"], rotations=x["rotations"])
+
+
+def test_altitude_error_is_raised_not_trapped(dev):
+    """forward.cu:267-272 traps the GPU; here the same condition is a Python exception and the GPU stays usable."""
+    from eogs2_amd import RastError
+
+    sc, rs, P, H, W = _small_scene(dev)
+    sc["means3D"][17, 2] = 1.0  # altitude 350 > 200
+    with pytest.raises(RastError, match="too high"):
+        _render(sc, rs, P, dev)
+    sc["means3D"][17, 2] = 0.0
+    color, _, _ = _render(sc, rs, P, dev)  # still works afterwards
+    assert torch.isfinite(color).all()
+
+
+def test_debug_flag_and_no_grad_and_mark_visible(dev):
+    from eogs2_amd import GaussianRasterizer
+
+    sc, rs, P, H, W = _small_scene(dev)
+    ref, radii, _ = _render(sc, rs, P, dev)
+    dbg, radii_d, _ = _render(sc, rs._replace(debug=True), P, dev)  # sync + check after every kernel group
+    assert torch.equal(ref, dbg) and torch.equal(radii, radii_d)
+    with torch.no_grad():
+        ng, _, _ = _render(sc, rs, P, dev)
+    assert torch.equal(ref, ng) and not ng.requires_grad
+    assert GaussianRasterizer(rs).markVisible(sc["means3D"]).all()
+
+
+def test_retain_graph_double_backward_call(dev):
+    """The workspaces saved by forward serve any number of backward calls (live flags depend on forward state only)."""
+    sc, rs, P, H, W = _small_scene(dev)
+    leaves = {k: sc[k].clone().requires_grad_(True) for k in ["means3D", "scales", "rotations", "opacities", "colors"]}
+    color, _, _ = _render(sc, rs, P, dev, leaves)
+    torch.autograd.backward([color], [sc["dL_dcolor"]], retain_graph=True)
+    g1 = {k: v.grad.clone() for k, v in leaves.items()}
+    for v in leaves.values():
+        v.grad = None
+    torch.autograd.backward([color], [3.0 * sc["dL_dcolor"]])
+    for k, v in leaves.items():
+        assert_close(v.grad, 3.0 * g1[k], f"second backward:{k}", allow_flips=False)
+
+
+def test_non_default_stream_and_strided_inputs(dev):
+    sc, rs, P, H, W = _small_scene(dev)
+    ref, _, _ = _render(sc, rs, P, dev)
+    # non-contiguous / fp64 inputs are made contiguous fp32 by the wrapper, like rasterize_points.cu:101-120
+    wide = torch.zeros(P, 7, device=dev, dtype=torch.float64)
+    wide[:, 1:4] = sc["means3D"]
+    sc2 = dict(sc, means3D=wide[:, 1:4])
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        out, _, _ = _render(sc2, rs, P, dev)
+    st.synchronize()
+    assert torch.equal(ref, out)
