@@ -159,6 +159,13 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
     }
   }
   LAUNCH_TRY(s, debug, "depth_sort_tail");
+  // keep the GPU busy while the caller sizes and allocates the binning workspace: the depth-order gather and the
+  // chunk scan only touch the geometry workspace
+  if (g_pinned[MISC_TOTAL_LO] | g_pinned[MISC_TOTAL_HI]) {
+    ProfScope ps(PS_BINNING, s);
+    launch_binning_head(g, P, s);
+  }
+  LAUNCH_TRY(s, debug, "binning_head");
   if (g_pinned[MISC_ERR] & 1u) return fail(EOGS_ERR_ALTITUDE, "Point is too high: altitude > 200");
   const uint64_t total = (uint64_t)g_pinned[MISC_TOTAL_LO] | ((uint64_t)g_pinned[MISC_TOTAL_HI] << 32);
   if (total >= ((uint64_t)1 << 31)) return fail(EOGS_ERR_OVERFLOW, "num_rendered overflows 31 bits");

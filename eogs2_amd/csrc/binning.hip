@@ -225,13 +225,11 @@ void launch_small_scan(uint32_t* data, uint32_t n, hipStream_t s) {
   hipLaunchKernelGGL(small_scan_kernel, dim3(1), dim3(BLK), 0, s, data, n);
 }
 
-// ---- expand step A: pair count of each chunk of 256 depth-sorted Gaussians (+ zeroes the tile ranges) ----
+// ---- expand step A: pair count of each chunk of 256 depth-sorted Gaussians ----
 __global__ __launch_bounds__(BLK) void expand_count_kernel(const uint32_t* __restrict__ sorted_ids,
                                                            const uint4* __restrict__ binfo, uint32_t P,
-                                                           uint4* __restrict__ sinfo, uint32_t* __restrict__ blocksum,
-                                                           uint2* __restrict__ ranges, uint32_t ntiles) {
+                                                           uint4* __restrict__ sinfo, uint32_t* __restrict__ blocksum) {
   __shared__ uint32_t s_w[4];
-  for (uint32_t i = blockIdx.x * BLK + threadIdx.x; i < ntiles; i += gridDim.x * BLK) ranges[i] = make_uint2(0u, 0u);
   const uint32_t k = blockIdx.x * BLK + threadIdx.x;
   uint32_t v = 0;
   if (k < P) {
@@ -267,8 +265,10 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint4* __restrict__ s
                                                      const uint32_t* __restrict__ pblock,
                                                      const uint32_t* __restrict__ blocksum, uint32_t P, uint32_t gsx,
                                                      uint32_t gsy, uint32_t* __restrict__ tkey,
-                                                     uint2* __restrict__ tval) {
+                                                     uint2* __restrict__ tval, uint2* __restrict__ ranges) {
   __shared__ uint32_t s_w[4];
+  // the tile ranges are rewritten after the sort (tile_ranges_kernel): clear them here
+  for (uint32_t i = blockIdx.x * BLK + threadIdx.x; i < gsx * gsy; i += gridDim.x * BLK) ranges[i] = make_uint2(0u, 0u);
   __shared__ uint32_t s_tk[EXPAND_STAGE];
   __shared__ uint2 s_tv[EXPAND_STAGE];
   const int lane = threadIdx.x & 63;
@@ -375,17 +375,20 @@ __global__ __launch_bounds__(BLK) void tile_ranges_kernel(const uint32_t* __rest
   if (i == R - 1) ranges[cur].y = R;
 }
 
+void launch_binning_head(const GeomWS& g, int P, hipStream_t s) {
+  hipLaunchKernelGGL(expand_count_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.svalA, g.binfo, (uint32_t)P, g.sinfo,
+                     g.blocksum);
+  launch_small_scan(g.blocksum, g.nblkE, s);
+}
+
 void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, hipStream_t s) {
   const uint32_t gsx = (uint32_t)((W + SUBX - 1) / SUBX), gsy = (uint32_t)((H + SUBY - 1) / SUBY);
   if (R <= 0) {
     (void)hipMemsetAsync(im.ranges, 0, (size_t)gsx * gsy * sizeof(uint2), s);
     return;
   }
-  hipLaunchKernelGGL(expand_count_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.svalA, g.binfo, (uint32_t)P, g.sinfo,
-                     g.blocksum, im.ranges, gsx * gsy);
-  launch_small_scan(g.blocksum, g.nblkE, s);
   hipLaunchKernelGGL(expand_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.sinfo, g.pblock, g.blocksum, (uint32_t)P, gsx, gsy,
-                     b.tkeyA, b.tvalA);
+                     b.tkeyA, b.tvalA, im.ranges);
   uint32_t *ka = b.tkeyA, *kb = b.tkeyB;
   uint2 *va = b.tvalA, *vb = b.tvalB;
   int shift = 0;

@@ -173,6 +173,8 @@ void launch_preprocess_fwd(const FwdPrepArgs& a, const GeomWS& g, hipStream_t s)
 void launch_depth_sort(const GeomWS& g, int P, int first, int last, hipStream_t s);
 void launch_small_scan(uint32_t* data, uint32_t n, hipStream_t s);
 void launch_scan_pblock(const GeomWS& g, int P, hipStream_t s);
+// part of binning that needs only the geometry workspace (queued by forward_prepare right after its sync)
+void launch_binning_head(const GeomWS& g, int P, hipStream_t s);
 void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, hipStream_t s);
 void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, int W,
                        const float* bg, float* out_color, float* out_invdepth, hipStream_t s);
