@@ -356,53 +356,37 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
   __shared__ float s_m[3 * BLK];
   __shared__ float s_s[3 * BLK];
   __shared__ float s_red[BLK / 64][18];
-  __shared__ __attribute__((aligned(16))) float s_sum[BLK][REC];
   const int t = threadIdx.x;
   const size_t row0 = (size_t)blockIdx.x * BLK;
   const int rows = (int)(((size_t)P - row0) < (size_t)BLK ? ((size_t)P - row0) : (size_t)BLK);
   stage_rows3(means3D, row0, rows, s_m);
   if (scales) stage_rows3(scales, row0, rows, s_s);
+  __syncthreads();
 
   const size_t idx = row0 + t;
   float vmsum[18];
 #pragma unroll
   for (int k = 0; k < 18; k++) vmsum[k] = 0.f;
 
-  // ---- stage 1: fixed-order sum of each Gaussian's live (tile,Gaussian) records (deterministic, no atomics).
-  // Records are laid out in Gaussian-id order, so the 256 Gaussians of this workgroup own one contiguous region.
-  // A quad of lanes serves one Gaussian: lanes c = 0..2 read the three float4 of a 48-byte record, so a
-  // wave-instruction reads 16 neighbouring record runs instead of 64 scattered 16-byte pieces.
-  {
-    const int c = t & 3;
-    const uint32_t wg_base = pblock[blockIdx.x];
-#pragma unroll 1
-    for (int pass = 0; pass < 4; pass++) {
-      const int local = pass * 64 + (t >> 2);
-      const size_t gi = row0 + local;
-      float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (local < rows && radii[gi] > 0) {
-        const uint4 bi1 = binfo[2 * gi + 1];
-        const uint32_t n = bi1.x;
-        const size_t s0 = (size_t)wg_base + bi1.y;
-        const float4* r4 = reinterpret_cast<const float4*>(records + s0 * REC);
-        for (uint32_t q = 0; q < n; q++) {
-          if (!live[s0 + q]) continue;  // pair behind every pixel's last contributor: no record was written
-          if (c < 3) {
-            const float4 v = r4[3 * q + c];
-            a4.x += v.x; a4.y += v.y; a4.z += v.z; a4.w += v.w;
-          }
-        }
-      }
-      if (c < 3) *reinterpret_cast<float4*>(&s_sum[local][4 * c]) = a4;
-    }
-  }
-  __syncthreads();
-
   if (t < rows) {
     float acc[REC];
 #pragma unroll
-    for (int k = 0; k < REC; k++) acc[k] = s_sum[t][k];
+    for (int k = 0; k < REC; k++) acc[k] = 0.f;
     const bool visible = radii[idx] > 0;
+    if (visible) {
+      // fixed-order sum of this Gaussian's (tile,Gaussian) records: deterministic, no atomics
+      const uint4 bi1 = binfo[2 * idx + 1];
+      const uint32_t n = bi1.x;
+      const size_t s0 = (size_t)pblock[blockIdx.x] + bi1.y;  // Gaussian-id order: a wave reads one contiguous region
+      const float4* r4 = reinterpret_cast<const float4*>(records + s0 * REC);
+      for (uint32_t q = 0; q < n; q++) {
+        if (!live[s0 + q]) continue;  // pair behind every pixel's last contributor: no record was written
+        const float4 a = r4[3 * q], b = r4[3 * q + 1], c = r4[3 * q + 2];
+        acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+        acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+        acc[8] += c.x; acc[9] += c.y; acc[10] += c.z;
+      }
+    }
     // record layout: 0,1 = dL/dmean2D (NDC units)  2,3,4 = dL/dconic (a,b,c)  5 = dL/dopacity  6..10 = dL/dcolor
     const float gxn = acc[0], gyn = acc[1];
     float dop = acc[5];
