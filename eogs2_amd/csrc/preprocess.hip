@@ -379,12 +379,31 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
       const uint32_t n = bi1.x;
       const size_t s0 = (size_t)pblock[blockIdx.x] + bi1.y;  // Gaussian-id order: a wave reads one contiguous region
       const float4* r4 = reinterpret_cast<const float4*>(records + s0 * REC);
-      for (uint32_t q = 0; q < n; q++) {
-        if (!live[s0 + q]) continue;  // pair behind every pixel's last contributor: no record was written
-        const float4 a = r4[3 * q], b = r4[3 * q + 1], c = r4[3 * q + 2];
-        acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
-        acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
-        acc[8] += c.x; acc[9] += c.y; acc[10] += c.z;
+      // Two memory round trips instead of 2n dependent ones: first all live flags of this Gaussian (independent byte
+      // loads -> a register bitmask), then the live records (independent loads driven by the mask). Dead pairs
+      // (behind every pixel's last contributor) were never written and are never read.
+      for (uint32_t q0 = 0; q0 < n; q0 += 32) {
+        const uint32_t m_n = n - q0 < 32u ? n - q0 : 32u;
+        uint32_t m = 0;
+#pragma unroll 4
+        for (uint32_t q = 0; q < m_n; q++) m |= (uint32_t)(live[s0 + q0 + q] != 0) << q;
+        while (m) {  // two live records per trip: six independent loads in flight, summed in list order
+          const uint32_t q1 = q0 + (uint32_t)__builtin_ctz(m);
+          m &= m - 1u;
+          const bool two = m != 0u;
+          const uint32_t q2 = two ? q0 + (uint32_t)__builtin_ctz(m) : q1;
+          m &= m - 1u;  // (0 & anything stays 0)
+          const float4 a = r4[3 * q1], b = r4[3 * q1 + 1], c = r4[3 * q1 + 2];
+          const float4 d = r4[3 * q2], e = r4[3 * q2 + 1], f = r4[3 * q2 + 2];
+          acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+          acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+          acc[8] += c.x; acc[9] += c.y; acc[10] += c.z;
+          if (two) {
+            acc[0] += d.x; acc[1] += d.y; acc[2] += d.z; acc[3] += d.w;
+            acc[4] += e.x; acc[5] += e.y; acc[6] += e.z; acc[7] += e.w;
+            acc[8] += f.x; acc[9] += f.y; acc[10] += f.z;
+          }
+        }
       }
     }
     // record layout: 0,1 = dL/dmean2D (NDC units)  2,3,4 = dL/dconic (a,b,c)  5 = dL/dopacity  6..10 = dL/dcolor
