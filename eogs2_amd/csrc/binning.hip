@@ -6,20 +6,22 @@
 //
 //   1. depth sort of the P Gaussians: stable LSD radix on the 32 depth bits, payload = Gaussian id (8 B/item,
 //      4 passes over P items instead of 6 passes over R pairs of 12 B);
-//   2. expand in depth order: pair slot = exclusive scan of the per-Gaussian tile counts over the depth-sorted
-//      Gaussians; a load-balanced workgroup expansion writes (tile id, pair slot) with contiguous lanes.
+//   2. expand in depth order: list position = exclusive scan of the per-Gaussian tile counts over the depth-sorted
+//      Gaussians (their 32-byte binning records are gathered once into depth order); a workgroup stages its pairs
+//      in LDS and writes (tile id, {Gaussian id, record slot}) with contiguous lanes.
 //      Lists are built per INTERNAL tile (SUBX x SUBY pixels = one wave64) and only for the internal tiles of the
 //      reference's 16-px tile rect in which the Gaussian can reach alpha >= 1/255 (exact hit mask computed
 //      in preprocess): a subset of the reference's candidates that contains every (pixel, Gaussian) pair
 //      the reference blends, so rendering results are unchanged;
-//   3. stable LSD radix on the tile id only (ceil(log2 T) bits, 1-2 passes, 8 B/pair): stability keeps the
+//   3. stable LSD radix on the tile id only (ceil(log2 T) bits, 1-2 passes, 12 B/pair): stability keeps the
 //      depth order inside every tile;
 //   4. tile ranges from the sorted tile ids.
 // A (tile, Gaussian) pair is unique, so (tile, depth bits, index) is a total order and the result is
 // bit-identical to the reference's stable 64-bit-key sort.
 //
-// All kernels: 256-thread workgroups (4 wave64), wave-level ranking by ballot/match, LDS only for
-// histograms and workgroup scans.  HBM-bound integer work.
+// The depth sort runs only as many 8-bit passes as the key range needs (EOGS depths share their top byte).
+// All kernels: 256-thread workgroups (4 wave64); radix ranking is wave-private (ballot match on the digit bits, no
+// workgroup barrier), keys are re-ordered through LDS so each digit run is written contiguously. HBM-bound integer work.
 #include "common.h"
 
 namespace {

@@ -3,14 +3,18 @@
 //  preprocess_fwd_kernel : affine projection, Sigma = R S^2 R^T, cov2D = T Sigma T^T + 0.3 I, conic,
 //                          radius, tile rect, depth key.  Reference semantics:
 //                          DGR/cuda_rasterizer/forward.cu:154-283 (+ auxiliary.h:40-55,70-78).
+//                          Additionally: the exact alpha >= 1/255 hit mask over the internal 8x8 tiles of the rect,
+//                          the 64-byte render record, the 32-byte binning record, per-workgroup pair counts and
+//                          depth-key range (no atomics: reduced by pblock_scan_kernel).
 //  gaussian_bwd_kernel   : sums the per-(tile,Gaussian) gradient records written by render_bwd, then
 //                          dL/dconic -> dL/dcov2D -> dL/dSigma (+ dL/dT), dL/dmean3D, dL/dscale, dL/dquat.
 //                          Reference semantics: DGR/cuda_rasterizer/backward.cu:147-327 (computeCov2DCUDA),
 //                          :399-454 (preprocessCUDA), :331-394 (computeCov3D) fused into one kernel, plus the
 //                          wrapper-side reductions of DGR/diff_gaussian_rasterization/__init__.py:179-201.
 //
-// HBM-bound, O(P): inputs arrive as the reference's AoS [P,3]/[P,4] rows; the 12-byte rows are staged
-// through LDS so that every global access is a contiguous dword/quad per lane.
+// HBM-bound, O(P): inputs arrive as the reference's AoS [P,3]/[P,4]/[P,5] rows; the 12-byte rows are staged
+// through LDS so that their global loads are contiguous dwords per lane. Records are read in Gaussian-id order
+// (a workgroup's 256 Gaussians own one contiguous region), flags first, then two records per trip.
 #include "common.h"
 
 namespace {
