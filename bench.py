@@ -65,29 +65,45 @@ def measured_traffic(kernel, a):
     return None, None
 
 
-def train_iteration(sc, P, H, W, dev, iters=5):
+def train_iteration(sc, P, H, W, dev, fused, iters=5):
     """Extra, reported beside the headline: one synthetic EOGS++ training iteration as the reference schedules it after
     iteration 1000 (GS/train_pan.py:278,305-316,375-391): three renders of the same Gaussians — the view (H x W), the
-    sun camera (2H x 2W, affine_cameras.py:366-367) and a random virtual camera (H x W) — each forward + backward through
-    the drop-in, gradients accumulated, then one fused Adam step on the five parameter tensors. Losses are replaced by
-    fixed upstream gradients dL/dcolor (the image-space losses are out of scope)."""
+    sun camera (2H x 2W, affine_cameras.py:366-367) and a random virtual camera (H x W) — each forward + backward,
+    gradients accumulated, then one fused Adam step on the five raw parameter tensors. Losses are replaced by fixed
+    upstream gradients dL/dcolor (the image-space losses are out of scope).
+    fused=False: per render, the reference's PyTorch ops (exp / sigmoid / normalize / SH2RGB / altitude / cat,
+    gaussian_model.py:109-137, renderer.py:91-96) feed the drop-in GaussianRasterizer — what a user of the reference gets.
+    fused=True: `eogs2_amd.fused.rasterize_raw`, activations inside the per-Gaussian HIP kernels."""
     from eogs2_amd import GaussianRasterizer
+    from eogs2_amd.fused import rasterize_raw
     from eogs2_amd.synthetic import make_camera, settings_for
 
-    params = {k: sc[k].clone().requires_grad_(True) for k in ("means3D", "colors", "opacities", "scales", "rotations")}
+    C0 = 0.28209479177387814
+    op = sc["opacities"].double()
+    raw = dict(xyz=sc["means3D"].clone(), f_dc=((sc["colors"][:, :3] - 0.5) / C0).reshape(P, 1, 3).contiguous(),
+               opacity=torch.log(op / (1 - op)).float(), scaling=torch.log(sc["scales"]), rotation=sc["rotations"] * 1.5)
+    params = {k: v.requires_grad_(True) for k, v in raw.items()}
     opt = torch.optim.Adam(list(params.values()), lr=1e-4, fused=True)
     views = []
     for seed, (h, w) in ((11, (H, W)), (12, (2 * H, 2 * W)), (13, (H, W))):
-        s2 = dict(sc, viewmatrix=make_camera(h, w, seed=seed, device=dev))
+        vm = make_camera(h, w, seed=seed, device=dev)
         g = torch.Generator().manual_seed(seed)
         dL = (torch.randn(5, h, w, generator=g) / (h * w)).to(dev)
-        views.append((GaussianRasterizer(settings_for(s2, h, w)), torch.zeros(P, 3, device=dev), dL))
+        views.append((settings_for(dict(sc, viewmatrix=vm), h, w), vm[:, 2].contiguous(), torch.zeros(P, 3, device=dev), dL))
 
     def it():
         opt.zero_grad(set_to_none=True)
-        for rast, m2, dL in views:
-            color, _, _ = rast(params["means3D"], m2, params["opacities"], colors_precomp=params["colors"],
-                               scales=params["scales"], rotations=params["rotations"])
+        for rs, alt, m2, dL in views:
+            if fused:
+                color, _, _ = rasterize_raw(params["xyz"], m2, params["f_dc"], params["opacity"], params["scaling"],
+                                            params["rotation"], alt, rs)
+            else:
+                rgb = (params["f_dc"] * C0 + 0.5).squeeze(1)
+                altitude = (params["xyz"] @ rs.viewmatrix[:3, :3] + rs.viewmatrix[3, :3])[..., 2].unsqueeze(-1)
+                colors = torch.cat([rgb, altitude, torch.ones_like(altitude)], dim=-1)
+                color, _, _ = GaussianRasterizer(rs)(
+                    params["xyz"], m2, torch.sigmoid(params["opacity"]), colors_precomp=colors,
+                    scales=torch.exp(params["scaling"]), rotations=torch.nn.functional.normalize(params["rotation"]))
             torch.autograd.backward([color], [dL])
         opt.step()
 
@@ -99,7 +115,9 @@ def train_iteration(sc, P, H, W, dev, iters=5):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
     return {"iters_per_s": 1.0 / dt, "ms_per_iter": dt * 1e3, "renders_per_iter": 3,
-            "what": f"3 renders ({H}x{W}, {2 * H}x{2 * W} sun camera, {H}x{W}) fwd+bwd + fused Adam, fixed dL/dcolor"}
+            "what": f"3 renders ({H}x{W}, {2 * H}x{2 * W} sun camera, {H}x{W}) fwd+bwd + fused Adam on raw parameters, "
+                    f"fixed dL/dcolor; activations " + ("inside the HIP kernels (EOGS_FLAG_RAW_PARAMS)" if fused
+                                                        else "as the reference's PyTorch ops")}
 
 
 def cpu_baseline(P_full, S_full):
@@ -251,7 +269,8 @@ def main():
             "roofline": roof, "pipeline": pipe, "kernels_ms": kern,
         }
         if world == 1 and not use_dist and not a.no_train_iter:
-            line["train_iter"] = train_iteration(sc, P, H, W, dev)
+            line["train_iter"] = train_iteration(sc, P, H, W, dev, fused=False)
+            line["train_iter_fused"] = train_iteration(sc, P, H, W, dev, fused=True)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(P, H)
         print(json.dumps(line), flush=True)

@@ -6,7 +6,7 @@ exports the same symbols over host pointers.
 """
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 EOGS_OK = 0
 ERR_NAMES = {
@@ -19,6 +19,7 @@ ERR_NAMES = {
 }
 FLAG_ANTIALIASING = 1
 FLAG_DEBUG = 2
+FLAG_RAW_PARAMS = 4
 
 _p = C.c_void_p
 _i = C.c_int
@@ -37,7 +38,7 @@ SIGNATURES = {
     "eogs_rast_binning_bytes": (_i, [_i, _i, _i, _i64, C.POINTER(_z)]),
     "eogs_rast_forward_prepare": (
         _i,
-        [_i, _i, _i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _u, _p, _p, _z, C.POINTER(_i64), _p],
+        [_i, _i, _i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _u, _p, _p, _z, C.POINTER(_i64), _p],
     ),
     "eogs_rast_forward_render": (
         _i,
@@ -47,7 +48,7 @@ SIGNATURES = {
         _i,
         [_i, _i, _i, _i64]
         + [_p] * 7  # bg, means3D, radii, colors, opacities, scales, rotations
-        + [_f, _p, _p, _p, _u]  # scale_modifier, cov3D_precomp, viewmatrix, projmatrix, flags
+        + [_f, _p, _p, _p, _p, _u]  # scale_modifier, cov3D_precomp, viewmatrix, projmatrix, alt_affine, flags
         + [_p] * 4  # out_color, out_invdepth, dL_dout_color, dL_dout_invdepth
         + [_p, _z, _p, _z, _p, _z]  # geom, binning, image workspaces
         + [_p] * 9  # 7 gradients + dL_dT_sum + dL_dvm_mean

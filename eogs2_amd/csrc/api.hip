@@ -112,8 +112,8 @@ int eogs_rast_binning_bytes(int P, int H, int W, int64_t R, size_t* bytes) {
 
 int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const float* scales, const float* rotations,
                               const float* cov3D_precomp, const float* opacities, const float* colors,
-                              float scale_modifier, const float* viewmatrix, const float* projmatrix, unsigned flags,
-                              int* radii, void* geom,
+                              float scale_modifier, const float* viewmatrix, const float* projmatrix,
+                              const float* alt_affine, unsigned flags, int* radii, void* geom,
                               size_t geom_bytes, int64_t* num_rendered, void* stream) {
   (void)projmatrix;
   g_err[0] = 0;
@@ -128,6 +128,9 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
   if (have_sr == have_cov || (!!scales != !!rotations))
     return fail(EOGS_ERR_INVALID_ARG,
                 "forward_prepare: provide exactly one of either scale/rotation pair or precomputed 3D covariance");
+  const bool raw = (flags & EOGS_FLAG_RAW_PARAMS) != 0;
+  if (raw && (!have_sr || !alt_affine))
+    return fail(EOGS_ERR_INVALID_ARG, "forward_prepare: EOGS_FLAG_RAW_PARAMS needs scales, rotations and alt_affine");
   char* base = ws_base(geom);
   const GeomWS g = geom_layout(base, P);
   if ((size_t)(base - (char*)geom) + g.bytes - 256 > geom_bytes)
@@ -138,7 +141,7 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
 
   HIP_TRY(hipMemsetAsync(g.misc, 0, MISC_WORDS * sizeof(uint32_t), s));
   FwdPrepArgs a{P, H, W, means3D, scales, rotations, cov3D_precomp, opacities, colors, viewmatrix, scale_modifier,
-                (flags & EOGS_FLAG_ANTIALIASING) != 0, radii};
+                (flags & EOGS_FLAG_ANTIALIASING) != 0, radii, raw, alt_affine};
   { ProfScope ps(PS_PREPROCESS, s); launch_preprocess_fwd(a, g, s); launch_scan_pblock(g, P, s); }
   LAUNCH_TRY(s, debug, "preprocess_fwd");
   HIP_TRY(hipMemcpyAsync(g_pinned, g.misc, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -210,7 +213,8 @@ int eogs_rast_forward_render(int P, int H, int W, int64_t R, const float* bg, un
 int eogs_rast_backward(int P, int H, int W, int64_t R, const float* bg, const float* means3D, const int* radii,
                        const float* colors, const float* opacities, const float* scales, const float* rotations,
                        float scale_modifier, const float* cov3D_precomp, const float* viewmatrix,
-                       const float* projmatrix, unsigned flags, const float* out_color, const float* out_invdepth,
+                       const float* projmatrix, const float* alt_affine, unsigned flags, const float* out_color,
+                       const float* out_invdepth,
                        const float* dL_dout_color, const float* dL_dout_invdepth, const void* geom, size_t geom_bytes,
                        const void* binning, size_t binning_bytes, const void* image, size_t image_bytes,
                        float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D,
@@ -225,13 +229,16 @@ int eogs_rast_backward(int P, int H, int W, int64_t R, const float* bg, const fl
     if (dL_dvm_mean) HIP_TRY(hipMemsetAsync(dL_dvm_mean, 0, 12 * sizeof(float), s));
     return EOGS_OK;
   }
-  if (!means3D || !radii || !colors || !opacities || !viewmatrix || !projmatrix || !dL_dout_color || !out_color ||
-      !geom || !image || !dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || !dL_dcov3D)
+  const bool raw = (flags & EOGS_FLAG_RAW_PARAMS) != 0;
+  if (!means3D || !radii || !opacities || !viewmatrix || !projmatrix || !dL_dout_color || !out_color || !geom ||
+      !image || !dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || (!raw && (!colors || !dL_dcov3D)))
     return fail(EOGS_ERR_INVALID_ARG, "backward: NULL argument");
   if (dL_dout_invdepth && !out_invdepth) return fail(EOGS_ERR_INVALID_ARG, "backward: out_invdepth required with dL_dout_invdepth");
   const bool have_sr = scales && rotations;
   if (have_sr == (cov3D_precomp != nullptr)) return fail(EOGS_ERR_INVALID_ARG, "backward: scale/rotation xor cov3D_precomp");
   if (have_sr && (!dL_dscales || !dL_drotations)) return fail(EOGS_ERR_INVALID_ARG, "backward: NULL scale/rotation gradient");
+  if (raw && (!have_sr || !alt_affine))
+    return fail(EOGS_ERR_INVALID_ARG, "backward: EOGS_FLAG_RAW_PARAMS needs scales, rotations and alt_affine");
   if (R > 0 && !binning) return fail(EOGS_ERR_INVALID_ARG, "backward: NULL binning workspace");
 
   char* gb = ws_base(geom);
@@ -255,7 +262,7 @@ int eogs_rast_backward(int P, int H, int W, int64_t R, const float* bg, const fl
   GaussBwdArgs a{P, H, W, means3D, have_sr ? scales : nullptr, have_sr ? rotations : nullptr, cov3D_precomp, opacities,
                  viewmatrix, projmatrix, radii, scale_modifier, (flags & EOGS_FLAG_ANTIALIASING) != 0,
                  dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, have_sr ? dL_dscales : nullptr,
-                 have_sr ? dL_drotations : nullptr, dL_dT_sum, dL_dvm_mean};
+                 have_sr ? dL_drotations : nullptr, dL_dT_sum, dL_dvm_mean, raw, alt_affine};
   { ProfScope ps(PS_GAUSS_BWD, s); launch_gaussian_bwd(a, g, b, s); }
   LAUNCH_TRY(s, debug, "gaussian_bwd");
   return EOGS_OK;

@@ -167,6 +167,8 @@ struct FwdPrepArgs {
   float scale_modifier;
   bool antialiasing;
   int* radii;
+  bool raw;  // EOGS_FLAG_RAW_PARAMS
+  const float* alt_affine;
 };
 void launch_preprocess_fwd(const FwdPrepArgs& a, const GeomWS& g, hipStream_t s);
 // passes [first, last) of the 4-pass depth sort (8 bits each); pass p reads buffer A if p is even, B if odd
@@ -189,6 +191,8 @@ struct GaussBwdArgs {
   bool antialiasing;
   float *dL_dmeans2D, *dL_dcolors, *dL_dopacity, *dL_dmeans3D, *dL_dcov3D, *dL_dscales, *dL_drotations;
   float *dL_dT_sum, *dL_dvm_mean;
+  bool raw;  // EOGS_FLAG_RAW_PARAMS
+  const float* alt_affine;
 };
 void launch_gaussian_bwd(const GaussBwdArgs& a, const GeomWS& g, const BinWS& b, hipStream_t s);
 void launch_selftest(uint32_t* out, hipStream_t s);

@@ -106,6 +106,21 @@ __device__ inline bool block_hit(float gx, float gy, float a, float b, float c, 
   return !(fminf(q1, q2) > tau_m);
 }
 
+constexpr float SH_C0 = 0.28209479177387814f;  // utils/sh_utils.py:25
+
+__device__ inline float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+
+// scaling_activation = exp (gaussian_model.py:41), rotation_activation = F.normalize, eps 1e-12 (gaussian_model.py:52)
+__device__ inline float raw_activate(float s[3], float q[4]) {
+#pragma unroll
+  for (int k = 0; k < 3; k++) s[k] = expf(s[k]);
+  const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const float inv = 1.f / fmaxf(n, 1e-12f);
+#pragma unroll
+  for (int k = 0; k < 4; k++) q[k] *= inv;
+  return inv;
+}
+
 __device__ inline float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -114,21 +129,26 @@ __device__ inline float wave_sum(float v) {
 
 }  // namespace
 
+// RAW (EOGS_FLAG_RAW_PARAMS): scales/rotations/opacities/colors are the model's raw parameters; the activations and
+// the [rgb, altitude, 1] feature assembly of renderer.py:72-96 happen here instead of in ~10 PyTorch kernels.
+template <bool RAW>
 __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
     int P, int H, int W, int gx, int gy,
     const float* __restrict__ means3D, const float* __restrict__ scales, const float* __restrict__ rotations,
     const float* __restrict__ cov3D_precomp, const float* __restrict__ opacities, const float* __restrict__ colors,
-    const float* __restrict__ vm, float scale_modifier, int antialiasing,
+    const float* __restrict__ vm, const float* __restrict__ alt, float scale_modifier, int antialiasing,
     int* __restrict__ radii, float4* __restrict__ packed, uint4* __restrict__ binfo, uint32_t* __restrict__ pblock,
     uint32_t* __restrict__ pbkey, uint32_t* __restrict__ skey, uint32_t* __restrict__ sval, uint32_t* __restrict__ misc) {
   __shared__ float s_m[3 * BLK];
   __shared__ float s_s[3 * BLK];
+  __shared__ float s_c[RAW ? 3 * BLK : 1];
   __shared__ uint32_t s_cnt[BLK / 64];
   const int t = threadIdx.x;
   const size_t row0 = (size_t)blockIdx.x * BLK;
   const int rows = (int)(((size_t)P - row0) < (size_t)BLK ? ((size_t)P - row0) : (size_t)BLK);
   stage_rows3(means3D, row0, rows, s_m);
   if (scales) stage_rows3(scales, row0, rows, s_s);
+  if (RAW) stage_rows3(colors, row0, rows, s_c);
   __syncthreads();
 
   const size_t idx = row0 + t;
@@ -148,8 +168,9 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
       c6[0] = a.x; c6[1] = a.y; c6[2] = b.x; c6[3] = b.y; c6[4] = c.x; c6[5] = c.y;
     } else {
       const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
-      const float s[3] = {s_s[3 * t], s_s[3 * t + 1], s_s[3 * t + 2]};
-      const float qq[4] = {q.x, q.y, q.z, q.w};
+      float s[3] = {s_s[3 * t], s_s[3 * t + 1], s_s[3 * t + 2]};
+      float qq[4] = {q.x, q.y, q.z, q.w};
+      if (RAW) raw_activate(s, qq);
       cov3d_from_scale_rot(s, scale_modifier, qq, c6);
     }
     float T[2][3];
@@ -186,7 +207,8 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
         radius = r;
         const float d = (float)(200.0 - (double)pv[2]);  // forward.cu:267
         if (d < 0) atomicOr(&misc[MISC_ERR], 1u);
-        const float ca = cz * det_inv, cb = -cy * det_inv, cc = cx * det_inv, op = opacities[idx] * hcs;
+        const float op_in = RAW ? sigmoidf(opacities[idx]) : opacities[idx];
+        const float ca = cz * det_inv, cb = -cy * det_inv, cc = cx * det_inv, op = op_in * hcs;
         // internal SUBX x SUBY tiles inside the reference's 16-px tile rect, clipped to the image
         const int gsx = (W + SUBX - 1) / SUBX, gsy = (H + SUBY - 1) / SUBY;
         const int sx0 = FX * x0, sy0 = FY * y0, sw = FX * (x1 - x0), sh = FY * (y1 - y0);
@@ -209,7 +231,17 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
         if (my_tiles) {
           // render record: one whole 64-byte line per Gaussian
           const float L2E = 1.4426950408889634f;
-          const float* f = colors + NCH * idx;
+          float f[NCH];
+          if (RAW) {
+            // SH2RGB of the DC band (utils/sh_utils.py:125-126), altitude = ECEF_to_UVA(xyz)[2], constant 1
+#pragma unroll
+            for (int k = 0; k < 3; k++) f[k] = s_c[3 * t + k] * SH_C0 + 0.5f;
+            f[3] = alt[0] * p[0] + alt[1] * p[1] + alt[2] * p[2] + alt[3];
+            f[4] = 1.f;
+          } else {
+#pragma unroll
+            for (int k = 0; k < NCH; k++) f[k] = colors[NCH * idx + k];
+          }
           packed[4 * idx + 0] = make_float4(px, py, ca * (-0.5f * L2E), cb * L2E);
           packed[4 * idx + 1] = make_float4(cc * (-0.5f * L2E), op, f[0], f[1]);
           packed[4 * idx + 2] = make_float4(f[2], f[3], f[4], 1.f / d);
@@ -335,9 +367,10 @@ __global__ __launch_bounds__(BLK) void pblock_scan_kernel(uint32_t* __restrict__
 void launch_preprocess_fwd(const FwdPrepArgs& a, const GeomWS& g, hipStream_t s) {
   const int gx = (a.W + TILE - 1) / TILE, gy = (a.H + TILE - 1) / TILE;
   const uint32_t nblk = ceil_div_u32((uint64_t)a.P, BLK);
-  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nblk), dim3(BLK), 0, s, a.P, a.H, a.W, gx, gy, a.means3D, a.scales,
-                     a.rotations, a.cov3D_precomp, a.opacities, a.colors, a.viewmatrix, a.scale_modifier, (int)a.antialiasing,
-                     a.radii, g.packed, g.binfo, g.pblock, g.pbkey, g.skeyA, g.svalA, g.misc);
+  auto* kern = a.raw ? preprocess_fwd_kernel<true> : preprocess_fwd_kernel<false>;
+  hipLaunchKernelGGL(kern, dim3(nblk), dim3(BLK), 0, s, a.P, a.H, a.W, gx, gy, a.means3D, a.scales, a.rotations,
+                     a.cov3D_precomp, a.opacities, a.colors, a.viewmatrix, a.alt_affine, a.scale_modifier,
+                     (int)a.antialiasing, a.radii, g.packed, g.binfo, g.pblock, g.pbkey, g.skeyA, g.svalA, g.misc);
 }
 
 void launch_scan_pblock(const GeomWS& g, int P, hipStream_t s) {
@@ -347,11 +380,12 @@ void launch_scan_pblock(const GeomWS& g, int P, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------------
 // Backward, per Gaussian.
 // ------------------------------------------------------------------------------------------------------
+template <bool RAW>
 __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
     int P, int H, int W,
     const float* __restrict__ means3D, const float* __restrict__ scales, const float* __restrict__ rotations,
     const float* __restrict__ cov3D_precomp, const float* __restrict__ opacities, const float* __restrict__ vm,
-    const float* __restrict__ proj, const int* __restrict__ radii, float scale_modifier, int antialiasing,
+    const float* __restrict__ proj, const float* __restrict__ alt, const int* __restrict__ radii, float scale_modifier, int antialiasing,
     const uint4* __restrict__ binfo, const uint32_t* __restrict__ pblock, const float* __restrict__ records,
     const uint8_t* __restrict__ live,
     float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
@@ -423,6 +457,8 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
       float c6[6];
       float q[4] = {1.f, 0.f, 0.f, 0.f};
       float s3[3] = {0.f, 0.f, 0.f};
+      float q_inv = 1.f, op_in = 0.f;
+      if (RAW || antialiasing) op_in = RAW ? sigmoidf(opacities[idx]) : opacities[idx];
       if (cov3D_precomp) {
         const float2* c2 = reinterpret_cast<const float2*>(cov3D_precomp + 6 * idx);
         float2 a = c2[0], b = c2[1], c = c2[2];
@@ -431,6 +467,7 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
         const float4 qq = reinterpret_cast<const float4*>(rotations)[idx];
         q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w;
         s3[0] = s_s[3 * t]; s3[1] = s_s[3 * t + 1]; s3[2] = s_s[3 * t + 2];
+        if (RAW) q_inv = raw_activate(s3, q);
         cov3d_from_scale_rot(s3, scale_modifier, q, c6);  // recomputed instead of stored: saves 48 B/Gaussian of HBM traffic
       }
       float T[2][3];
@@ -448,7 +485,7 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
         c_yy += h_var;
         const float det_p = c_xx * c_yy - c_xy * c_xy;
         const float hcs = sqrtf(fmaxf(0.000025f, det_cov / det_p));
-        const float d_hcs = dop * opacities[idx];
+        const float d_hcs = dop * op_in;
         dop = dop * hcs;
         d_inside_root = (det_cov / det_p) <= 0.000025f ? 0.f : d_hcs / (2 * hcs);
       } else {
@@ -527,16 +564,34 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
         dq[2] = 2 * x * (D[1][0] + D[0][1]) + 2 * r * (D[2][0] - D[0][2]) + 2 * z * (D[1][2] + D[2][1]) - 4 * y * (D[2][2] + D[0][0]);
         dq[3] = 2 * r * (D[0][1] - D[1][0]) + 2 * x * (D[2][0] + D[0][2]) + 2 * y * (D[1][2] + D[2][1]) - 4 * z * (D[1][1] + D[0][0]);
       }
+      if (RAW) {
+        // chain through the activations: exp, normalize, sigmoid, and the altitude feature's dependence on xyz
+#pragma unroll
+        for (int k = 0; k < 3; k++) dscale[k] *= s3[k];
+        const float dot = q[0] * dq[0] + q[1] * dq[1] + q[2] * dq[2] + q[3] * dq[3];
+#pragma unroll
+        for (int k = 0; k < 4; k++) dq[k] = (dq[k] - q[k] * dot) * q_inv;
+        dop *= op_in * (1.f - op_in);
+#pragma unroll
+        for (int k = 0; k < 3; k++) dmean3[k] += alt[k] * acc[9];
+      }
     }
     // every output row is written (zeros for culled Gaussians): no memset pass over 144 B/Gaussian
     dL_dmeans2D[3 * idx] = gxn; dL_dmeans2D[3 * idx + 1] = gyn; dL_dmeans2D[3 * idx + 2] = 0.f;
+    if (RAW) {
 #pragma unroll
-    for (int ch = 0; ch < NCH; ch++) dL_dcolors[NCH * idx + ch] = acc[6 + ch];
+      for (int ch = 0; ch < 3; ch++) dL_dcolors[3 * idx + ch] = SH_C0 * acc[6 + ch];
+    } else {
+#pragma unroll
+      for (int ch = 0; ch < NCH; ch++) dL_dcolors[NCH * idx + ch] = acc[6 + ch];
+    }
     dL_dopacity[idx] = dop;
 #pragma unroll
     for (int k = 0; k < 3; k++) dL_dmeans3D[3 * idx + k] = dmean3[k];
+    if (dL_dcov3D) {
 #pragma unroll
-    for (int k = 0; k < 6; k++) dL_dcov3D[6 * idx + k] = dcov[k];
+      for (int k = 0; k < 6; k++) dL_dcov3D[6 * idx + k] = dcov[k];
+    }
     if (dL_dscales) {
 #pragma unroll
       for (int k = 0; k < 3; k++) dL_dscales[3 * idx + k] = dscale[k];
@@ -583,8 +638,9 @@ void launch_gaussian_bwd(const GaussBwdArgs& a, const GeomWS& g, const BinWS& b,
   if (a.dL_dT_sum) (void)hipMemsetAsync(a.dL_dT_sum, 0, 6 * sizeof(float), s);
   if (a.dL_dvm_mean) (void)hipMemsetAsync(a.dL_dvm_mean, 0, 12 * sizeof(float), s);
   const uint32_t nblk = ceil_div_u32((uint64_t)a.P, BLK);
-  hipLaunchKernelGGL(gaussian_bwd_kernel, dim3(nblk), dim3(BLK), 0, s, a.P, a.H, a.W, a.means3D, a.scales, a.rotations,
-                     a.cov3D_precomp, a.opacities, a.viewmatrix, a.projmatrix, a.radii, a.scale_modifier,
+  auto* kern = a.raw ? gaussian_bwd_kernel<true> : gaussian_bwd_kernel<false>;
+  hipLaunchKernelGGL(kern, dim3(nblk), dim3(BLK), 0, s, a.P, a.H, a.W, a.means3D, a.scales, a.rotations,
+                     a.cov3D_precomp, a.opacities, a.viewmatrix, a.projmatrix, a.alt_affine, a.radii, a.scale_modifier,
                      (int)a.antialiasing, g.binfo, g.pblock, b.records, b.live, a.dL_dmeans2D, a.dL_dcolors, a.dL_dopacity,
                      a.dL_dmeans3D, a.dL_dcov3D, a.dL_dscales, a.dL_drotations, a.dL_dT_sum, a.dL_dvm_mean);
 }

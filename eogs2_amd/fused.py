@@ -1,0 +1,73 @@
+"""Opt-in fused front end: rasterize straight from the model's raw parameters.
+
+The reference runs, before every render, a chain of small PyTorch kernels over all Gaussians —
+`exp(_scaling)`, `sigmoid(_opacity)`, `normalize(_rotation)` (scene/gaussian_model.py:41,49,52,109-137),
+`SH2RGB(_features_dc)`, `ECEF_to_UVA(_xyz)[..., 2]`, `ones_like`, `cat` (gaussian_renderer/renderer.py:91-96) —
+and autograd replays their backward after the rasterizer's. `rasterize_raw` hands the raw tensors to the C-ABI
+with `EOGS_FLAG_RAW_PARAMS` (include/eogs_rast.h): the per-Gaussian HIP kernels apply the activations while
+loading and chain their derivatives while storing, so the ~17 elementwise launches (and their [P,·]
+intermediates) per render disappear. Results equal the unfused composition to fp32 rounding
+(tests/test_gpu_parity.py::test_fused_matches_unfused).
+
+Same no-fallback rule as `rasterizer.py`: arithmetic only in the HIP library.
+"""
+import torch
+
+from .rasterizer import NUM_CHANNELS, _run_backward, _run_forward
+
+
+class _RasterizeRaw(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, means2D, f_dc, opacity_logit, log_scaling, raw_rotation, viewmat, alt_affine, raster_settings):
+        rs = raster_settings
+        P = xyz.shape[0]
+        if f_dc.numel() != P * 3:
+            raise RuntimeError("f_dc must have dimensions (num_points, 3) or (num_points, 1, 3)")
+        num_rendered, color, radii, invdepths, geom, binning, img = _run_forward(
+            rs, viewmat, xyz, f_dc.reshape(P, 3), opacity_logit, log_scaling, raw_rotation, None,
+            alt_affine=alt_affine, raw=True,
+        )
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(radii)
+        ctx.save_for_backward(xyz, f_dc, opacity_logit, log_scaling, raw_rotation, alt_affine, radii,
+                              geom, binning, img, color, invdepths)
+        return color, radii, invdepths
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _, grad_out_depth):
+        rs = ctx.raster_settings
+        (xyz, f_dc, opacity_logit, log_scaling, raw_rotation, alt_affine, radii,
+         geom, binning, img, color, invdepths) = ctx.saved_tensors
+        P = xyz.shape[0]
+        want_vm = ctx.needs_input_grad[6]
+        if P == 0:
+            z = torch.zeros_like
+            return (z(xyz), z(xyz), z(f_dc), z(opacity_logit), z(log_scaling), z(raw_rotation),
+                    torch.zeros_like(rs.viewmatrix) if want_vm else None, None, None)
+        d_means2D, d_fdc, d_logit, d_xyz, _cov, d_logscale, d_rawrot, grad_viewmatrix = _run_backward(
+            rs, ctx.num_rendered, grad_out_color, grad_out_depth, xyz, None, opacity_logit, log_scaling, raw_rotation,
+            None, radii, geom, binning, img, color, invdepths, want_vm, alt_affine=alt_affine, raw=True,
+        )
+        return (d_xyz, d_means2D, d_fdc.view(f_dc.shape), d_logit.view(opacity_logit.shape), d_logscale, d_rawrot,
+                grad_viewmatrix, None, None)
+
+
+def rasterize_raw(xyz, means2D, f_dc, opacity_logit, log_scaling, raw_rotation, alt_affine, raster_settings):
+    """(color[5,H,W], radii[P], invdepths[1,H,W]) from raw parameters.
+
+    Equivalent to the reference's
+        GaussianRasterizer(raster_settings)(means3D=xyz, means2D=means2D, shs=None,
+            colors_precomp=cat([SH2RGB(f_dc), (xyz @ A[:3,2] + A[3,2])[:, None], 1]),
+            opacities=sigmoid(opacity_logit), scales=exp(log_scaling), rotations=normalize(raw_rotation))
+    with `alt_affine = camera.affine[:, 2]` (4 floats; no gradient flows into it — the reference's `affine` is a buffer).
+    `means2D` only receives the screen-space gradient, as in the reference.
+    """
+    if alt_affine.numel() != 4:
+        raise RuntimeError("alt_affine must have 4 elements (camera.affine[:, 2])")
+    return _RasterizeRaw.apply(xyz, means2D, f_dc, opacity_logit, log_scaling, raw_rotation,
+                               raster_settings.viewmatrix, alt_affine, raster_settings)
+
+
+__all__ = ["rasterize_raw", "NUM_CHANNELS"]

@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._abi import FLAG_ANTIALIASING, FLAG_DEBUG, RastError
+from ._abi import FLAG_ANTIALIASING, FLAG_DEBUG, FLAG_RAW_PARAMS, RastError
 
 NUM_CHANNELS = 5  # DGR/cuda_rasterizer/config.h:15
 
@@ -116,6 +116,142 @@ def rasterize_gaussians(
     )
 
 
+def _run_forward(rs, viewmat, means3D, colors, opacities, scales, rotations, cov3Ds_precomp, alt_affine=None, raw=False):
+    """Marshalling of DGR/rasterize_points.cu:35-131 over the C-ABI.
+
+    Returns (num_rendered, color, radii, invdepths, geom, binning, img). With `raw` the per-Gaussian tensors are the
+    model's raw parameters (EOGS_FLAG_RAW_PARAMS, include/eogs_rast.h) and `colors` is f_dc [P,3].
+    """
+    abi = _backend()
+    # DGR/rasterize_points.cu:58-60
+    if means3D.ndim != 2 or means3D.shape[1] != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    dev = means3D.device
+    P = means3D.shape[0]
+    H, W = int(rs.image_height), int(rs.image_width)
+    flags = _flags(rs) | (FLAG_RAW_PARAMS if raw else 0)
+    ncol = 3 if raw else NUM_CHANNELS
+
+    with _Ctx(abi, dev) as cx:
+        # outputs as DGR/rasterize_points.cu:69-76 (zero images when P == 0: forward is skipped)
+        color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+        invdepths = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        empty_u8 = torch.empty((0,), dtype=torch.uint8, device=dev)
+        geom = binning = img = empty_u8
+        num_rendered = 0
+        if P == 0:
+            color.zero_()
+            invdepths.zero_()
+        else:
+            # DGR/cuda_rasterizer/rasterizer_impl.cu:244-247
+            if colors is None or colors.numel() == 0:
+                raise RuntimeError("For non-RGB, provide precomputed Gaussian colors!")
+            if colors.shape[0] != P or colors.shape[-1] != ncol or colors.numel() != P * ncol:
+                raise RuntimeError(f"colors_precomp must have dimensions (num_points, {ncol})")
+            m3 = _f32(means3D, dev)
+            col = _f32(colors, dev)
+            opa = _f32(opacities, dev)
+            sc = _f32(scales, dev)
+            rot = _f32(rotations, dev)
+            cov = _f32(cov3Ds_precomp, dev)
+            vm = _f32(viewmat, dev)
+            pm = _f32(rs.projmatrix, dev)
+            bg = _f32(rs.bg, dev)
+            alt = _f32(alt_affine, dev)
+            if opa is None or opa.numel() != P:
+                raise RuntimeError("opacities must have num_points elements")
+            if bg is None or bg.numel() != NUM_CHANNELS:
+                raise RuntimeError(f"bg must have {NUM_CHANNELS} elements")
+            if raw and (alt is None or alt.numel() != 4 or sc is None or rot is None):
+                raise RuntimeError("raw-parameter mode needs log-scales, raw rotations and a 4-element alt_affine")
+
+            nbytes = ctypes.c_size_t()
+            abi.check(abi.geom_bytes(P, ctypes.byref(nbytes)))
+            geom = torch.empty((nbytes.value,), dtype=torch.uint8, device=dev)
+            abi.check(abi.image_bytes(H, W, ctypes.byref(nbytes)))
+            img = torch.empty((nbytes.value,), dtype=torch.uint8, device=dev)
+
+            R = ctypes.c_int64()
+            abi.check(
+                abi.forward_prepare(
+                    P, H, W, _ptr(m3), _ptr(sc), _ptr(rot), _ptr(cov), _ptr(opa), _ptr(col),
+                    float(rs.scale_modifier), _ptr(vm), _ptr(pm), _ptr(alt), flags,
+                    _ptr(radii), _ptr(geom), geom.numel(), ctypes.byref(R), cx.stream,
+                )
+            )
+            num_rendered = R.value
+            abi.check(abi.binning_bytes(P, H, W, num_rendered, ctypes.byref(nbytes)))
+            binning = torch.empty((nbytes.value,), dtype=torch.uint8, device=dev)
+            abi.check(
+                abi.forward_render(
+                    P, H, W, num_rendered, _ptr(bg), flags,
+                    _ptr(geom), geom.numel(), _ptr(binning), binning.numel(), _ptr(img), img.numel(),
+                    _ptr(color), _ptr(invdepths), cx.stream,
+                )
+            )
+    return num_rendered, color, radii, invdepths, geom, binning, img
+
+
+def _run_backward(rs, num_rendered, grad_out_color, grad_out_depth, means3D, colors, opacities, scales, rotations,
+                  cov3Ds_precomp, radii, geom, binning, img, color, invdepths, want_vm, alt_affine=None, raw=False):
+    """Marshalling of DGR/rasterize_points.cu:133-224 over the C-ABI (P > 0).
+
+    Returns (d_means2D, d_colors, d_opacity[P,1], d_means3D, d_cov3D|None, d_scales|None, d_rot|None, grad_viewmatrix|None).
+    """
+    abi = _backend()
+    dev = means3D.device
+    P = means3D.shape[0]
+    H, W = int(rs.image_height), int(rs.image_width)
+    f32 = dict(dtype=torch.float32, device=dev)
+    flags = _flags(rs) | (FLAG_RAW_PARAMS if raw else 0)
+    grad_viewmatrix = torch.zeros_like(rs.viewmatrix) if want_vm else None
+
+    with _Ctx(abi, dev) as cx:
+        g_color = _f32(grad_out_color, dev)
+        if g_color is None:
+            g_color = torch.zeros((NUM_CHANNELS, H, W), **f32)
+        # the reference always receives a materialised (usually all-zero) invdepth gradient;
+        # here an unused invdepth output arrives as None and its work is skipped
+        g_depth = _f32(grad_out_depth, dev)
+        have_sr = scales is not None and scales.numel() != 0
+
+        d_means2D = torch.empty((P, 3), **f32)
+        d_colors = torch.empty((P, 3 if raw else NUM_CHANNELS), **f32)
+        d_opacity = torch.empty((P, 1), **f32)
+        d_means3D = torch.empty((P, 3), **f32)
+        d_cov3D = None if raw else torch.empty((P, 6), **f32)
+        d_scales = torch.empty((P, 3), **f32) if have_sr else None
+        d_rot = torch.empty((P, 4), **f32) if have_sr else None
+        dT_sum = torch.empty((6,), **f32) if want_vm else None
+        dvm_mean = torch.empty((12,), **f32) if want_vm else None
+
+        abi.check(
+            abi.backward(
+                P, H, W, num_rendered,
+                _ptr(_f32(rs.bg, dev)), _ptr(_f32(means3D, dev)), _ptr(radii), _ptr(_f32(colors, dev)),
+                _ptr(_f32(opacities, dev)), _ptr(_f32(scales, dev)), _ptr(_f32(rotations, dev)),
+                float(rs.scale_modifier), _ptr(_f32(cov3Ds_precomp, dev)),
+                _ptr(_f32(rs.viewmatrix, dev)), _ptr(_f32(rs.projmatrix, dev)), _ptr(_f32(alt_affine, dev)), flags,
+                _ptr(color), _ptr(invdepths), _ptr(g_color), _ptr(g_depth),
+                _ptr(geom), geom.numel(), _ptr(binning), binning.numel(), _ptr(img), img.numel(),
+                _ptr(d_means2D), _ptr(d_colors), _ptr(d_opacity), _ptr(d_means3D), _ptr(d_cov3D),
+                _ptr(d_scales), _ptr(d_rot), _ptr(dT_sum), _ptr(dvm_mean), cx.stream,
+            )
+        )
+
+        if want_vm:
+            # DGR/diff_gaussian_rasterization/__init__.py:174-202, on the reduced sums.
+            # (NCD2Screen @ dL_dT^T).sum(0): row k of the (3,2) result is scaled by NCD2Screen[k,k].
+            with torch.no_grad():
+                ncd = torch.tensor([W / 2, H / 2, 1.0], **f32)
+                dL_dA = ncd[:, None] * dT_sum.view(2, 3).t()
+                grad_viewmatrix[:3, :2] += dL_dA.to(grad_viewmatrix.dtype)
+                grad_viewmatrix[:3, :3] += dvm_mean[:9].view(3, 3).to(grad_viewmatrix.dtype)
+                grad_viewmatrix[-1, :3] += dvm_mean[9:].to(grad_viewmatrix.dtype)
+    return d_means2D, d_colors, d_opacity, d_means3D, d_cov3D, d_scales, d_rot, grad_viewmatrix
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(
@@ -131,72 +267,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         viewmat,
         raster_settings,
     ):
-        abi = _backend()
         rs = raster_settings
-        # DGR/rasterize_points.cu:58-60
-        if means3D.ndim != 2 or means3D.shape[1] != 3:
-            raise RuntimeError("means3D must have dimensions (num_points, 3)")
-        dev = means3D.device
-        P = means3D.shape[0]
-        H, W = int(rs.image_height), int(rs.image_width)
-        flags = _flags(rs)
-
-        with _Ctx(abi, dev) as cx:
-            # outputs as DGR/rasterize_points.cu:69-76 (zero images when P == 0: forward is skipped)
-            color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
-            invdepths = torch.empty((1, H, W), dtype=torch.float32, device=dev)
-            radii = torch.empty((P,), dtype=torch.int32, device=dev)
-            empty_u8 = torch.empty((0,), dtype=torch.uint8, device=dev)
-            geom = binning = img = empty_u8
-            num_rendered = 0
-            if P == 0:
-                color.zero_()
-                invdepths.zero_()
-            else:
-                # DGR/cuda_rasterizer/rasterizer_impl.cu:244-247
-                if colors_precomp is None or colors_precomp.numel() == 0:
-                    raise RuntimeError("For non-RGB, provide precomputed Gaussian colors!")
-                if colors_precomp.shape[0] != P or colors_precomp.shape[-1] != NUM_CHANNELS:
-                    raise RuntimeError(f"colors_precomp must have dimensions (num_points, {NUM_CHANNELS})")
-                m3 = _f32(means3D, dev)
-                col = _f32(colors_precomp, dev)
-                opa = _f32(opacities, dev)
-                sc = _f32(scales, dev)
-                rot = _f32(rotations, dev)
-                cov = _f32(cov3Ds_precomp, dev)
-                vm = _f32(viewmat, dev)
-                pm = _f32(rs.projmatrix, dev)
-                bg = _f32(rs.bg, dev)
-                if opa is None or opa.numel() != P:
-                    raise RuntimeError("opacities must have num_points elements")
-                if bg is None or bg.numel() != NUM_CHANNELS:
-                    raise RuntimeError(f"bg must have {NUM_CHANNELS} elements")
-
-                nbytes = ctypes.c_size_t()
-                abi.check(abi.geom_bytes(P, ctypes.byref(nbytes)))
-                geom = torch.empty((nbytes.value,), dtype=torch.uint8, device=dev)
-                abi.check(abi.image_bytes(H, W, ctypes.byref(nbytes)))
-                img = torch.empty((nbytes.value,), dtype=torch.uint8, device=dev)
-
-                R = ctypes.c_int64()
-                abi.check(
-                    abi.forward_prepare(
-                        P, H, W, _ptr(m3), _ptr(sc), _ptr(rot), _ptr(cov), _ptr(opa), _ptr(col),
-                        float(rs.scale_modifier), _ptr(vm), _ptr(pm), flags,
-                        _ptr(radii), _ptr(geom), geom.numel(), ctypes.byref(R), cx.stream,
-                    )
-                )
-                num_rendered = R.value
-                abi.check(abi.binning_bytes(P, H, W, num_rendered, ctypes.byref(nbytes)))
-                binning = torch.empty((nbytes.value,), dtype=torch.uint8, device=dev)
-                abi.check(
-                    abi.forward_render(
-                        P, H, W, num_rendered, _ptr(bg), flags,
-                        _ptr(geom), geom.numel(), _ptr(binning), binning.numel(), _ptr(img), img.numel(),
-                        _ptr(color), _ptr(invdepths), cx.stream,
-                    )
-                )
-
+        num_rendered, color, radii, invdepths, geom, binning, img = _run_forward(
+            rs, viewmat, means3D, colors_precomp, opacities, scales, rotations, cov3Ds_precomp
+        )
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.set_materialize_grads(False)
@@ -209,65 +283,25 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out_color, _, grad_out_depth):
-        abi = _backend()
         rs = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, opacities,
          geom, binning, img, color, invdepths) = ctx.saved_tensors
         dev = means3D.device
         P = means3D.shape[0]
-        H, W = int(rs.image_height), int(rs.image_width)
         f32 = dict(dtype=torch.float32, device=dev)
         want_vm = ctx.needs_input_grad[8]
 
-        grad_viewmatrix = torch.zeros_like(rs.viewmatrix) if want_vm else None
         if P == 0:
             z = lambda *s: torch.zeros(s, **f32)
             return (z(0, 3), z(0, 3), None, z(0, NUM_CHANNELS), z(*opacities.shape), z(*scales.shape) if scales.numel() else None,
-                    z(*rotations.shape) if rotations.numel() else None, None, grad_viewmatrix, None)
+                    z(*rotations.shape) if rotations.numel() else None, None,
+                    torch.zeros_like(rs.viewmatrix) if want_vm else None, None)
 
-        with _Ctx(abi, dev) as cx:
-            g_color = _f32(grad_out_color, dev)
-            if g_color is None:
-                g_color = torch.zeros((NUM_CHANNELS, H, W), **f32)
-            # the reference always receives a materialised (usually all-zero) invdepth gradient;
-            # here an unused invdepth output arrives as None and its work is skipped
-            g_depth = _f32(grad_out_depth, dev)
-            have_sr = scales is not None and scales.numel() != 0
-
-            d_means2D = torch.empty((P, 3), **f32)
-            d_colors = torch.empty((P, NUM_CHANNELS), **f32)
-            d_opacity = torch.empty((P, 1), **f32)
-            d_means3D = torch.empty((P, 3), **f32)
-            d_cov3D = torch.empty((P, 6), **f32)
-            d_scales = torch.empty((P, 3), **f32) if have_sr else None
-            d_rot = torch.empty((P, 4), **f32) if have_sr else None
-            dT_sum = torch.empty((6,), **f32) if want_vm else None
-            dvm_mean = torch.empty((12,), **f32) if want_vm else None
-
-            abi.check(
-                abi.backward(
-                    P, H, W, ctx.num_rendered,
-                    _ptr(_f32(rs.bg, dev)), _ptr(_f32(means3D, dev)), _ptr(radii), _ptr(_f32(colors_precomp, dev)),
-                    _ptr(_f32(opacities, dev)), _ptr(_f32(scales, dev)), _ptr(_f32(rotations, dev)),
-                    float(rs.scale_modifier), _ptr(_f32(cov3Ds_precomp, dev)),
-                    _ptr(_f32(rs.viewmatrix, dev)), _ptr(_f32(rs.projmatrix, dev)), _flags(rs),
-                    _ptr(color), _ptr(invdepths), _ptr(g_color), _ptr(g_depth),
-                    _ptr(geom), geom.numel(), _ptr(binning), binning.numel(), _ptr(img), img.numel(),
-                    _ptr(d_means2D), _ptr(d_colors), _ptr(d_opacity), _ptr(d_means3D), _ptr(d_cov3D),
-                    _ptr(d_scales), _ptr(d_rot), _ptr(dT_sum), _ptr(dvm_mean), cx.stream,
-                )
-            )
-
-            if want_vm:
-                # DGR/diff_gaussian_rasterization/__init__.py:174-202, on the reduced sums.
-                # (NCD2Screen @ dL_dT^T).sum(0): row k of the (3,2) result is scaled by NCD2Screen[k,k].
-                with torch.no_grad():
-                    ncd = torch.tensor([W / 2, H / 2, 1.0], **f32)
-                    dL_dA = ncd[:, None] * dT_sum.view(2, 3).t()
-                    grad_viewmatrix[:3, :2] += dL_dA.to(grad_viewmatrix.dtype)
-                    grad_viewmatrix[:3, :3] += dvm_mean[:9].view(3, 3).to(grad_viewmatrix.dtype)
-                    grad_viewmatrix[-1, :3] += dvm_mean[9:].to(grad_viewmatrix.dtype)
-
+        have_sr = scales is not None and scales.numel() != 0
+        d_means2D, d_colors, d_opacity, d_means3D, d_cov3D, d_scales, d_rot, grad_viewmatrix = _run_backward(
+            rs, ctx.num_rendered, grad_out_color, grad_out_depth, means3D, colors_precomp, opacities, scales, rotations,
+            cov3Ds_precomp, radii, geom, binning, img, color, invdepths, want_vm,
+        )
         return (
             d_means3D,
             d_means2D,

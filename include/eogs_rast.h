@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EOGS_RAST_ABI_VERSION 2
+#define EOGS_RAST_ABI_VERSION 3
 #define EOGS_RAST_CHANNELS 5 /* DGR/cuda_rasterizer/config.h:15 NUM_CHANNELS */
 #define EOGS_RAST_TILE 16    /* DGR/cuda_rasterizer/config.h:16-17 BLOCK_X/BLOCK_Y */
 
@@ -49,6 +49,20 @@ extern "C" {
 /* flags */
 #define EOGS_FLAG_ANTIALIASING 1u /* raster_settings.antialiasing */
 #define EOGS_FLAG_DEBUG 2u        /* raster_settings.debug: sync + check after every kernel (DGR/cuda_rasterizer/auxiliary.h:178-185) */
+/* Opt-in (no counterpart in the reference's extension): the per-Gaussian inputs are the model's RAW parameters
+ * and the activations + feature assembly that the reference performs in PyTorch before every render are applied
+ * inside the per-Gaussian kernels (and chained through in backward):
+ *   scales    = log-scales,  s = exp(.)            (src/gaussiansplatting/scene/gaussian_model.py:41,109-111)
+ *   rotations = raw quats,   q = r / max(|r|,1e-12) (gaussian_model.py:52,113-115, F.normalize)
+ *   opacities = logits,      o = sigmoid(.)        (gaussian_model.py:49,135-137)
+ *   colors    = f_dc f32[P,3]; feature = [0.28209479177387814 f_dc + 0.5, altitude, 1] with
+ *               altitude = xyz . alt_affine[0:3] + alt_affine[3]
+ *               (src/gaussiansplatting/gaussian_renderer/renderer.py:91-96, utils/sh_utils.py:125-126,
+ *                scene/cameras/affine_cameras.py:432-438: alt_affine = affine[0:4, 2])
+ * cov3D_precomp must be NULL. Backward then returns gradients with respect to the raw parameters:
+ * dL_dscales = d/d log-scale, dL_drotations = d/d raw quat, dL_dopacity = d/d logit, dL_dcolors = f32[P,3] d/d f_dc,
+ * dL_dmeans3D includes the altitude-feature path; dL_dcov3D may be NULL. */
+#define EOGS_FLAG_RAW_PARAMS 4u
 
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char* eogs_rast_last_error(void);
@@ -71,12 +85,13 @@ int eogs_rast_binning_bytes(int P, int H, int W, int64_t num_rendered, size_t* b
  * Exactly one of (scales, rotations) / cov3D_precomp must be non-NULL. `colors` (colors_precomp, f32[P,5]) is
  * required when P > 0 (EOGS_ERR_NO_COLORS otherwise, DGR/cuda_rasterizer/rasterizer_impl.cu:244-247): the
  * per-Gaussian render record is written once, whole, by the preprocess kernel.
+ * alt_affine: f32[4], required with EOGS_FLAG_RAW_PARAMS, otherwise ignored (pass NULL).
  * Writes radii[P] and *num_rendered (host). */
 int eogs_rast_forward_prepare(
     int P, int H, int W,
     const float* means3D, const float* scales, const float* rotations,
     const float* cov3D_precomp, const float* opacities, const float* colors, float scale_modifier,
-    const float* viewmatrix, const float* projmatrix, unsigned flags,
+    const float* viewmatrix, const float* projmatrix, const float* alt_affine, unsigned flags,
     int* radii, void* geom, size_t geom_bytes,
     int64_t* num_rendered, void* stream);
 
@@ -114,7 +129,7 @@ int eogs_rast_backward(
     const float* bg, const float* means3D, const int* radii, const float* colors,
     const float* opacities, const float* scales, const float* rotations,
     float scale_modifier, const float* cov3D_precomp,
-    const float* viewmatrix, const float* projmatrix, unsigned flags,
+    const float* viewmatrix, const float* projmatrix, const float* alt_affine, unsigned flags,
     const float* out_color, const float* out_invdepth,
     const float* dL_dout_color, const float* dL_dout_invdepth,
     const void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes,

@@ -214,7 +214,7 @@ static void cov2d(const float T[3][3], const float cov3D[6], float* cxx, float* 
 /* Forward phase 1: FORWARD::preprocessCUDA + InclusiveSum                                     */
 /* DGR/cuda_rasterizer/forward.cu:154-283, rasterizer_impl.cu:250-284                          */
 /* ------------------------------------------------------------------------------------------- */
-int eogs_rast_forward_prepare(
+static int forward_prepare_activated(
     int P, int H, int W,
     const float* means3D, const float* scales, const float* rotations,
     const float* cov3D_precomp, const float* opacities, const float* colors, float scale_modifier,
@@ -431,7 +431,7 @@ int eogs_rast_forward_render(
 /* Backward: BACKWARD::renderCUDA, computeCov2DCUDA, BACKWARD::preprocessCUDA + computeCov3D   */
 /* DGR/cuda_rasterizer/backward.cu:457-643, 147-327, 399-454, 331-394                          */
 /* ------------------------------------------------------------------------------------------- */
-int eogs_rast_backward(
+static int backward_activated(
     int P, int H, int W, int64_t R,
     const float* bg, const float* means3D, const int* radii, const float* colors,
     const float* opacities, const float* scales, const float* rotations,
@@ -681,6 +681,141 @@ int eogs_rast_backward(
 
   free(acc_mean2D); free(acc_conic); free(acc_opac); free(acc_color); free(acc_invd);
   return EOGS_OK;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* Exported forward_prepare / backward, with the opt-in EOGS_FLAG_RAW_PARAMS front end.          */
+/* The raw-parameter mode restates, around the rasterizer above, the PyTorch ops the reference   */
+/* runs before each render: gaussian_model.py:41,49,52,109-137 (exp / sigmoid / F.normalize),    */
+/* gaussian_renderer/renderer.py:91-96 (SH2RGB, ECEF_to_UVA altitude, ones, cat) and             */
+/* utils/sh_utils.py:25,125-126; their backward is the textbook chain rule, in double.           */
+/* ------------------------------------------------------------------------------------------- */
+#define SH_C0 0.28209479177387814
+
+typedef struct {
+  float *scales, *rotations, *opacities, *colors; /* activated copies */
+} Activated;
+
+static void activated_free(Activated* a) {
+  free(a->scales); free(a->rotations); free(a->opacities); free(a->colors);
+}
+
+static int activate_raw(int P, const float* means3D, const float* log_scales, const float* raw_rot,
+                        const float* logits, const float* f_dc, const float* alt, Activated* a) {
+  const size_t n = (size_t)P;
+  a->scales = (float*)malloc(n * 3 * 4);
+  a->rotations = (float*)malloc(n * 4 * 4);
+  a->opacities = (float*)malloc(n * 4);
+  a->colors = f_dc ? (float*)malloc(n * C_ * 4) : NULL;
+  if (!a->scales || !a->rotations || !a->opacities || (f_dc && !a->colors)) {
+    activated_free(a);
+    return 0;
+  }
+  for (size_t i = 0; i < n; i++) {
+    for (int k = 0; k < 3; k++) a->scales[3 * i + k] = expf(log_scales[3 * i + k]);
+    const float* r = raw_rot + 4 * i;
+    const float nr = sqrtf(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
+    const float den = fmaxf(nr, 1e-12f);
+    for (int k = 0; k < 4; k++) a->rotations[4 * i + k] = r[k] / den;
+    a->opacities[i] = 1.f / (1.f + expf(-logits[i]));
+    if (f_dc) {
+      const float* p = means3D + 3 * i;
+      for (int k = 0; k < 3; k++) a->colors[C_ * i + k] = (float)(f_dc[3 * i + k] * SH_C0 + 0.5);
+      a->colors[C_ * i + 3] = p[0] * alt[0] + p[1] * alt[1] + p[2] * alt[2] + alt[3];
+      a->colors[C_ * i + 4] = 1.f;
+    }
+  }
+  return 1;
+}
+
+int eogs_rast_forward_prepare(
+    int P, int H, int W,
+    const float* means3D, const float* scales, const float* rotations,
+    const float* cov3D_precomp, const float* opacities, const float* colors, float scale_modifier,
+    const float* viewmatrix, const float* projmatrix, const float* alt_affine, unsigned flags,
+    int* radii, void* geom, size_t geom_bytes,
+    int64_t* num_rendered, void* stream) {
+  if (!(flags & EOGS_FLAG_RAW_PARAMS) || P <= 0)
+    return forward_prepare_activated(P, H, W, means3D, scales, rotations, cov3D_precomp, opacities, colors,
+                                     scale_modifier, viewmatrix, projmatrix, flags, radii, geom, geom_bytes,
+                                     num_rendered, stream);
+  g_err[0] = 0;
+  if (!colors) return fail(EOGS_ERR_NO_COLORS, "For non-RGB, provide precomputed Gaussian colors!");
+  if (!means3D || !scales || !rotations || cov3D_precomp || !opacities || !alt_affine)
+    return fail(EOGS_ERR_INVALID_ARG, "forward_prepare: EOGS_FLAG_RAW_PARAMS needs scales, rotations and alt_affine");
+  Activated a;
+  if (!activate_raw(P, means3D, scales, rotations, opacities, colors, alt_affine, &a))
+    return fail(EOGS_ERR_DEVICE, "forward_prepare: out of host memory");
+  const int rc = forward_prepare_activated(P, H, W, means3D, a.scales, a.rotations, NULL, a.opacities, a.colors,
+                                           scale_modifier, viewmatrix, projmatrix, flags, radii, geom, geom_bytes,
+                                           num_rendered, stream);
+  activated_free(&a);
+  return rc;
+}
+
+int eogs_rast_backward(
+    int P, int H, int W, int64_t R,
+    const float* bg, const float* means3D, const int* radii, const float* colors,
+    const float* opacities, const float* scales, const float* rotations,
+    float scale_modifier, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* alt_affine, unsigned flags,
+    const float* out_color, const float* out_invdepth,
+    const float* dL_dout_color, const float* dL_dout_invdepth,
+    const void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes,
+    const void* image, size_t image_bytes,
+    float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity,
+    float* dL_dmeans3D, float* dL_dcov3D, float* dL_dscales, float* dL_drotations,
+    float* dL_dT_sum, float* dL_dvm_mean, void* stream) {
+  if (!(flags & EOGS_FLAG_RAW_PARAMS) || P <= 0)
+    return backward_activated(P, H, W, R, bg, means3D, radii, colors, opacities, scales, rotations, scale_modifier,
+                              cov3D_precomp, viewmatrix, projmatrix, flags, out_color, out_invdepth, dL_dout_color,
+                              dL_dout_invdepth, geom, geom_bytes, binning, binning_bytes, image, image_bytes,
+                              dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dscales,
+                              dL_drotations, dL_dT_sum, dL_dvm_mean, stream);
+  g_err[0] = 0;
+  if (!means3D || !scales || !rotations || cov3D_precomp || !opacities || !alt_affine || !dL_dcolors ||
+      !dL_dopacity || !dL_dmeans3D || !dL_dscales || !dL_drotations || !geom)
+    return fail(EOGS_ERR_INVALID_ARG, "backward: EOGS_FLAG_RAW_PARAMS needs scales, rotations and alt_affine");
+  if (geom_bytes < geom_layout(NULL, P, NULL)) return fail(EOGS_ERR_WORKSPACE, "backward: workspace too small");
+  const size_t n = (size_t)P;
+  Activated a;
+  if (!activate_raw(P, means3D, scales, rotations, opacities, NULL, alt_affine, &a))
+    return fail(EOGS_ERR_DEVICE, "backward: out of host memory");
+  Geom g;
+  geom_layout((char*)geom, P, &g); /* the activated [P,5] features were kept by forward */
+  float* d_col5 = (float*)malloc(n * C_ * 4);
+  float* d_cov = dL_dcov3D ? dL_dcov3D : (float*)malloc(n * 6 * 4);
+  int rc = EOGS_ERR_DEVICE;
+  if (d_col5 && d_cov)
+    rc = backward_activated(P, H, W, R, bg, means3D, radii, g.colors, a.opacities, a.scales, a.rotations,
+                            scale_modifier, NULL, viewmatrix, projmatrix, flags, out_color, out_invdepth,
+                            dL_dout_color, dL_dout_invdepth, geom, geom_bytes, binning, binning_bytes, image,
+                            image_bytes, dL_dmeans2D, d_col5, dL_dopacity, dL_dmeans3D, d_cov, dL_dscales,
+                            dL_drotations, dL_dT_sum, dL_dvm_mean, stream);
+  else
+    fail(EOGS_ERR_DEVICE, "backward: out of host memory");
+  if (rc == EOGS_OK) {
+    for (size_t i = 0; i < n; i++) {
+      for (int k = 0; k < 3; k++) {
+        dL_dcolors[3 * i + k] = (float)(SH_C0 * (double)d_col5[C_ * i + k]);
+        dL_dmeans3D[3 * i + k] = (float)((double)dL_dmeans3D[3 * i + k] + (double)alt_affine[k] * d_col5[C_ * i + 3]);
+        dL_dscales[3 * i + k] = (float)((double)dL_dscales[3 * i + k] * a.scales[3 * i + k]);
+      }
+      const double o = a.opacities[i];
+      dL_dopacity[i] = (float)((double)dL_dopacity[i] * o * (1.0 - o));
+      const float* r = rotations + 4 * i;
+      const double nr = sqrt((double)r[0] * r[0] + (double)r[1] * r[1] + (double)r[2] * r[2] + (double)r[3] * r[3]);
+      const double den = nr > 1e-12 ? nr : 1e-12;
+      double dot = 0;
+      for (int k = 0; k < 4; k++) dot += (double)a.rotations[4 * i + k] * dL_drotations[4 * i + k];
+      for (int k = 0; k < 4; k++)
+        dL_drotations[4 * i + k] = (float)(((double)dL_drotations[4 * i + k] - a.rotations[4 * i + k] * dot) / den);
+    }
+  }
+  free(d_col5);
+  if (!dL_dcov3D) free(d_cov);
+  activated_free(&a);
+  return rc;
 }
 
 /* checkFrustum (rasterizer_impl.cu:54-66): in_frustum's culling is commented out and the function

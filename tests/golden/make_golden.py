@@ -60,7 +60,7 @@ def stub_forward(bg, means3D, colors, opacity, scales, rotations, scale_modifier
         abi.check(abi.image_bytes(H, W, ctypes.byref(n))); img = u8(n.value)
         m, sc, ro, cv, op, vm, pm = map(_c, (means3D, scales, rotations, cov3D_precomp, opacity, viewmatrix, projmatrix))
         col, b = _c(colors), _c(bg)
-        abi.check(abi.forward_prepare(P, H, W, _p(m), _p(sc), _p(ro), _p(cv), _p(op), _p(col), float(scale_modifier), _p(vm), _p(pm),
+        abi.check(abi.forward_prepare(P, H, W, _p(m), _p(sc), _p(ro), _p(cv), _p(op), _p(col), float(scale_modifier), _p(vm), _p(pm), None,
                                       flags, _p(radii), _p(geom), geom.numel(), ctypes.byref(R), None))
         abi.check(abi.binning_bytes(P, H, W, R.value, ctypes.byref(n))); binning = u8(n.value)
         abi.check(abi.forward_render(P, H, W, R.value, _p(b), flags, _p(geom), geom.numel(), _p(binning), binning.numel(),
@@ -85,7 +85,7 @@ def stub_backward(bg, means3D, radii, colors, opacities, scales, rotations, scal
         vm, pm, cv = _c(viewmatrix), _c(projmatrix), _c(cov3D_precomp)
         abi.check(abi.backward(
             P, H, W, R, _p(args[0]), _p(args[1]), _p(radii), _p(args[3]), _p(args[4]), _p(args[5]), _p(args[6]),
-            float(scale_modifier), _p(cv), _p(vm), _p(pm), flags, None, None, _p(gcol), _p(gdep),
+            float(scale_modifier), _p(cv), _p(vm), _p(pm), None, flags, None, None, _p(gcol), _p(gdep),
             _p(geom), geom.numel(), _p(binning), binning.numel(), _p(img), img.numel(),
             _p(d_m2), _p(d_col), _p(d_op), _p(d_m3), _p(d_cov), _p(d_sc) if have_sr else None, _p(d_rot) if have_sr else None,
             _p(dTs), _p(dvm), None))

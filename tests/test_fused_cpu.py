@@ -1,0 +1,90 @@
+"""CPU: the raw-parameter (fused activations) front end, SURVEY.md §8 row f1.
+
+The host wiring (eogs2_amd/fused.py, eogs2_amd/render.py) runs over the oracle library (test-only injection) and
+is checked against the reference's own PyTorch formulation of the same ops differentiated by autograd
+(gaussian_model.py:41-52,109-137; gaussian_renderer/renderer.py:91-96) feeding the unfused rasterizer.
+"""
+import types
+
+import pytest
+import torch
+
+from util import assert_close, raw_params_from_scene, run_raw
+
+from eogs2_amd.synthetic import make_scene
+
+
+@pytest.mark.parametrize("aa", [False, True])
+def test_oracle_fused_matches_autograd_composition(oracle_backend, aa):
+    H, W, P = 48, 40, 300
+    scene = make_scene(P, H, W, seed=21, opacity="trained", scale_mult=3.0)
+    raw, alt = raw_params_from_scene(scene)
+    dinv = torch.randn(1, H, W) / (H * W)
+    a = run_raw(raw, alt, scene, H, W, aa, fused=True, dL_dinvdepth=dinv)
+    b = run_raw(raw, alt, scene, H, W, aa, fused=False, dL_dinvdepth=dinv)
+    assert torch.equal(a["out_radii"], b["out_radii"])
+    assert int((a["out_radii"] > 0).sum()) > P // 2
+    for k in a:
+        if k != "out_radii":
+            assert_close(a[k], b[k], k, rtol=2e-5)
+    assert float(a["g_raw_rotation"].abs().max()) > 0 and float(a["g_opacity_logit"].abs().max()) > 0
+
+
+class _Cam:
+    def __init__(self, vm, H, W):
+        self.FoVx = self.FoVy = 1.0
+        self.affine = vm
+        self.world_view_transform = vm
+        self.full_proj_transform = vm
+        self.learn_wv_only_lastparam = True
+        self.last_row = torch.tensor([0.01, -0.02, 0.03, 0.0], requires_grad=True)
+        self.image_height, self.image_width = H, W
+        self.camera_center = torch.zeros(3)
+        self.image_name = "synthetic"
+
+    def ECEF_to_UVA(self, xyz):
+        return xyz @ self.affine[:3, :3] + self.affine[3, :3]
+
+
+class _Model:
+    active_sh_degree = 0
+
+    def __init__(self, raw):
+        self._xyz = raw["xyz"].clone().requires_grad_(True)
+        self._features_dc = raw["f_dc"].clone().requires_grad_(True)
+        self._opacity = raw["opacity_logit"].clone().requires_grad_(True)
+        self._scaling = raw["log_scaling"].clone().requires_grad_(True)
+        self._rotation = raw["raw_rotation"].clone().requires_grad_(True)
+
+    get_xyz = property(lambda s: s._xyz)
+    get_opacity = property(lambda s: torch.sigmoid(s._opacity))
+    get_scaling = property(lambda s: torch.exp(s._scaling))
+    get_rotation = property(lambda s: torch.nn.functional.normalize(s._rotation))
+
+    def params(self):
+        return dict(xyz=self._xyz, f_dc=self._features_dc, opacity=self._opacity, scaling=self._scaling,
+                    rotation=self._rotation)
+
+
+def test_render_entry_point_fused_vs_reference_ops(oracle_backend):
+    """`render()` with the reference's signature: the fused path and the reference's op sequence give the same
+    image, radii and gradients — including the learnable last row of the view matrix (learn_wv_only_lastparam)."""
+    from eogs2_amd.render import render
+
+    H, W, P = 40, 56, 200
+    scene = make_scene(P, H, W, seed=5, opacity="trained", scale_mult=3.0)
+    raw, _ = raw_params_from_scene(scene)
+    pipe = types.SimpleNamespace(debug=False, antialiasing=False, compute_cov3D_python=False, require_radii=True)
+    res = {}
+    for fused in (True, False):
+        cam, pc = _Cam(scene["viewmatrix"], H, W), _Model(raw)
+        out = render(cam, pc, pipe, scene["bg"], fused=fused)
+        assert set(out) == {"render", "viewspace_points", "visibility_filter", "radii"}
+        (out["render"] * scene["dL_dcolor"]).sum().backward()
+        res[fused] = dict(render=out["render"].detach(), radii=out["radii"], vsp=out["viewspace_points"].grad,
+                          last_row=cam.last_row.grad, **{k: v.grad for k, v in pc.params().items()})
+    assert torch.equal(res[True]["radii"], res[False]["radii"])
+    assert float(res[True]["last_row"].abs().max()) > 0
+    for k in res[True]:
+        if k != "radii":
+            assert_close(res[True][k], res[False][k], k, rtol=2e-5)
