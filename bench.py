@@ -17,6 +17,7 @@ Extra objects in the JSON line:
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -118,6 +119,57 @@ def train_iteration(sc, P, H, W, dev, fused, iters=5):
             "what": f"3 renders ({H}x{W}, {2 * H}x{2 * W} sun camera, {H}x{W}) fwd+bwd + fused Adam on raw parameters, "
                     f"fixed dL/dcolor; activations " + ("inside the HIP kernels (EOGS_FLAG_RAW_PARAMS)" if fused
                                                         else "as the reference's PyTorch ops")}
+
+
+def photometric_loss_bench(abi, dev, H, W, iters=20):
+    """Extra: `(1-l) L1 + l (1-SSIM)` forward + backward on a 3 x H x W render, l = 0.2
+    (GS/utils/image_utils.py:27-28, arguments/__init__.py:257). `fused` = eogs2_amd.losses.photometric_loss (one HIP
+    kernel each way); `torch_ops` = the reference's op sequence (5 depthwise 11x11 conv2d + elementwise,
+    GS/utils/loss_utils.py:18-19,45-85) in PyTorch on the same GPU, i.e. what the reference's loss costs after the drop-in."""
+    import torch.nn.functional as F
+
+    from eogs2_amd.losses import photometric_loss
+
+    g = torch.Generator().manual_seed(3)
+    gt = torch.rand(3, H, W, generator=g).to(dev)
+    img = (gt + 0.05 * torch.randn(3, H, W, generator=g).to(dev)).clamp(0, 1).requires_grad_(True)
+    w1 = torch.tensor([math.exp(-((x - 5) ** 2) / (2 * 1.5**2)) for x in range(11)])
+    w1 = (w1 / w1.sum()).unsqueeze(1)
+    win = w1.mm(w1.t()).float().expand(3, 1, 11, 11).contiguous().to(dev)
+
+    def torch_ops():
+        conv = lambda t: F.conv2d(t, win, padding=5, groups=3)
+        mu1, mu2 = conv(img), conv(gt)
+        mu1_sq, mu2_sq, mu12 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+        s11, s22, s12 = conv(img * img) - mu1_sq, conv(gt * gt) - mu2_sq, conv(img * gt) - mu12
+        m = ((2 * mu12 + 0.01**2) * (2 * s12 + 0.03**2)) / ((mu1_sq + mu2_sq + 0.01**2) * (s11 + s22 + 0.03**2))
+        return 0.8 * torch.abs(img - gt).mean() + 0.2 * (1.0 - m.mean())
+
+    def timed(fn):
+        for _ in range(3):
+            img.grad = None
+            fn().backward()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            img.grad = None
+            fn().backward()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e3
+
+    t_ref = timed(torch_ops)
+    v_ref = float(torch_ops())
+    abi.profile_reset()
+    abi.profile_enable(1)
+    t_fused = timed(lambda: photometric_loss(img, gt, 0.2)[0])
+    abi.profile_enable(0)
+    kern = {k: ms / (iters + 3) for k, (ms, n) in abi.profile().items() if n and k.startswith("loss_")}
+    v_fused = float(photometric_loss(img, gt, 0.2)[0])
+    alg = {"loss_fwd": 20 * 3 * H * W, "loss_bwd": 24 * 3 * H * W}  # B: fwd reads 2 images, writes 3 maps; bwd reads 5, writes 1
+    return {"workload": f"3x{H}x{W}, lambda_dssim=0.2, fwd+bwd", "fused_ms": t_fused, "torch_ops_ms": t_ref,
+            "value_fused": v_fused, "value_torch_ops": v_ref, "kernels_ms": kern,
+            "roofline": {k: {"algorithmic_bytes": alg[k], "achieved_GBps": alg[k] / (kern[k] * 1e-3) / 1e9,
+                             "frac": alg[k] / (kern[k] * 1e-3) / 1e9 / HBM_PEAK_GBS} for k in kern}}
 
 
 def cpu_baseline(P_full, S_full):
@@ -236,7 +288,7 @@ def main():
 
     if rank == 0:
         ms_step = dt / a.steps * 1e3
-        kern = {k: ms / a.steps for k, (ms, n) in prof.items()}  # device ms per step of each kernel group
+        kern = {k: ms / a.steps for k, (ms, n) in prof.items() if n}  # device ms per step of each kernel group
         dom = max(kern, key=kern.get) if kern else None
         npx = H * W
         alg = {
@@ -271,6 +323,7 @@ def main():
         if world == 1 and not use_dist and not a.no_train_iter:
             line["train_iter"] = train_iteration(sc, P, H, W, dev, fused=False)
             line["train_iter_fused"] = train_iteration(sc, P, H, W, dev, fused=True)
+            line["photometric_loss"] = photometric_loss_bench(abi, dev, H, W)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(P, H)
         print(json.dumps(line), flush=True)

@@ -20,6 +20,8 @@ ERR_NAMES = {
 FLAG_ANTIALIASING = 1
 FLAG_DEBUG = 2
 FLAG_RAW_PARAMS = 4
+LOSS_L1 = 1
+LOSS_SSIM = 2
 
 _p = C.c_void_p
 _i = C.c_int
@@ -60,7 +62,13 @@ SIGNATURES = {
     "eogs_rast_profile_slots": (_i, []),
     "eogs_rast_profile_get": (_i, [_i, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_char_p)]),
     "eogs_rast_selftest": (_i, [_p, C.POINTER(_u), _p]),
+    # include/eogs_loss.h
+    "eogs_loss_bytes": (_i, [_i, _i, _i, _u, C.POINTER(_z)]),
+    "eogs_loss_forward": (_i, [_i, _i, _i, _p, _p, _u, _f, _f, _f, _p, _p, _p, _z, _p]),
+    "eogs_loss_backward": (_i, [_i, _i, _i, _p, _p, _u, _f, _f, _p, _p, _p, _z, _p, _p]),
 }
+# symbols only the HIP library exports (the CPU oracle of the loss is oracle/loss_oracle.py, not a C-ABI twin)
+HIP_ONLY = ("eogs_loss_bytes", "eogs_loss_forward", "eogs_loss_backward")
 
 
 class RastError(RuntimeError):
@@ -75,7 +83,11 @@ class RastABI:
     def __init__(self, path):
         self.path = str(path)
         self.cdll = C.CDLL(self.path)
+        self.cdll.eogs_rast_backend.restype = C.c_char_p
+        oracle_lib = self.cdll.eogs_rast_backend().decode() == "cpu-oracle"
         for name, (res, args) in SIGNATURES.items():
+            if oracle_lib and name in HIP_ONLY:
+                continue
             fn = getattr(self.cdll, name)  # AttributeError if the library lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
@@ -91,7 +103,7 @@ class RastABI:
             raise RastError(code, self.cdll.eogs_rast_last_error().decode())
 
     def __getattr__(self, name):
-        return getattr(self.cdll, "eogs_rast_" + name)
+        return getattr(self.cdll, ("eogs_" if name.startswith("loss_") else "eogs_rast_") + name)
 
     def profile(self):
         """{group name: (total device ms, launches)} accumulated since the last profile_reset()."""

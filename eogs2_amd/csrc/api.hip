@@ -36,8 +36,9 @@ int check_launch(hipStream_t s, bool debug, const char* what) {
   return EOGS_OK;
 }
 // ---- optional per-kernel-group timing with hipEvents on the launch stream ----
-enum { PS_PREPROCESS, PS_DEPTH_SORT, PS_BINNING, PS_RENDER_FWD, PS_RENDER_BWD, PS_GAUSS_BWD, PS_COUNT };
-const char* const kSlotNames[PS_COUNT] = {"preprocess_fwd", "depth_sort", "binning", "render_fwd", "render_bwd", "gaussian_bwd"};
+enum { PS_PREPROCESS, PS_DEPTH_SORT, PS_BINNING, PS_RENDER_FWD, PS_RENDER_BWD, PS_GAUSS_BWD, PS_LOSS_FWD, PS_LOSS_BWD, PS_COUNT };
+const char* const kSlotNames[PS_COUNT] = {"preprocess_fwd", "depth_sort", "binning", "render_fwd", "render_bwd", "gaussian_bwd",
+                                          "loss_fwd", "loss_bwd"};
 struct Pending { int slot; hipEvent_t a, b; };
 // process-wide (autograd runs backward on its own thread), guarded by g_prof_mu
 std::mutex g_prof_mu;
@@ -309,6 +310,54 @@ int eogs_rast_selftest(void* scratch, unsigned* failed, void* stream) {
   launch_selftest((uint32_t*)scratch, s);
   LAUNCH_TRY(s, true, "selftest");
   HIP_TRY(hipMemcpy(failed, scratch, 4, hipMemcpyDeviceToHost));
+  return EOGS_OK;
+}
+
+// ---- include/eogs_loss.h ----
+int eogs_loss_bytes(int planes, int H, int W, unsigned mode, size_t* bytes) {
+  if (planes < 0 || H < 0 || W < 0 || !bytes || !(mode & (EOGS_LOSS_L1 | EOGS_LOSS_SSIM)))
+    return fail(EOGS_ERR_INVALID_ARG, "loss_bytes: bad argument");
+  *bytes = loss_layout(nullptr, planes, H, W, mode).bytes;
+  return EOGS_OK;
+}
+
+static int loss_check(const char* who, int planes, int H, int W, const void* img, const void* gt, unsigned mode,
+                      const void* ws, size_t ws_bytes, LossWS* out) {
+  if (planes <= 0 || H <= 0 || W <= 0 || !(mode & (EOGS_LOSS_L1 | EOGS_LOSS_SSIM)) ||
+      (mode & ~(EOGS_LOSS_L1 | EOGS_LOSS_SSIM)))
+    return fail(EOGS_ERR_INVALID_ARG, "%s: bad sizes or mode", who);
+  if (planes > 65535 || (H + 31) / 32 > 65535) return fail(EOGS_ERR_INVALID_ARG, "%s: too many planes / rows for one launch", who);
+  if (!img || !gt || !ws) return fail(EOGS_ERR_INVALID_ARG, "%s: NULL argument", who);
+  char* base = ws_base(const_cast<void*>(ws));
+  *out = loss_layout(base, planes, H, W, mode);
+  if ((size_t)(base - (const char*)ws) + out->bytes - 256 > ws_bytes) return fail(EOGS_ERR_WORKSPACE, "%s: workspace too small", who);
+  return EOGS_OK;
+}
+
+int eogs_loss_forward(int planes, int H, int W, const float* img, const float* gt, unsigned mode, float w_l1,
+                      float w_ssim, float bias, float* out, float* plane_sums, void* ws, size_t ws_bytes, void* stream) {
+  g_err[0] = 0;
+  LossWS w;
+  const int rc = loss_check("loss_forward", planes, H, W, img, gt, mode, ws, ws_bytes, &w);
+  if (rc != EOGS_OK) return rc;
+  if (!out) return fail(EOGS_ERR_INVALID_ARG, "loss_forward: NULL out");
+  hipStream_t s = (hipStream_t)stream;
+  { ProfScope ps(PS_LOSS_FWD, s); launch_loss_fwd(w, planes, H, W, img, gt, mode, w_l1, w_ssim, bias, out, plane_sums, s); }
+  LAUNCH_TRY(s, false, "loss_fwd");
+  return EOGS_OK;
+}
+
+int eogs_loss_backward(int planes, int H, int W, const float* img, const float* gt, unsigned mode, float w_l1,
+                       float w_ssim, const float* upstream, const float* plane_grad, const void* ws, size_t ws_bytes,
+                       float* dL_dimg, void* stream) {
+  g_err[0] = 0;
+  LossWS w;
+  const int rc = loss_check("loss_backward", planes, H, W, img, gt, mode, ws, ws_bytes, &w);
+  if (rc != EOGS_OK) return rc;
+  if (!dL_dimg) return fail(EOGS_ERR_INVALID_ARG, "loss_backward: NULL dL_dimg");
+  hipStream_t s = (hipStream_t)stream;
+  { ProfScope ps(PS_LOSS_BWD, s); launch_loss_bwd(w, planes, H, W, img, gt, mode, w_l1, w_ssim, upstream, plane_grad, dL_dimg, s); }
+  LAUNCH_TRY(s, false, "loss_bwd");
   return EOGS_OK;
 }
 

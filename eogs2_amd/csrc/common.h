@@ -5,6 +5,7 @@
 #include <stddef.h>
 
 #include "eogs_rast.h"
+#include "eogs_loss.h"
 
 #define NCH EOGS_RAST_CHANNELS  // 5 feature channels
 #define TILE EOGS_RAST_TILE     // 16x16 pixel tiles: the reference's binning granularity (tile rect, radii)
@@ -196,3 +197,23 @@ struct GaussBwdArgs {
 };
 void launch_gaussian_bwd(const GaussBwdArgs& a, const GeomWS& g, const BinWS& b, hipStream_t s);
 void launch_selftest(uint32_t* out, hipStream_t s);
+
+// ---- photometric loss (loss.hip, include/eogs_loss.h) ----
+#define LOSS_WIN EOGS_LOSS_WINDOW
+struct LossWindow {
+  float w[LOSS_WIN];
+};
+struct LossWS {
+  float* partial;    // [planes][tiles][2] per-workgroup {sum|x-y|, sum SSIM}
+  float* plane_tmp;  // [planes][2]
+  float* maps;       // [3][planes][H][W] dSSIM/d{mu1, E[x^2], E[xy]} (EOGS_LOSS_SSIM only)
+  size_t map_stride;
+  int tiles;
+  size_t bytes;
+};
+LossWS loss_layout(char* base, int planes, int H, int W, unsigned mode);
+void launch_loss_fwd(const LossWS& w, int planes, int H, int W, const float* img, const float* gt, unsigned mode,
+                     float w_l1, float w_ssim, float bias, float* out, float* plane_sums, hipStream_t s);
+void launch_loss_bwd(const LossWS& w, int planes, int H, int W, const float* img, const float* gt, unsigned mode,
+                     float w_l1, float w_ssim, const float* upstream, const float* plane_grad, float* dimg,
+                     hipStream_t s);

@@ -20,14 +20,18 @@ def _view_grads(view):
     from eogs2_amd import GaussianRasterizer, _lib
     from eogs2_amd.synthetic import make_camera, make_scene, settings_for
 
+    product_get = _lib.get
     _lib.get = oracle.abi  # test-only checker backend (CPU tensors)
-    sc = make_scene(P, H, W, seed=0, opacity="trained", scale_mult=3.0)
-    sc["viewmatrix"] = make_camera(H, W, seed=view)
-    params = {k: sc[k].clone().requires_grad_(True) for k in NAMES}
-    color, radii, _ = GaussianRasterizer(settings_for(sc, H, W))(
-        params["means3D"], torch.zeros(P, 3), params["opacities"], colors_precomp=params["colors"],
-        scales=params["scales"], rotations=params["rotations"])
-    (color * sc["dL_dcolor"]).sum().backward()
+    try:
+        sc = make_scene(P, H, W, seed=0, opacity="trained", scale_mult=3.0)
+        sc["viewmatrix"] = make_camera(H, W, seed=view)
+        params = {k: sc[k].clone().requires_grad_(True) for k in NAMES}
+        color, radii, _ = GaussianRasterizer(settings_for(sc, H, W))(
+            params["means3D"], torch.zeros(P, 3), params["opacities"], colors_precomp=params["colors"],
+            scales=params["scales"], rotations=params["rotations"])
+        (color * sc["dL_dcolor"]).sum().backward()
+    finally:
+        _lib.get = product_get
     return params, radii
 
 
