@@ -36,6 +36,13 @@ __device__ inline uint32_t wave_incl_scan_u32(uint32_t v) {
   return v;
 }
 
+// LDS produced and consumed by the same wave (in-order LDS pipeline): only the compiler must not reorder.
+__device__ inline void wave_lds_sync_b() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Exclusive scan across the 256 threads of a workgroup; `total` = sum over the workgroup. s_w: 4 words of LDS.
 __device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, uint32_t& total) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -255,15 +262,14 @@ __global__ __launch_bounds__(BLK) void expand_count_kernel(const uint32_t* __res
 // Gaussians with more than 32 tiles are emitted by the whole wave, one after the other.
 #define EXPAND_STAGE 3072  // pairs a workgroup of 256 Gaussians can stage in LDS (36 KB)
 struct ExpandItem {
-  uint32_t id, c, pos0, rbase, sx0, sy0, sw, wc;
+  uint32_t id, c, pos0, rbase, sx0, sy0, sw, sh;
   unsigned long long m;
 };
 __device__ inline uint32_t tile_of(const ExpandItem& it, uint32_t bit_or_q, uint32_t gsx) {
-  const uint32_t wdt = it.m ? it.sw : it.wc;
-  const uint32_t row = bit_or_q / wdt, col = bit_or_q - row * wdt;
+  const uint32_t row = bit_or_q / it.sw, col = bit_or_q - row * it.sw;
   return (it.sy0 + row) * gsx + it.sx0 + col;
 }
-__global__ __launch_bounds__(BLK) void expand_kernel(const uint4* __restrict__ sinfo,
+__global__ __launch_bounds__(BLK) void expand_kernel(const uint4* __restrict__ sinfo, const float4* __restrict__ bext,
                                                      const uint32_t* __restrict__ pblock,
                                                      const uint32_t* __restrict__ blocksum, uint32_t P, uint32_t gsx,
                                                      uint32_t gsy, uint32_t* __restrict__ tkey,
@@ -276,7 +282,9 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint4* __restrict__ s
   const int lane = threadIdx.x & 63;
   const uint32_t k = blockIdx.x * BLK + threadIdx.x;
   ExpandItem it;
-  it.id = 0; it.c = 0; it.m = 0ull; it.sx0 = it.sy0 = 0; it.sw = it.wc = 1; it.rbase = 0;
+  it.id = 0; it.c = 0; it.m = 0ull; it.sx0 = it.sy0 = 0; it.sw = 1; it.sh = 0; it.rbase = 0;
+  float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0;  // SpanParams of a BK_SPANS Gaussian
+  bool spans = false;
   uint4 ia = make_uint4(0u, 0u, 0u, 0u), ib = ia;
   if (k < P) {
     ia = sinfo[2 * (size_t)k];
@@ -287,18 +295,22 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint4* __restrict__ s
   uint32_t tot;
   it.pos0 = blocksum[blockIdx.x] + block_excl_scan(it.c, s_w, tot);
   if (it.c) {
-    const uint32_t x0 = ia.x & 0xFFFFu, x1 = ia.x >> 16, y0 = ia.y & 0xFFFFu;
     it.m = ((unsigned long long)ia.w << 32) | ia.z;
-    it.sx0 = FX * x0; it.sy0 = FY * y0; it.sw = FX * (x1 - x0);
-    const uint32_t sx1 = FX * x1 < gsx ? FX * x1 : gsx;
-    it.wc = sx1 - it.sx0;
+    it.sx0 = ia.x & 0xFFFFu; it.sy0 = ia.y & 0xFFFFu;
+    it.sw = (ia.x >> 16) - it.sx0;  // internal-tile rect, already clipped (preprocess_fwd_kernel)
+    it.sh = (ia.y >> 16) - it.sy0;
     it.rbase = pblock[it.id / BLK] + ib.y;  // pblock is 4 bytes per 256 Gaussians: cache resident
+    spans = ib.w == BK_SPANS;
+    if (spans) {
+      e0 = bext[2 * (size_t)it.id];
+      e1 = bext[2 * (size_t)it.id + 1];
+    }
   }
   // Workgroups whose pairs fit the LDS stage (the common case: ~4 pairs per Gaussian) place them there at their
   // workgroup-local position and stream them out with consecutive lanes writing consecutive addresses.
   const uint32_t wg0 = blocksum[blockIdx.x];
   // workgroup-uniform; Gaussians with many tiles go through the wave-cooperative path below instead
-  const bool staged = !__syncthreads_or(it.c > 64u) && tot <= (uint32_t)EXPAND_STAGE;
+  const bool staged = !__syncthreads_or(it.c > 64u || spans) && tot <= (uint32_t)EXPAND_STAGE;
   if (staged) {
     if (it.c) {
       unsigned long long m = it.m;
@@ -321,7 +333,7 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint4* __restrict__ s
     return;
   }
   // small Gaussians: every lane emits its own pairs
-  if (it.c && it.c <= 32u) {
+  if (it.c && it.c <= 32u && !spans) {
     unsigned long long m = it.m;
     for (uint32_t q = 0; q < it.c; q++) {
       uint32_t sel = q;
@@ -333,15 +345,56 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint4* __restrict__ s
       tval[it.pos0 + q] = make_uint2(it.id, it.rbase + q);
     }
   }
-  // large Gaussians: the wave emits them cooperatively, 64 pairs per step
-  unsigned long long big = __ballot(it.c > 32u);
+  // large Gaussians: the wave emits them cooperatively, one after the other
+  uint32_t* wstage = s_tk + (threadIdx.x >> 6) * (EXPAND_STAGE / 4);  // wave-private (the staged path returned above)
+  unsigned long long big = __ballot(it.c > 32u || spans);
   while (big) {
     const int src = __builtin_ctzll(big);
     big &= big - 1ull;
     ExpandItem g;
     g.id = __shfl(it.id, src, 64); g.c = __shfl(it.c, src, 64); g.pos0 = __shfl(it.pos0, src, 64);
     g.rbase = __shfl(it.rbase, src, 64); g.sx0 = __shfl(it.sx0, src, 64); g.sy0 = __shfl(it.sy0, src, 64);
-    g.sw = __shfl(it.sw, src, 64); g.wc = __shfl(it.wc, src, 64);
+    g.sw = __shfl(it.sw, src, 64); g.sh = __shfl(it.sh, src, 64);
+    if (__shfl((int)spans, src, 64)) {
+      // BK_SPANS: lane = row of the rect (64 rows per step). Each row's column span is re-evaluated with the bits
+      // preprocess counted with; a wave scan of the span lengths gives every row its place in the Gaussian's run.
+      SpanParams sp;
+      sp.gx = __shfl(e0.x, src, 64); sp.gy = __shfl(e0.y, src, 64); sp.ex = __shfl(e0.z, src, 64);
+      sp.ey = __shfl(e0.w, src, 64); sp.boa = __shfl(e1.x, src, 64); sp.boc = __shfl(e1.y, src, 64);
+      sp.ta = __shfl(e1.z, src, 64); sp.da = __shfl(e1.w, src, 64);
+      uint32_t done = 0;  // pairs of this Gaussian emitted so far
+      for (uint32_t r0 = 0; r0 < g.sh; r0 += 64) {
+        const uint32_t row = r0 + (uint32_t)lane;
+        int c0 = 0, c1 = 0;
+        if (row < g.sh) row_span(sp, (int)(g.sy0 + row), (int)g.sx0, (int)(g.sx0 + g.sw), c0, c1);
+        const uint32_t len = (uint32_t)(c1 - c0);
+        const uint32_t inc = wave_incl_scan_u32(len);
+        const uint32_t chunk = __shfl(inc, 63, 64), off = inc - len;
+        const uint32_t t0 = (g.sy0 + row) * gsx + (uint32_t)c0;
+        if (chunk <= (uint32_t)(EXPAND_STAGE / 4)) {
+          // through wave-private LDS so that consecutive lanes write consecutive addresses
+          for (uint32_t j = 0; j < len; j++) wstage[off + j] = t0 + j;
+          wave_lds_sync_b();
+          for (uint32_t i = lane; i < chunk && done + i < g.c; i += 64) {
+            tkey[g.pos0 + done + i] = wstage[i];
+            tval[g.pos0 + done + i] = make_uint2(g.id, g.rbase + done + i);
+          }
+          wave_lds_sync_b();
+        } else {
+          for (uint32_t j = 0; j < len && done + off + j < g.c; j++) {
+            tkey[g.pos0 + done + off + j] = t0 + j;
+            tval[g.pos0 + done + off + j] = make_uint2(g.id, g.rbase + done + off + j);
+          }
+        }
+        done += chunk;
+      }
+      // never taken (the spans are a pure function of the stored bits); keeps every slot a valid tile id regardless
+      for (uint32_t i = done + lane; i < g.c; i += 64) {
+        tkey[g.pos0 + i] = g.sy0 * gsx + g.sx0;
+        tval[g.pos0 + i] = make_uint2(g.id, g.rbase + i);
+      }
+      continue;
+    }
     const uint32_t mlo = __shfl((uint32_t)it.m, src, 64), mhi = __shfl((uint32_t)(it.m >> 32), src, 64);
     g.m = ((unsigned long long)mhi << 32) | mlo;
     for (uint32_t q = lane; q < g.c; q += 64) {
@@ -389,7 +442,7 @@ void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int
     (void)hipMemsetAsync(im.ranges, 0, (size_t)gsx * gsy * sizeof(uint2), s);
     return;
   }
-  hipLaunchKernelGGL(expand_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.sinfo, g.pblock, g.blocksum, (uint32_t)P, gsx, gsy,
+  hipLaunchKernelGGL(expand_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.sinfo, g.bext, g.pblock, g.blocksum, (uint32_t)P, gsx, gsy,
                      b.tkeyA, b.tvalA, im.ranges);
   uint32_t *ka = b.tkeyA, *kb = b.tkeyB;
   uint2 *va = b.tvalA, *vb = b.tvalB;

@@ -32,6 +32,51 @@
 #define SORTR_ITEMS 8    // tile sort of R pairs: 2048 keys per workgroup (12-byte items: key + {id, slot})
 #define EXPAND_ITEMS 1   // expand: 256 depth-sorted Gaussians per workgroup
 
+// ---- which internal tiles a Gaussian is listed in (GeomWS::binfo) ----
+#define BK_RECT 0u
+#define BK_MASK 1u
+#define BK_SPANS 2u
+// Per-Gaussian constants of the row-span test, computed once by preprocess and stored (GeomWS::bext): expand
+// re-evaluates row_span() on the same bits, so the emitted tiles are exactly the counted ones.
+// Ellipse q(u,v) = a u^2 + 2 b u v + c v^2 <= tau_m around (gx,gy), det = ac - b^2:
+struct SpanParams {
+  float gx, gy;  // centre (pixels)
+  float ex, ey;  // half extents sqrt(tau_m c/det), sqrt(tau_m a/det)
+  float boa, boc;  // b/a, b/c
+  float ta, da;  // tau_m/a, det/a^2:  u(v) = -(b/a) v +- sqrt(ta - da v^2)
+};
+__device__ inline SpanParams span_params(float gx, float gy, float a, float b, float c, float tau_m) {
+  const float det = a * c - b * b;
+  SpanParams p;
+  p.gx = gx; p.gy = gy;
+  p.ex = sqrtf(tau_m * c / det); p.ey = sqrtf(tau_m * a / det);
+  p.boa = b / a; p.boc = b / c;
+  p.ta = tau_m / a; p.da = det / (a * a);
+  return p;
+}
+// Internal tiles of row sy (pixel centres y in [SUBY sy, SUBY sy + SUBY-1]) whose continuous block intersects the
+// ellipse: a column range [c0,c1) inside [sx0,sx1). The ellipse cut by the row band is convex, so its x-projection is
+// one interval [gx+ul, gx+ur]; u_max(v) = -(b/a) v + sqrt(ta - da v^2) is concave, hence maximal at the rightmost
+// point's v = -(b/c) ex clamped to the band (likewise for the left end). Same predicate as block_hit() in
+// preprocess.hip, in closed form per row.
+__device__ inline void row_span(const SpanParams& p, int sy, int sx0, int sx1, int& c0, int& c1) {
+  c0 = c1 = sx0;
+  const float v0 = (float)(sy * SUBY) - p.gy;
+  const float w0 = fmaxf(v0, -p.ey), w1 = fminf(v0 + (float)(SUBY - 1), p.ey);
+  if (!(w0 <= w1)) return;  // the band misses the ellipse
+  const float vr = fminf(fmaxf(-p.boc * p.ex, w0), w1), vl = fminf(fmaxf(p.boc * p.ex, w0), w1);
+  const float ur = -p.boa * vr + sqrtf(fmaxf(p.ta - p.da * vr * vr, 0.f));
+  const float ul = -p.boa * vl - sqrtf(fmaxf(p.ta - p.da * vl * vl, 0.f));
+  const float xr = p.gx + ur + (1e-3f * fabsf(ur) + 1e-2f), xl = p.gx + ul - (1e-3f * fabsf(ul) + 1e-2f);
+  // internal tile j covers [SUBX j, SUBX j + SUBX-1]
+  const float j0 = fmaxf(ceilf((xl - (float)(SUBX - 1)) * (1.f / SUBX)), (float)sx0);
+  const float j1 = fminf(floorf(xr * (1.f / SUBX)) + 1.f, (float)sx1);
+  if (j0 < j1) {
+    c0 = (int)j0;
+    c1 = (int)j1;
+  }
+}
+
 static inline size_t ws_align(size_t x) { return (x + 255u) & ~(size_t)255u; }
 
 template <typename T>
@@ -49,11 +94,14 @@ struct GeomWS {
                         //   {gx, gy, A, B} {C, opacity, f0, f1} {f2, f3, f4, 1/depth} {pad}
                         //   with the conic pre-scaled by log2 e: A = -a log2e/2, B = b log2e, C = -c log2e/2
   uint4* binfo;         // 2 x uint4 = 32 bytes per Gaussian, everything binning needs, written once by preprocess:
-                        //   [0] = {x0 | x1<<16, y0 | y1<<16 (the reference's 16-px tile rect), mask lo, mask hi}
-                        //   [1] = {tiles (internal tiles listed, 0 = none), lpre, Gaussian id (filled in sinfo), 0}
-                        //   mask bit (sy-FY*y0)*FX*(x1-x0) + (sx-FX*x0): internal tile (sx,sy) can reach alpha >= 1/255;
-                        //   mask == 0 with tiles > 0: every internal tile of the rect (clipped to the image) is listed;
+                        //   [0] = {sx0 | sx1<<16, sy0 | sy1<<16 (internal-tile rect, clipped), mask lo, mask hi}
+                        //   [1] = {tiles (internal tiles listed, 0 = none), lpre, Gaussian id, kind}
+                        //   kind BK_MASK : mask bit (sy-sy0)*(sx1-sx0) + (sx-sx0) set <=> internal tile (sx,sy) can reach
+                        //                  alpha >= 1/255 (rects of <= 64 internal tiles)
+                        //   kind BK_SPANS: larger rects; the listed tiles of row sy are row_span(bext[id], sy) (below)
+                        //   kind BK_RECT : every internal tile of the rect (NaN opacity only)
                         //   lpre = exclusive prefix of `tiles` inside the Gaussian's preprocess workgroup (256 Gaussians)
+  float4* bext;         // 2 x float4 = 32 bytes per Gaussian, written for BK_SPANS only: SpanParams
   uint4* sinfo;         // the same records in DEPTH order (gathered once by expand_count_kernel)
   uint32_t* pbkey;      // per preprocess workgroup: {max depth key, max ~key} over its listed Gaussians
   uint32_t* pblock;     // per preprocess workgroup: total, then (scan_pblock_kernel) exclusive prefix over workgroups.
@@ -79,6 +127,7 @@ static inline GeomWS geom_layout(char* base, int P) {
   o = ws_carve(base, o, g.packed, n * 4);
   o = ws_carve(base, o, g.binfo, n * 2);
   o = ws_carve(base, o, g.sinfo, n * 2);
+  o = ws_carve(base, o, g.bext, n * 2);
   o = ws_carve(base, o, g.pblock, (size_t)ceil_div_u32(n, BLK) + 1);
   o = ws_carve(base, o, g.pbkey, (size_t)ceil_div_u32(n, BLK) * 2);
   o = ws_carve(base, o, g.skeyA, n);

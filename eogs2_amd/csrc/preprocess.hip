@@ -137,7 +137,8 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
     const float* __restrict__ means3D, const float* __restrict__ scales, const float* __restrict__ rotations,
     const float* __restrict__ cov3D_precomp, const float* __restrict__ opacities, const float* __restrict__ colors,
     const float* __restrict__ vm, const float* __restrict__ alt, float scale_modifier, int antialiasing,
-    int* __restrict__ radii, float4* __restrict__ packed, uint4* __restrict__ binfo, uint32_t* __restrict__ pblock,
+    int* __restrict__ radii, float4* __restrict__ packed, uint4* __restrict__ binfo, float4* __restrict__ bext,
+    uint32_t* __restrict__ pblock,
     uint32_t* __restrict__ pbkey, uint32_t* __restrict__ skey, uint32_t* __restrict__ sval, uint32_t* __restrict__ misc) {
   __shared__ float s_m[3 * BLK];
   __shared__ float s_s[3 * BLK];
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
   __syncthreads();
 
   const size_t idx = row0 + t;
-  uint32_t my_tiles = 0, key_bits = 0;
+  uint32_t my_tiles = 0, key_bits = 0, bkind = BK_RECT;
   uint4 bi0 = make_uint4(0u, 0u, 0u, 0u);
   if (t < rows) {
     const float p[3] = {s_m[3 * t], s_m[3 * t + 1], s_m[3 * t + 2]};
@@ -209,14 +210,36 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
         if (d < 0) atomicOr(&misc[MISC_ERR], 1u);
         const float op_in = RAW ? sigmoidf(opacities[idx]) : opacities[idx];
         const float ca = cz * det_inv, cb = -cy * det_inv, cc = cx * det_inv, op = op_in * hcs;
-        // internal SUBX x SUBY tiles inside the reference's 16-px tile rect, clipped to the image
+        // Internal SUBX x SUBY tiles: the reference's 16-px tile rect clipped to the image, intersected with the
+        // bounding box of the ellipse alpha >= 1/255 (q <= tau  =>  |dx| <= sqrt(tau cov_xx), |dy| <= sqrt(tau cov_yy),
+        // cov = conic^-1 = the 2D covariance incl. the 0.3 dilation). Pixels outside that box skip this Gaussian in
+        // the reference too (forward.cu:374-376), so dropping their tiles changes nothing; for low opacities the box
+        // is much smaller than the 3-sigma rect (tau = 1.87 at opacity 0.01: 1.37 sigma).
         const int gsx = (W + SUBX - 1) / SUBX, gsy = (H + SUBY - 1) / SUBY;
-        const int sx0 = FX * x0, sy0 = FY * y0, sw = FX * (x1 - x0), sh = FY * (y1 - y0);
-        const int sx1 = FX * x1 < gsx ? FX * x1 : gsx, sy1 = FY * y1 < gsy ? FY * y1 : gsy;
+        int sx0 = FX * x0, sy0 = FY * y0;
+        int sx1 = FX * x1 < gsx ? FX * x1 : gsx, sy1 = FY * y1 < gsy ? FY * y1 : gsy;
+        const float tau = 2.f * __logf(255.f * op);
+        const float tau_m = tau + 1e-3f * (1.f + fabsf(tau));
+        bool any = true;
+        if (op < 1.f / 255.f) {
+          any = false;  // alpha = op * G <= op < 1/255 at every pixel (G <= 1): never blended
+        } else if (tau_m >= 0.f && tau_m < 3.0e38f) {
+          const float ex = sqrtf(tau_m * cx) * 1.001f + 1e-2f, ey = sqrtf(tau_m * cz) * 1.001f + 1e-2f;
+          // pixel centres are the integers: hit pixels lie in [ceil(px - ex), floor(px + ex)]
+          const float fx0 = floorf((px - ex) * (1.f / SUBX)), fx1 = floorf((px + ex) * (1.f / SUBX)) + 1.f;
+          const float fy0 = floorf((py - ey) * (1.f / SUBY)), fy1 = floorf((py + ey) * (1.f / SUBY)) + 1.f;
+          if (fx0 > (float)sx0) sx0 = (int)fminf(fx0, (float)sx1);
+          if (fy0 > (float)sy0) sy0 = (int)fminf(fy0, (float)sy1);
+          if (fx1 < (float)sx1) sx1 = (int)fmaxf(fx1, (float)sx0);
+          if (fy1 < (float)sy1) sy1 = (int)fmaxf(fy1, (float)sy0);
+        }  // else (NaN / inf opacity): keep the whole rect, like the reference's blend of a NaN alpha
+        const int sw = sx1 - sx0, sh = sy1 - sy0;
         unsigned long long m = 0ull;
-        if (sw * sh <= MASK_MAX_SUBTILES) {
-          const float tau = 2.f * __logf(255.f * op);
-          const float tau_m = tau + 1e-3f * (1.f + fabsf(tau));
+        uint32_t kind = BK_RECT;
+        if (!any || sw <= 0 || sh <= 0) {
+          my_tiles = 0;
+        } else if (sw * sh <= MASK_MAX_SUBTILES) {
+          kind = BK_MASK;
           const float b_c = cb / cc, b_a = cb / ca;
           for (int sy = sy0; sy < sy1; sy++)
             for (int sx = sx0; sx < sx1; sx++) {
@@ -225,9 +248,25 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
                 m |= 1ull << ((sy - sy0) * sw + (sx - sx0));
             }
           my_tiles = (uint32_t)__popcll(m);
+        } else if (tau_m >= 0.f && tau_m < 3.0e38f && ca * cc - cb * cb > 0.f) {
+          // larger footprints: per-row column spans in closed form (common.h row_span); expand re-evaluates them
+          kind = BK_SPANS;
+          const SpanParams sp = span_params(px, py, ca, cb, cc, tau_m);
+          uint32_t cnt = 0;
+          for (int sy = sy0; sy < sy1; sy++) {
+            int c0, c1;
+            row_span(sp, sy, sx0, sx1, c0, c1);
+            cnt += (uint32_t)(c1 - c0);
+          }
+          my_tiles = cnt;
+          if (cnt) {
+            bext[2 * idx] = make_float4(sp.gx, sp.gy, sp.ex, sp.ey);
+            bext[2 * idx + 1] = make_float4(sp.boa, sp.boc, sp.ta, sp.da);
+          }
         } else {
-          my_tiles = (uint32_t)((sx1 - sx0) * (sy1 - sy0));
+          my_tiles = (uint32_t)(sw * sh);
         }
+        bkind = kind;
         if (my_tiles) {
           // render record: one whole 64-byte line per Gaussian
           const float L2E = 1.4426950408889634f;
@@ -246,7 +285,8 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
           packed[4 * idx + 1] = make_float4(cc * (-0.5f * L2E), op, f[0], f[1]);
           packed[4 * idx + 2] = make_float4(f[2], f[3], f[4], 1.f / d);
           packed[4 * idx + 3] = make_float4(0.f, 0.f, 0.f, 0.f);
-          bi0 = make_uint4((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16), (uint32_t)m,
+          // internal-tile rect [sx0,sx1) x [sy0,sy1) (16 bits each) + hit mask relative to it (0 = every tile)
+          bi0 = make_uint4((uint32_t)sx0 | ((uint32_t)sx1 << 16), (uint32_t)sy0 | ((uint32_t)sy1 << 16), (uint32_t)m,
                            (uint32_t)(m >> 32));
           key_bits = __float_as_uint(d);
           skey[idx] = key_bits;
@@ -273,7 +313,7 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
   const uint32_t pre = (w > 0 ? w0 : 0u) + (w > 1 ? w1 : 0u) + (w > 2 ? w2 : 0u);
   if (t < rows) {
     binfo[2 * idx] = bi0;
-    binfo[2 * idx + 1] = make_uint4(my_tiles, pre + inc - my_tiles, (uint32_t)idx, 0u);
+    binfo[2 * idx + 1] = make_uint4(my_tiles, pre + inc - my_tiles, (uint32_t)idx, bkind);
   }
   // range of the depth keys of listed Gaussians (lets the host drop sort passes whose digit is constant) and the
   // workgroup's pair count: plain stores, reduced by pblock_scan_kernel (same-address atomics from 16k waves cost
@@ -370,7 +410,7 @@ void launch_preprocess_fwd(const FwdPrepArgs& a, const GeomWS& g, hipStream_t s)
   auto* kern = a.raw ? preprocess_fwd_kernel<true> : preprocess_fwd_kernel<false>;
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(BLK), 0, s, a.P, a.H, a.W, gx, gy, a.means3D, a.scales, a.rotations,
                      a.cov3D_precomp, a.opacities, a.colors, a.viewmatrix, a.alt_affine, a.scale_modifier,
-                     (int)a.antialiasing, a.radii, g.packed, g.binfo, g.pblock, g.pbkey, g.skeyA, g.svalA, g.misc);
+                     (int)a.antialiasing, a.radii, g.packed, g.binfo, g.bext, g.pblock, g.pbkey, g.skeyA, g.svalA, g.misc);
 }
 
 void launch_scan_pblock(const GeomWS& g, int P, hipStream_t s) {

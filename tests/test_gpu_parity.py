@@ -51,11 +51,15 @@ def _compare(out, ref, name, means3D=None):
             m = torch.as_tensor(np.asarray(means3D)).abs().double()
             scale = max(float((m.t() @ g2).max()), float(g2.sum(0).max()), float(r.abs().max()), 1e-30)
             err = float((v.cpu().double() - r.double()).abs().max()) / scale
-            assert err <= 1e-4, f"{name}:{k}: {err:.3e} of the magnitude sum"
+            from util import GRAD_RTOL, RTOL
+
+            assert err <= GRAD_RTOL.get(name, RTOL), f"{name}:{k}: {err:.3e} of the magnitude sum"
             continue
         from util import GRAD_RTOL, RTOL
 
-        assert_close(v, r, f"{name}:{k}", rtol=GRAD_RTOL.get(name, RTOL) if k.startswith("g_") else RTOL)
+        # flip_floor: one pixel whose T < 1e-4 termination (or alpha >= 1/255 test) lands on the other side of the
+        # threshold moves a handful of per-Gaussian gradient entries, whatever the tensor size
+        assert_close(v, r, f"{name}:{k}", rtol=GRAD_RTOL.get(name, RTOL) if k.startswith("g_") else RTOL, flip_floor=3)
 
 
 @pytest.mark.parametrize("name", GOLDEN)
@@ -74,7 +78,7 @@ SEEDED = [
     (3000, 64, 64, 12, 0.7, 8.0, False, False),      # long lists (>256/tile), early termination
     (20000, 256, 256, 13, "trained", 1.0, False, False),
     (777, 33, 47, 14, "trained", 4.0, False, True),    # ragged image, ragged P
-    (400, 200, 168, 15, "trained", 14.0, False, False),  # tile rects > 64 internal tiles: unmasked listing path
+    (400, 200, 168, 15, "trained", 14.0, False, False),  # rects > 64 internal tiles: row-span listing path
     (1, 64, 64, 16, 0.9, 30.0, False, False),            # one Gaussian covering every tile
     (4000, 517, 1021, 17, "trained", 1.0, True, True),   # odd sizes: partial 8x8 and 16x16 tiles on both edges
     (1500, 96, 96, 18, 0.003, 3.0, False, False),        # opacity < 1/255: visible radii, nothing ever blended
@@ -148,6 +152,31 @@ def test_wide_altitude_range_uses_all_sort_passes(dev, monkeypatch):
     ref = run_case(case, torch.device("cpu"), GaussianRasterizer, GaussianRasterizationSettings)
     monkeypatch.setattr(_lib, "get", lambda: hip)
     _compare(got, {k: v.cpu().numpy() for k, v in ref.items()}, "wide-altitude", case["means3D"])
+
+
+@pytest.mark.parametrize("opacity,aniso,scale_mult,aa", [("trained", 1.5, 8.0, False), (0.02, 1.2, 12.0, True),
+                                                         ("trained", 2.0, 5.0, True)])
+def test_row_span_listing_anisotropic(dev, monkeypatch, opacity, aniso, scale_mult, aa):
+    """Large, thin, arbitrarily rotated Gaussians: footprints beyond 64 internal tiles are listed by per-row column
+    spans (common.h row_span) — counted in preprocess, re-evaluated in expand. Low opacity makes the alpha >= 1/255
+    ellipse much smaller than the 3-sigma rect; every result must still equal the oracle's (which walks the full rect)."""
+    import oracle
+    from eogs2_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib
+    from eogs2_amd.synthetic import make_scene
+
+    P, H, W = 500, 232, 280
+    sc = make_scene(P, H, W, seed=41, opacity=opacity, scale_mult=scale_mult, anisotropy=aniso)
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(P, 4, generator=g)
+    sc["rotations"] = (q / q.norm(dim=1, keepdim=True)).contiguous()
+    case = {k: v.numpy() for k, v in sc.items()}
+    case.update(H=H, W=W, antialiasing=aa)
+    got = run_case(case, dev, GaussianRasterizer, GaussianRasterizationSettings)
+    hip = _lib.get()
+    monkeypatch.setattr(_lib, "get", lambda: oracle.abi())
+    ref = run_case(case, torch.device("cpu"), GaussianRasterizer, GaussianRasterizationSettings)
+    monkeypatch.setattr(_lib, "get", lambda: hip)
+    _compare(got, {k: v.cpu().numpy() for k, v in ref.items()}, f"aniso{aniso}", case["means3D"])
 
 
 def test_sun_camera_size_2048(dev):
