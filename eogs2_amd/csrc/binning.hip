@@ -255,12 +255,15 @@ __global__ __launch_bounds__(BLK) void expand_count_kernel(const uint32_t* __res
 }
 
 // ---- expand step C: emission of (internal tile id, record slot) in depth order ----
-// One lane per depth-sorted Gaussian. The q-th listed tile of a Gaussian is the q-th set bit of its hit mask
-// (walked incrementally: ctz, clear lowest bit) or, for unmasked Gaussians, the q-th tile of its clipped rect.
+// One lane per depth-sorted Gaussian. Its listed tiles are, by kind (GeomWS::binfo): the set bits of the hit mask, the
+// per-row column spans (row_span, re-evaluated on the bits preprocess counted with), or the whole rect.
 // Output position = depth-order offset (exclusive scan of the counts); payload = {Gaussian id, record slot in
 // Gaussian-id order}, carried through the tile sort so the render kernels read both with one coalesced load.
-// Gaussians with more than 32 tiles are emitted by the whole wave, one after the other.
-#define EXPAND_STAGE 3072  // pairs a workgroup of 256 Gaussians can stage in LDS (36 KB)
+// Gaussians with at most EXPAND_LANE_MAX tiles are walked by their own lane into an LDS window (tile id + owner lane),
+// EXPAND_STAGE pairs per round, and streamed out with consecutive lanes writing consecutive addresses; larger ones
+// are emitted by the whole wave, one after the other, straight to their (reserved) global positions.
+#define EXPAND_STAGE 6144     // pairs per LDS window (24 KB of tile ids + 12 KB of owner lanes)
+#define EXPAND_LANE_MAX 256u  // a single lane walks at most this many pairs
 struct ExpandItem {
   uint32_t id, c, pos0, rbase, sx0, sy0, sw, sh;
   unsigned long long m;
@@ -277,14 +280,15 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint4* __restrict__ s
   __shared__ uint32_t s_w[4];
   // the tile ranges are rewritten after the sort (tile_ranges_kernel): clear them here
   for (uint32_t i = blockIdx.x * BLK + threadIdx.x; i < gsx * gsy; i += gridDim.x * BLK) ranges[i] = make_uint2(0u, 0u);
-  __shared__ uint32_t s_tk[EXPAND_STAGE];
-  __shared__ uint2 s_tv[EXPAND_STAGE];
+  __shared__ uint32_t s_tk[EXPAND_STAGE];   // staged tile ids
+  __shared__ uint16_t s_own[EXPAND_STAGE];  // ... and the lane that owns each staged pair
+  __shared__ uint32_t s_id[BLK], s_l0[BLK], s_gp[BLK], s_rb[BLK];
   const int lane = threadIdx.x & 63;
   const uint32_t k = blockIdx.x * BLK + threadIdx.x;
   ExpandItem it;
   it.id = 0; it.c = 0; it.m = 0ull; it.sx0 = it.sy0 = 0; it.sw = 1; it.sh = 0; it.rbase = 0;
   float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0;  // SpanParams of a BK_SPANS Gaussian
-  bool spans = false;
+  uint32_t kind = BK_RECT;
   uint4 ia = make_uint4(0u, 0u, 0u, 0u), ib = ia;
   if (k < P) {
     ia = sinfo[2 * (size_t)k];
@@ -300,54 +304,58 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint4* __restrict__ s
     it.sw = (ia.x >> 16) - it.sx0;  // internal-tile rect, already clipped (preprocess_fwd_kernel)
     it.sh = (ia.y >> 16) - it.sy0;
     it.rbase = pblock[it.id / BLK] + ib.y;  // pblock is 4 bytes per 256 Gaussians: cache resident
-    spans = ib.w == BK_SPANS;
-    if (spans) {
+    kind = ib.w;
+    if (kind == BK_SPANS) {
       e0 = bext[2 * (size_t)it.id];
       e1 = bext[2 * (size_t)it.id + 1];
     }
   }
-  // Workgroups whose pairs fit the LDS stage (the common case: ~4 pairs per Gaussian) place them there at their
-  // workgroup-local position and stream them out with consecutive lanes writing consecutive addresses.
-  const uint32_t wg0 = blocksum[blockIdx.x];
-  // workgroup-uniform; Gaussians with many tiles go through the wave-cooperative path below instead
-  const bool staged = !__syncthreads_or(it.c > 64u || spans) && tot <= (uint32_t)EXPAND_STAGE;
-  if (staged) {
-    if (it.c) {
-      unsigned long long m = it.m;
-      const uint32_t l0 = it.pos0 - wg0;
-      for (uint32_t q = 0; q < it.c; q++) {
-        uint32_t sel = q;
-        if (it.m) {
-          sel = (uint32_t)__builtin_ctzll(m);
-          m &= m - 1ull;
+  SpanParams sp;
+  sp.gx = e0.x; sp.gy = e0.y; sp.ex = e0.z; sp.ey = e0.w; sp.boa = e1.x; sp.boc = e1.y; sp.ta = e1.z; sp.da = e1.w;
+
+  // ---- lane-walked Gaussians: compact local positions among themselves, staged in rounds of EXPAND_STAGE ----
+  const bool mine = it.c != 0u && it.c <= EXPAND_LANE_MAX;
+  uint32_t ltot;
+  const uint32_t l0 = block_excl_scan(mine ? it.c : 0u, s_w, ltot);
+  s_id[threadIdx.x] = it.id; s_l0[threadIdx.x] = l0; s_gp[threadIdx.x] = it.pos0; s_rb[threadIdx.x] = it.rbase;
+  for (uint32_t base = 0; base < ltot; base += EXPAND_STAGE) {
+    __syncthreads();  // s_id.. visible (first round) / previous window drained
+    if (mine && l0 < base + EXPAND_STAGE && l0 + it.c > base) {
+      uint32_t l = l0;  // local position of the next pair of this lane
+      auto put = [&](uint32_t tile) {
+        const uint32_t w = l - base;  // wraps below the window: fails the unsigned test
+        if (w < (uint32_t)EXPAND_STAGE) {
+          s_tk[w] = tile;
+          s_own[w] = (uint16_t)threadIdx.x;
         }
-        s_tk[l0 + q] = tile_of(it, sel, gsx);
-        s_tv[l0 + q] = make_uint2(it.id, it.rbase + q);
+        l++;
+      };
+      if (kind == BK_MASK) {
+        for (unsigned long long m = it.m; m; m &= m - 1ull) put(tile_of(it, (uint32_t)__builtin_ctzll(m), gsx));
+      } else if (kind == BK_SPANS) {
+        for (uint32_t row = 0; row < it.sh; row++) {
+          int c0, c1;
+          row_span(sp, (int)(it.sy0 + row), (int)it.sx0, (int)(it.sx0 + it.sw), c0, c1);
+          const uint32_t t0 = (it.sy0 + row) * gsx;
+          for (int c = c0; c < c1; c++) put(t0 + (uint32_t)c);
+        }
+      } else {
+        for (uint32_t q = 0; q < it.c; q++) put(tile_of(it, q, gsx));
       }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < tot; i += BLK) {
-      tkey[wg0 + i] = s_tk[i];
-      tval[wg0 + i] = s_tv[i];
-    }
-    return;
-  }
-  // small Gaussians: every lane emits its own pairs
-  if (it.c && it.c <= 32u && !spans) {
-    unsigned long long m = it.m;
-    for (uint32_t q = 0; q < it.c; q++) {
-      uint32_t sel = q;
-      if (it.m) {
-        sel = (uint32_t)__builtin_ctzll(m);
-        m &= m - 1ull;
-      }
-      tkey[it.pos0 + q] = tile_of(it, sel, gsx);
-      tval[it.pos0 + q] = make_uint2(it.id, it.rbase + q);
+    const uint32_t nwin = ltot - base < (uint32_t)EXPAND_STAGE ? ltot - base : (uint32_t)EXPAND_STAGE;
+    for (uint32_t i = threadIdx.x; i < nwin; i += BLK) {
+      const uint32_t o = s_own[i], q = base + i - s_l0[o];  // q-th listed tile of its Gaussian
+      tkey[s_gp[o] + q] = s_tk[i];
+      tval[s_gp[o] + q] = make_uint2(s_id[o], s_rb[o] + q);
     }
   }
-  // large Gaussians: the wave emits them cooperatively, one after the other
-  uint32_t* wstage = s_tk + (threadIdx.x >> 6) * (EXPAND_STAGE / 4);  // wave-private (the staged path returned above)
-  unsigned long long big = __ballot(it.c > 32u || spans);
+
+  // ---- large Gaussians: the wave emits them cooperatively, one after the other ----
+  __syncthreads();  // the last window is drained: s_tk becomes four wave-private staging areas
+  uint32_t* wstage = s_tk + (threadIdx.x >> 6) * (EXPAND_STAGE / 4);
+  unsigned long long big = __ballot(it.c > EXPAND_LANE_MAX);
   while (big) {
     const int src = __builtin_ctzll(big);
     big &= big - 1ull;
@@ -355,57 +363,48 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint4* __restrict__ s
     g.id = __shfl(it.id, src, 64); g.c = __shfl(it.c, src, 64); g.pos0 = __shfl(it.pos0, src, 64);
     g.rbase = __shfl(it.rbase, src, 64); g.sx0 = __shfl(it.sx0, src, 64); g.sy0 = __shfl(it.sy0, src, 64);
     g.sw = __shfl(it.sw, src, 64); g.sh = __shfl(it.sh, src, 64);
-    if (__shfl((int)spans, src, 64)) {
-      // BK_SPANS: lane = row of the rect (64 rows per step). Each row's column span is re-evaluated with the bits
-      // preprocess counted with; a wave scan of the span lengths gives every row its place in the Gaussian's run.
-      SpanParams sp;
-      sp.gx = __shfl(e0.x, src, 64); sp.gy = __shfl(e0.y, src, 64); sp.ex = __shfl(e0.z, src, 64);
-      sp.ey = __shfl(e0.w, src, 64); sp.boa = __shfl(e1.x, src, 64); sp.boc = __shfl(e1.y, src, 64);
-      sp.ta = __shfl(e1.z, src, 64); sp.da = __shfl(e1.w, src, 64);
-      uint32_t done = 0;  // pairs of this Gaussian emitted so far
-      for (uint32_t r0 = 0; r0 < g.sh; r0 += 64) {
-        const uint32_t row = r0 + (uint32_t)lane;
-        int c0 = 0, c1 = 0;
-        if (row < g.sh) row_span(sp, (int)(g.sy0 + row), (int)g.sx0, (int)(g.sx0 + g.sw), c0, c1);
-        const uint32_t len = (uint32_t)(c1 - c0);
-        const uint32_t inc = wave_incl_scan_u32(len);
-        const uint32_t chunk = __shfl(inc, 63, 64), off = inc - len;
-        const uint32_t t0 = (g.sy0 + row) * gsx + (uint32_t)c0;
-        if (chunk <= (uint32_t)(EXPAND_STAGE / 4)) {
-          // through wave-private LDS so that consecutive lanes write consecutive addresses
-          for (uint32_t j = 0; j < len; j++) wstage[off + j] = t0 + j;
-          wave_lds_sync_b();
-          for (uint32_t i = lane; i < chunk && done + i < g.c; i += 64) {
-            tkey[g.pos0 + done + i] = wstage[i];
-            tval[g.pos0 + done + i] = make_uint2(g.id, g.rbase + done + i);
-          }
-          wave_lds_sync_b();
-        } else {
-          for (uint32_t j = 0; j < len && done + off + j < g.c; j++) {
-            tkey[g.pos0 + done + off + j] = t0 + j;
-            tval[g.pos0 + done + off + j] = make_uint2(g.id, g.rbase + done + off + j);
-          }
-        }
-        done += chunk;
-      }
-      // never taken (the spans are a pure function of the stored bits); keeps every slot a valid tile id regardless
-      for (uint32_t i = done + lane; i < g.c; i += 64) {
-        tkey[g.pos0 + i] = g.sy0 * gsx + g.sx0;
-        tval[g.pos0 + i] = make_uint2(g.id, g.rbase + i);
+    if (__shfl(kind, src, 64) != BK_SPANS) {  // whole rect (a mask never has more than 64 tiles)
+      for (uint32_t q = lane; q < g.c; q += 64) {
+        tkey[g.pos0 + q] = tile_of(g, q, gsx);
+        tval[g.pos0 + q] = make_uint2(g.id, g.rbase + q);
       }
       continue;
     }
-    const uint32_t mlo = __shfl((uint32_t)it.m, src, 64), mhi = __shfl((uint32_t)(it.m >> 32), src, 64);
-    g.m = ((unsigned long long)mhi << 32) | mlo;
-    for (uint32_t q = lane; q < g.c; q += 64) {
-      uint32_t sel = q;
-      if (g.m) {  // masked => c <= 64: drop the q lowest set bits
-        unsigned long long m = g.m;
-        for (uint32_t d = 0; d < q; d++) m &= m - 1ull;
-        sel = (uint32_t)__builtin_ctzll(m);
+    // BK_SPANS: lane = row of the rect (64 rows per step); a wave scan of the span lengths gives every row its place
+    SpanParams gs;
+    gs.gx = __shfl(sp.gx, src, 64); gs.gy = __shfl(sp.gy, src, 64); gs.ex = __shfl(sp.ex, src, 64);
+    gs.ey = __shfl(sp.ey, src, 64); gs.boa = __shfl(sp.boa, src, 64); gs.boc = __shfl(sp.boc, src, 64);
+    gs.ta = __shfl(sp.ta, src, 64); gs.da = __shfl(sp.da, src, 64);
+    uint32_t done = 0;  // pairs of this Gaussian emitted so far
+    for (uint32_t r0 = 0; r0 < g.sh; r0 += 64) {
+      const uint32_t row = r0 + (uint32_t)lane;
+      int c0 = 0, c1 = 0;
+      if (row < g.sh) row_span(gs, (int)(g.sy0 + row), (int)g.sx0, (int)(g.sx0 + g.sw), c0, c1);
+      const uint32_t len = (uint32_t)(c1 - c0);
+      const uint32_t inc = wave_incl_scan_u32(len);
+      const uint32_t chunk = __shfl(inc, 63, 64), off = inc - len;
+      const uint32_t t0 = (g.sy0 + row) * gsx + (uint32_t)c0;
+      if (chunk <= (uint32_t)(EXPAND_STAGE / 4)) {
+        // through wave-private LDS so that consecutive lanes write consecutive addresses
+        for (uint32_t j = 0; j < len; j++) wstage[off + j] = t0 + j;
+        wave_lds_sync_b();
+        for (uint32_t i = lane; i < chunk && done + i < g.c; i += 64) {
+          tkey[g.pos0 + done + i] = wstage[i];
+          tval[g.pos0 + done + i] = make_uint2(g.id, g.rbase + done + i);
+        }
+        wave_lds_sync_b();
+      } else {
+        for (uint32_t j = 0; j < len && done + off + j < g.c; j++) {
+          tkey[g.pos0 + done + off + j] = t0 + j;
+          tval[g.pos0 + done + off + j] = make_uint2(g.id, g.rbase + done + off + j);
+        }
       }
-      tkey[g.pos0 + q] = tile_of(g, sel, gsx);
-      tval[g.pos0 + q] = make_uint2(g.id, g.rbase + q);
+      done += chunk;
+    }
+    // never taken (the spans are a pure function of the stored bits); keeps every slot a valid tile id regardless
+    for (uint32_t i = done + lane; i < g.c; i += 64) {
+      tkey[g.pos0 + i] = g.sy0 * gsx + g.sx0;
+      tval[g.pos0 + i] = make_uint2(g.id, g.rbase + i);
     }
   }
 }
@@ -449,7 +448,10 @@ void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int
   int shift = 0;
   for (int pass = 0; pass < b.passes; pass++) {
     const int nbits = (b.tile_bits - shift) < b.bits_per_pass ? (b.tile_bits - shift) : b.bits_per_pass;
-    radix_pass<SORTR_ITEMS, uint2>(ka, va, kb, vb, (uint32_t)R, shift, nbits, b.hist, b.nblkR, b.dtotal, s);
+    if (b.sort_items == SORTR_ITEMS_BIG)
+      radix_pass<SORTR_ITEMS_BIG, uint2>(ka, va, kb, vb, (uint32_t)R, shift, nbits, b.hist, b.nblkR, b.dtotal, s);
+    else
+      radix_pass<SORTR_ITEMS, uint2>(ka, va, kb, vb, (uint32_t)R, shift, nbits, b.hist, b.nblkR, b.dtotal, s);
     shift += nbits;
     uint32_t* tk = ka; ka = kb; kb = tk;
     uint2* tv = va; va = vb; vb = tv;
