@@ -66,17 +66,39 @@ def measured_traffic(kernel, a):
     return None, None
 
 
+def _torch_photometric(img, gt, win, lam=0.2):
+    """The reference's op sequence for (1-l) L1 + l (1-SSIM) (GS/utils/loss_utils.py:18-19,45-85, image_utils.py:27-28)
+    in PyTorch on the GPU: what the loss costs a user of the reference after the drop-in."""
+    import torch.nn.functional as F
+
+    C = img.shape[0]
+    conv = lambda t: F.conv2d(t[None], win[:C], padding=5, groups=C)[0]
+    mu1, mu2 = conv(img), conv(gt)
+    mu1_sq, mu2_sq, mu12 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    s11, s22, s12 = conv(img * img) - mu1_sq, conv(gt * gt) - mu2_sq, conv(img * gt) - mu12
+    m = ((2 * mu12 + 0.01**2) * (2 * s12 + 0.03**2)) / ((mu1_sq + mu2_sq + 0.01**2) * (s11 + s22 + 0.03**2))
+    return (1.0 - lam) * torch.abs(img - gt).mean() + lam * (1.0 - m.mean())
+
+
+def _ssim_window(dev, C=3):
+    w1 = torch.tensor([math.exp(-((x - 5) ** 2) / (2 * 1.5**2)) for x in range(11)])
+    w1 = (w1 / w1.sum()).unsqueeze(1)
+    return w1.mm(w1.t()).float().expand(C, 1, 11, 11).contiguous().to(dev)
+
+
 def train_iteration(sc, P, H, W, dev, fused, iters=5):
     """Extra, reported beside the headline: one synthetic EOGS++ training iteration as the reference schedules it after
     iteration 1000 (GS/train_pan.py:278,305-316,375-391): three renders of the same Gaussians — the view (H x W), the
     sun camera (2H x 2W, affine_cameras.py:366-367) and a random virtual camera (H x W) — each forward + backward,
-    gradients accumulated, then one fused Adam step on the five raw parameter tensors. Losses are replaced by fixed
-    upstream gradients dL/dcolor (the image-space losses are out of scope).
-    fused=False: per render, the reference's PyTorch ops (exp / sigmoid / normalize / SH2RGB / altitude / cat,
-    gaussian_model.py:109-137, renderer.py:91-96) feed the drop-in GaussianRasterizer — what a user of the reference gets.
-    fused=True: `eogs2_amd.fused.rasterize_raw`, activations inside the per-Gaussian HIP kernels."""
+    the photometric loss (1-l) L1 + l (1-SSIM), l = 0.2, on the view's RGB against a synthetic ground truth, fixed
+    upstream gradients for everything else (resampling / shadow / regularisers are out of scope), then
+    one fused Adam step on the five raw parameter tensors.
+    fused=False: the reference's PyTorch ops around the drop-in GaussianRasterizer (activations, feature assembly,
+    SSIM as five depthwise conv2d) — what a user of the reference gets after the drop-in alone.
+    fused=True: `eogs2_amd.fused.rasterize_raw` (§8 f1) + `eogs2_amd.losses.photometric_loss` (§8 f2)."""
     from eogs2_amd import GaussianRasterizer
     from eogs2_amd.fused import rasterize_raw
+    from eogs2_amd.losses import photometric_loss
     from eogs2_amd.synthetic import make_camera, settings_for
 
     C0 = 0.28209479177387814
@@ -85,16 +107,18 @@ def train_iteration(sc, P, H, W, dev, fused, iters=5):
                opacity=torch.log(op / (1 - op)).float(), scaling=torch.log(sc["scales"]), rotation=sc["rotations"] * 1.5)
     params = {k: v.requires_grad_(True) for k, v in raw.items()}
     opt = torch.optim.Adam(list(params.values()), lr=1e-4, fused=True)
+    win = _ssim_window(dev)
     views = []
     for seed, (h, w) in ((11, (H, W)), (12, (2 * H, 2 * W)), (13, (H, W))):
         vm = make_camera(h, w, seed=seed, device=dev)
         g = torch.Generator().manual_seed(seed)
         dL = (torch.randn(5, h, w, generator=g) / (h * w)).to(dev)
         views.append((settings_for(dict(sc, viewmatrix=vm), h, w), vm[:, 2].contiguous(), torch.zeros(P, 3, device=dev), dL))
+    gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(5)).to(dev)
 
     def it():
         opt.zero_grad(set_to_none=True)
-        for rs, alt, m2, dL in views:
+        for vi, (rs, alt, m2, dL) in enumerate(views):
             if fused:
                 color, _, _ = rasterize_raw(params["xyz"], m2, params["f_dc"], params["opacity"], params["scaling"],
                                             params["rotation"], alt, rs)
@@ -105,7 +129,11 @@ def train_iteration(sc, P, H, W, dev, fused, iters=5):
                 color, _, _ = GaussianRasterizer(rs)(
                     params["xyz"], m2, torch.sigmoid(params["opacity"]), colors_precomp=colors,
                     scales=torch.exp(params["scaling"]), rotations=torch.nn.functional.normalize(params["rotation"]))
-            torch.autograd.backward([color], [dL])
+            if vi == 0:
+                loss = photometric_loss(color[:3], gt, 0.2)[0] if fused else _torch_photometric(color[:3], gt, win)
+                (loss + (color[3:] * dL[3:]).sum()).backward()
+            else:
+                torch.autograd.backward([color], [dL])
         opt.step()
 
     it()
@@ -116,9 +144,9 @@ def train_iteration(sc, P, H, W, dev, fused, iters=5):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
     return {"iters_per_s": 1.0 / dt, "ms_per_iter": dt * 1e3, "renders_per_iter": 3,
-            "what": f"3 renders ({H}x{W}, {2 * H}x{2 * W} sun camera, {H}x{W}) fwd+bwd + fused Adam on raw parameters, "
-                    f"fixed dL/dcolor; activations " + ("inside the HIP kernels (EOGS_FLAG_RAW_PARAMS)" if fused
-                                                        else "as the reference's PyTorch ops")}
+            "what": f"3 renders ({H}x{W}, {2 * H}x{2 * W} sun camera, {H}x{W}) fwd+bwd + L1/DSSIM loss on the view + fused "
+                    f"Adam on raw parameters; activations and loss " + ("inside HIP kernels (EOGS_FLAG_RAW_PARAMS, "
+                    "eogs_loss_*)" if fused else "as the reference's PyTorch ops")}
 
 
 def photometric_loss_bench(abi, dev, H, W, iters=20):
@@ -126,24 +154,15 @@ def photometric_loss_bench(abi, dev, H, W, iters=20):
     (GS/utils/image_utils.py:27-28, arguments/__init__.py:257). `fused` = eogs2_amd.losses.photometric_loss (one HIP
     kernel each way); `torch_ops` = the reference's op sequence (5 depthwise 11x11 conv2d + elementwise,
     GS/utils/loss_utils.py:18-19,45-85) in PyTorch on the same GPU, i.e. what the reference's loss costs after the drop-in."""
-    import torch.nn.functional as F
-
     from eogs2_amd.losses import photometric_loss
 
     g = torch.Generator().manual_seed(3)
     gt = torch.rand(3, H, W, generator=g).to(dev)
     img = (gt + 0.05 * torch.randn(3, H, W, generator=g).to(dev)).clamp(0, 1).requires_grad_(True)
-    w1 = torch.tensor([math.exp(-((x - 5) ** 2) / (2 * 1.5**2)) for x in range(11)])
-    w1 = (w1 / w1.sum()).unsqueeze(1)
-    win = w1.mm(w1.t()).float().expand(3, 1, 11, 11).contiguous().to(dev)
+    win = _ssim_window(dev)
 
     def torch_ops():
-        conv = lambda t: F.conv2d(t, win, padding=5, groups=3)
-        mu1, mu2 = conv(img), conv(gt)
-        mu1_sq, mu2_sq, mu12 = mu1.pow(2), mu2.pow(2), mu1 * mu2
-        s11, s22, s12 = conv(img * img) - mu1_sq, conv(gt * gt) - mu2_sq, conv(img * gt) - mu12
-        m = ((2 * mu12 + 0.01**2) * (2 * s12 + 0.03**2)) / ((mu1_sq + mu2_sq + 0.01**2) * (s11 + s22 + 0.03**2))
-        return 0.8 * torch.abs(img - gt).mean() + 0.2 * (1.0 - m.mean())
+        return _torch_photometric(img, gt, win)
 
     def timed(fn):
         for _ in range(3):
