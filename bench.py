@@ -92,7 +92,7 @@ def train_iteration(sc, P, H, W, dev, fused, iters=5):
     sun camera (2H x 2W, affine_cameras.py:366-367) and a random virtual camera (H x W) — each forward + backward,
     the photometric loss (1-l) L1 + l (1-SSIM), l = 0.2, on the view's RGB against a synthetic ground truth, fixed
     upstream gradients for everything else (resampling / shadow / regularisers are out of scope), then
-    one fused Adam step on the five raw parameter tensors.
+    one Adam step on the five raw parameter tensors (torch.optim.Adam as the reference configures it, or FusedAdam).
     fused=False: the reference's PyTorch ops around the drop-in GaussianRasterizer (activations, feature assembly,
     SSIM as five depthwise conv2d) — what a user of the reference gets after the drop-in alone.
     fused=True: `eogs2_amd.fused.rasterize_raw` (§8 f1) + `eogs2_amd.losses.photometric_loss` (§8 f2)."""
@@ -106,7 +106,12 @@ def train_iteration(sc, P, H, W, dev, fused, iters=5):
     raw = dict(xyz=sc["means3D"].clone(), f_dc=((sc["colors"][:, :3] - 0.5) / C0).reshape(P, 1, 3).contiguous(),
                opacity=torch.log(op / (1 - op)).float(), scaling=torch.log(sc["scales"]), rotation=sc["rotations"] * 1.5)
     params = {k: v.requires_grad_(True) for k, v in raw.items()}
-    opt = torch.optim.Adam(list(params.values()), lr=1e-4, fused=True)
+    if fused:
+        from eogs2_amd.optim import FusedAdam
+
+        opt = FusedAdam([{"params": [v], "lr": 1e-4, "name": k} for k, v in params.items()], lr=0.0, eps=1e-15)
+    else:  # the reference's optimizer (gaussian_model.py:262)
+        opt = torch.optim.Adam([{"params": [v], "lr": 1e-4, "name": k} for k, v in params.items()], lr=0.0, eps=1e-15)
     win = _ssim_window(dev)
     views = []
     for seed, (h, w) in ((11, (H, W)), (12, (2 * H, 2 * W)), (13, (H, W))):
@@ -144,9 +149,9 @@ def train_iteration(sc, P, H, W, dev, fused, iters=5):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
     return {"iters_per_s": 1.0 / dt, "ms_per_iter": dt * 1e3, "renders_per_iter": 3,
-            "what": f"3 renders ({H}x{W}, {2 * H}x{2 * W} sun camera, {H}x{W}) fwd+bwd + L1/DSSIM loss on the view + fused "
-                    f"Adam on raw parameters; activations and loss " + ("inside HIP kernels (EOGS_FLAG_RAW_PARAMS, "
-                    "eogs_loss_*)" if fused else "as the reference's PyTorch ops")}
+            "what": f"3 renders ({H}x{W}, {2 * H}x{2 * W} sun camera, {H}x{W}) fwd+bwd + L1/DSSIM loss on the view + Adam "
+                    f"on raw parameters; activations, loss and optimizer " + ("inside HIP kernels (EOGS_FLAG_RAW_PARAMS, "
+                    "eogs_loss_*, eogs_adam_step)" if fused else "as the reference's PyTorch ops")}
 
 
 def photometric_loss_bench(abi, dev, H, W, iters=20):
@@ -189,6 +194,61 @@ def photometric_loss_bench(abi, dev, H, W, iters=20):
             "value_fused": v_fused, "value_torch_ops": v_ref, "kernels_ms": kern,
             "roofline": {k: {"algorithmic_bytes": alg[k], "achieved_GBps": alg[k] / (kern[k] * 1e-3) / 1e9,
                              "frac": alg[k] / (kern[k] * 1e-3) / 1e9 / HBM_PEAK_GBS} for k in kern}}
+
+
+def optimizer_bench(abi, dev, P, iters=20):
+    """Extra: the reference's optimizer step — torch.optim.Adam over six single-tensor groups
+    (GS/scene/gaussian_model.py:228-262) — and its prune (`_prune_optimizer` + `prune_points`, :466-505: 21 boolean-mask
+    gathers) against eogs2_amd.optim.FusedAdam / prune_optimizer (one launch / one scan + one gather)."""
+    from eogs2_amd.optim import FusedAdam, prune_optimizer
+
+    shapes = {"xyz": (3,), "f_dc": (1, 3), "f_rest": (0, 3), "opacity": (1,), "scaling": (3,), "rotation": (4,)}
+
+    def groups():
+        g = torch.Generator().manual_seed(0)
+        return [{"params": [torch.nn.Parameter(torch.randn((P,) + s, generator=g).to(dev))], "lr": 1e-3, "name": n}
+                for n, s in shapes.items()]
+
+    def timed(fn, n=iters):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    out = {}
+    for name, ctor in (("torch_adam_ms", lambda l: torch.optim.Adam(l, lr=0.0, eps=1e-15)),
+                       ("fused_adam_ms", lambda l: FusedAdam(l, lr=0.0, eps=1e-15))):
+        opt = ctor(groups())
+        for gr in opt.param_groups:
+            gr["params"][0].grad = torch.randn_like(gr["params"][0])
+        out[name] = timed(opt.step)
+    # prune 10 % of the Gaussians: parameters, both moments, three statistics
+    keep = torch.rand(P, generator=torch.Generator().manual_seed(1)).to(dev) < 0.9
+    stats = [torch.rand(P, 1, device=dev), torch.rand(P, 1, device=dev), torch.rand(P, device=dev)]
+
+    def ref_prune():
+        for gr in opt.param_groups:  # what _prune_optimizer does per group, without replacing anything
+            p = gr["params"][0]
+            st = opt.state[p]
+            _ = (st["exp_avg"][keep], st["exp_avg_sq"][keep], p.data[keep])
+        _ = [t[keep] for t in stats]
+
+    def fused_prune():
+        from eogs2_amd.optim import compact_rows
+
+        flat = []
+        for gr in opt.param_groups:
+            p = gr["params"][0]
+            flat += [p.data, opt.state[p]["exp_avg"], opt.state[p]["exp_avg_sq"]]
+        compact_rows(keep, flat + stats)
+
+    out["torch_prune_ms"] = timed(ref_prune, 10)
+    out["fused_prune_ms"] = timed(fused_prune, 10)
+    out["what"] = f"{P} Gaussians, six parameter groups (59 floats of state per Gaussian incl. moments + 3 statistics); prune keeps 90 %"
+    return out
 
 
 def cpu_baseline(P_full, S_full):
@@ -343,6 +403,7 @@ def main():
             line["train_iter"] = train_iteration(sc, P, H, W, dev, fused=False)
             line["train_iter_fused"] = train_iteration(sc, P, H, W, dev, fused=True)
             line["photometric_loss"] = photometric_loss_bench(abi, dev, H, W)
+            line["optimizer"] = optimizer_bench(abi, dev, P)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(P, H)
         print(json.dumps(line), flush=True)

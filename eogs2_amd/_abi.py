@@ -66,9 +66,21 @@ SIGNATURES = {
     "eogs_loss_bytes": (_i, [_i, _i, _i, _u, C.POINTER(_z)]),
     "eogs_loss_forward": (_i, [_i, _i, _i, _p, _p, _u, _f, _f, _f, _p, _p, _p, _z, _p]),
     "eogs_loss_backward": (_i, [_i, _i, _i, _p, _p, _u, _f, _f, _p, _p, _p, _z, _p, _p]),
+    # include/eogs_optim.h
+    "eogs_adam_step": (_i, [_i, _p, C.c_double, C.c_double, C.c_double, _i64, _p]),
+    "eogs_compact_bytes": (_i, [_i64, C.POINTER(_z)]),
+    "eogs_compact_plan": (_i, [_i64, _p, _p, _z, C.POINTER(_i64), _p]),
+    "eogs_compact_apply": (_i, [_i64, _p, _i, _p, _p, _p, _p, _z, _p]),
 }
 # symbols only the HIP library exports (the CPU oracle of the loss is oracle/loss_oracle.py, not a C-ABI twin)
-HIP_ONLY = ("eogs_loss_bytes", "eogs_loss_forward", "eogs_loss_backward")
+HIP_ONLY = ("eogs_loss_bytes", "eogs_loss_forward", "eogs_loss_backward", "eogs_adam_step", "eogs_compact_bytes",
+            "eogs_compact_plan", "eogs_compact_apply")
+
+
+class AdamTensor(C.Structure):
+    """eogs_adam_tensor (include/eogs_optim.h)"""
+
+    _fields_ = [("param", _p), ("grad", _p), ("exp_avg", _p), ("exp_avg_sq", _p), ("numel", _i64), ("lr", _f)]
 
 
 class RastError(RuntimeError):
@@ -103,7 +115,8 @@ class RastABI:
             raise RastError(code, self.cdll.eogs_rast_last_error().decode())
 
     def __getattr__(self, name):
-        return getattr(self.cdll, ("eogs_" if name.startswith("loss_") else "eogs_rast_") + name)
+        short = name.startswith(("loss_", "adam_", "compact_"))
+        return getattr(self.cdll, ("eogs_" if short else "eogs_rast_") + name)
 
     def profile(self):
         """{group name: (total device ms, launches)} accumulated since the last profile_reset()."""

@@ -36,9 +36,10 @@ int check_launch(hipStream_t s, bool debug, const char* what) {
   return EOGS_OK;
 }
 // ---- optional per-kernel-group timing with hipEvents on the launch stream ----
-enum { PS_PREPROCESS, PS_DEPTH_SORT, PS_BINNING, PS_RENDER_FWD, PS_RENDER_BWD, PS_GAUSS_BWD, PS_LOSS_FWD, PS_LOSS_BWD, PS_COUNT };
+enum { PS_PREPROCESS, PS_DEPTH_SORT, PS_BINNING, PS_RENDER_FWD, PS_RENDER_BWD, PS_GAUSS_BWD, PS_LOSS_FWD, PS_LOSS_BWD, PS_ADAM,
+       PS_COMPACT, PS_COUNT };
 const char* const kSlotNames[PS_COUNT] = {"preprocess_fwd", "depth_sort", "binning", "render_fwd", "render_bwd", "gaussian_bwd",
-                                          "loss_fwd", "loss_bwd"};
+                                          "loss_fwd", "loss_bwd", "adam", "compact"};
 struct Pending { int slot; hipEvent_t a, b; };
 // process-wide (autograd runs backward on its own thread), guarded by g_prof_mu
 std::mutex g_prof_mu;
@@ -358,6 +359,70 @@ int eogs_loss_backward(int planes, int H, int W, const float* img, const float* 
   hipStream_t s = (hipStream_t)stream;
   { ProfScope ps(PS_LOSS_BWD, s); launch_loss_bwd(w, planes, H, W, img, gt, mode, w_l1, w_ssim, upstream, plane_grad, dL_dimg, s); }
   LAUNCH_TRY(s, false, "loss_bwd");
+  return EOGS_OK;
+}
+
+// ---- include/eogs_optim.h ----
+int eogs_adam_step(int n, const eogs_adam_tensor* tensors, double beta1, double beta2, double eps, int64_t step, void* stream) {
+  g_err[0] = 0;
+  if (n < 0 || n > EOGS_ADAM_MAX_TENSORS || (n > 0 && !tensors) || step < 1)
+    return fail(EOGS_ERR_INVALID_ARG, "adam_step: bad argument (at most 16 tensors, step >= 1)");
+  for (int i = 0; i < n; i++)
+    if (tensors[i].numel < 0 || (tensors[i].numel > 0 && (!tensors[i].param || !tensors[i].grad || !tensors[i].exp_avg ||
+                                                          !tensors[i].exp_avg_sq)))
+      return fail(EOGS_ERR_INVALID_ARG, "adam_step: NULL tensor");
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  { ProfScope ps(PS_ADAM, s); rc = launch_adam(n, tensors, beta1, beta2, eps, step, s); }
+  if (rc) return fail(EOGS_ERR_OVERFLOW, "adam_step: too many elements for one launch");
+  LAUNCH_TRY(s, false, "adam");
+  return EOGS_OK;
+}
+
+int eogs_compact_bytes(int64_t n_rows, size_t* bytes) {
+  if (n_rows < 0 || !bytes) return fail(EOGS_ERR_INVALID_ARG, "compact_bytes: bad argument");
+  *bytes = compact_layout(nullptr, n_rows).bytes;
+  return EOGS_OK;
+}
+
+static int compact_check(const char* who, int64_t n_rows, const void* keep, const void* ws, size_t ws_bytes, CompactWS* w) {
+  if (n_rows < 0 || n_rows > (int64_t)0x7FFFFFFF * 128) return fail(EOGS_ERR_INVALID_ARG, "%s: bad row count", who);
+  if ((n_rows > 0 && !keep) || !ws) return fail(EOGS_ERR_INVALID_ARG, "%s: NULL argument", who);
+  char* base = ws_base(const_cast<void*>(ws));
+  *w = compact_layout(base, n_rows);
+  if ((size_t)(base - (const char*)ws) + w->bytes - 256 > ws_bytes) return fail(EOGS_ERR_WORKSPACE, "%s: workspace too small", who);
+  return EOGS_OK;
+}
+
+int eogs_compact_plan(int64_t n_rows, const uint8_t* keep, void* ws, size_t ws_bytes, int64_t* n_keep, void* stream) {
+  g_err[0] = 0;
+  CompactWS w;
+  const int rc = compact_check("compact_plan", n_rows, keep, ws, ws_bytes, &w);
+  if (rc != EOGS_OK) return rc;
+  if (!n_keep) return fail(EOGS_ERR_INVALID_ARG, "compact_plan: NULL n_keep");
+  hipStream_t s = (hipStream_t)stream;
+  { ProfScope ps(PS_COMPACT, s); launch_compact_plan(w, n_rows, keep, s); }
+  LAUNCH_TRY(s, false, "compact_plan");
+  uint32_t total = 0;
+  HIP_TRY(hipMemcpyAsync(&total, w.blk + w.nblk, sizeof total, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  *n_keep = (int64_t)total;
+  return EOGS_OK;
+}
+
+int eogs_compact_apply(int64_t n_rows, const uint8_t* keep, int n_tensors, const void* const* src, void* const* dst,
+                       const int* row_bytes, const void* ws, size_t ws_bytes, void* stream) {
+  g_err[0] = 0;
+  CompactWS w;
+  const int rc = compact_check("compact_apply", n_rows, keep, ws, ws_bytes, &w);
+  if (rc != EOGS_OK) return rc;
+  if (n_tensors < 0 || (n_tensors > 0 && (!src || !dst || !row_bytes))) return fail(EOGS_ERR_INVALID_ARG, "compact_apply: bad tensor list");
+  for (int t = 0; t < n_tensors; t++)
+    if (row_bytes[t] < 0 || row_bytes[t] > 256 || (row_bytes[t] & 3) || (row_bytes[t] > 0 && n_rows > 0 && (!src[t] || !dst[t])))
+      return fail(EOGS_ERR_INVALID_ARG, "compact_apply: row sizes must be multiples of 4 up to 256 bytes, pointers non-NULL");
+  hipStream_t s = (hipStream_t)stream;
+  { ProfScope ps(PS_COMPACT, s); launch_compact_apply(w, n_rows, keep, n_tensors, src, dst, row_bytes, s); }
+  LAUNCH_TRY(s, false, "compact_apply");
   return EOGS_OK;
 }
 

@@ -6,6 +6,7 @@
 
 #include "eogs_rast.h"
 #include "eogs_loss.h"
+#include "eogs_optim.h"
 
 #define NCH EOGS_RAST_CHANNELS  // 5 feature channels
 #define TILE EOGS_RAST_TILE     // 16x16 pixel tiles: the reference's binning granularity (tile rect, radii)
@@ -269,3 +270,16 @@ void launch_loss_fwd(const LossWS& w, int planes, int H, int W, const float* img
 void launch_loss_bwd(const LossWS& w, int planes, int H, int W, const float* img, const float* gt, unsigned mode,
                      float w_l1, float w_ssim, const float* upstream, const float* plane_grad, float* dimg,
                      hipStream_t s);
+
+// ---- optimizer / compaction (optim.hip, include/eogs_optim.h) ----
+#define EOGS_COMPACT_MAX_TENSORS 24  // tensors per compaction launch (more are split over launches)
+struct CompactWS {
+  uint32_t* blk;  // [nblk + 1] kept rows per 256-row workgroup -> exclusive prefix, total at [nblk]
+  uint32_t nblk;
+  size_t bytes;
+};
+CompactWS compact_layout(char* base, int64_t n_rows);
+int launch_adam(int n, const eogs_adam_tensor* tensors, double beta1, double beta2, double eps, int64_t step, hipStream_t s);
+void launch_compact_plan(const CompactWS& w, int64_t n_rows, const uint8_t* keep, hipStream_t s);
+void launch_compact_apply(const CompactWS& w, int64_t n_rows, const uint8_t* keep, int n_tensors, const void* const* src,
+                          void* const* dst, const int* row_bytes, hipStream_t s);

@@ -37,3 +37,14 @@ def test_loss_host_wrapper_has_no_cpu_fallback():
 
     with pytest.raises(RuntimeError):
         ssim(torch.rand(3, 16, 16), torch.rand(3, 16, 16))
+
+
+def test_optimizer_has_no_cpu_fallback():
+    from eogs2_amd.optim import FusedAdam, compact_rows
+
+    p = torch.nn.Parameter(torch.zeros(8, 3))
+    p.grad = torch.ones(8, 3)
+    with pytest.raises(RuntimeError):
+        FusedAdam([{"params": [p], "lr": 1e-3, "name": "xyz"}], lr=0.0, eps=1e-15).step()
+    with pytest.raises(RuntimeError):
+        compact_rows(torch.ones(8, dtype=torch.bool), [torch.zeros(8, 3)])
