@@ -196,6 +196,52 @@ def photometric_loss_bench(abi, dev, H, W, iters=20):
                              "frac": alg[k] / (kern[k] * 1e-3) / 1e9 / HBM_PEAK_GBS} for k in kern}}
 
 
+def resample_bench(abi, dev, H, W, iters=20):
+    """Extra: the virtual-camera resample of GS/gaussian_renderer/renderer_cc_shadow.py:32-50 (einsum,
+    grid_sample, out-of-view fill) forward + backward for the sun camera (2H x 2W render sampled on the H x W grid) and a
+    random virtual camera (H x W): the reference's PyTorch ops on the same GPU vs eogs2_amd.resample.resample."""
+    from eogs2_amd.resample import resample
+
+    def ref_ops(vr, M, uva):
+        uv = torch.einsum("...ij,...j->...i", M, uva)[..., :2]
+        s = torch.nn.functional.grid_sample(vr.unsqueeze(0), uv.unsqueeze(0), align_corners=True).squeeze(0)
+        rgb, a = s[:3], s[3]
+        a[(uv.abs() > 1).any(-1)] = -100
+        return torch.cat([rgb, a[None]], 0), uv
+
+    out = {}
+    U, V = torch.meshgrid(torch.linspace(-1, 1, W, device=dev), torch.linspace(-1, 1, H, device=dev), indexing="xy")
+    M = torch.eye(3, device=dev)
+    M[:2, 2] = torch.tensor([0.01, -0.02], device=dev)
+    for name, f in (("sun_2x", 2), ("random_1x", 1)):
+        vr = torch.rand(5, H * f, W * f, device=dev, requires_grad=True)
+        alt = torch.rand(H, W, device=dev, requires_grad=True)
+        w = torch.randn(4, H, W, device=dev)
+        for tag, fn in (("torch_ops_ms", ref_ops), ("fused_ms", resample)):
+            def run():
+                vr.grad = alt.grad = None
+                s, uv = fn(vr, M, torch.stack((U, V, alt), dim=-1))
+                ((s * w).sum() + uv.sum()).backward()
+            for _ in range(3):
+                run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                run()
+            torch.cuda.synchronize()
+            out[f"{name}_{tag}"] = (time.perf_counter() - t0) / iters * 1e3
+            if tag == "fused_ms":
+                abi.profile_reset()
+                abi.profile_enable(1)
+                for _ in range(5):
+                    run()
+                abi.profile_enable(0)
+                out[f"{name}_kernels_ms"] = {k: ms / n for k, (ms, n) in abi.profile().items()
+                                             if n and k.startswith("resample_")}
+    out["what"] = f"true camera {H}x{W}; timings include the small PyTorch ops around the call (stack, weighted sum)"
+    return out
+
+
 def optimizer_bench(abi, dev, P, iters=20):
     """Extra: the reference's optimizer step — torch.optim.Adam over six single-tensor groups
     (GS/scene/gaussian_model.py:228-262) — and its prune (`_prune_optimizer` + `prune_points`, :466-505: 21 boolean-mask
@@ -404,6 +450,7 @@ def main():
             line["train_iter_fused"] = train_iteration(sc, P, H, W, dev, fused=True)
             line["photometric_loss"] = photometric_loss_bench(abi, dev, H, W)
             line["optimizer"] = optimizer_bench(abi, dev, P)
+            line["resample"] = resample_bench(abi, dev, H, W)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(P, H)
         print(json.dumps(line), flush=True)

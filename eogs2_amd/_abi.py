@@ -71,10 +71,13 @@ SIGNATURES = {
     "eogs_compact_bytes": (_i, [_i64, C.POINTER(_z)]),
     "eogs_compact_plan": (_i, [_i64, _p, _p, _z, C.POINTER(_i64), _p]),
     "eogs_compact_apply": (_i, [_i64, _p, _i, _p, _p, _p, _p, _z, _p]),
+    # include/eogs_resample.h
+    "eogs_resample_forward": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _f, _p, _p, _p]),
+    "eogs_resample_backward": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p]),
 }
 # symbols only the HIP library exports (the CPU oracle of the loss is oracle/loss_oracle.py, not a C-ABI twin)
 HIP_ONLY = ("eogs_loss_bytes", "eogs_loss_forward", "eogs_loss_backward", "eogs_adam_step", "eogs_compact_bytes",
-            "eogs_compact_plan", "eogs_compact_apply")
+            "eogs_compact_plan", "eogs_compact_apply", "eogs_resample_forward", "eogs_resample_backward")
 
 
 class AdamTensor(C.Structure):
@@ -115,7 +118,7 @@ class RastABI:
             raise RastError(code, self.cdll.eogs_rast_last_error().decode())
 
     def __getattr__(self, name):
-        short = name.startswith(("loss_", "adam_", "compact_"))
+        short = name.startswith(("loss_", "adam_", "compact_", "resample_"))
         return getattr(self.cdll, ("eogs_" if short else "eogs_rast_") + name)
 
     def profile(self):

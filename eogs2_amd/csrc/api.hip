@@ -37,9 +37,9 @@ int check_launch(hipStream_t s, bool debug, const char* what) {
 }
 // ---- optional per-kernel-group timing with hipEvents on the launch stream ----
 enum { PS_PREPROCESS, PS_DEPTH_SORT, PS_BINNING, PS_RENDER_FWD, PS_RENDER_BWD, PS_GAUSS_BWD, PS_LOSS_FWD, PS_LOSS_BWD, PS_ADAM,
-       PS_COMPACT, PS_COUNT };
+       PS_COMPACT, PS_RESAMPLE_FWD, PS_RESAMPLE_BWD, PS_COUNT };
 const char* const kSlotNames[PS_COUNT] = {"preprocess_fwd", "depth_sort", "binning", "render_fwd", "render_bwd", "gaussian_bwd",
-                                          "loss_fwd", "loss_bwd", "adam", "compact"};
+                                          "loss_fwd", "loss_bwd", "adam", "compact", "resample_fwd", "resample_bwd"};
 struct Pending { int slot; hipEvent_t a, b; };
 // process-wide (autograd runs backward on its own thread), guarded by g_prof_mu
 std::mutex g_prof_mu;
@@ -423,6 +423,41 @@ int eogs_compact_apply(int64_t n_rows, const uint8_t* keep, int n_tensors, const
   hipStream_t s = (hipStream_t)stream;
   { ProfScope ps(PS_COMPACT, s); launch_compact_apply(w, n_rows, keep, n_tensors, src, dst, row_bytes, s); }
   LAUNCH_TRY(s, false, "compact_apply");
+  return EOGS_OK;
+}
+
+// ---- include/eogs_resample.h ----
+static int resample_check(const char* who, int C, int Hv, int Wv, int H, int W, int n_out, int fill_channel) {
+  if (C <= 0 || Hv <= 0 || Wv <= 0 || H <= 0 || W <= 0 || n_out <= 0 || n_out > C || fill_channel >= n_out ||
+      (int64_t)H * W > 0x7FFFFFFF || (int64_t)Hv * Wv > 0x7FFFFFFF)
+    return fail(EOGS_ERR_INVALID_ARG, "%s: bad sizes", who);
+  return EOGS_OK;
+}
+
+int eogs_resample_forward(int C, int Hv, int Wv, int H, int W, int n_out, const float* virtual_render, const float* uva,
+                          const float* cam2virt, int fill_channel, float fill_value, float* sample, float* uv,
+                          void* stream) {
+  g_err[0] = 0;
+  const int rc = resample_check("resample_forward", C, Hv, Wv, H, W, n_out, fill_channel);
+  if (rc != EOGS_OK) return rc;
+  if (!virtual_render || !uva || !cam2virt || !sample || !uv) return fail(EOGS_ERR_INVALID_ARG, "resample_forward: NULL argument");
+  hipStream_t s = (hipStream_t)stream;
+  { ProfScope ps(PS_RESAMPLE_FWD, s); launch_resample_fwd(C, Hv, Wv, H, W, n_out, virtual_render, uva, cam2virt, fill_channel, fill_value, sample, uv, s); }
+  LAUNCH_TRY(s, false, "resample_fwd");
+  return EOGS_OK;
+}
+
+int eogs_resample_backward(int C, int Hv, int Wv, int H, int W, int n_out, const float* virtual_render, const float* uva,
+                           const float* cam2virt, int fill_channel, const float* dL_dsample, const float* dL_duv,
+                           float* dL_dvirtual, float* dL_duva, void* stream) {
+  g_err[0] = 0;
+  const int rc = resample_check("resample_backward", C, Hv, Wv, H, W, n_out, fill_channel);
+  if (rc != EOGS_OK) return rc;
+  if (!virtual_render || !uva || !cam2virt || !dL_dsample || !dL_dvirtual || !dL_duva)
+    return fail(EOGS_ERR_INVALID_ARG, "resample_backward: NULL argument");
+  hipStream_t s = (hipStream_t)stream;
+  { ProfScope ps(PS_RESAMPLE_BWD, s); launch_resample_bwd(C, Hv, Wv, H, W, n_out, virtual_render, uva, cam2virt, fill_channel, dL_dsample, dL_duv, dL_dvirtual, dL_duva, s); }
+  LAUNCH_TRY(s, false, "resample_bwd");
   return EOGS_OK;
 }
 

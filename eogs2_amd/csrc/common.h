@@ -7,6 +7,7 @@
 #include "eogs_rast.h"
 #include "eogs_loss.h"
 #include "eogs_optim.h"
+#include "eogs_resample.h"
 
 #define NCH EOGS_RAST_CHANNELS  // 5 feature channels
 #define TILE EOGS_RAST_TILE     // 16x16 pixel tiles: the reference's binning granularity (tile rect, radii)
@@ -283,3 +284,10 @@ int launch_adam(int n, const eogs_adam_tensor* tensors, double beta1, double bet
 void launch_compact_plan(const CompactWS& w, int64_t n_rows, const uint8_t* keep, hipStream_t s);
 void launch_compact_apply(const CompactWS& w, int64_t n_rows, const uint8_t* keep, int n_tensors, const void* const* src,
                           void* const* dst, const int* row_bytes, hipStream_t s);
+
+// ---- virtual-camera resample (resample.hip, include/eogs_resample.h) ----
+void launch_resample_fwd(int C, int Hv, int Wv, int H, int W, int n_out, const float* vr, const float* uva,
+                         const float* M, int fill_channel, float fill_value, float* sample, float* uv, hipStream_t s);
+void launch_resample_bwd(int C, int Hv, int Wv, int H, int W, int n_out, const float* vr, const float* uva,
+                         const float* M, int fill_channel, const float* gs, const float* guv, float* gvr, float* guva,
+                         hipStream_t s);
