@@ -73,11 +73,12 @@ SIGNATURES = {
     "eogs_compact_apply": (_i, [_i64, _p, _i, _p, _p, _p, _p, _z, _p]),
     # include/eogs_resample.h
     "eogs_resample_forward": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _f, _p, _p, _p]),
-    "eogs_resample_backward": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p]),
+    "eogs_resample_bytes": (_i, [_i, _i, C.POINTER(_z)]),
+    "eogs_resample_backward": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _z, _p]),
 }
 # symbols only the HIP library exports (the CPU oracle of the loss is oracle/loss_oracle.py, not a C-ABI twin)
 HIP_ONLY = ("eogs_loss_bytes", "eogs_loss_forward", "eogs_loss_backward", "eogs_adam_step", "eogs_compact_bytes",
-            "eogs_compact_plan", "eogs_compact_apply", "eogs_resample_forward", "eogs_resample_backward")
+            "eogs_compact_plan", "eogs_compact_apply", "eogs_resample_forward", "eogs_resample_bytes", "eogs_resample_backward")
 
 
 class AdamTensor(C.Structure):

@@ -447,16 +447,23 @@ int eogs_resample_forward(int C, int Hv, int Wv, int H, int W, int n_out, const 
   return EOGS_OK;
 }
 
+int eogs_resample_bytes(int H, int W, size_t* bytes) {
+  if (H <= 0 || W <= 0 || !bytes) return fail(EOGS_ERR_INVALID_ARG, "resample_bytes: bad argument");
+  *bytes = resample_bwd_ws_bytes(H, W);
+  return EOGS_OK;
+}
+
 int eogs_resample_backward(int C, int Hv, int Wv, int H, int W, int n_out, const float* virtual_render, const float* uva,
                            const float* cam2virt, int fill_channel, const float* dL_dsample, const float* dL_duv,
-                           float* dL_dvirtual, float* dL_duva, void* stream) {
+                           float* dL_dvirtual, float* dL_duva, void* ws, size_t ws_bytes, void* stream) {
   g_err[0] = 0;
   const int rc = resample_check("resample_backward", C, Hv, Wv, H, W, n_out, fill_channel);
   if (rc != EOGS_OK) return rc;
   if (!virtual_render || !uva || !cam2virt || !dL_dsample || !dL_dvirtual || !dL_duva)
     return fail(EOGS_ERR_INVALID_ARG, "resample_backward: NULL argument");
+  if (ws && ws_bytes < resample_bwd_ws_bytes(H, W)) return fail(EOGS_ERR_WORKSPACE, "resample_backward: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  { ProfScope ps(PS_RESAMPLE_BWD, s); launch_resample_bwd(C, Hv, Wv, H, W, n_out, virtual_render, uva, cam2virt, fill_channel, dL_dsample, dL_duv, dL_dvirtual, dL_duva, s); }
+  { ProfScope ps(PS_RESAMPLE_BWD, s); launch_resample_bwd(C, Hv, Wv, H, W, n_out, virtual_render, uva, cam2virt, fill_channel, dL_dsample, dL_duv, dL_dvirtual, dL_duva, ws, s); }
   LAUNCH_TRY(s, false, "resample_bwd");
   return EOGS_OK;
 }

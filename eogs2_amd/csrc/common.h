@@ -288,6 +288,7 @@ void launch_compact_apply(const CompactWS& w, int64_t n_rows, const uint8_t* kee
 // ---- virtual-camera resample (resample.hip, include/eogs_resample.h) ----
 void launch_resample_fwd(int C, int Hv, int Wv, int H, int W, int n_out, const float* vr, const float* uva,
                          const float* M, int fill_channel, float fill_value, float* sample, float* uv, hipStream_t s);
+size_t resample_bwd_ws_bytes(int H, int W);
 void launch_resample_bwd(int C, int Hv, int Wv, int H, int W, int n_out, const float* vr, const float* uva,
                          const float* M, int fill_channel, const float* gs, const float* guv, float* gvr, float* guva,
-                         hipStream_t s);
+                         void* ws, hipStream_t s);

@@ -56,56 +56,161 @@ __global__ __launch_bounds__(BLK) void resample_fwd_kernel(int C, int Hv, int Wv
   }
 }
 
-__global__ __launch_bounds__(BLK) void resample_bwd_kernel(int C, int Hv, int Wv, int HW, int n_out,
-                                                           const float* __restrict__ vr, const float* __restrict__ uva,
-                                                           const float* __restrict__ M, int fill_channel,
-                                                           const float* __restrict__ gs, const float* __restrict__ guv,
-                                                           float* __restrict__ gvr, float* __restrict__ guva) {
-  const int p = blockIdx.x * BLK + threadIdx.x;
-  if (p >= HW) return;
-  const float a = uva[3 * (size_t)p], b = uva[3 * (size_t)p + 1], c = uva[3 * (size_t)p + 2];
-  const float u = M[0] * a + M[1] * b + M[2] * c, v = M[3] * a + M[4] * b + M[5] * c;
-  const Taps t = make_taps(u, v, Wv, Hv);
-  const float wx0 = 1.f - t.wx1, wy0 = 1.f - t.wy1;
+// ---- backward ----
+// dL/duva needs only per-pixel data. dL/dvirtual_render is a scatter of four taps per output pixel; global fp32 atomics
+// sustain only ~26 G/s here (0.7 ms for a 1024^2 grid), so the scatter is turned into a gather by VIRTUAL tile:
+//   pixel kernel : per 16x16 output tile, dL/duva and the bounding box of the cells its pixels touch;
+//   tile kernel  : one workgroup per 64x32 virtual tile accumulates, in LDS, the taps of every output tile whose box
+//                  meets it (recomputing the few coordinates involved), then writes its tile with plain stores.
+// No global atomics, no memset; every virtual pixel is written exactly once.
+constexpr int OT = 16;  // output tile edge (256 pixels = one workgroup)
+
+__device__ inline void lds_add(float* p, float v) {  // ds_add_f32, result unused
+  (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+constexpr int VTX = 64, VTY = 32;  // virtual tile (32 KB of LDS for four channels)
+
+template <bool ATOMIC_SCATTER>
+__global__ __launch_bounds__(BLK) void resample_bwd_pixel_kernel(int Hv, int Wv, int H, int W, int n_out,
+                                                                 const float* __restrict__ vr, const float* __restrict__ uva,
+                                                                 const float* __restrict__ M, int fill_channel,
+                                                                 const float* __restrict__ gs, const float* __restrict__ guv,
+                                                                 float* __restrict__ gvr, float* __restrict__ guva,
+                                                                 int4* __restrict__ bbox) {
+  __shared__ int s_box[4][BLK / 64];
+  const int tx = threadIdx.x & (OT - 1), ty = threadIdx.x >> 4;
+  const int x = blockIdx.x * OT + tx, y = blockIdx.y * OT + ty;
+  const bool live = x < W && y < H;
+  const int HW = H * W;
+  const size_t p = (size_t)y * W + x;
+  int bx0 = 0x7FFFFFFF, by0 = 0x7FFFFFFF, bx1 = -0x7FFFFFFF, by1 = -0x7FFFFFFF;
+  if (live) {
+    const float a = uva[3 * p], b = uva[3 * p + 1], c = uva[3 * p + 2];
+    const float u = M[0] * a + M[1] * b + M[2] * c, v = M[3] * a + M[4] * b + M[5] * c;
+    const Taps t = make_taps(u, v, Wv, Hv);
+    const float wx0 = 1.f - t.wx1, wy0 = 1.f - t.wy1;
+    const size_t plane = (size_t)Hv * Wv;
+    const size_t o00 = (size_t)t.y0 * Wv + t.x0;
+    const bool outside = fabsf(u) > 1.f || fabsf(v) > 1.f;
+    float gix = 0.f, giy = 0.f;
+    for (int ch = 0; ch < n_out; ch++) {
+      float g = gs[(size_t)ch * HW + p];
+      if (ch == fill_channel && outside) g = 0.f;  // the value was overwritten by a constant
+      const float* src = vr + ch * plane;
+      float* dst = gvr + ch * plane;
+      if (t.in_y0 && t.in_x0) {
+        const float val = src[o00];
+        if (ATOMIC_SCATTER) unsafeAtomicAdd(dst + o00, g * wx0 * wy0);
+        gix -= val * wy0 * g; giy -= val * wx0 * g;
+      }
+      if (t.in_y0 && t.in_x1) {
+        const float val = src[o00 + 1];
+        if (ATOMIC_SCATTER) unsafeAtomicAdd(dst + o00 + 1, g * t.wx1 * wy0);
+        gix += val * wy0 * g; giy -= val * t.wx1 * g;
+      }
+      if (t.in_y1 && t.in_x0) {
+        const float val = src[o00 + Wv];
+        if (ATOMIC_SCATTER) unsafeAtomicAdd(dst + o00 + Wv, g * wx0 * t.wy1);
+        gix -= val * t.wy1 * g; giy += val * wx0 * g;
+      }
+      if (t.in_y1 && t.in_x1) {
+        const float val = src[o00 + Wv + 1];
+        if (ATOMIC_SCATTER) unsafeAtomicAdd(dst + o00 + Wv + 1, g * t.wx1 * t.wy1);
+        gix += val * t.wy1 * g; giy += val * t.wx1 * g;
+      }
+    }
+    // d(ix)/du = (Wv-1)/2 (align_corners=True)
+    float gu = gix * (0.5f * (float)(Wv - 1)), gv = giy * (0.5f * (float)(Hv - 1));
+    if (guv) {
+      const float2 e = reinterpret_cast<const float2*>(guv)[p];
+      gu += e.x; gv += e.y;
+    }
+    guva[3 * p] = M[0] * gu + M[3] * gv;
+    guva[3 * p + 1] = M[1] * gu + M[4] * gv;
+    guva[3 * p + 2] = M[2] * gu + M[5] * gv;
+    if ((t.in_x0 || t.in_x1) && (t.in_y0 || t.in_y1)) {  // cells [x0, x0+1] x [y0, y0+1], clamped values
+      bx0 = t.x0; bx1 = t.x0 + 1; by0 = t.y0; by1 = t.y0 + 1;
+    }
+  }
+  if (!ATOMIC_SCATTER) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      bx0 = min(bx0, __shfl_xor(bx0, o, 64)); by0 = min(by0, __shfl_xor(by0, o, 64));
+      bx1 = max(bx1, __shfl_xor(bx1, o, 64)); by1 = max(by1, __shfl_xor(by1, o, 64));
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_box[0][w] = bx0; s_box[1][w] = by0; s_box[2][w] = bx1; s_box[3][w] = by1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int k = 1; k < BLK / 64; k++) {
+        bx0 = min(bx0, s_box[0][k]); by0 = min(by0, s_box[1][k]); bx1 = max(bx1, s_box[2][k]); by1 = max(by1, s_box[3][k]);
+      }
+      bbox[blockIdx.y * gridDim.x + blockIdx.x] = make_int4(bx0, by0, bx1, by1);  // empty: x0 > x1
+    }
+  }
+}
+
+template <int NACC>
+__global__ __launch_bounds__(BLK) void resample_bwd_tile_kernel(int C, int Hv, int Wv, int H, int W, int n_out,
+                                                                const float* __restrict__ uva, const float* __restrict__ M,
+                                                                int fill_channel, const float* __restrict__ gs,
+                                                                const int4* __restrict__ bbox, int ntx, int nty,
+                                                                float* __restrict__ gvr) {
+  __shared__ float s_acc[NACC][VTY][VTX];
+  __shared__ uint32_t s_list[1024];
+  __shared__ uint32_t s_n;
+  const int vx0 = blockIdx.x * VTX, vy0 = blockIdx.y * VTY;
+  for (int e = threadIdx.x; e < NACC * VTY * VTX; e += BLK) (&s_acc[0][0][0])[e] = 0.f;
+  const int HW = H * W;
+  const int nt = ntx * nty;
+  for (int scanned = 0; scanned < nt; scanned += 1024) {  // candidate output tiles: 1024 boxes per round
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const int lim = min(scanned + 1024, nt);
+    for (int t = scanned + threadIdx.x; t < lim; t += BLK) {
+      const int4 bb = bbox[t];
+      if (bb.x <= vx0 + VTX - 1 && bb.z >= vx0 && bb.y <= vy0 + VTY - 1 && bb.w >= vy0)
+        s_list[atomicAdd(&s_n, 1u)] = (uint32_t)t;
+    }
+    __syncthreads();
+    const uint32_t n = s_n;
+    for (uint32_t k = 0; k < n; k++) {
+      const int t = (int)s_list[k];
+      const int x = (t % ntx) * OT + (threadIdx.x & (OT - 1)), y = (t / ntx) * OT + (threadIdx.x >> 4);
+      if (x >= W || y >= H) continue;
+      const size_t p = (size_t)y * W + x;
+      const float a = uva[3 * p], b = uva[3 * p + 1], c = uva[3 * p + 2];
+      const float u = M[0] * a + M[1] * b + M[2] * c, v = M[3] * a + M[4] * b + M[5] * c;
+      const Taps tp = make_taps(u, v, Wv, Hv);
+      const int lx = tp.x0 - vx0, ly = tp.y0 - vy0;
+      if (lx < -1 || lx >= VTX || ly < -1 || ly >= VTY) continue;
+      const float wx0 = 1.f - tp.wx1, wy0 = 1.f - tp.wy1;
+      const bool outside = fabsf(u) > 1.f || fabsf(v) > 1.f;
+      const bool cx0 = lx >= 0 && tp.in_x0, cx1 = lx + 1 < VTX && tp.in_x1;
+      const bool cy0 = ly >= 0 && tp.in_y0, cy1 = ly + 1 < VTY && tp.in_y1;
+#pragma unroll
+      for (int ch = 0; ch < NACC; ch++) {
+        if (ch >= n_out) break;
+        float g = gs[(size_t)ch * HW + p];
+        if (ch == fill_channel && outside) g = 0.f;
+        if (cy0 && cx0) lds_add(&s_acc[ch][ly][lx], g * wx0 * wy0);
+        if (cy0 && cx1) lds_add(&s_acc[ch][ly][lx + 1], g * tp.wx1 * wy0);
+        if (cy1 && cx0) lds_add(&s_acc[ch][ly + 1][lx], g * wx0 * tp.wy1);
+        if (cy1 && cx1) lds_add(&s_acc[ch][ly + 1][lx + 1], g * tp.wx1 * tp.wy1);
+      }
+    }
+    __syncthreads();
+  }
+  // every virtual pixel of the tile, every channel (channels >= n_out get zeros): plain coalesced stores
   const size_t plane = (size_t)Hv * Wv;
-  const size_t o00 = (size_t)t.y0 * Wv + t.x0;
-  const bool outside = fabsf(u) > 1.f || fabsf(v) > 1.f;
-  float gix = 0.f, giy = 0.f;
-  for (int ch = 0; ch < n_out; ch++) {
-    float g = gs[(size_t)ch * HW + p];
-    if (ch == fill_channel && outside) g = 0.f;  // the value was overwritten by a constant
-    const float* src = vr + ch * plane;
-    float* dst = gvr + ch * plane;
-    if (t.in_y0 && t.in_x0) {
-      const float val = src[o00];
-      unsafeAtomicAdd(dst + o00, g * wx0 * wy0);
-      gix -= val * wy0 * g; giy -= val * wx0 * g;
-    }
-    if (t.in_y0 && t.in_x1) {
-      const float val = src[o00 + 1];
-      unsafeAtomicAdd(dst + o00 + 1, g * t.wx1 * wy0);
-      gix += val * wy0 * g; giy -= val * t.wx1 * g;
-    }
-    if (t.in_y1 && t.in_x0) {
-      const float val = src[o00 + Wv];
-      unsafeAtomicAdd(dst + o00 + Wv, g * wx0 * t.wy1);
-      gix -= val * t.wy1 * g; giy += val * wx0 * g;
-    }
-    if (t.in_y1 && t.in_x1) {
-      const float val = src[o00 + Wv + 1];
-      unsafeAtomicAdd(dst + o00 + Wv + 1, g * t.wx1 * t.wy1);
-      gix += val * t.wy1 * g; giy += val * t.wx1 * g;
+  for (int e = threadIdx.x; e < VTY * VTX; e += BLK) {
+    const int ly = e / VTX, lx = e - ly * VTX;
+    const int gx = vx0 + lx, gy = vy0 + ly;
+    if (gx < Wv && gy < Hv) {
+      for (int ch = 0; ch < C; ch++)
+        gvr[ch * plane + (size_t)gy * Wv + gx] = (ch < NACC && ch < n_out) ? s_acc[ch < NACC ? ch : 0][ly][lx] : 0.f;
     }
   }
-  // d(ix)/du = (Wv-1)/2 (align_corners=True)
-  float gu = gix * (0.5f * (float)(Wv - 1)), gv = giy * (0.5f * (float)(Hv - 1));
-  if (guv) {
-    const float2 e = reinterpret_cast<const float2*>(guv)[p];
-    gu += e.x; gv += e.y;
-  }
-  guva[3 * (size_t)p] = M[0] * gu + M[3] * gv;
-  guva[3 * (size_t)p + 1] = M[1] * gu + M[4] * gv;
-  guva[3 * (size_t)p + 2] = M[2] * gu + M[5] * gv;
 }
 
 }  // namespace
@@ -117,11 +222,24 @@ void launch_resample_fwd(int C, int Hv, int Wv, int H, int W, int n_out, const f
                      fill_channel, fill_value, sample, uv);
 }
 
+size_t resample_bwd_ws_bytes(int H, int W) {
+  const size_t nt = (size_t)((W + OT - 1) / OT) * ((H + OT - 1) / OT);
+  return (nt * sizeof(int4) + 255) / 256 * 256 + 256;
+}
+
 void launch_resample_bwd(int C, int Hv, int Wv, int H, int W, int n_out, const float* vr, const float* uva,
                          const float* M, int fill_channel, const float* gs, const float* guv, float* gvr, float* guva,
-                         hipStream_t s) {
-  const int HW = H * W;
-  (void)hipMemsetAsync(gvr, 0, (size_t)C * Hv * Wv * sizeof(float), s);
-  hipLaunchKernelGGL(resample_bwd_kernel, dim3((HW + BLK - 1) / BLK), dim3(BLK), 0, s, C, Hv, Wv, HW, n_out, vr, uva, M,
-                     fill_channel, gs, guv, gvr, guva);
+                         void* ws, hipStream_t s) {
+  const int ntx = (W + OT - 1) / OT, nty = (H + OT - 1) / OT;
+  if (n_out > 4 || !ws) {  // more channels than the LDS tile holds (the reference keeps 4): atomic scatter
+    (void)hipMemsetAsync(gvr, 0, (size_t)C * Hv * Wv * sizeof(float), s);
+    hipLaunchKernelGGL(resample_bwd_pixel_kernel<true>, dim3(ntx, nty), dim3(BLK), 0, s, Hv, Wv, H, W, n_out, vr, uva, M,
+                       fill_channel, gs, guv, gvr, guva, (int4*)nullptr);
+    return;
+  }
+  int4* bbox = reinterpret_cast<int4*>(ws_base(ws));
+  hipLaunchKernelGGL(resample_bwd_pixel_kernel<false>, dim3(ntx, nty), dim3(BLK), 0, s, Hv, Wv, H, W, n_out, vr, uva, M,
+                     fill_channel, gs, guv, gvr, guva, bbox);
+  hipLaunchKernelGGL(resample_bwd_tile_kernel<4>, dim3((Wv + VTX - 1) / VTX, (Hv + VTY - 1) / VTY), dim3(BLK), 0, s, C, Hv, Wv,
+                     H, W, n_out, uva, M, fill_channel, gs, bbox, ntx, nty, gvr);
 }

@@ -10,6 +10,8 @@
 Gradients flow to `virtual_render` and `rendered_uva` (hence to the true camera's altitude render); `cam2virt` is
 treated as a constant, as in the reference where it is built from fixed camera matrices. No CPU / eager fallback.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -57,8 +59,11 @@ class _Resample(torch.autograd.Function):
             guv = _f32c(g_uv, dev) if g_uv is not None else None
             g_vr = torch.empty((C, Hv, Wv), dtype=torch.float32, device=dev)
             g_uva = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+            n = ctypes.c_size_t()
+            abi.check(abi.resample_bytes(H, W, ctypes.byref(n)))
+            ws = torch.empty((n.value,), dtype=torch.uint8, device=dev)
             abi.check(abi.resample_backward(C, Hv, Wv, H, W, n_out, _ptr(vr), _ptr(uva), _ptr(M), fill_channel, _ptr(gs),
-                                            _ptr(guv), _ptr(g_vr), _ptr(g_uva), cx.stream))
+                                            _ptr(guv), _ptr(g_vr), _ptr(g_uva), _ptr(ws), ws.numel(), cx.stream))
         return g_vr, g_uva, None, None, None, None
 
 

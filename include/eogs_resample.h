@@ -33,16 +33,20 @@ int eogs_resample_forward(int C, int Hv, int Wv, int H, int W, int n_out, const 
                           const float* uva, const float* cam2virt, int fill_channel, float fill_value,
                           float* sample, float* uv, void* stream);
 
+/* Backward workspace (bounding boxes of the cells touched by each 16x16 output tile). */
+int eogs_resample_bytes(int H, int W, size_t* bytes);
+
 /* Backward.
  *   dL_dsample f32[n_out,H,W]; dL_duv f32[H,W,2] or NULL
- *   dL_dvirtual f32[C,Hv,Wv]: fully overwritten (zero-filled, then fp32 atomic adds of the four bilinear taps — the same
- *     scheme, and the same run-to-run rounding freedom, as PyTorch's grid_sampler_2d_backward)
+ *   dL_dvirtual f32[C,Hv,Wv]: fully overwritten. The four-tap scatter is evaluated as a gather per virtual tile with the
+ *     sums formed in LDS (no global atomics); like PyTorch's grid_sampler_2d_backward the summation order, hence the
+ *     last bit, is not fixed run to run. With n_out > 4 or ws == NULL it falls back to global fp32 atomic adds.
  *   dL_duva f32[H,W,3]: cam2virt[0:2,:]^T (dL_duv + the sampler's gradient with respect to the coordinates), fully overwritten
  * cam2virt itself receives no gradient (the reference derives it from fixed camera matrices). */
 int eogs_resample_backward(int C, int Hv, int Wv, int H, int W, int n_out, const float* virtual_render,
                            const float* uva, const float* cam2virt, int fill_channel,
                            const float* dL_dsample, const float* dL_duv,
-                           float* dL_dvirtual, float* dL_duva, void* stream);
+                           float* dL_dvirtual, float* dL_duva, void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }
