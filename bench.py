@@ -55,7 +55,13 @@ def measured_traffic(kernel, a):
 
     if a.gaussians != (1 << 20) or a.size != 1024 or a.opacity != "init":
         return None, None
-    for d in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_v*", "pmc_mean_per_dispatch.json")), reverse=True):
+    import re
+
+    def ver(path):  # profiles/r01_v12/...: (round, version), numeric
+        m = re.search(r"r(\d+)_v(\d+)", path)
+        return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
+
+    for d in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_v*", "pmc_mean_per_dispatch.json")), key=ver, reverse=True):
         try:
             pm = json.load(open(d))
         except Exception:
