@@ -75,10 +75,14 @@ SIGNATURES = {
     "eogs_resample_forward": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _f, _p, _p, _p]),
     "eogs_resample_bytes": (_i, [_i, _i, C.POINTER(_z)]),
     "eogs_resample_backward": (_i, [_i, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _z, _p]),
+    # include/eogs_knn.h
+    "eogs_knn_bytes": (_i, [_i, C.POINTER(_z)]),
+    "eogs_knn_mean_dist2": (_i, [_i, _p, _p, _p, _z, _p]),
 }
 # symbols only the HIP library exports (the CPU oracle of the loss is oracle/loss_oracle.py, not a C-ABI twin)
 HIP_ONLY = ("eogs_loss_bytes", "eogs_loss_forward", "eogs_loss_backward", "eogs_adam_step", "eogs_compact_bytes",
-            "eogs_compact_plan", "eogs_compact_apply", "eogs_resample_forward", "eogs_resample_bytes", "eogs_resample_backward")
+            "eogs_compact_plan", "eogs_compact_apply", "eogs_resample_forward", "eogs_resample_bytes", "eogs_resample_backward", "eogs_knn_bytes",
+            "eogs_knn_mean_dist2")
 
 
 class AdamTensor(C.Structure):
@@ -119,7 +123,7 @@ class RastABI:
             raise RastError(code, self.cdll.eogs_rast_last_error().decode())
 
     def __getattr__(self, name):
-        short = name.startswith(("loss_", "adam_", "compact_", "resample_"))
+        short = name.startswith(("loss_", "adam_", "compact_", "resample_", "knn_"))
         return getattr(self.cdll, ("eogs_" if short else "eogs_rast_") + name)
 
     def profile(self):

@@ -37,9 +37,9 @@ int check_launch(hipStream_t s, bool debug, const char* what) {
 }
 // ---- optional per-kernel-group timing with hipEvents on the launch stream ----
 enum { PS_PREPROCESS, PS_DEPTH_SORT, PS_BINNING, PS_RENDER_FWD, PS_RENDER_BWD, PS_GAUSS_BWD, PS_LOSS_FWD, PS_LOSS_BWD, PS_ADAM,
-       PS_COMPACT, PS_RESAMPLE_FWD, PS_RESAMPLE_BWD, PS_COUNT };
+       PS_COMPACT, PS_RESAMPLE_FWD, PS_RESAMPLE_BWD, PS_KNN, PS_COUNT };
 const char* const kSlotNames[PS_COUNT] = {"preprocess_fwd", "depth_sort", "binning", "render_fwd", "render_bwd", "gaussian_bwd",
-                                          "loss_fwd", "loss_bwd", "adam", "compact", "resample_fwd", "resample_bwd"};
+                                          "loss_fwd", "loss_bwd", "adam", "compact", "resample_fwd", "resample_bwd", "knn"};
 struct Pending { int slot; hipEvent_t a, b; };
 // process-wide (autograd runs backward on its own thread), guarded by g_prof_mu
 std::mutex g_prof_mu;
@@ -465,6 +465,27 @@ int eogs_resample_backward(int C, int Hv, int Wv, int H, int W, int n_out, const
   hipStream_t s = (hipStream_t)stream;
   { ProfScope ps(PS_RESAMPLE_BWD, s); launch_resample_bwd(C, Hv, Wv, H, W, n_out, virtual_render, uva, cam2virt, fill_channel, dL_dsample, dL_duv, dL_dvirtual, dL_duva, ws, s); }
   LAUNCH_TRY(s, false, "resample_bwd");
+  return EOGS_OK;
+}
+
+// ---- include/eogs_knn.h ----
+int eogs_knn_bytes(int P, size_t* bytes) {
+  if (P < 0 || !bytes) return fail(EOGS_ERR_INVALID_ARG, "knn_bytes: bad argument");
+  *bytes = knn_layout(nullptr, P).bytes;
+  return EOGS_OK;
+}
+
+int eogs_knn_mean_dist2(int P, const float* points, float* mean_dist2, void* ws, size_t ws_bytes, void* stream) {
+  g_err[0] = 0;
+  if (P < 0) return fail(EOGS_ERR_INVALID_ARG, "knn_mean_dist2: bad size");
+  if (P == 0) return EOGS_OK;
+  if (!points || !mean_dist2 || !ws) return fail(EOGS_ERR_INVALID_ARG, "knn_mean_dist2: NULL argument");
+  char* base = ws_base(ws);
+  const KnnWS w = knn_layout(base, P);
+  if ((size_t)(base - (char*)ws) + w.bytes - 256 > ws_bytes) return fail(EOGS_ERR_WORKSPACE, "knn_mean_dist2: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  { ProfScope ps(PS_KNN, s); launch_knn(w, P, points, mean_dist2, s); }
+  LAUNCH_TRY(s, false, "knn");
   return EOGS_OK;
 }
 

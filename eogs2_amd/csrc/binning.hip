@@ -206,6 +206,15 @@ void launch_depth_sort(const GeomWS& g, int P, int first, int last, hipStream_t 
   }
 }
 
+void launch_sort_u32(uint32_t* keyA, uint32_t* valA, uint32_t* keyB, uint32_t* valB, uint32_t n, int passes, uint32_t* hist,
+                     uint32_t nblk, uint32_t* dtotal, hipStream_t s) {
+  for (int pass = 0; pass < passes; pass++) {
+    const bool a2b = (pass & 1) == 0;
+    radix_pass<SORTP_ITEMS, uint32_t>(a2b ? keyA : keyB, a2b ? valA : valB, a2b ? keyB : keyA, a2b ? valB : valA, n,
+                                      8 * pass, 8, hist, nblk, dtotal, s);
+  }
+}
+
 // ---- exclusive scan of a small array in place (single workgroup, 16 elements per thread per round);
 //      data[n] receives the total ----
 __global__ __launch_bounds__(BLK) void small_scan_kernel(uint32_t* __restrict__ data, uint32_t n) {

@@ -8,6 +8,7 @@
 #include "eogs_loss.h"
 #include "eogs_optim.h"
 #include "eogs_resample.h"
+#include "eogs_knn.h"
 
 #define NCH EOGS_RAST_CHANNELS  // 5 feature channels
 #define TILE EOGS_RAST_TILE     // 16x16 pixel tiles: the reference's binning granularity (tile rect, radii)
@@ -292,3 +293,17 @@ size_t resample_bwd_ws_bytes(int H, int W);
 void launch_resample_bwd(int C, int Hv, int Wv, int H, int W, int n_out, const float* vr, const float* uva,
                          const float* M, int fill_channel, const float* gs, const float* guv, float* gvr, float* guva,
                          void* ws, hipStream_t s);
+
+// ---- 3-nearest-neighbour statistic (knn.hip, include/eogs_knn.h) ----
+struct KnnWS {
+  uint32_t *keyA, *keyB, *valA, *valB, *hist, *dtotal;  // Morton sort ping-pong + radix histograms
+  float4* sorted;                                       // points in Morton order
+  float* boxes;                                         // (nbox + 1) x {lo[3], hi[3]}; the last one is the scene box
+  uint32_t nblk, nbox;
+  size_t bytes;
+};
+KnnWS knn_layout(char* base, int P);
+void launch_knn(const KnnWS& w, int P, const float* pts, float* out, hipStream_t s);
+// `passes` stable 8-bit LSD passes over 32-bit keys with a 32-bit payload, ping-ponging A -> B -> A ... (binning.hip)
+void launch_sort_u32(uint32_t* keyA, uint32_t* valA, uint32_t* keyB, uint32_t* valB, uint32_t n, int passes, uint32_t* hist,
+                     uint32_t nblk, uint32_t* dtotal, hipStream_t s);
