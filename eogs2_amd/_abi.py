@@ -58,6 +58,7 @@ SIGNATURES = {
     ),
     "eogs_rast_mark_visible": (_i, [_i, _p, _p, _p, _p, _p]),
     "eogs_rast_profile_enable": (_i, [_i]),
+    "eogs_rast_profile_select": (_i, [_u]),
     "eogs_rast_profile_reset": (_i, []),
     "eogs_rast_profile_slots": (_i, []),
     "eogs_rast_profile_get": (_i, [_i, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_char_p)]),
@@ -125,6 +126,14 @@ class RastABI:
     def __getattr__(self, name):
         short = name.startswith(("loss_", "adam_", "compact_", "resample_", "knn_"))
         return getattr(self.cdll, ("eogs_" if short else "eogs_rast_") + name)
+
+    def profile_slot_names(self):
+        names = []
+        for i in range(self.cdll.eogs_rast_profile_slots()):
+            ms, n, nm = C.c_double(), _i64(), C.c_char_p()
+            self.check(self.cdll.eogs_rast_profile_get(i, C.byref(ms), C.byref(n), C.byref(nm)))
+            names.append(nm.value.decode())
+        return names
 
     def profile(self):
         """{group name: (total device ms, launches)} accumulated since the last profile_reset()."""

@@ -44,10 +44,23 @@ struct Pending { int slot; hipEvent_t a, b; };
 // process-wide (autograd runs backward on its own thread), guarded by g_prof_mu
 std::mutex g_prof_mu;
 std::atomic<bool> g_prof_on{false};
+std::atomic<uint32_t> g_prof_mask{0xFFFFFFFFu};  // bit per slot: which kernel groups are bracketed
 double g_prof_ms[PS_COUNT];
 int64_t g_prof_n[PS_COUNT];
 Pending g_pending[4096];
 int g_npending = 0;
+
+// events are pooled: creating / destroying a hipEvent per bracket costs several microseconds of host time each
+hipEvent_t g_pool[8192];
+int g_npool = 0;
+bool prof_get_event(hipEvent_t* e) {  // caller holds g_prof_mu
+  if (g_npool > 0) { *e = g_pool[--g_npool]; return true; }
+  return hipEventCreate(e) == hipSuccess;
+}
+void prof_put_event(hipEvent_t e) {  // caller holds g_prof_mu
+  if (g_npool < 8192) g_pool[g_npool++] = e;
+  else (void)hipEventDestroy(e);
+}
 
 void prof_drain() {  // caller holds g_prof_mu
   for (int i = 0; i < g_npending; i++) {
@@ -56,21 +69,21 @@ void prof_drain() {  // caller holds g_prof_mu
       g_prof_ms[g_pending[i].slot] += ms;
       g_prof_n[g_pending[i].slot] += 1;
     }
-    (void)hipEventDestroy(g_pending[i].a);
-    (void)hipEventDestroy(g_pending[i].b);
+    prof_put_event(g_pending[i].a);
+    prof_put_event(g_pending[i].b);
   }
   g_npending = 0;
 }
 struct ProfScope {
   hipStream_t s; int idx = -1;
   ProfScope(int slot, hipStream_t st) : s(st) {
-    if (!g_prof_on.load(std::memory_order_relaxed)) return;
+    if (!g_prof_on.load(std::memory_order_relaxed) || !((g_prof_mask.load(std::memory_order_relaxed) >> slot) & 1u)) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (g_npending == 4096) prof_drain();
     Pending& p = g_pending[g_npending];
     p.slot = slot;
-    if (hipEventCreate(&p.a) != hipSuccess) return;
-    if (hipEventCreate(&p.b) != hipSuccess) { (void)hipEventDestroy(p.a); return; }
+    if (!prof_get_event(&p.a)) return;
+    if (!prof_get_event(&p.b)) { prof_put_event(p.a); return; }
     idx = g_npending++;
     (void)hipEventRecord(p.a, s);
   }
@@ -284,6 +297,10 @@ int eogs_rast_profile_enable(int on) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if (!on) prof_drain();
   g_prof_on = on != 0;
+  return EOGS_OK;
+}
+int eogs_rast_profile_select(unsigned slot_mask) {
+  g_prof_mask = slot_mask;
   return EOGS_OK;
 }
 int eogs_rast_profile_reset(void) {

@@ -151,6 +151,9 @@ int eogs_rast_mark_visible(int P, const float* means3D, const float* viewmatrix,
  * group's name ("preprocess_fwd", "depth_sort", "binning", "render_fwd", "render_bwd", "gaussian_bwd").
  * The oracle implements them as no-ops (0 slots). Process-wide (backward may run on another thread). */
 int eogs_rast_profile_enable(int on);
+/* Restricts the bracketing to the slots whose bit is set (default: all). Each bracket costs two event records
+ * (about 3.4 us of queue time each on the MI355X), so a timed region brackets only the kernel it needs. */
+int eogs_rast_profile_select(unsigned slot_mask);
 int eogs_rast_profile_reset(void);
 int eogs_rast_profile_slots(void);
 int eogs_rast_profile_get(int slot, double* total_ms, int64_t* launches, const char** name);

@@ -831,6 +831,7 @@ int eogs_rast_mark_visible(int P, const float* means3D, const float* viewmatrix,
 
 /* diagnostics: no-ops in the oracle */
 int eogs_rast_profile_enable(int on) { (void)on; return EOGS_OK; }
+int eogs_rast_profile_select(unsigned slot_mask) { (void)slot_mask; return EOGS_OK; }
 int eogs_rast_profile_reset(void) { return EOGS_OK; }
 int eogs_rast_profile_slots(void) { return 0; }
 int eogs_rast_profile_get(int slot, double* total_ms, int64_t* launches, const char** name) {
