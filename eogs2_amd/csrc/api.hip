@@ -14,6 +14,24 @@ namespace {
 thread_local char g_err[512] = "";
 thread_local uint32_t* g_pinned = nullptr;  // MISC_WORDS u32, pinned host memory (one per calling thread)
 
+// per calling thread and device: a non-blocking side stream + event for the num_rendered readback
+struct Side { int dev; hipStream_t stream; hipEvent_t ev; };
+thread_local Side g_side[16];
+thread_local int g_nside = 0;
+Side* side_for_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  for (int i = 0; i < g_nside; i++)
+    if (g_side[i].dev == dev) return &g_side[i];
+  if (g_nside == 16) return nullptr;
+  Side sd;
+  sd.dev = dev;
+  if (hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&sd.ev, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(sd.stream); return nullptr; }
+  g_side[g_nside] = sd;
+  return &g_side[g_nside++];
+}
+
 int fail(int code, const char* fmt, const char* detail = "") {
   snprintf(g_err, sizeof g_err, fmt, detail);
   return code;
@@ -159,11 +177,17 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
                 (flags & EOGS_FLAG_ANTIALIASING) != 0, radii, raw, alt_affine};
   { ProfScope ps(PS_PREPROCESS, s); launch_preprocess_fwd(a, g, s); launch_scan_pblock(g, P, s); }
   LAUNCH_TRY(s, debug, "preprocess_fwd");
-  HIP_TRY(hipMemcpyAsync(g_pinned, g.misc, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-  // the depth sort does not depend on num_rendered: its first three passes run while the host waits for the readback
+  // The pair count is read back on a side stream that waits only for the two kernels above, so the host wakes up
+  // while the caller's stream is still busy with the depth sort (which does not depend on num_rendered) and has the
+  // rest of the forward queued before the GPU runs dry.
+  Side* sd = side_for_current_device();
+  if (!sd) return fail(EOGS_ERR_DEVICE, "forward_prepare: cannot create the readback stream");
+  HIP_TRY(hipEventRecord(sd->ev, s));
+  HIP_TRY(hipStreamWaitEvent(sd->stream, sd->ev, 0));
+  HIP_TRY(hipMemcpyAsync(g_pinned, g.misc, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, sd->stream));
   { ProfScope ps(PS_DEPTH_SORT, s); launch_depth_sort(g, P, 0, 3, s); }
   LAUNCH_TRY(s, debug, "depth_sort");
-  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipStreamSynchronize(sd->stream));
   {
     // Fourth pass (bits 24..31) only if the listed Gaussians' keys differ there. EOGS altitudes span far less than
     // a factor of two around 200 - altitude, so they normally share sign, exponent-high bits: one digit, no pass.
