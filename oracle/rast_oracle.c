@@ -6,7 +6,7 @@
  * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and
  * only as the checker.
  *
- * PARITY PIN: the reference's arithmetic is CUDA-only (nvcc + CUB + un-vendored
+ * PARITY UNPINNED (against reference outputs): the reference's arithmetic is CUDA-only (nvcc + CUB + un-vendored
  * glm) and its tests hold no golden vectors for this path,
  * so this oracle cannot be checked against reference outputs.  It is pinned
  * instead (tests/test_oracle_pins.py) against (1) an independent dense
