@@ -38,7 +38,7 @@ def test_wave64_primitives_selftest(dev):
     assert failed.value == 0, f"wave64 primitive self-test failed: mask {failed.value:#x}"
 
 
-def _compare(out, ref, name, means3D=None):
+def _compare(out, ref, name, means3D=None, sweep=False):
     assert np.array_equal(out["out_radii"].cpu().numpy(), np.asarray(ref["out_radii"])), f"{name}: radii differ"
     for k, v in out.items():
         if k == "out_radii":
@@ -53,12 +53,22 @@ def _compare(out, ref, name, means3D=None):
             err = float((v.cpu().double() - r.double()).abs().max()) / scale
             from util import GRAD_RTOL, RTOL
 
-            assert err <= GRAD_RTOL.get(name, RTOL), f"{name}:{k}: {err:.3e} of the magnitude sum"
+            # (sweep: the [:3,:2] block comes from the covariance backward, the worst-conditioned part: x4)
+            assert err <= GRAD_RTOL.get(name, RTOL) * (4 if sweep else 1), f"{name}:{k}: {err:.3e} of the magnitude sum"
             continue
         from util import GRAD_RTOL, RTOL
 
         # flip_floor: one pixel whose T < 1e-4 termination (or alpha >= 1/255 test) lands on the other side of the
         # threshold moves a handful of per-Gaussian gradient entries, whatever the tensor size
+        if sweep:
+            # Randomised scenes leave the reference's operating regime (large low-opacity Gaussians: long, shallow
+            # alpha = 1/255 contours). One flipped pixel changes an image by up to |c| / 255 — a few per cent of the
+            # image scale when the accumulated opacity is low — and touches the gradient entries of the flipped
+            # Gaussian and of everything behind it at that pixel. Outliers: a handful, bounded in size.
+            grad = k.startswith("g_")
+            assert_close(v, r, f"{name}:{k}", rtol=GRAD_RTOL.get(name, RTOL) if grad else RTOL,
+                         flip_floor=16 if grad else 10, flip_rtol=5e-2 if grad else 2e-2)
+            continue
         assert_close(v, r, f"{name}:{k}", rtol=GRAD_RTOL.get(name, RTOL) if k.startswith("g_") else RTOL, flip_floor=3)
 
 
@@ -177,6 +187,41 @@ def test_row_span_listing_anisotropic(dev, monkeypatch, opacity, aniso, scale_mu
     ref = run_case(case, torch.device("cpu"), GaussianRasterizer, GaussianRasterizationSettings)
     monkeypatch.setattr(_lib, "get", lambda: hip)
     _compare(got, {k: v.cpu().numpy() for k, v in ref.items()}, f"aniso{aniso}", case["means3D"])
+
+
+@pytest.mark.parametrize("seed", list(range(200, 224)))
+def test_randomised_sweep_against_oracle(dev, monkeypatch, seed):
+    """Random small configurations (sizes, opacity law, footprint, anisotropy, rotation, antialiasing, inverse-depth
+    gradient): every listing kind (mask / row spans / whole rect), partial tiles and long lists get hit by chance."""
+    import oracle
+    from eogs2_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib
+    from eogs2_amd.synthetic import make_scene
+
+    g = torch.Generator().manual_seed(seed)
+    r = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    P, H, W = r(1, 3000), r(9, 200), r(9, 260)
+    opacity = ["init", "trained", 0.3, 0.02, 0.95][r(0, 4)]
+    scale_mult = [0.5, 1.0, 2.5, 6.0, 15.0][r(0, 4)]
+    # log-normal axis ratios up to ~e^(3*1.2): beyond that the fp32 covariance backward of the reference algorithm is
+    # itself ill-conditioned (HIP and oracle then sit equally far, tens of per cent, from a float64 evaluation)
+    aniso = [0.0, 0.3, 0.7, 1.2][r(0, 3)]
+    aa, dgrad = bool(r(0, 1)), bool(r(0, 1))
+    sc = make_scene(P, H, W, seed=seed, opacity=opacity, scale_mult=scale_mult, anisotropy=aniso)
+    if r(0, 1):
+        q = torch.randn(P, 4, generator=g)
+        sc["rotations"] = (q / q.norm(dim=1, keepdim=True)).contiguous()
+    case = {k: v.numpy() for k, v in sc.items()}
+    case.update(H=H, W=W, antialiasing=aa)
+    if dgrad:
+        case["dL_dinvdepth"] = (torch.randn(1, H, W, generator=g) / (H * W) * 100).numpy()
+    got = run_case(case, dev, GaussianRasterizer, GaussianRasterizationSettings)
+    hip = _lib.get()
+    monkeypatch.setattr(_lib, "get", lambda: oracle.abi())
+    ref = run_case(case, torch.device("cpu"), GaussianRasterizer, GaussianRasterizationSettings)
+    monkeypatch.setattr(_lib, "get", lambda: hip)
+    stress = scale_mult >= 6.0 or aniso >= 0.7  # cancellation-heavy gradient sums: tests/util.py GRAD_RTOL
+    _compare(got, {k: v.cpu().numpy() for k, v in ref.items()}, "seed15" if stress else f"sweep{seed}", case["means3D"],
+             sweep=True)
 
 
 def test_sun_camera_size_2048(dev):

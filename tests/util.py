@@ -41,14 +41,15 @@ def closeness(a, b):
     return float(err.max()), float((err > RTOL).double().mean()), scale
 
 
-def assert_close(a, b, what, rtol=RTOL, allow_flips=True, flip_floor=0):
+def assert_close(a, b, what, rtol=RTOL, allow_flips=True, flip_floor=0, flip_rtol=FLIP_RTOL):
     """flip_floor: number of threshold-flip elements tolerated regardless of tensor size (used where the two sides
-    evaluate the activations with different exp implementations, so opacities differ by an ulp)."""
+    evaluate the activations with different exp implementations, so opacities differ by an ulp).
+    flip_rtol: bound on the size of such an outlier, relative to the tensor's scale."""
     assert tuple(a.shape) == tuple(b.shape), f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
     mx, frac, scale = closeness(a, b)
     if allow_flips:
         n = max(int(torch.as_tensor(b).numel()), 1)
-        ok = (mx <= rtol) or (frac <= max(FLIP_FRAC, (flip_floor + 0.5) / n) and mx <= FLIP_RTOL)
+        ok = (mx <= rtol) or (frac <= max(FLIP_FRAC, (flip_floor + 0.5) / n) and mx <= flip_rtol)
     else:
         ok = mx <= rtol
     assert ok, f"{what}: max err {mx:.3e} (x scale {scale:.3e}), fraction beyond {RTOL:g}: {frac:.3e}"
