@@ -327,29 +327,39 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint4* __restrict__ s
   uint32_t ltot;
   const uint32_t l0 = block_excl_scan(mine ? it.c : 0u, s_w, ltot);
   s_id[threadIdx.x] = it.id; s_l0[threadIdx.x] = l0; s_gp[threadIdx.x] = it.pos0; s_rb[threadIdx.x] = it.rbase;
+  // per-lane cursor, carried across rounds so that every pair is generated exactly once
+  uint32_t l = l0;                     // local position of the lane's next pair
+  const uint32_t l_end = mine ? l0 + it.c : l0;
+  unsigned long long m_rem = it.m;     // BK_MASK: bits still to emit
+  uint32_t row = 0, q_cur = 0;         // BK_SPANS: current row / BK_RECT: next index
+  int c_cur = 0, c_end = 0;            // BK_SPANS: remaining columns of the current row
   for (uint32_t base = 0; base < ltot; base += EXPAND_STAGE) {
     __syncthreads();  // s_id.. visible (first round) / previous window drained
-    if (mine && l0 < base + EXPAND_STAGE && l0 + it.c > base) {
-      uint32_t l = l0;  // local position of the next pair of this lane
-      auto put = [&](uint32_t tile) {
-        const uint32_t w = l - base;  // wraps below the window: fails the unsigned test
-        if (w < (uint32_t)EXPAND_STAGE) {
-          s_tk[w] = tile;
-          s_own[w] = (uint16_t)threadIdx.x;
-        }
-        l++;
-      };
+    const uint32_t wend = base + EXPAND_STAGE < l_end ? base + EXPAND_STAGE : l_end;  // this lane stops here this round
+    if (l < wend) {  // (l >= base always: windows are consecutive and the lane stopped at the previous window's end)
       if (kind == BK_MASK) {
-        for (unsigned long long m = it.m; m; m &= m - 1ull) put(tile_of(it, (uint32_t)__builtin_ctzll(m), gsx));
+        for (; l < wend; l++, m_rem &= m_rem - 1ull) {
+          s_tk[l - base] = tile_of(it, (uint32_t)__builtin_ctzll(m_rem), gsx);
+          s_own[l - base] = (uint16_t)threadIdx.x;
+        }
       } else if (kind == BK_SPANS) {
-        for (uint32_t row = 0; row < it.sh; row++) {
-          int c0, c1;
-          row_span(sp, (int)(it.sy0 + row), (int)it.sx0, (int)(it.sx0 + it.sw), c0, c1);
-          const uint32_t t0 = (it.sy0 + row) * gsx;
-          for (int c = c0; c < c1; c++) put(t0 + (uint32_t)c);
+        while (l < wend) {
+          if (c_cur >= c_end) {  // next non-empty row
+            row_span(sp, (int)(it.sy0 + row), (int)it.sx0, (int)(it.sx0 + it.sw), c_cur, c_end);
+            row++;
+            if (row > it.sh) break;  // never: the spans add up to it.c
+            continue;
+          }
+          s_tk[l - base] = (it.sy0 + row - 1) * gsx + (uint32_t)c_cur;
+          s_own[l - base] = (uint16_t)threadIdx.x;
+          c_cur++;
+          l++;
         }
       } else {
-        for (uint32_t q = 0; q < it.c; q++) put(tile_of(it, q, gsx));
+        for (; l < wend; l++, q_cur++) {
+          s_tk[l - base] = tile_of(it, q_cur, gsx);
+          s_own[l - base] = (uint16_t)threadIdx.x;
+        }
       }
     }
     __syncthreads();
