@@ -465,21 +465,28 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
         uint32_t m = 0;
 #pragma unroll 4
         for (uint32_t q = 0; q < m_n; q++) m |= (uint32_t)(live[s0 + q0 + q] != 0) << q;
-        while (m) {  // two live records per trip: six independent loads in flight, summed in list order
-          const uint32_t q1 = q0 + (uint32_t)__builtin_ctz(m);
-          m &= m - 1u;
-          const bool two = m != 0u;
-          const uint32_t q2 = two ? q0 + (uint32_t)__builtin_ctz(m) : q1;
-          m &= m - 1u;  // (0 & anything stays 0)
-          const float4 a = r4[3 * q1], b = r4[3 * q1 + 1], c = r4[3 * q1 + 2];
-          const float4 d = r4[3 * q2], e = r4[3 * q2 + 1], f = r4[3 * q2 + 2];
-          acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
-          acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
-          acc[8] += c.x; acc[9] += c.y; acc[10] += c.z;
-          if (two) {
-            acc[0] += d.x; acc[1] += d.y; acc[2] += d.z; acc[3] += d.w;
-            acc[4] += e.x; acc[5] += e.y; acc[6] += e.z; acc[7] += e.w;
-            acc[8] += f.x; acc[9] += f.y; acc[10] += f.z;
+        while (m) {  // up to four live records per trip: twelve independent loads in flight, summed in list order
+          uint32_t q[4];
+          bool have[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            have[u] = m != 0u;
+            q[u] = have[u] ? q0 + (uint32_t)__builtin_ctz(m) : q0;
+            m &= m - 1u;  // (0 & anything stays 0)
+          }
+          float4 ra[4], rb[4], rc[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const uint32_t qq = have[u] ? q[u] : q[0];  // a valid address either way
+            ra[u] = r4[3 * qq]; rb[u] = r4[3 * qq + 1]; rc[u] = r4[3 * qq + 2];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            if (have[u]) {
+              acc[0] += ra[u].x; acc[1] += ra[u].y; acc[2] += ra[u].z; acc[3] += ra[u].w;
+              acc[4] += rb[u].x; acc[5] += rb[u].y; acc[6] += rb[u].z; acc[7] += rb[u].w;
+              acc[8] += rc[u].x; acc[9] += rc[u].y; acc[10] += rc[u].z;
+            }
           }
         }
       }
