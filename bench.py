@@ -430,7 +430,9 @@ def main():
     # num_rendered of this rank's view, straight from the API's own bookkeeping
     color = step()
     torch.cuda.synchronize()
-    R = int(color.grad_fn.num_rendered) if hasattr(color.grad_fn, "num_rendered") else -1
+    nr = int(color.grad_fn.num_rendered) if hasattr(color.grad_fn, "num_rendered") else -1
+    # the API's num_rendered packs both counts: (tile, Gaussian) record slots below, sorted list entries above
+    R, R_entries = (nr & 0xFFFFFFFF, nr >> 32) if nr >= 0 else (-1, -1)
 
     if rank == 0:
         ms_step = dt / a.steps * 1e3
@@ -470,7 +472,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{P} Gaussians x {H}x{W} x 5 channels, opacity={a.opacity}, 1 view per GPU, "
                                    f"fwd+bwd" + (" + RCCL grad all-reduce (56 B/Gaussian)" if use_dist else ""),
-                       "gaussians": P, "height": H, "width": W, "num_rendered": R, "parallelism": f"view-dp{world}"},
+                       "gaussians": P, "height": H, "width": W, "num_rendered": R, "list_entries": R_entries,
+                       "parallelism": f"view-dp{world}"},
             "roofline": roof, "pipeline": pipe, "kernels_ms": kern, "kernel_rooflines": per_kernel,
         }
         if world == 1 and not use_dist and not a.no_train_iter:

@@ -153,8 +153,9 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
   if (P < 0 || H <= 0 || W <= 0 || !num_rendered) return fail(EOGS_ERR_INVALID_ARG, "forward_prepare: bad sizes");
   *num_rendered = 0;
   if (P == 0) return EOGS_OK;
-  if (((W + TILE - 1) / TILE) > 32767 || ((H + TILE - 1) / TILE) > 32767)
-    return fail(EOGS_ERR_INVALID_ARG, "forward_prepare: image too large for 16-bit internal tile coordinates");
+  if (((W + TILE - 1) / TILE) > 32767 || ((H + TILE - 1) / TILE) > 32767 ||
+      (uint64_t)macro_grid_x(W) * macro_grid_y(H) > (1u << MACRO_KEY_BITS))
+    return fail(EOGS_ERR_INVALID_ARG, "forward_prepare: image too large (at most 65536 blocks of 32x32 pixels)");
   if (!means3D || !opacities || !viewmatrix || !radii || !geom) return fail(EOGS_ERR_INVALID_ARG, "forward_prepare: NULL input");
   if (!colors) return fail(EOGS_ERR_NO_COLORS, "For non-RGB, provide precomputed Gaussian colors!");
   const bool have_sr = scales && rotations, have_cov = cov3D_precomp != nullptr;
@@ -210,8 +211,9 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
   LAUNCH_TRY(s, debug, "binning_head");
   if (g_pinned[MISC_ERR] & 1u) return fail(EOGS_ERR_ALTITUDE, "Point is too high: altitude > 200");
   const uint64_t total = (uint64_t)g_pinned[MISC_TOTAL_LO] | ((uint64_t)g_pinned[MISC_TOTAL_HI] << 32);
-  if (total >= ((uint64_t)1 << 31)) return fail(EOGS_ERR_OVERFLOW, "num_rendered overflows 31 bits");
-  *num_rendered = (int64_t)total;
+  const uint64_t entries = (uint64_t)g_pinned[MISC_MACRO_LO] | ((uint64_t)g_pinned[MISC_MACRO_HI] << 32);
+  if (total >= ((uint64_t)1 << 31) || entries >= ((uint64_t)1 << 31)) return fail(EOGS_ERR_OVERFLOW, "num_rendered overflows 31 bits");
+  *num_rendered = nr_pack((uint32_t)total, (uint32_t)entries);
   return EOGS_OK;
 }
 

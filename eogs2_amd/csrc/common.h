@@ -28,6 +28,8 @@
 #define MISC_ERR 2       // bit0: altitude > 200
 #define MISC_KEY_MAX 4   // max depth key over listed Gaussians
 #define MISC_KEY_NMIN 5  // max of ~key = ~min depth key (zero-initialised like the rest of misc)
+#define MISC_MACRO_LO 6  // number of (macro block, Gaussian) list entries (u64, lo/hi)
+#define MISC_MACRO_HI 7
 #define MISC_WORDS 64
 
 // ---- radix sort geometry ----
@@ -82,6 +84,67 @@ __device__ inline void row_span(const SpanParams& p, int sy, int sx0, int sx1, i
   }
 }
 
+// ---- macro tiles: the unit of the sorted lists ----
+// Lists are sorted per MACRO x MACRO block of internal tiles (32 x 32 pixels); every list entry carries a MACRO*MACRO-bit
+// sub-mask (in the upper half of its 32-bit sort key) saying which internal tiles of the block the Gaussian is listed
+// in. A render wave (one internal tile) scans its block's list and keeps the entries whose bit is set (ballot +
+// prefix compaction into LDS), so the sort moves one entry per (block, Gaussian) instead of one per (tile, Gaussian).
+#define MACRO 4
+#define MACRO_SUB (MACRO * MACRO)
+#define MACRO_KEY_BITS 16  // block id in the low half of the key, sub-mask in the high half
+static_assert(MACRO_SUB <= 16, "the sub-mask lives in the upper 16 bits of the sort key");
+
+// Walks the macro row MY of a Gaussian's listing (kind, mask m or span constants sp, internal-tile rect
+// [sx0,sx1) x [sy0,sy1)) and calls emit(MX, sub) for every block with a non-empty sub-mask, left to right.
+// Used by preprocess (counting) and expand (emission): same code, same bits, same result.
+template <class Emit>
+__device__ inline void walk_macro_row(uint32_t kind, unsigned long long m, const SpanParams& sp, int sx0, int sy0, int sx1,
+                                      int sy1, int MY, Emit&& emit) {
+  const int sw = sx1 - sx0;
+  int c0[MACRO], c1[MACRO];
+  unsigned long long w[MACRO];
+  int lo = 0x7FFFFFFF, hi = -1;  // columns with any hit in this macro row
+#pragma unroll
+  for (int dy = 0; dy < MACRO; dy++) {
+    const int fy = MY * MACRO + dy;
+    c0[dy] = c1[dy] = 0;
+    w[dy] = 0ull;
+    if (fy < sy0 || fy >= sy1) continue;
+    if (kind == BK_MASK) {  // sw * sh <= 64: row fy is sw bits of m
+      w[dy] = (m >> ((fy - sy0) * sw)) & (sw >= 64 ? ~0ull : ((1ull << sw) - 1ull));
+      if (w[dy]) {
+        lo = min(lo, sx0 + (int)__builtin_ctzll(w[dy]));
+        hi = max(hi, sx0 + 63 - (int)__builtin_clzll(w[dy]));
+      }
+    } else {
+      if (kind == BK_SPANS) row_span(sp, fy, sx0, sx1, c0[dy], c1[dy]);
+      else { c0[dy] = sx0; c1[dy] = sx1; }
+      if (c1[dy] > c0[dy]) {
+        lo = min(lo, c0[dy]);
+        hi = max(hi, c1[dy] - 1);
+      }
+    }
+  }
+  if (hi < 0) return;
+  for (int MX = lo / MACRO; MX <= hi / MACRO; MX++) {
+    const int X0 = MX * MACRO;
+    uint32_t sub = 0;
+#pragma unroll
+    for (int dy = 0; dy < MACRO; dy++) {
+      uint32_t nib;
+      if (kind == BK_MASK) {
+        const int off = X0 - sx0;
+        nib = (uint32_t)((off >= 0 ? (w[dy] >> off) : (w[dy] << (-off))) & ((1ull << MACRO) - 1ull));
+      } else {
+        const int a = max(c0[dy], X0) - X0, b = min(c1[dy], X0 + MACRO) - X0;
+        nib = b > a ? (((1u << (b - a)) - 1u) << a) : 0u;
+      }
+      sub |= nib << (dy * MACRO);
+    }
+    if (sub) emit(MX, sub);
+  }
+}
+
 static inline size_t ws_align(size_t x) { return (x + 255u) & ~(size_t)255u; }
 
 template <typename T>
@@ -108,7 +171,7 @@ struct GeomWS {
                         //   lpre = exclusive prefix of `tiles` inside the Gaussian's preprocess workgroup (256 Gaussians)
   float4* bext;         // 2 x float4 = 32 bytes per Gaussian, written for BK_SPANS only: SpanParams
   uint4* sinfo;         // the same records in DEPTH order (gathered once by expand_count_kernel)
-  uint32_t* pbkey;      // per preprocess workgroup: {max depth key, max ~key} over its listed Gaussians
+  uint32_t* pbkey;      // per preprocess workgroup: {max depth key, max ~key, list entries} over its listed Gaussians
   uint32_t* pblock;     // per preprocess workgroup: total, then (scan_pblock_kernel) exclusive prefix over workgroups.
                         // record slot of (Gaussian i, its q-th tile) = pblock[i/256] + lpre[i] + q: records are laid out
                         // in Gaussian-id order, so gaussian_bwd streams them
@@ -134,7 +197,7 @@ static inline GeomWS geom_layout(char* base, int P) {
   o = ws_carve(base, o, g.sinfo, n * 2);
   o = ws_carve(base, o, g.bext, n * 2);
   o = ws_carve(base, o, g.pblock, (size_t)ceil_div_u32(n, BLK) + 1);
-  o = ws_carve(base, o, g.pbkey, (size_t)ceil_div_u32(n, BLK) * 2);
+  o = ws_carve(base, o, g.pbkey, (size_t)ceil_div_u32(n, BLK) * 3);
   o = ws_carve(base, o, g.skeyA, n);
   o = ws_carve(base, o, g.skeyB, n);
   o = ws_carve(base, o, g.svalA, n);
@@ -149,9 +212,9 @@ static inline GeomWS geom_layout(char* base, int P) {
 
 // Binning workspace: everything that is O(R) (R = number of (tile,Gaussian) pairs).
 struct BinWS {
-  uint32_t* tkeyA;  // tile ids, ping-pong
+  uint32_t* tkeyA;  // sort keys {macro block id | sub-mask << 16}, ping-pong
   uint32_t* tkeyB;
-  uint2* tvalA;     // payload {Gaussian id, record slot (Gaussian-id order)}, ping-pong
+  uint2* tvalA;     // payload {Gaussian id, record slot of the entry's first listed internal tile}, ping-pong
   uint2* tvalB;
   uint32_t* hist;   // [nbins][nblkR]
   uint32_t* dtotal; // [256]
@@ -170,10 +233,18 @@ static inline int ceil_log2_u32(uint32_t n) {  // smallest b with (1<<b) >= n
   return b;
 }
 
+// num_rendered as handed across the C-ABI packs both pair counts of a forward: the record slots (one per listed
+// internal tile, backward scratch) in the low 32 bits and the sorted list entries (one per listed macro block) above.
+static inline uint32_t nr_slots(int64_t R) { return (uint32_t)((uint64_t)R & 0xFFFFFFFFull); }
+static inline uint32_t nr_entries(int64_t R) { return (uint32_t)((uint64_t)R >> 32); }
+static inline int64_t nr_pack(uint32_t slots, uint32_t entries) { return (int64_t)(((uint64_t)entries << 32) | slots); }
+static inline uint32_t macro_grid_x(int W) { return (uint32_t)(((W + SUBX - 1) / SUBX + MACRO - 1) / MACRO); }
+static inline uint32_t macro_grid_y(int H) { return (uint32_t)(((H + SUBY - 1) / SUBY + MACRO - 1) / MACRO); }
+
 static inline BinWS bin_layout(char* base, int H, int W, int64_t R) {
   BinWS b;
-  size_t n = (size_t)R, o = 0;
-  uint32_t T = (uint32_t)((W + SUBX - 1) / SUBX) * (uint32_t)((H + SUBY - 1) / SUBY);
+  size_t n = (size_t)nr_entries(R), nslots = (size_t)nr_slots(R), o = 0;
+  uint32_t T = macro_grid_x(W) * macro_grid_y(H);
   b.tile_bits = ceil_log2_u32(T) < 1 ? 1 : ceil_log2_u32(T);
   b.passes = (b.tile_bits + 7) / 8;
   b.bits_per_pass = (b.tile_bits + b.passes - 1) / b.passes;
@@ -185,8 +256,8 @@ static inline BinWS bin_layout(char* base, int H, int W, int64_t R) {
   o = ws_carve(base, o, b.tvalB, n);
   o = ws_carve(base, o, b.hist, (size_t)256 * (b.nblkR ? b.nblkR : 1));
   o = ws_carve(base, o, b.dtotal, 256);
-  o = ws_carve(base, o, b.records, n * REC);
-  o = ws_carve(base, o, b.live, n);
+  o = ws_carve(base, o, b.records, nslots * REC);
+  o = ws_carve(base, o, b.live, nslots);
   b.point_list = (b.passes & 1) ? b.tvalB : b.tvalA;
   b.sorted_keys = (b.passes & 1) ? b.tkeyB : b.tkeyA;
   b.bytes = ws_align(o) + 256;
@@ -195,7 +266,7 @@ static inline BinWS bin_layout(char* base, int H, int W, int64_t R) {
 
 // Image workspace: O(H*W) + O(tiles).
 struct ImgWS {
-  uint2* ranges;       // per internal tile [start,end) into point_list
+  uint2* ranges;       // per macro block [start,end) into point_list
   float* final_T;      // transmittance after the last blended Gaussian
   uint32_t* n_contrib; // 1 + list index of the last blended Gaussian
   size_t bytes;
@@ -204,7 +275,7 @@ struct ImgWS {
 static inline ImgWS img_layout(char* base, int H, int W) {
   ImgWS im;
   size_t n = (size_t)H * W, o = 0;
-  size_t T = (size_t)((W + SUBX - 1) / SUBX) * ((H + SUBY - 1) / SUBY);
+  size_t T = (size_t)macro_grid_x(W) * macro_grid_y(H);
   o = ws_carve(base, o, im.ranges, T);
   o = ws_carve(base, o, im.final_T, n);
   o = ws_carve(base, o, im.n_contrib, n);

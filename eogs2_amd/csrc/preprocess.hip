@@ -153,7 +153,7 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
   __syncthreads();
 
   const size_t idx = row0 + t;
-  uint32_t my_tiles = 0, key_bits = 0, bkind = BK_RECT;
+  uint32_t my_tiles = 0, my_entries = 0, key_bits = 0, bkind = BK_RECT;
   uint4 bi0 = make_uint4(0u, 0u, 0u, 0u);
   if (t < rows) {
     const float p[3] = {s_m[3 * t], s_m[3 * t + 1], s_m[3 * t + 2]};
@@ -236,6 +236,7 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
         const int sw = sx1 - sx0, sh = sy1 - sy0;
         unsigned long long m = 0ull;
         uint32_t kind = BK_RECT;
+        SpanParams sp = {};
         if (!any || sw <= 0 || sh <= 0) {
           my_tiles = 0;
         } else if (sw * sh <= MASK_MAX_SUBTILES) {
@@ -251,20 +252,26 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
         } else if (tau_m >= 0.f && tau_m < 3.0e38f && ca * cc - cb * cb > 0.f) {
           // larger footprints: per-row column spans in closed form (common.h row_span); expand re-evaluates them
           kind = BK_SPANS;
-          const SpanParams sp = span_params(px, py, ca, cb, cc, tau_m);
-          uint32_t cnt = 0;
-          for (int sy = sy0; sy < sy1; sy++) {
-            int c0, c1;
-            row_span(sp, sy, sx0, sx1, c0, c1);
-            cnt += (uint32_t)(c1 - c0);
-          }
-          my_tiles = cnt;
-          if (cnt) {
+          sp = span_params(px, py, ca, cb, cc, tau_m);
+          my_tiles = 1;  // counted by the macro walk below
+        } else {
+          my_tiles = (uint32_t)(sw * sh);
+        }
+        // list entries = macro blocks with at least one listed internal tile (the unit the sort moves); for
+        // BK_SPANS the walk also yields the number of listed internal tiles (record slots)
+        if (my_tiles) {
+          uint32_t ent = 0, fine = 0;
+          for (int MY = sy0 / MACRO; MY <= (sy1 - 1) / MACRO; MY++)
+            walk_macro_row(kind, m, sp, sx0, sy0, sx1, sy1, MY, [&](int, uint32_t sub) {
+              ent++;
+              fine += (uint32_t)__popc(sub);
+            });
+          my_tiles = fine;
+          my_entries = ent;
+          if (kind == BK_SPANS && fine) {
             bext[2 * idx] = make_float4(sp.gx, sp.gy, sp.ex, sp.ey);
             bext[2 * idx + 1] = make_float4(sp.boa, sp.boc, sp.ta, sp.da);
           }
-        } else {
-          my_tiles = (uint32_t)(sw * sh);
         }
         bkind = kind;
         if (my_tiles) {
@@ -313,30 +320,33 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
   const uint32_t pre = (w > 0 ? w0 : 0u) + (w > 1 ? w1 : 0u) + (w > 2 ? w2 : 0u);
   if (t < rows) {
     binfo[2 * idx] = bi0;
-    binfo[2 * idx + 1] = make_uint4(my_tiles, pre + inc - my_tiles, (uint32_t)idx, bkind);
+    binfo[2 * idx + 1] = make_uint4(my_tiles, pre + inc - my_tiles, (uint32_t)idx, bkind | (my_entries << 2));
   }
   // range of the depth keys of listed Gaussians (lets the host drop sort passes whose digit is constant) and the
   // workgroup's pair count: plain stores, reduced by pblock_scan_kernel (same-address atomics from 16k waves cost
   // 0.36 ms here)
-  __shared__ uint32_t s_k[2][BLK / 64];
-  uint32_t kmax = my_tiles ? key_bits : 0u, knmin = my_tiles ? ~key_bits : 0u;
+  __shared__ uint32_t s_k[3][BLK / 64];
+  uint32_t kmax = my_tiles ? key_bits : 0u, knmin = my_tiles ? ~key_bits : 0u, esum = my_tiles ? my_entries : 0u;
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
     const uint32_t a = __shfl_xor(kmax, o, 64), b = __shfl_xor(knmin, o, 64);
     kmax = a > kmax ? a : kmax;
     knmin = b > knmin ? b : knmin;
+    esum += __shfl_xor(esum, o, 64);
   }
-  if (lane == 0) { s_k[0][w] = kmax; s_k[1][w] = knmin; }
+  if (lane == 0) { s_k[0][w] = kmax; s_k[1][w] = knmin; s_k[2][w] = esum; }
   __syncthreads();
   if (t == 0) {
     pblock[blockIdx.x] = w0 + w1 + w2 + w3;
-    uint32_t a = s_k[0][0], b = s_k[1][0];
+    uint32_t a = s_k[0][0], b = s_k[1][0], e = s_k[2][0];
     for (int i = 1; i < BLK / 64; i++) {
       a = s_k[0][i] > a ? s_k[0][i] : a;
       b = s_k[1][i] > b ? s_k[1][i] : b;
+      e += s_k[2][i];
     }
-    pbkey[2 * blockIdx.x] = a;
-    pbkey[2 * blockIdx.x + 1] = b;
+    pbkey[3 * blockIdx.x] = a;
+    pbkey[3 * blockIdx.x + 1] = b;
+    pbkey[3 * blockIdx.x + 2] = e;
   }
 }
 
@@ -346,7 +356,7 @@ __global__ __launch_bounds__(BLK) void pblock_scan_kernel(uint32_t* __restrict__
                                                           uint32_t nblk, uint32_t* __restrict__ misc) {
   __shared__ uint32_t s_w[4];
   __shared__ uint32_t s_k[2][BLK / 64];
-  unsigned long long carry = 0ull;
+  unsigned long long carry = 0ull, entries = 0ull;
   uint32_t kmax = 0, knmin = 0;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (uint32_t b0 = 0; b0 < nblk; b0 += BLK * 16) {
@@ -357,9 +367,10 @@ __global__ __launch_bounds__(BLK) void pblock_scan_kernel(uint32_t* __restrict__
       v[k] = 0;
       if (i0 + k < nblk) {
         v[k] = pblock[i0 + k];
-        const uint32_t a = pbkey[2 * (i0 + k)], b = pbkey[2 * (i0 + k) + 1];
+        const uint32_t a = pbkey[3 * (i0 + k)], b = pbkey[3 * (i0 + k) + 1];
         kmax = a > kmax ? a : kmax;
         knmin = b > knmin ? b : knmin;
+        entries += pbkey[3 * (i0 + k) + 2];
       }
       sum += v[k];
     }
@@ -388,14 +399,22 @@ __global__ __launch_bounds__(BLK) void pblock_scan_kernel(uint32_t* __restrict__
     kmax = a > kmax ? a : kmax;
     knmin = b > knmin ? b : knmin;
   }
-  if (lane == 0) { s_k[0][w] = kmax; s_k[1][w] = knmin; }
+  // total list entries: every thread holds a partial sum
+  __shared__ unsigned long long s_e[BLK / 64];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) entries += __shfl_xor(entries, o, 64);
+  if (lane == 0) { s_k[0][w] = kmax; s_k[1][w] = knmin; s_e[w] = entries; }
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t a = s_k[0][0], b = s_k[1][0];
+    unsigned long long e = s_e[0];
     for (int i = 1; i < BLK / 64; i++) {
       a = s_k[0][i] > a ? s_k[0][i] : a;
       b = s_k[1][i] > b ? s_k[1][i] : b;
+      e += s_e[i];
     }
+    misc[MISC_MACRO_LO] = (uint32_t)e;
+    misc[MISC_MACRO_HI] = (uint32_t)(e >> 32);
     pblock[nblk] = (uint32_t)carry;
     misc[MISC_TOTAL_LO] = (uint32_t)carry;
     misc[MISC_TOTAL_HI] = (uint32_t)(carry >> 32);

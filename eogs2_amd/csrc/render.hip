@@ -85,29 +85,45 @@ struct Cand {
   float4 q1;  // C op f0 f1
   float4 q2;  // f2 f3 f4 1/depth
   uint32_t slot;
+  bool hit;  // the entry lists this wave's internal tile
 };
 
-__device__ inline Cand load_cand(uint32_t k, uint32_t end, const uint2* __restrict__ point_list,
-                                 const float4* __restrict__ packed) {
+// Lane i examines entry k of the macro block's list: the sub-mask in the upper half of the sort key says whether the
+// Gaussian is listed in this wave's internal tile (bit `sub`); only then is its 64-byte render record gathered. The
+// record slot of (entry, internal tile) is the entry's first slot plus the number of listed tiles before this one.
+__device__ inline Cand load_cand(uint32_t k, uint32_t end, uint32_t sub, const uint32_t* __restrict__ keys,
+                                 const uint2* __restrict__ point_list, const float4* __restrict__ packed) {
   Cand c;
   c.q0 = c.q1 = c.q2 = make_float4(0.f, 0.f, 0.f, 0.f);
   c.slot = 0;
+  c.hit = false;
   if (k < end) {
-    const uint2 e = point_list[k];  // {Gaussian id, record slot}: one coalesced 8-byte load per lane
-    c.slot = e.y;
-    const float4* r = packed + 4 * (size_t)e.x;  // one 64-byte line per list entry
-    c.q0 = r[0]; c.q1 = r[1]; c.q2 = r[2];
+    const uint32_t mask = keys[k] >> MACRO_KEY_BITS;  // coalesced 4-byte load per lane
+    if ((mask >> sub) & 1u) {
+      const uint2 e = point_list[k];  // {Gaussian id, first record slot of the entry}
+      c.hit = true;
+      c.slot = e.y + (uint32_t)__popc(mask & ((1u << sub) - 1u));
+      const float4* r = packed + 4 * (size_t)e.x;  // one 64-byte line per list entry
+      c.q0 = r[0]; c.q1 = r[1]; c.q2 = r[2];
+    }
   }
   return c;
 }
 
-// lane i parks its entry in the wave's LDS slab; afterwards any lane can read any entry at a wave-uniform address
-// (LDS broadcast, no bank conflicts) and gets the values in VGPRs: VALU ops on VGPR operands issue in ~2.4 cycles,
-// the same ops on SGPR operands (v_readlane broadcast) in ~4.2, and a v_readlane with a variable lane costs ~8
-// (measured, tools/ubench.hip).
-__device__ inline void park(float* slab, int lane, const Cand& c) {
-  float4* d = reinterpret_cast<float4*>(slab + lane * ENT);
-  d[0] = c.q0; d[1] = c.q1; d[2] = c.q2;
+// The hit lanes park their entries, compacted in list order, in the wave's LDS slab (rank = number of hit lanes below);
+// afterwards any lane can read any entry at a wave-uniform address (LDS broadcast, no bank conflicts) and gets the
+// values in VGPRs: VALU ops on VGPR operands issue in ~2.4 cycles, the same ops on SGPR operands (v_readlane
+// broadcast) in ~4.2, and a v_readlane with a variable lane costs ~8 (measured, tools/ubench.hip).
+// Returns the number of parked entries (wave-uniform).
+__device__ inline int park(float* slab, uint32_t* sslot, int lane, const Cand& c) {
+  const unsigned long long hm = __builtin_amdgcn_ballot_w64(c.hit);
+  if (c.hit) {
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+    float4* d = reinterpret_cast<float4*>(slab + rank * ENT);
+    d[0] = c.q0; d[1] = c.q1; d[2] = c.q2;
+    if (sslot) sslot[rank] = c.slot;
+  }
+  return (int)__popcll(hm);
 }
 struct Ent {
   float4 q0, q1, q2;
@@ -122,7 +138,8 @@ __device__ inline Ent fetch(const float* slab, int j) {
 }  // namespace
 
 __global__ __launch_bounds__(BLK) void render_fwd_kernel(
-    const uint2* __restrict__ ranges, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, const float4* __restrict__ packed, const float* __restrict__ bg,
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx,
+    const float4* __restrict__ packed, const float* __restrict__ bg,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
     float* __restrict__ out_invdepth) {
   __shared__ __attribute__((aligned(16))) float s_slab[BLK / 64][64 * ENT];
@@ -134,7 +151,9 @@ __global__ __launch_bounds__(BLK) void render_fwd_kernel(
   const bool inside = px < W && py < H;
   const uint32_t pix_id = (uint32_t)py * (uint32_t)W + (uint32_t)px;
   const float pxf = (float)px, pyf = (float)py;
-  const uint2 range = ranges[tile];
+  const int ftx = tile % gsx, fty = tile / gsx;
+  const uint2 range = ranges[(fty / MACRO) * gmx + ftx / MACRO];  // the macro block's list
+  const uint32_t sub = (uint32_t)((fty % MACRO) * MACRO + ftx % MACRO);
 
   float T = 1.0f;
   uint32_t last_contributor = 0;
@@ -142,15 +161,15 @@ __global__ __launch_bounds__(BLK) void render_fwd_kernel(
   float invd = 0.f;
   bool done = !inside;
 
-  Cand nxt = load_cand(range.x + lane, range.y, point_list, packed);
+  uint32_t jbase = 0;  // entries of THIS tile seen so far: list positions are counted over the tile's own entries
+  Cand nxt = load_cand(range.x + lane, range.y, sub, keys, point_list, packed);
   for (uint32_t c0 = range.x; c0 < range.y; c0 += 64) {
     wave_lds_sync();  // previous chunk's reads are done
-    park(slab, lane, nxt);
-    nxt = load_cand(c0 + 64 + lane, range.y, point_list, packed);  // in flight during this chunk
+    const int n = park(slab, nullptr, lane, nxt);
+    nxt = load_cand(c0 + 64 + lane, range.y, sub, keys, point_list, packed);  // in flight during this chunk
     wave_lds_sync();
     if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;  // every pixel of the tile has terminated
-    const int n = (int)((range.y - c0) < 64u ? (range.y - c0) : 64u);
-    const uint32_t jbase = c0 - range.x;
+    if (n == 0) continue;
     // one list entry against this lane's pixel; returns nothing, all state is captured by reference
     auto blend = [&](const Ent& e, int j) {
       const float dx = e.q0.x - pxf, dy = e.q0.y - pyf;
@@ -180,6 +199,7 @@ __global__ __launch_bounds__(BLK) void render_fwd_kernel(
       blend(eb, j + 1);
     }
     if (j < n) blend(ea, j);
+    jbase += (uint32_t)n;
   }
   if (inside) {
     const size_t HW = (size_t)H * W;
@@ -199,8 +219,8 @@ static inline uint32_t render_grid(int ntiles) {
 void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, int W,
                        const float* bg, float* out_color, float* out_invdepth, hipStream_t s) {
   const int gsx = (W + SUBX - 1) / SUBX, gsy = (H + SUBY - 1) / SUBY, ntiles = gsx * gsy;
-  hipLaunchKernelGGL(render_fwd_kernel, dim3(render_grid(ntiles)), dim3(BLK), 0, s, im.ranges, b.point_list, W, H,
-                     gsx, ntiles, g.packed, bg, im.final_T, im.n_contrib, out_color, out_invdepth);
+  hipLaunchKernelGGL(render_fwd_kernel, dim3(render_grid(ntiles)), dim3(BLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H,
+                     gsx, ntiles, (int)macro_grid_x(W), g.packed, bg, im.final_T, im.n_contrib, out_color, out_invdepth);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -289,7 +309,8 @@ __device__ inline void transpose_round(int nsurv, int lane, const float* slab, c
 }  // namespace
 
 __global__ __launch_bounds__(BLK) void render_bwd_kernel(
-    const uint2* __restrict__ ranges, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib,
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx,
+    const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ out_color, const float* __restrict__ out_invdepth, const float* __restrict__ dL_dpix,
     const float* __restrict__ dL_dinv, float* __restrict__ records, uint8_t* __restrict__ live_flag) {
   __shared__ __attribute__((aligned(16))) float s_slab[BLK / 64][64 * ENT];
@@ -311,7 +332,9 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
   const bool inside = px < W && py < H;
   const uint32_t pix_id = (uint32_t)py * (uint32_t)W + (uint32_t)px;
   const float pxf = (float)px, pyf = (float)py;
-  const uint2 range = ranges[tile];
+  const int ftx = tile % gsx, fty = tile / gsx;
+  const uint2 range = ranges[(fty / MACRO) * gmx + ftx / MACRO];  // the macro block's list
+  const uint32_t sub = (uint32_t)((fty % MACRO) * MACRO + ftx % MACRO);
   const size_t HW = (size_t)H * W;
   const bool have_inv = dL_dinv != nullptr;
 
@@ -341,17 +364,16 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
   const float bx0 = (float)tx0, by0 = (float)ty0;
   float T = 1.0f, Dacc = 0.f;
 
-  // the list is only walked up to the last contributor: pairs behind it are dead (never gathered, never written)
-  const uint32_t end = range.x + tile_last < range.y ? range.x + tile_last : range.y;
-  Cand nxt = load_cand(range.x + lane, end, point_list, packed);
-  for (uint32_t c0 = range.x; c0 < end; c0 += 64) {
+  // the block's list is only walked until this tile's last contributor has been seen: entries behind it are dead
+  // (never gathered, never written). Positions count the tile's own entries, exactly as in the forward kernel.
+  uint32_t jbase = 0;
+  Cand nxt = load_cand(range.x + lane, range.y, sub, keys, point_list, packed);
+  for (uint32_t c0 = range.x; c0 < range.y && jbase < tile_last; c0 += 64) {
     wave_lds_sync();
-    park(slab, lane, nxt);
-    sslot[lane] = nxt.slot;
-    nxt = load_cand(c0 + 64 + lane, end, point_list, packed);
+    const int jn = park(slab, sslot, lane, nxt);
+    nxt = load_cand(c0 + 64 + lane, range.y, sub, keys, point_list, packed);
     wave_lds_sync();
-    const int jn = (int)((end - c0) < 64u ? (end - c0) : 64u);
-    const uint32_t jbase = c0 - range.x;
+    if (jn == 0) continue;
     int k = 0;
     unsigned long long kj = 0ull;  // list positions (within the chunk) of the survivors of the current round
     auto grad = [&](const Ent& e, int j) {
@@ -397,6 +419,7 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
       wave_lds_sync();
       transpose_round(k, lane, slab, su, sv, spix, kj, sslot, bx0, by0, kx, ky, records, live_flag);
     }
+    jbase += (uint32_t)jn;
   }
 }
 
@@ -405,9 +428,9 @@ void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, 
                        const float* dL_dinvdepth, hipStream_t s) {
   const int gsx = (W + SUBX - 1) / SUBX, gsy = (H + SUBY - 1) / SUBY, ntiles = gsx * gsy;
   (void)R;  // live flags are cleared once per forward (tile_ranges_kernel)
-  hipLaunchKernelGGL(render_bwd_kernel, dim3(render_grid(ntiles)), dim3(BLK), 0, s, im.ranges, b.point_list, W, H,
-                     gsx, ntiles, g.packed, im.n_contrib, out_color, out_invdepth, dL_dcolor, dL_dinvdepth, b.records,
-                     b.live);
+  hipLaunchKernelGGL(render_bwd_kernel, dim3(render_grid(ntiles)), dim3(BLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H,
+                     gsx, ntiles, (int)macro_grid_x(W), g.packed, im.n_contrib, out_color, out_invdepth, dL_dcolor, dL_dinvdepth,
+                     b.records, b.live);
 }
 
 // ---- self test of the wave64 primitives (diagnostics) ----
