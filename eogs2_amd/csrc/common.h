@@ -89,7 +89,7 @@ __device__ inline void row_span(const SpanParams& p, int sy, int sx0, int sx1, i
 // sub-mask (in the upper half of its 32-bit sort key) saying which internal tiles of the block the Gaussian is listed
 // in. A render wave (one internal tile) scans its block's list and keeps the entries whose bit is set (ballot +
 // prefix compaction into LDS), so the sort moves one entry per (block, Gaussian) instead of one per (tile, Gaussian).
-#define MACRO 4
+#define MACRO 2
 #define MACRO_SUB (MACRO * MACRO)
 #define MACRO_KEY_BITS 16  // block id in the low half of the key, sub-mask in the high half
 static_assert(MACRO_SUB <= 16, "the sub-mask lives in the upper 16 bits of the sort key");

@@ -43,6 +43,8 @@ namespace {
 
 #define LN2 0.6931471805599453f
 #define ENT 12   // floats per staged list entry: gx gy A B | C op f0 f1 | f2 f3 f4 1/depth
+#define FWD_CAP 96   // slab entries, forward: up to FWD_MIN-1 waiting + 64 appended
+#define FWD_MIN 32   // forward processes the slab once it holds this many entries (or the list is exhausted)
 #define KSURV 8  // survivors per transposition round (backward)
 // u/v matrices [survivor k][pixel p] in LDS, laid out as two half-matrices (pixels 0..31 / 32..63) with row stride 33 and
 // 268 floats between the halves: bank(k,p) = 12*(p>>5) + k + (p&31) mod 32. The pixel-parallel writes (lane = p, fixed k)
@@ -88,24 +90,37 @@ struct Cand {
   bool hit;  // the entry lists this wave's internal tile
 };
 
-// Lane i examines entry k of the macro block's list: the sub-mask in the upper half of the sort key says whether the
-// Gaussian is listed in this wave's internal tile (bit `sub`); only then is its 64-byte render record gathered. The
-// record slot of (entry, internal tile) is the entry's first slot plus the number of listed tiles before this one.
-__device__ inline Cand load_cand(uint32_t k, uint32_t end, uint32_t sub, const uint32_t* __restrict__ keys,
-                                 const uint2* __restrict__ point_list, const float4* __restrict__ packed) {
+// List entries are fetched in two pipelined stages so that no dependent global load is ever waited for inside a chunk:
+//   peek   (two chunks ahead): lane i reads entry k's sort key (block id | sub-mask << 16) and payload
+//          {Gaussian id, first record slot} — coalesced, unconditional;
+//   gather (one chunk ahead) : if the sub-mask lists this wave's internal tile (bit `sub`), the Gaussian's 64-byte render
+//          record is gathered; the record slot of (entry, internal tile) is the entry's first slot plus the number of
+//          listed tiles before this one.
+struct Peek {
+  uint32_t key;
+  uint2 e;
+};
+__device__ inline Peek peek_cand(uint32_t k, uint32_t end, const uint32_t* __restrict__ keys,
+                                 const uint2* __restrict__ point_list) {
+  Peek p;
+  p.key = 0u;  // empty sub-mask: never a hit
+  p.e = make_uint2(0u, 0u);
+  if (k < end) {
+    p.key = keys[k];
+    p.e = point_list[k];
+  }
+  return p;
+}
+__device__ inline Cand gather_cand(const Peek& p, uint32_t sub, const float4* __restrict__ packed) {
   Cand c;
   c.q0 = c.q1 = c.q2 = make_float4(0.f, 0.f, 0.f, 0.f);
   c.slot = 0;
-  c.hit = false;
-  if (k < end) {
-    const uint32_t mask = keys[k] >> MACRO_KEY_BITS;  // coalesced 4-byte load per lane
-    if ((mask >> sub) & 1u) {
-      const uint2 e = point_list[k];  // {Gaussian id, first record slot of the entry}
-      c.hit = true;
-      c.slot = e.y + (uint32_t)__popc(mask & ((1u << sub) - 1u));
-      const float4* r = packed + 4 * (size_t)e.x;  // one 64-byte line per list entry
-      c.q0 = r[0]; c.q1 = r[1]; c.q2 = r[2];
-    }
+  const uint32_t mask = p.key >> MACRO_KEY_BITS;
+  c.hit = ((mask >> sub) & 1u) != 0u;
+  if (c.hit) {
+    c.slot = p.e.y + (uint32_t)__popc(mask & ((1u << sub) - 1u));
+    const float4* r = packed + 4 * (size_t)p.e.x;  // one 64-byte line per list entry
+    c.q0 = r[0]; c.q1 = r[1]; c.q2 = r[2];
   }
   return c;
 }
@@ -114,11 +129,11 @@ __device__ inline Cand load_cand(uint32_t k, uint32_t end, uint32_t sub, const u
 // afterwards any lane can read any entry at a wave-uniform address (LDS broadcast, no bank conflicts) and gets the
 // values in VGPRs: VALU ops on VGPR operands issue in ~2.4 cycles, the same ops on SGPR operands (v_readlane
 // broadcast) in ~4.2, and a v_readlane with a variable lane costs ~8 (measured, tools/ubench.hip).
-// Returns the number of parked entries (wave-uniform).
-__device__ inline int park(float* slab, uint32_t* sslot, int lane, const Cand& c) {
+// Entries are appended behind the `fill` entries already waiting in the slab. Returns the number appended (wave-uniform).
+__device__ inline int park(float* slab, uint32_t* sslot, int lane, const Cand& c, int fill) {
   const unsigned long long hm = __builtin_amdgcn_ballot_w64(c.hit);
   if (c.hit) {
-    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
+    const int rank = fill + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
     float4* d = reinterpret_cast<float4*>(slab + rank * ENT);
     d[0] = c.q0; d[1] = c.q1; d[2] = c.q2;
     if (sslot) sslot[rank] = c.slot;
@@ -142,7 +157,7 @@ __global__ __launch_bounds__(BLK) void render_fwd_kernel(
     const float4* __restrict__ packed, const float* __restrict__ bg,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
     float* __restrict__ out_invdepth) {
-  __shared__ __attribute__((aligned(16))) float s_slab[BLK / 64][64 * ENT];
+  __shared__ __attribute__((aligned(16))) float s_slab[BLK / 64][FWD_CAP * ENT];
   const int lane = threadIdx.x & 63;
   const int tile = tile_of_wave();
   if (tile >= ntiles) return;  // wave-uniform; waves never synchronise with each other
@@ -161,15 +176,21 @@ __global__ __launch_bounds__(BLK) void render_fwd_kernel(
   float invd = 0.f;
   bool done = !inside;
 
-  uint32_t jbase = 0;  // entries of THIS tile seen so far: list positions are counted over the tile's own entries
-  Cand nxt = load_cand(range.x + lane, range.y, sub, keys, point_list, packed);
+  uint32_t jbase = 0;  // entries of THIS tile processed so far: list positions are counted over the tile's own entries
+  int fill = 0;        // entries waiting in the slab
+  Cand nxt = gather_cand(peek_cand(range.x + lane, range.y, keys, point_list), sub, packed);
+  Peek pk = peek_cand(range.x + 64 + lane, range.y, keys, point_list);
   for (uint32_t c0 = range.x; c0 < range.y; c0 += 64) {
     wave_lds_sync();  // previous chunk's reads are done
-    const int n = park(slab, nullptr, lane, nxt);
-    nxt = load_cand(c0 + 64 + lane, range.y, sub, keys, point_list, packed);  // in flight during this chunk
+    fill += park(slab, nullptr, lane, nxt, fill);
+    nxt = gather_cand(pk, sub, packed);                                  // chunk c0+64: in flight during this chunk
+    pk = peek_cand(c0 + 128 + lane, range.y, keys, point_list);  // chunk c0+128
     wave_lds_sync();
     if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;  // every pixel of the tile has terminated
-    if (n == 0) continue;
+    // a block's list holds the entries of all its internal tiles: keep appending until the inner loop is worth entering
+    if (fill < FWD_MIN && c0 + 64 < range.y) continue;
+    const int n = fill;
+    fill = 0;
     // one list entry against this lane's pixel; returns nothing, all state is captured by reference
     auto blend = [&](const Ent& e, int j) {
       const float dx = e.q0.x - pxf, dy = e.q0.y - pyf;
@@ -264,15 +285,15 @@ __device__ inline void group8_sum11(float (&c)[11]) {
 // (backward.cu:624-640):
 //   dL/dmean2D = o (W/2, H/2) * (-(a M_dx + b M_dy), -(c M_dy + b M_dx)),  dL/dconic = -o/2 (M_dxdx, M_dxdy, M_dydy),
 //   dL/dopacity = M_1,  dL/dcolour = sum u g.
-__device__ inline void transpose_round(int nsurv, int lane, const float* slab, const float* s_u, const float* s_v,
-                                       const float* s_pix, unsigned long long kj_packed, const uint32_t* s_slot, float bx0,
-                                       float by0, float kx, float ky, float* __restrict__ records,
-                                       uint8_t* __restrict__ live_flag) {
+// The survivors' geometry and record slots sit in the round buffer `rb` (8 words per survivor, written when the entry
+// survived), so a round may span several list chunks.
+__device__ inline void transpose_round(int nsurv, int lane, const float* rb, const float* s_u, const float* s_v,
+                                       const float* s_pix, float bx0, float by0, float kx, float ky,
+                                       float* __restrict__ records, uint8_t* __restrict__ live_flag) {
   const int k = lane >> 3, o = lane & 7;
   const bool live = k < nsurv;
-  const uint32_t jk = live ? (uint32_t)(kj_packed >> (8 * k)) & 63u : 0u;  // 8 bits per survivor, wave-uniform word
-  const float4 q0 = *reinterpret_cast<const float4*>(slab + jk * ENT);      // gx gy A B
-  const float2 q1 = *reinterpret_cast<const float2*>(slab + jk * ENT + 4);  // C op
+  const float4 q0 = *reinterpret_cast<const float4*>(rb + k * 8);      // gx gy A B
+  const float4 q1 = *reinterpret_cast<const float4*>(rb + k * 8 + 4);  // C op slot -
   const float gxr = q0.x - bx0;            // centre relative to the tile origin
   const float dy = q0.y - (by0 + (float)o);
   float S0 = 0.f, Sx = 0.f, Sxx = 0.f;
@@ -297,7 +318,7 @@ __device__ inline void transpose_round(int nsurv, int lane, const float* slab, c
     const float m2x = op * kx * (2.f * A * acc[1] - B * acc[2]);   // -a = 2A/log2e, -b = -B/log2e
     const float m2y = op * ky * (2.f * Cq * acc[2] - B * acc[1]);  // -c = 2C/log2e
     const float ho = -0.5f * op;
-    const uint32_t slot = s_slot[jk];
+    const uint32_t slot = __float_as_uint(q1.z);
     float4* dst = reinterpret_cast<float4*>(records + (size_t)slot * REC);
     dst[0] = make_float4(m2x, m2y, ho * acc[3], ho * acc[4]);
     dst[1] = make_float4(ho * acc[5], acc[0], acc[6], acc[7]);
@@ -314,6 +335,7 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
     const float* __restrict__ out_color, const float* __restrict__ out_invdepth, const float* __restrict__ dL_dpix,
     const float* __restrict__ dL_dinv, float* __restrict__ records, uint8_t* __restrict__ live_flag) {
   __shared__ __attribute__((aligned(16))) float s_slab[BLK / 64][64 * ENT];
+  __shared__ __attribute__((aligned(16))) float s_round[BLK / 64][KSURV * 8];
   __shared__ __attribute__((aligned(16))) float s_u[BLK / 64][UV_SIZE];
   __shared__ __attribute__((aligned(16))) float s_v[BLK / 64][UV_SIZE];
   __shared__ __attribute__((aligned(16))) float s_pix[BLK / 64][64 * 8 + 32];
@@ -327,6 +349,7 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
   float* sv = s_v[w];
   float* spix = s_pix[w];
   uint32_t* sslot = s_slot[w];
+  float* rb = s_round[w];
   const int tx0 = (tile % gsx) * SUBX, ty0 = (tile / gsx) * SUBY;
   const int px = tx0 + (lane & 7), py = ty0 + (lane >> 3);
   const bool inside = px < W && py < H;
@@ -366,16 +389,30 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
 
   // the block's list is only walked until this tile's last contributor has been seen: entries behind it are dead
   // (never gathered, never written). Positions count the tile's own entries, exactly as in the forward kernel.
-  uint32_t jbase = 0;
-  Cand nxt = load_cand(range.x + lane, range.y, sub, keys, point_list, packed);
+  uint32_t jbase = 0;  // entries of this tile already processed
+  int k = 0, kstashed = 0;      // survivors waiting in the current transposition round (rounds span chunks), and how many
+                                // of them already have their geometry in the round buffer
+  unsigned long long kj = 0ull;  // slab positions of the survivors not yet stashed, 8 bits each
+  Cand nxt = gather_cand(peek_cand(range.x + lane, range.y, keys, point_list), sub, packed);
+  Peek pk = peek_cand(range.x + 64 + lane, range.y, keys, point_list);
   for (uint32_t c0 = range.x; c0 < range.y && jbase < tile_last; c0 += 64) {
     wave_lds_sync();
-    const int jn = park(slab, sslot, lane, nxt);
-    nxt = load_cand(c0 + 64 + lane, range.y, sub, keys, point_list, packed);
+    const int jn = park(slab, sslot, lane, nxt, 0);
+    nxt = gather_cand(pk, sub, packed);
+    pk = peek_cand(c0 + 128 + lane, range.y, keys, point_list);
     wave_lds_sync();
     if (jn == 0) continue;
-    int k = 0;
-    unsigned long long kj = 0ull;  // list positions (within the chunk) of the survivors of the current round
+    // survivors [from, to) of the current round live in this chunk's slab: lane i copies survivor i's geometry and
+    // record slot into the round buffer (the slab is overwritten by the next chunk, the round may outlive it)
+    auto stash = [&](int from, int to) {
+      if (lane >= from && lane < to) {
+        const uint32_t jk = (uint32_t)(kj >> (8 * lane)) & 63u;
+        const float4 a = *reinterpret_cast<const float4*>(slab + jk * ENT);
+        const float2 b = *reinterpret_cast<const float2*>(slab + jk * ENT + 4);
+        *reinterpret_cast<float4*>(rb + lane * 8) = a;
+        *reinterpret_cast<float4*>(rb + lane * 8 + 4) = make_float4(b.x, b.y, __uint_as_float(sslot[jk]), 0.f);
+      }
+    };
     auto grad = [&](const Ent& e, int j) {
       const float dx = e.q0.x - pxf, dy = e.q0.y - pyf;
       const float p = (e.q0.z * dx - e.q0.w * dy) * dx + e.q1.x * dy * dy;
@@ -399,10 +436,12 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
       sv[uv_index(k, lane)] = G_eff * dLda;  // v = G dL/dalpha
       kj |= (unsigned long long)j << (8 * k);
       if (++k == KSURV) {
+        stash(kstashed, KSURV);
         wave_lds_sync();
-        transpose_round(KSURV, lane, slab, su, sv, spix, kj, sslot, bx0, by0, kx, ky, records, live_flag);
+        transpose_round(KSURV, lane, rb, su, sv, spix, bx0, by0, kx, ky, records, live_flag);
         wave_lds_sync();
         k = 0;
+        kstashed = 0;
         kj = 0ull;
       }
     };
@@ -415,11 +454,15 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
       grad(eb, j + 1);
     }
     if (j < jn) grad(ea, j);
-    if (k) {
-      wave_lds_sync();
-      transpose_round(k, lane, slab, su, sv, spix, kj, sslot, bx0, by0, kx, ky, records, live_flag);
-    }
     jbase += (uint32_t)jn;
+    if (k > kstashed) {  // survivors waiting for the next chunk: keep what the round needs of them
+      stash(kstashed, k);
+      kstashed = k;
+    }
+  }
+  if (k) {  // the last, partial round
+    wave_lds_sync();
+    transpose_round(k, lane, rb, su, sv, spix, bx0, by0, kx, ky, records, live_flag);
   }
 }
 
