@@ -438,7 +438,7 @@ def main():
     torch.cuda.synchronize()
     nr = int(color.grad_fn.num_rendered) if hasattr(color.grad_fn, "num_rendered") else -1
     # the API's num_rendered packs both counts: (tile, Gaussian) record slots below, sorted list entries above
-    R, R_entries = (nr & 0xFFFFFFFF, nr >> 32) if nr >= 0 else (-1, -1)
+    R, R_entries = (nr & 0x7FFFFFFF, (nr >> 32) & 0x3FFFFFFF) if nr >= 0 else (-1, -1)
 
     if rank == 0:
         ms_step = dt / a.steps * 1e3
@@ -479,6 +479,7 @@ def main():
             "config": {"workload": f"{P} Gaussians x {H}x{W} x 5 channels, opacity={a.opacity}, 1 view per GPU, "
                                    f"fwd+bwd" + (" + RCCL grad all-reduce (56 B/Gaussian)" if use_dist else ""),
                        "gaussians": P, "height": H, "width": W, "num_rendered": R, "list_entries": R_entries,
+                       "list_block_px": 32 if nr >= 0 and (nr >> 62) & 1 else 8,
                        "parallelism": f"view-dp{world}"},
             "roofline": roof, "pipeline": pipe, "kernels_ms": kern, "kernel_rooflines": per_kernel,
         }

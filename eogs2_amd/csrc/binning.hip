@@ -245,7 +245,7 @@ void launch_small_scan(uint32_t* data, uint32_t n, hipStream_t s) {
 
 // ---- expand step A: pair count of each chunk of 256 depth-sorted Gaussians ----
 __global__ __launch_bounds__(BLK) void expand_count_kernel(const uint32_t* __restrict__ sorted_ids,
-                                                           const uint4* __restrict__ binfo, uint32_t P,
+                                                           const uint4* __restrict__ binfo, uint32_t P, int big,
                                                            uint4* __restrict__ sinfo, uint32_t* __restrict__ blocksum) {
   __shared__ uint32_t s_w[4];
   const uint32_t k = blockIdx.x * BLK + threadIdx.x;
@@ -256,11 +256,176 @@ __global__ __launch_bounds__(BLK) void expand_count_kernel(const uint32_t* __res
     const uint4 a = binfo[2 * (size_t)id], b = binfo[2 * (size_t)id + 1];
     sinfo[2 * (size_t)k] = a;
     sinfo[2 * (size_t)k + 1] = b;
-    v = b.x ? (b.w >> 2) : 0u;  // list entries (macro blocks) of this Gaussian
+    v = b.x ? (big ? (b.w >> 2) : b.x) : 0u;  // list entries of this Gaussian at the chosen block size
   }
   uint32_t tot;
   (void)block_excl_scan(v, s_w, tot);
   if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
+}
+
+#define EXPAND_LANE_MAX 256u  // a single lane walks at most this many list entries
+// ---- expand step C, block size 1: emission of (internal tile id, record slot) in depth order ----
+// One lane per depth-sorted Gaussian. Its listed tiles are, by kind (GeomWS::binfo): the set bits of the hit mask, the
+// per-row column spans (row_span, re-evaluated on the bits preprocess counted with), or the whole rect.
+// Output position = depth-order offset (exclusive scan of the counts); payload = {Gaussian id, record slot in
+// Gaussian-id order}, carried through the tile sort so the render kernels read both with one coalesced load.
+// Gaussians with at most EXPAND_LANE_MAX tiles are walked by their own lane into an LDS window (tile id + owner lane),
+// FINE_STAGE pairs per round, and streamed out with consecutive lanes writing consecutive addresses; larger ones
+// are emitted by the whole wave, one after the other, straight to their (reserved) global positions.
+#define FINE_STAGE 6144     // pairs per LDS window (24 KB of tile ids + 12 KB of owner lanes)
+struct FineItem {
+  uint32_t id, c, pos0, rbase, sx0, sy0, sw, sh;
+  unsigned long long m;
+};
+__device__ inline uint32_t fine_tile_of(const FineItem& it, uint32_t bit_or_q, uint32_t gsx) {
+  const uint32_t row = bit_or_q / it.sw, col = bit_or_q - row * it.sw;
+  return (it.sy0 + row) * gsx + it.sx0 + col;
+}
+__global__ __launch_bounds__(BLK) void expand_fine_kernel(const uint4* __restrict__ sinfo, const float4* __restrict__ bext,
+                                                     const uint32_t* __restrict__ pblock,
+                                                     const uint32_t* __restrict__ blocksum, uint32_t P, uint32_t gsx,
+                                                     uint32_t gsy, uint32_t* __restrict__ tkey,
+                                                     uint2* __restrict__ tval, uint2* __restrict__ ranges) {
+  __shared__ uint32_t s_w[4];
+  // the tile ranges are rewritten after the sort (tile_ranges_kernel): clear them here
+  for (uint32_t i = blockIdx.x * BLK + threadIdx.x; i < gsx * gsy; i += gridDim.x * BLK) ranges[i] = make_uint2(0u, 0u);
+  __shared__ uint32_t s_tk[FINE_STAGE];   // staged tile ids
+  __shared__ uint16_t s_own[FINE_STAGE];  // ... and the lane that owns each staged pair
+  __shared__ uint32_t s_id[BLK], s_l0[BLK], s_gp[BLK], s_rb[BLK];
+  const int lane = threadIdx.x & 63;
+  const uint32_t k = blockIdx.x * BLK + threadIdx.x;
+  FineItem it;
+  it.id = 0; it.c = 0; it.m = 0ull; it.sx0 = it.sy0 = 0; it.sw = 1; it.sh = 0; it.rbase = 0;
+  float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0;  // SpanParams of a BK_SPANS Gaussian
+  uint32_t kind = BK_RECT;
+  uint4 ia = make_uint4(0u, 0u, 0u, 0u), ib = ia;
+  if (k < P) {
+    ia = sinfo[2 * (size_t)k];
+    ib = sinfo[2 * (size_t)k + 1];
+    it.c = ib.x;
+    it.id = ib.z;
+  }
+  uint32_t tot;
+  it.pos0 = blocksum[blockIdx.x] + block_excl_scan(it.c, s_w, tot);
+  if (it.c) {
+    it.m = ((unsigned long long)ia.w << 32) | ia.z;
+    it.sx0 = ia.x & 0xFFFFu; it.sy0 = ia.y & 0xFFFFu;
+    it.sw = (ia.x >> 16) - it.sx0;  // internal-tile rect, already clipped (preprocess_fwd_kernel)
+    it.sh = (ia.y >> 16) - it.sy0;
+    it.rbase = pblock[it.id / BLK] + ib.y;  // pblock is 4 bytes per 256 Gaussians: cache resident
+    kind = ib.w & 3u;  // (the upper bits hold the entry count at block size BLOCK_BIG)
+    if (kind == BK_SPANS) {
+      e0 = bext[2 * (size_t)it.id];
+      e1 = bext[2 * (size_t)it.id + 1];
+    }
+  }
+  SpanParams sp;
+  sp.gx = e0.x; sp.gy = e0.y; sp.ex = e0.z; sp.ey = e0.w; sp.boa = e1.x; sp.boc = e1.y; sp.ta = e1.z; sp.da = e1.w;
+
+  // ---- lane-walked Gaussians: compact local positions among themselves, staged in rounds of FINE_STAGE ----
+  const bool mine = it.c != 0u && it.c <= EXPAND_LANE_MAX;
+  uint32_t ltot;
+  const uint32_t l0 = block_excl_scan(mine ? it.c : 0u, s_w, ltot);
+  s_id[threadIdx.x] = it.id; s_l0[threadIdx.x] = l0; s_gp[threadIdx.x] = it.pos0; s_rb[threadIdx.x] = it.rbase;
+  // per-lane cursor, carried across rounds so that every pair is generated exactly once
+  uint32_t l = l0;                     // local position of the lane's next pair
+  const uint32_t l_end = mine ? l0 + it.c : l0;
+  unsigned long long m_rem = it.m;     // BK_MASK: bits still to emit
+  uint32_t row = 0, q_cur = 0;         // BK_SPANS: current row / BK_RECT: next index
+  int c_cur = 0, c_end = 0;            // BK_SPANS: remaining columns of the current row
+  for (uint32_t base = 0; base < ltot; base += FINE_STAGE) {
+    __syncthreads();  // s_id.. visible (first round) / previous window drained
+    const uint32_t wend = base + FINE_STAGE < l_end ? base + FINE_STAGE : l_end;  // this lane stops here this round
+    if (l < wend) {  // (l >= base always: windows are consecutive and the lane stopped at the previous window's end)
+      if (kind == BK_MASK) {
+        for (; l < wend; l++, m_rem &= m_rem - 1ull) {
+          s_tk[l - base] = fine_tile_of(it, (uint32_t)__builtin_ctzll(m_rem), gsx);
+          s_own[l - base] = (uint16_t)threadIdx.x;
+        }
+      } else if (kind == BK_SPANS) {
+        while (l < wend) {
+          if (c_cur >= c_end) {  // next non-empty row
+            row_span(sp, (int)(it.sy0 + row), (int)it.sx0, (int)(it.sx0 + it.sw), c_cur, c_end);
+            row++;
+            if (row > it.sh) break;  // never: the spans add up to it.c
+            continue;
+          }
+          s_tk[l - base] = (it.sy0 + row - 1) * gsx + (uint32_t)c_cur;
+          s_own[l - base] = (uint16_t)threadIdx.x;
+          c_cur++;
+          l++;
+        }
+      } else {
+        for (; l < wend; l++, q_cur++) {
+          s_tk[l - base] = fine_tile_of(it, q_cur, gsx);
+          s_own[l - base] = (uint16_t)threadIdx.x;
+        }
+      }
+    }
+    __syncthreads();
+    const uint32_t nwin = ltot - base < (uint32_t)FINE_STAGE ? ltot - base : (uint32_t)FINE_STAGE;
+    for (uint32_t i = threadIdx.x; i < nwin; i += BLK) {
+      const uint32_t o = s_own[i], q = base + i - s_l0[o];  // q-th listed tile of its Gaussian
+      tkey[s_gp[o] + q] = s_tk[i];
+      tval[s_gp[o] + q] = make_uint2(s_id[o], s_rb[o] + q);
+    }
+  }
+
+  // ---- large Gaussians: the wave emits them cooperatively, one after the other ----
+  __syncthreads();  // the last window is drained: s_tk becomes four wave-private staging areas
+  uint32_t* wstage = s_tk + (threadIdx.x >> 6) * (FINE_STAGE / 4);
+  unsigned long long big = __ballot(it.c > EXPAND_LANE_MAX);
+  while (big) {
+    const int src = __builtin_ctzll(big);
+    big &= big - 1ull;
+    FineItem g;
+    g.id = __shfl(it.id, src, 64); g.c = __shfl(it.c, src, 64); g.pos0 = __shfl(it.pos0, src, 64);
+    g.rbase = __shfl(it.rbase, src, 64); g.sx0 = __shfl(it.sx0, src, 64); g.sy0 = __shfl(it.sy0, src, 64);
+    g.sw = __shfl(it.sw, src, 64); g.sh = __shfl(it.sh, src, 64);
+    if (__shfl(kind, src, 64) != BK_SPANS) {  // whole rect (a mask never has more than 64 tiles)
+      for (uint32_t q = lane; q < g.c; q += 64) {
+        tkey[g.pos0 + q] = fine_tile_of(g, q, gsx);
+        tval[g.pos0 + q] = make_uint2(g.id, g.rbase + q);
+      }
+      continue;
+    }
+    // BK_SPANS: lane = row of the rect (64 rows per step); a wave scan of the span lengths gives every row its place
+    SpanParams gs;
+    gs.gx = __shfl(sp.gx, src, 64); gs.gy = __shfl(sp.gy, src, 64); gs.ex = __shfl(sp.ex, src, 64);
+    gs.ey = __shfl(sp.ey, src, 64); gs.boa = __shfl(sp.boa, src, 64); gs.boc = __shfl(sp.boc, src, 64);
+    gs.ta = __shfl(sp.ta, src, 64); gs.da = __shfl(sp.da, src, 64);
+    uint32_t done = 0;  // pairs of this Gaussian emitted so far
+    for (uint32_t r0 = 0; r0 < g.sh; r0 += 64) {
+      const uint32_t row = r0 + (uint32_t)lane;
+      int c0 = 0, c1 = 0;
+      if (row < g.sh) row_span(gs, (int)(g.sy0 + row), (int)g.sx0, (int)(g.sx0 + g.sw), c0, c1);
+      const uint32_t len = (uint32_t)(c1 - c0);
+      const uint32_t inc = wave_incl_scan_u32(len);
+      const uint32_t chunk = __shfl(inc, 63, 64), off = inc - len;
+      const uint32_t t0 = (g.sy0 + row) * gsx + (uint32_t)c0;
+      if (chunk <= (uint32_t)(FINE_STAGE / 4)) {
+        // through wave-private LDS so that consecutive lanes write consecutive addresses
+        for (uint32_t j = 0; j < len; j++) wstage[off + j] = t0 + j;
+        wave_lds_sync_b();
+        for (uint32_t i = lane; i < chunk && done + i < g.c; i += 64) {
+          tkey[g.pos0 + done + i] = wstage[i];
+          tval[g.pos0 + done + i] = make_uint2(g.id, g.rbase + done + i);
+        }
+        wave_lds_sync_b();
+      } else {
+        for (uint32_t j = 0; j < len && done + off + j < g.c; j++) {
+          tkey[g.pos0 + done + off + j] = t0 + j;
+          tval[g.pos0 + done + off + j] = make_uint2(g.id, g.rbase + done + off + j);
+        }
+      }
+      done += chunk;
+    }
+    // never taken (the spans are a pure function of the stored bits); keeps every slot a valid tile id regardless
+    for (uint32_t i = done + lane; i < g.c; i += 64) {
+      tkey[g.pos0 + i] = g.sy0 * gsx + g.sx0;
+      tval[g.pos0 + i] = make_uint2(g.id, g.rbase + i);
+    }
+  }
 }
 
 // ---- expand step C: emission of the list entries in depth order ----
@@ -272,11 +437,11 @@ __global__ __launch_bounds__(BLK) void expand_count_kernel(const uint32_t* __res
 // Gaussians with at most EXPAND_LANE_MAX entries are walked by their own lane into an LDS window and streamed out with
 // consecutive lanes writing consecutive addresses; larger ones are emitted by the whole wave, one macro row per lane.
 #define EXPAND_STAGE 4096     // entries per LDS window (16 KB keys + 16 KB slots + 8 KB owner lanes)
-#define EXPAND_LANE_MAX 256u  // a single lane walks at most this many entries
 struct ExpandItem {
   uint32_t id, c, pos0, rbase, sx0, sy0, sx1, sy1, kind;
   unsigned long long m;
 };
+template <int MACRO>
 __global__ __launch_bounds__(BLK) void expand_kernel(const uint4* __restrict__ sinfo, const float4* __restrict__ bext,
                                                      const uint32_t* __restrict__ pblock,
                                                      const uint32_t* __restrict__ blocksum, uint32_t P, uint32_t gmx,
@@ -298,7 +463,7 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint4* __restrict__ s
   if (k < P) {
     ia = sinfo[2 * (size_t)k];
     ib = sinfo[2 * (size_t)k + 1];
-    it.c = ib.x ? (ib.w >> 2) : 0u;
+    it.c = ib.x ? (MACRO > 1 ? (ib.w >> 2) : ib.x) : 0u;
     it.id = ib.z;
   }
   uint32_t tot;
@@ -326,11 +491,11 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint4* __restrict__ s
     __syncthreads();  // s_id.. visible (first round) / previous window drained
     if (mine && l0 < base + EXPAND_STAGE && l0 + it.c > base) {
       uint32_t l = l0, slot = it.rbase;
-      for (int MY = (int)it.sy0 / MACRO; MY <= ((int)it.sy1 - 1) / MACRO; MY++)
-        walk_macro_row(it.kind, it.m, sp, (int)it.sx0, (int)it.sy0, (int)it.sx1, (int)it.sy1, MY, [&](int MX, uint32_t sub) {
+      for (int MY = (int)it.sy0 / MACRO; MY <= ((int)it.sy1 - 1) / MACRO; MY++)  // MACRO: template parameter
+        walk_macro_row<MACRO>(it.kind, it.m, sp, (int)it.sx0, (int)it.sy0, (int)it.sx1, (int)it.sy1, MY, [&](int MX, uint32_t sub) {
           const uint32_t w = l - base;  // wraps below the window: fails the unsigned test
           if (w < (uint32_t)EXPAND_STAGE) {
-            s_tk[w] = ((uint32_t)MY * gmx + (uint32_t)MX) | (sub << MACRO_KEY_BITS);
+            s_tk[w] = ((uint32_t)MY * gmx + (uint32_t)MX) | (MACRO > 1 ? sub << MACRO_KEY_BITS : 0u);
             s_sl[w] = slot;
             s_own[w] = (uint16_t)threadIdx.x;
           }
@@ -368,16 +533,16 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint4* __restrict__ s
       const int MY = r0 + lane;
       uint32_t ne = 0, nf = 0;  // this lane's macro row: entries and listed internal tiles
       if (MY <= MY1)
-        walk_macro_row(g.kind, g.m, gs, (int)g.sx0, (int)g.sy0, (int)g.sx1, (int)g.sy1, MY, [&](int, uint32_t sub) {
+        walk_macro_row<MACRO>(g.kind, g.m, gs, (int)g.sx0, (int)g.sy0, (int)g.sx1, (int)g.sy1, MY, [&](int, uint32_t sub) {
           ne++;
           nf += (uint32_t)__popc(sub);
         });
       const uint32_t ie = wave_incl_scan_u32(ne), jf = wave_incl_scan_u32(nf);
       uint32_t l = done + ie - ne, slot = slot0 + jf - nf;
       if (MY <= MY1)
-        walk_macro_row(g.kind, g.m, gs, (int)g.sx0, (int)g.sy0, (int)g.sx1, (int)g.sy1, MY, [&](int MX, uint32_t sub) {
+        walk_macro_row<MACRO>(g.kind, g.m, gs, (int)g.sx0, (int)g.sy0, (int)g.sx1, (int)g.sy1, MY, [&](int MX, uint32_t sub) {
           if (l < g.c) {  // always (same walk as the count)
-            tkey[g.pos0 + l] = ((uint32_t)MY * gmx + (uint32_t)MX) | (sub << MACRO_KEY_BITS);
+            tkey[g.pos0 + l] = ((uint32_t)MY * gmx + (uint32_t)MX) | (MACRO > 1 ? sub << MACRO_KEY_BITS : 0u);
             tval[g.pos0 + l] = make_uint2(g.id, slot);
           }
           l++;
@@ -390,11 +555,10 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint4* __restrict__ s
 }
 
 // ---- block ranges from the sorted keys (identifyTileRanges, rasterizer_impl.cu:116-138) ----
-__global__ __launch_bounds__(BLK) void tile_ranges_kernel(const uint32_t* __restrict__ skeys, uint32_t R,
+__global__ __launch_bounds__(BLK) void tile_ranges_kernel(const uint32_t* __restrict__ skeys, uint32_t R, uint32_t kmask,
                                                           uint2* __restrict__ ranges) {
   const uint32_t i = blockIdx.x * BLK + threadIdx.x;
   if (i >= R) return;
-  const uint32_t kmask = (1u << MACRO_KEY_BITS) - 1u;
   const uint32_t cur = skeys[i] & kmask;
   if (i == 0) ranges[cur].x = 0;
   else {
@@ -407,14 +571,15 @@ __global__ __launch_bounds__(BLK) void tile_ranges_kernel(const uint32_t* __rest
   if (i == R - 1) ranges[cur].y = R;
 }
 
-void launch_binning_head(const GeomWS& g, int P, hipStream_t s) {
-  hipLaunchKernelGGL(expand_count_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.svalA, g.binfo, (uint32_t)P, g.sinfo,
-                     g.blocksum);
+void launch_binning_head(const GeomWS& g, int P, int block, hipStream_t s) {
+  hipLaunchKernelGGL(expand_count_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.svalA, g.binfo, (uint32_t)P, (int)(block > 1),
+                     g.sinfo, g.blocksum);
   launch_small_scan(g.blocksum, g.nblkE, s);
 }
 
 void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, hipStream_t s) {
-  const uint32_t gmx = macro_grid_x(W), nblocks = gmx * macro_grid_y(H);
+  const int M = b.block;
+  const uint32_t gmx = macro_grid_x(W, M), nblocks = gmx * macro_grid_y(H, M);
   const uint32_t Re = nr_entries(R), Rs = nr_slots(R);
   if (Re == 0) {
     (void)hipMemsetAsync(im.ranges, 0, (size_t)nblocks * sizeof(uint2), s);
@@ -423,8 +588,12 @@ void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int
   // The backward's per-record live flags: which records get written depends only on forward state (lists and
   // n_contrib), so one clear per forward serves every backward over this workspace.
   (void)hipMemsetAsync(b.live, 0, (size_t)Rs, s);
-  hipLaunchKernelGGL(expand_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.sinfo, g.bext, g.pblock, g.blocksum, (uint32_t)P, gmx,
-                     nblocks, b.tkeyA, b.tvalA, im.ranges);
+  if (M > 1)
+    hipLaunchKernelGGL(expand_kernel<BLOCK_BIG>, dim3(g.nblkE), dim3(BLK), 0, s, g.sinfo, g.bext, g.pblock, g.blocksum,
+                       (uint32_t)P, gmx, nblocks, b.tkeyA, b.tvalA, im.ranges);
+  else  // per-tile lists: the specialised walker (set bits / spans directly, cursors carried across LDS windows)
+    hipLaunchKernelGGL(expand_fine_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.sinfo, g.bext, g.pblock, g.blocksum, (uint32_t)P,
+                       gmx, macro_grid_y(H, 1), b.tkeyA, b.tvalA, im.ranges);
   uint32_t *ka = b.tkeyA, *kb = b.tkeyB;
   uint2 *va = b.tvalA, *vb = b.tvalB;
   int shift = 0;
@@ -439,5 +608,5 @@ void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int
     uint2* tv = va; va = vb; vb = tv;
   }
   hipLaunchKernelGGL(tile_ranges_kernel, dim3(ceil_div_u32((uint64_t)Re, BLK)), dim3(BLK), 0, s, b.sorted_keys, Re,
-                     im.ranges);
+                     M > 1 ? (1u << MACRO_KEY_BITS) - 1u : 0xFFFFFFFFu, im.ranges);
 }

@@ -84,20 +84,23 @@ __device__ inline void row_span(const SpanParams& p, int sy, int sx0, int sx1, i
   }
 }
 
-// ---- macro tiles: the unit of the sorted lists ----
-// Lists are sorted per MACRO x MACRO block of internal tiles (32 x 32 pixels); every list entry carries a MACRO*MACRO-bit
-// sub-mask (in the upper half of its 32-bit sort key) saying which internal tiles of the block the Gaussian is listed
-// in. A render wave (one internal tile) scans its block's list and keeps the entries whose bit is set (ballot +
-// prefix compaction into LDS), so the sort moves one entry per (block, Gaussian) instead of one per (tile, Gaussian).
-#define MACRO 2
-#define MACRO_SUB (MACRO * MACRO)
-#define MACRO_KEY_BITS 16  // block id in the low half of the key, sub-mask in the high half
-static_assert(MACRO_SUB <= 16, "the sub-mask lives in the upper 16 bits of the sort key");
+// ---- blocks: the unit of the sorted lists, chosen per forward ----
+// Lists are sorted per M x M block of internal tiles. M = 1: one list per internal tile (small footprints: every list
+// entry is used by the wave that reads it). M = BLOCK_BIG = 4 (32 x 32 pixels): every list entry carries an M*M-bit
+// sub-mask (upper half of its 32-bit sort key) saying which internal tiles of the block the Gaussian is listed in; a
+// render wave (one internal tile) scans its block's list and keeps the entries whose bit is set (ballot + prefix
+// compaction into LDS), so the sort moves one entry per (block, Gaussian) instead of one per (tile, Gaussian) — 4-7x
+// fewer for footprints of tens of pixels, where binning otherwise costs as much as rendering. forward_prepare picks
+// the mode from the two pair counts it reads back (api.hip) and hands it on inside num_rendered.
+#define BLOCK_BIG 4
+#define EOGS_BLOCK_SWITCH 10  // listed internal tiles per Gaussian (average) above which a forward uses BLOCK_BIG
+#define MACRO_KEY_BITS 16  // M > 1: block id in the low half of the key, sub-mask in the high half
+static_assert(BLOCK_BIG * BLOCK_BIG <= 16, "the sub-mask lives in the upper 16 bits of the sort key");
 
 // Walks the macro row MY of a Gaussian's listing (kind, mask m or span constants sp, internal-tile rect
 // [sx0,sx1) x [sy0,sy1)) and calls emit(MX, sub) for every block with a non-empty sub-mask, left to right.
 // Used by preprocess (counting) and expand (emission): same code, same bits, same result.
-template <class Emit>
+template <int MACRO, class Emit>
 __device__ inline void walk_macro_row(uint32_t kind, unsigned long long m, const SpanParams& sp, int sx0, int sy0, int sx1,
                                       int sy1, int MY, Emit&& emit) {
   const int sw = sx1 - sx0;
@@ -221,7 +224,7 @@ struct BinWS {
   float* records;   // backward scratch: REC floats per record slot (Gaussian-id order, see GeomWS::pblock)
   uint8_t* live;    // backward scratch: 1 = the pair's record was written (dead pairs are never touched)
   uint32_t nblkR;
-  int tile_bits, passes, bits_per_pass, sort_items;
+  int tile_bits, passes, bits_per_pass, sort_items, block;
   uint2* point_list;     // = tval buffer holding the sorted result: per list entry {Gaussian id, record slot}
   uint32_t* sorted_keys; // = tkey buffer holding the sorted result
   size_t bytes;
@@ -233,18 +236,23 @@ static inline int ceil_log2_u32(uint32_t n) {  // smallest b with (1<<b) >= n
   return b;
 }
 
-// num_rendered as handed across the C-ABI packs both pair counts of a forward: the record slots (one per listed
-// internal tile, backward scratch) in the low 32 bits and the sorted list entries (one per listed macro block) above.
-static inline uint32_t nr_slots(int64_t R) { return (uint32_t)((uint64_t)R & 0xFFFFFFFFull); }
-static inline uint32_t nr_entries(int64_t R) { return (uint32_t)((uint64_t)R >> 32); }
-static inline int64_t nr_pack(uint32_t slots, uint32_t entries) { return (int64_t)(((uint64_t)entries << 32) | slots); }
-static inline uint32_t macro_grid_x(int W) { return (uint32_t)(((W + SUBX - 1) / SUBX + MACRO - 1) / MACRO); }
-static inline uint32_t macro_grid_y(int H) { return (uint32_t)(((H + SUBY - 1) / SUBY + MACRO - 1) / MACRO); }
+// num_rendered as handed across the C-ABI packs what a forward decided: the record slots (one per listed internal tile,
+// backward scratch) in bits 0..30, the sorted list entries (one per listed block) in bits 32..61, the block size in
+// bit 62 (set: BLOCK_BIG, clear: 1; then entries == slots).
+static inline uint32_t nr_slots(int64_t R) { return (uint32_t)((uint64_t)R & 0x7FFFFFFFull); }
+static inline uint32_t nr_entries(int64_t R) { return (uint32_t)(((uint64_t)R >> 32) & 0x3FFFFFFFull); }
+static inline int nr_block(int64_t R) { return (((uint64_t)R >> 62) & 1ull) ? BLOCK_BIG : 1; }
+static inline int64_t nr_pack(uint32_t slots, uint32_t entries, int block) {
+  return (int64_t)(((uint64_t)(block > 1) << 62) | ((uint64_t)entries << 32) | slots);
+}
+static inline uint32_t macro_grid_x(int W, int M) { return (uint32_t)(((W + SUBX - 1) / SUBX + M - 1) / M); }
+static inline uint32_t macro_grid_y(int H, int M) { return (uint32_t)(((H + SUBY - 1) / SUBY + M - 1) / M); }
 
 static inline BinWS bin_layout(char* base, int H, int W, int64_t R) {
   BinWS b;
   size_t n = (size_t)nr_entries(R), nslots = (size_t)nr_slots(R), o = 0;
-  uint32_t T = macro_grid_x(W) * macro_grid_y(H);
+  b.block = nr_block(R);
+  uint32_t T = macro_grid_x(W, b.block) * macro_grid_y(H, b.block);
   b.tile_bits = ceil_log2_u32(T) < 1 ? 1 : ceil_log2_u32(T);
   b.passes = (b.tile_bits + 7) / 8;
   b.bits_per_pass = (b.tile_bits + b.passes - 1) / b.passes;
@@ -266,7 +274,7 @@ static inline BinWS bin_layout(char* base, int H, int W, int64_t R) {
 
 // Image workspace: O(H*W) + O(tiles).
 struct ImgWS {
-  uint2* ranges;       // per macro block [start,end) into point_list
+  uint2* ranges;       // per block (M x M internal tiles, M chosen per forward) [start,end) into point_list
   float* final_T;      // transmittance after the last blended Gaussian
   uint32_t* n_contrib; // 1 + list index of the last blended Gaussian
   size_t bytes;
@@ -275,7 +283,7 @@ struct ImgWS {
 static inline ImgWS img_layout(char* base, int H, int W) {
   ImgWS im;
   size_t n = (size_t)H * W, o = 0;
-  size_t T = (size_t)macro_grid_x(W) * macro_grid_y(H);
+  size_t T = (size_t)macro_grid_x(W, 1) * macro_grid_y(H, 1);  // enough for either block size
   o = ws_carve(base, o, im.ranges, T);
   o = ws_carve(base, o, im.final_T, n);
   o = ws_carve(base, o, im.n_contrib, n);
@@ -303,7 +311,7 @@ void launch_depth_sort(const GeomWS& g, int P, int first, int last, hipStream_t 
 void launch_small_scan(uint32_t* data, uint32_t n, hipStream_t s);
 void launch_scan_pblock(const GeomWS& g, int P, hipStream_t s);
 // part of binning that needs only the geometry workspace (queued by forward_prepare right after its sync)
-void launch_binning_head(const GeomWS& g, int P, hipStream_t s);
+void launch_binning_head(const GeomWS& g, int P, int block, hipStream_t s);
 void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, hipStream_t s);
 void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, int W,
                        const float* bg, float* out_color, float* out_invdepth, hipStream_t s);

@@ -257,12 +257,12 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
         } else {
           my_tiles = (uint32_t)(sw * sh);
         }
-        // list entries = macro blocks with at least one listed internal tile (the unit the sort moves); for
-        // BK_SPANS the walk also yields the number of listed internal tiles (record slots)
+        // list entries at block size BLOCK_BIG = blocks with at least one listed internal tile (at block size 1 the
+        // entries are the listed tiles themselves); for BK_SPANS the walk also yields the number of listed tiles
         if (my_tiles) {
           uint32_t ent = 0, fine = 0;
-          for (int MY = sy0 / MACRO; MY <= (sy1 - 1) / MACRO; MY++)
-            walk_macro_row(kind, m, sp, sx0, sy0, sx1, sy1, MY, [&](int, uint32_t sub) {
+          for (int MY = sy0 / BLOCK_BIG; MY <= (sy1 - 1) / BLOCK_BIG; MY++)
+            walk_macro_row<BLOCK_BIG>(kind, m, sp, sx0, sy0, sx1, sy1, MY, [&](int, uint32_t sub) {
               ent++;
               fine += (uint32_t)__popc(sub);
             });

@@ -100,25 +100,27 @@ struct Peek {
   uint32_t key;
   uint2 e;
 };
+template <int MACRO>
 __device__ inline Peek peek_cand(uint32_t k, uint32_t end, const uint32_t* __restrict__ keys,
                                  const uint2* __restrict__ point_list) {
   Peek p;
   p.key = 0u;  // empty sub-mask: never a hit
   p.e = make_uint2(0u, 0u);
   if (k < end) {
-    p.key = keys[k];
+    p.key = MACRO > 1 ? keys[k] : 1u;  // block size 1: every entry of the tile's own list is a hit
     p.e = point_list[k];
   }
   return p;
 }
+template <int MACRO>
 __device__ inline Cand gather_cand(const Peek& p, uint32_t sub, const float4* __restrict__ packed) {
   Cand c;
   c.q0 = c.q1 = c.q2 = make_float4(0.f, 0.f, 0.f, 0.f);
   c.slot = 0;
-  const uint32_t mask = p.key >> MACRO_KEY_BITS;
-  c.hit = ((mask >> sub) & 1u) != 0u;
+  const uint32_t mask = MACRO > 1 ? p.key >> MACRO_KEY_BITS : p.key;  // block size 1: peek_cand's in-range flag
+  c.hit = MACRO > 1 ? ((mask >> sub) & 1u) != 0u : mask != 0u;
   if (c.hit) {
-    c.slot = p.e.y + (uint32_t)__popc(mask & ((1u << sub) - 1u));
+    c.slot = MACRO > 1 ? p.e.y + (uint32_t)__popc(mask & ((1u << sub) - 1u)) : p.e.y;
     const float4* r = packed + 4 * (size_t)p.e.x;  // one 64-byte line per list entry
     c.q0 = r[0]; c.q1 = r[1]; c.q2 = r[2];
   }
@@ -152,6 +154,7 @@ __device__ inline Ent fetch(const float* slab, int j) {
 
 }  // namespace
 
+template <int MACRO>
 __global__ __launch_bounds__(BLK) void render_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx,
     const float4* __restrict__ packed, const float* __restrict__ bg,
@@ -178,13 +181,13 @@ __global__ __launch_bounds__(BLK) void render_fwd_kernel(
 
   uint32_t jbase = 0;  // entries of THIS tile processed so far: list positions are counted over the tile's own entries
   int fill = 0;        // entries waiting in the slab
-  Cand nxt = gather_cand(peek_cand(range.x + lane, range.y, keys, point_list), sub, packed);
-  Peek pk = peek_cand(range.x + 64 + lane, range.y, keys, point_list);
+  Cand nxt = gather_cand<MACRO>(peek_cand<MACRO>(range.x + lane, range.y, keys, point_list), sub, packed);
+  Peek pk = peek_cand<MACRO>(range.x + 64 + lane, range.y, keys, point_list);
   for (uint32_t c0 = range.x; c0 < range.y; c0 += 64) {
     wave_lds_sync();  // previous chunk's reads are done
     fill += park(slab, nullptr, lane, nxt, fill);
-    nxt = gather_cand(pk, sub, packed);                                  // chunk c0+64: in flight during this chunk
-    pk = peek_cand(c0 + 128 + lane, range.y, keys, point_list);  // chunk c0+128
+    nxt = gather_cand<MACRO>(pk, sub, packed);                                  // chunk c0+64: in flight during this chunk
+    pk = peek_cand<MACRO>(c0 + 128 + lane, range.y, keys, point_list);  // chunk c0+128
     wave_lds_sync();
     if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;  // every pixel of the tile has terminated
     // a block's list holds the entries of all its internal tiles: keep appending until the inner loop is worth entering
@@ -240,8 +243,9 @@ static inline uint32_t render_grid(int ntiles) {
 void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, int W,
                        const float* bg, float* out_color, float* out_invdepth, hipStream_t s) {
   const int gsx = (W + SUBX - 1) / SUBX, gsy = (H + SUBY - 1) / SUBY, ntiles = gsx * gsy;
-  hipLaunchKernelGGL(render_fwd_kernel, dim3(render_grid(ntiles)), dim3(BLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H,
-                     gsx, ntiles, (int)macro_grid_x(W), g.packed, bg, im.final_T, im.n_contrib, out_color, out_invdepth);
+  auto* kern = b.block > 1 ? render_fwd_kernel<BLOCK_BIG> : render_fwd_kernel<1>;
+  hipLaunchKernelGGL(kern, dim3(render_grid(ntiles)), dim3(BLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H, gsx,
+                     ntiles, (int)macro_grid_x(W, b.block), g.packed, bg, im.final_T, im.n_contrib, out_color, out_invdepth);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -329,6 +333,7 @@ __device__ inline void transpose_round(int nsurv, int lane, const float* rb, con
 
 }  // namespace
 
+template <int MACRO>
 __global__ __launch_bounds__(BLK) void render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx,
     const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib,
@@ -393,13 +398,13 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
   int k = 0, kstashed = 0;      // survivors waiting in the current transposition round (rounds span chunks), and how many
                                 // of them already have their geometry in the round buffer
   unsigned long long kj = 0ull;  // slab positions of the survivors not yet stashed, 8 bits each
-  Cand nxt = gather_cand(peek_cand(range.x + lane, range.y, keys, point_list), sub, packed);
-  Peek pk = peek_cand(range.x + 64 + lane, range.y, keys, point_list);
+  Cand nxt = gather_cand<MACRO>(peek_cand<MACRO>(range.x + lane, range.y, keys, point_list), sub, packed);
+  Peek pk = peek_cand<MACRO>(range.x + 64 + lane, range.y, keys, point_list);
   for (uint32_t c0 = range.x; c0 < range.y && jbase < tile_last; c0 += 64) {
     wave_lds_sync();
     const int jn = park(slab, sslot, lane, nxt, 0);
-    nxt = gather_cand(pk, sub, packed);
-    pk = peek_cand(c0 + 128 + lane, range.y, keys, point_list);
+    nxt = gather_cand<MACRO>(pk, sub, packed);
+    pk = peek_cand<MACRO>(c0 + 128 + lane, range.y, keys, point_list);
     wave_lds_sync();
     if (jn == 0) continue;
     // survivors [from, to) of the current round live in this chunk's slab: lane i copies survivor i's geometry and
@@ -471,9 +476,10 @@ void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, 
                        const float* dL_dinvdepth, hipStream_t s) {
   const int gsx = (W + SUBX - 1) / SUBX, gsy = (H + SUBY - 1) / SUBY, ntiles = gsx * gsy;
   (void)R;  // live flags are cleared once per forward (tile_ranges_kernel)
-  hipLaunchKernelGGL(render_bwd_kernel, dim3(render_grid(ntiles)), dim3(BLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H,
-                     gsx, ntiles, (int)macro_grid_x(W), g.packed, im.n_contrib, out_color, out_invdepth, dL_dcolor, dL_dinvdepth,
-                     b.records, b.live);
+  auto* kern = b.block > 1 ? render_bwd_kernel<BLOCK_BIG> : render_bwd_kernel<1>;
+  hipLaunchKernelGGL(kern, dim3(render_grid(ntiles)), dim3(BLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H, gsx,
+                     ntiles, (int)macro_grid_x(W, b.block), g.packed, im.n_contrib, out_color, out_invdepth, dL_dcolor,
+                     dL_dinvdepth, b.records, b.live);
 }
 
 // ---- self test of the wave64 primitives (diagnostics) ----

@@ -86,7 +86,8 @@ int eogs_rast_binning_bytes(int P, int H, int W, int64_t num_rendered, size_t* b
  * required when P > 0 (EOGS_ERR_NO_COLORS otherwise, DGR/cuda_rasterizer/rasterizer_impl.cu:244-247): the
  * per-Gaussian render record is written once, whole, by the preprocess kernel.
  * alt_affine: f32[4], required with EOGS_FLAG_RAW_PARAMS, otherwise ignored (pass NULL).
- * Writes radii[P] and *num_rendered (host). */
+ * Writes radii[P] and *num_rendered (host). num_rendered is an opaque token for the three calls below (it packs this
+ * library's pair counts and list granularity, see csrc/common.h nr_pack); 0 means nothing is listed. */
 int eogs_rast_forward_prepare(
     int P, int H, int W,
     const float* means3D, const float* scales, const float* rotations,
