@@ -555,10 +555,12 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint4* __restrict__ s
 }
 
 // ---- block ranges from the sorted keys (identifyTileRanges, rasterizer_impl.cu:116-138) ----
+// With per-tile lists (one record slot per entry) it also clears the backward's per-record live flags.
 __global__ __launch_bounds__(BLK) void tile_ranges_kernel(const uint32_t* __restrict__ skeys, uint32_t R, uint32_t kmask,
-                                                          uint2* __restrict__ ranges) {
+                                                          uint2* __restrict__ ranges, uint8_t* __restrict__ live) {
   const uint32_t i = blockIdx.x * BLK + threadIdx.x;
   if (i >= R) return;
+  if (live) live[i] = 0;
   const uint32_t cur = skeys[i] & kmask;
   if (i == 0) ranges[cur].x = 0;
   else {
@@ -587,7 +589,7 @@ void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int
   }
   // The backward's per-record live flags: which records get written depends only on forward state (lists and
   // n_contrib), so one clear per forward serves every backward over this workspace.
-  (void)hipMemsetAsync(b.live, 0, (size_t)Rs, s);
+  if (M > 1) (void)hipMemsetAsync(b.live, 0, (size_t)Rs, s);  // (per-tile lists: cleared by tile_ranges_kernel)
   if (M > 1)
     hipLaunchKernelGGL(expand_kernel<BLOCK_BIG>, dim3(g.nblkE), dim3(BLK), 0, s, g.sinfo, g.bext, g.pblock, g.blocksum,
                        (uint32_t)P, gmx, nblocks, b.tkeyA, b.tvalA, im.ranges);
@@ -608,5 +610,5 @@ void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int
     uint2* tv = va; va = vb; vb = tv;
   }
   hipLaunchKernelGGL(tile_ranges_kernel, dim3(ceil_div_u32((uint64_t)Re, BLK)), dim3(BLK), 0, s, b.sorted_keys, Re,
-                     M > 1 ? (1u << MACRO_KEY_BITS) - 1u : 0xFFFFFFFFu, im.ranges);
+                     M > 1 ? (1u << MACRO_KEY_BITS) - 1u : 0xFFFFFFFFu, im.ranges, M > 1 ? (uint8_t*)nullptr : b.live);
 }

@@ -242,13 +242,19 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
         } else if (sw * sh <= MASK_MAX_SUBTILES) {
           kind = BK_MASK;
           const float b_c = cb / cc, b_a = cb / ca;
+          // (a rect of at most 64 tiles spans at most ceil(64/BLOCK_BIG)+1 blocks in a row: block bits fit 64 bits)
+          const int bx0 = sx0 / BLOCK_BIG, by0 = sy0 / BLOCK_BIG, bw = (sx1 - 1) / BLOCK_BIG - bx0 + 1;
+          unsigned long long blocks = 0ull;  // blocks (BLOCK_BIG x BLOCK_BIG tiles) with at least one listed tile
           for (int sy = sy0; sy < sy1; sy++)
             for (int sx = sx0; sx < sx1; sx++) {
               const float bx = (float)(sx * SUBX), by = (float)(sy * SUBY);
-              if (block_hit(px, py, ca, cb, cc, b_c, b_a, tau_m, bx, by, bx + (SUBX - 1), by + (SUBY - 1)))
+              if (block_hit(px, py, ca, cb, cc, b_c, b_a, tau_m, bx, by, bx + (SUBX - 1), by + (SUBY - 1))) {
                 m |= 1ull << ((sy - sy0) * sw + (sx - sx0));
+                blocks |= 1ull << ((sy / BLOCK_BIG - by0) * bw + (sx / BLOCK_BIG - bx0));
+              }
             }
           my_tiles = (uint32_t)__popcll(m);
+          my_entries = (uint32_t)__popcll(blocks);
         } else if (tau_m >= 0.f && tau_m < 3.0e38f && ca * cc - cb * cb > 0.f) {
           // larger footprints: per-row column spans in closed form (common.h row_span); expand re-evaluates them
           kind = BK_SPANS;
@@ -259,7 +265,7 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
         }
         // list entries at block size BLOCK_BIG = blocks with at least one listed internal tile (at block size 1 the
         // entries are the listed tiles themselves); for BK_SPANS the walk also yields the number of listed tiles
-        if (my_tiles) {
+        if (my_tiles && kind != BK_MASK) {
           uint32_t ent = 0, fine = 0;
           for (int MY = sy0 / BLOCK_BIG; MY <= (sy1 - 1) / BLOCK_BIG; MY++)
             walk_macro_row<BLOCK_BIG>(kind, m, sp, sx0, sy0, sx1, sy1, MY, [&](int, uint32_t sub) {
