@@ -2,6 +2,7 @@
 // Orchestration only: argument checks, workspace carving, kernel launches. The library never allocates
 // device memory; the only host allocation is a small pinned staging buffer for the num_rendered readback.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -205,11 +206,15 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
   const uint64_t entries_big = (uint64_t)g_pinned[MISC_MACRO_LO] | ((uint64_t)g_pinned[MISC_MACRO_HI] << 32);
   // List granularity of this forward (common.h "blocks"). Per-tile lists while footprints are small: every entry a
   // wave reads is one it uses. Lists per 32 x 32-pixel block once a Gaussian is listed in many tiles: the sort then
-  // moves 4-7x fewer entries, which outweighs the block-list scan in the render waves (measured crossover at about ten
+  // moves 4-7x fewer entries, which outweighs the block-list scan in the render waves (measured crossover at about eight
   // listed tiles per Gaussian: 1024^2 trained -8 %, 2048^2 trained -28 %, 1024^2 at opacity 0.01 +13 % if forced).
   // Block ids must fit the low half of the sort key.
   const bool big_fits = (uint64_t)macro_grid_x(W, BLOCK_BIG) * macro_grid_y(H, BLOCK_BIG) <= (1u << MACRO_KEY_BITS);
-  const int block = (big_fits && total > (uint64_t)EOGS_BLOCK_SWITCH * (uint64_t)P) ? BLOCK_BIG : 1;
+  static const double block_switch = [] {  // tuning aid: EOGS_BLOCK_SWITCH=<tiles per Gaussian> overrides the default
+    const char* e = getenv("EOGS_BLOCK_SWITCH");
+    return e ? atof(e) : (double)EOGS_BLOCK_SWITCH;
+  }();
+  const int block = (big_fits && (double)total > block_switch * (double)P) ? BLOCK_BIG : 1;
   const uint64_t entries = block > 1 ? entries_big : total;
   // keep the GPU busy while the caller sizes and allocates the binning workspace: the depth-order gather and the
   // chunk scan only touch the geometry workspace
