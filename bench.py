@@ -72,6 +72,30 @@ def measured_traffic(kernel, a):
     return None, None
 
 
+def measured_valu(kernel, a):
+    """VALU wave-instructions per launch of `kernel` from the same committed PMC passes (SQ_INSTS_VALU), for the
+    instruction-issue bound the render kernels actually sit at."""
+    import glob
+    import re
+
+    if a.gaussians != (1 << 20) or a.size != 1024 or a.opacity != "init":
+        return None
+
+    def ver(path):
+        m = re.search(r"r(\d+)_v(\d+)", path)
+        return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
+
+    for d in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_v*", "pmc_mean_per_dispatch.json")), key=ver, reverse=True):
+        try:
+            pm = json.load(open(d))
+        except Exception:
+            continue
+        for name, c in pm.items():
+            if name.startswith(kernel + "_kernel") and "SQ_INSTS_VALU" in c:
+                return float(c["SQ_INSTS_VALU"])
+    return None
+
+
 def _torch_photometric(img, gt, win, lam=0.2):
     """The reference's op sequence for (1-l) L1 + l (1-SSIM) (GS/utils/loss_utils.py:18-19,45-85, image_utils.py:27-28)
     in PyTorch on the GPU: what the loss costs a user of the reference after the drop-in."""
@@ -460,6 +484,15 @@ def main():
             roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                     "algorithmic_bytes": alg[dom], "kernel_ms": kern[dom]}
+            valu = measured_valu(dom, a)
+            if valu:
+                # the bound this kernel really runs at: VALU issue. 1024 SIMDs x 2.4 GHz; a wave64 VALU instruction
+                # occupies its SIMD for 2.4 (all-VGPR fma/mul/add) to 4.2 cycles (SGPR operand, cmp, cndmask, DPP) and
+                # 8.5 for v_exp/v_rcp (tools/ubench.hip)
+                cyc = kern[dom] * 1e-3 * 2.4e9 * 1024 / valu
+                roof["valu_issue"] = {"valu_wave_insts": valu, "simd_cycles_per_valu_inst": cyc,
+                                      "floor_simd_cycles_per_inst": [2.4, 4.2],
+                                      "insts_per_pair": valu / max(R, 1)}
         # every kernel group against the HBM roofline (the render kernels are VALU-issue-bound: DESIGN.md §4)
         per_kernel = {}
         for k, ms in kern.items():
