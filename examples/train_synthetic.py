@@ -1,0 +1,135 @@
+"""End-to-end use of the MI355X path on synthetic data: the structure of one EOGS++ training iteration
+(src/gaussiansplatting/train_pan.py:262-400,663-690) with every heavy step on the HIP library.
+
+    python examples/train_synthetic.py [--gaussians 200000] [--size 512] [--iters 200]
+
+Per iteration: render the view through `eogs2_amd.render.render` (raw-parameter front end, §8 f1), render a sun-like
+virtual camera at twice the resolution and resample it onto the view (`eogs2_amd.resample`, §8 f2), photometric loss
+against a target image (`eogs2_amd.losses.photometric_loss`, §8 f2) plus an altitude-consistency term on the resample,
+`FusedAdam` step (§8 f3), transparent-Gaussian prune by stream compaction (`prune_optimizer`, §8 f3). The target is the
+render of the unperturbed scene, so the loss must fall. Initial scales come from `simple_knn._C.distCUDA2` (§8 f4).
+"""
+import argparse
+import math
+import os
+import sys
+import time
+import types
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from eogs2_amd.losses import photometric_loss  # noqa: E402
+from eogs2_amd.optim import FusedAdam, prune_optimizer  # noqa: E402
+from eogs2_amd.render import render  # noqa: E402
+from eogs2_amd.resample import resample  # noqa: E402
+from eogs2_amd.synthetic import make_camera, make_scene  # noqa: E402
+from simple_knn._C import distCUDA2  # noqa: E402
+
+C0 = 0.28209479177387814
+
+
+class Camera:
+    """The attributes gaussian_renderer/renderer.py reads from an AffineCamera."""
+
+    def __init__(self, vm, H, W):
+        self.FoVx = self.FoVy = 1.0
+        self.affine = self.world_view_transform = self.full_proj_transform = vm
+        self.learn_wv_only_lastparam = False
+        self.image_height, self.image_width = H, W
+        self.camera_center = torch.zeros(3, device=vm.device)
+
+
+class Gaussians:
+    """The attributes renderer.py / gaussian_model.py use: raw parameters, one optimizer group each."""
+
+    active_sh_degree = 0
+
+    def __init__(self, xyz, rgb, opacity, scales, rotations):
+        P = xyz.shape[0]
+        self._xyz = torch.nn.Parameter(xyz.clone())
+        self._features_dc = torch.nn.Parameter(((rgb - 0.5) / C0).reshape(P, 1, 3).contiguous())
+        self._features_rest = torch.nn.Parameter(torch.zeros(P, 0, 3, device=xyz.device))
+        self._opacity = torch.nn.Parameter(torch.log(opacity / (1 - opacity)))
+        self._scaling = torch.nn.Parameter(torch.log(scales))
+        self._rotation = torch.nn.Parameter(rotations.clone())
+        lrs = dict(xyz=2e-5, f_dc=2.5e-3, f_rest=1.25e-4, opacity=2.5e-2, scaling=5e-3, rotation=1e-3)
+        groups = [dict(params=[getattr(self, "_" + n)], lr=lr, name=k)
+                  for k, n, lr in (("xyz", "xyz", lrs["xyz"]), ("f_dc", "features_dc", lrs["f_dc"]),
+                                   ("f_rest", "features_rest", lrs["f_rest"]), ("opacity", "opacity", lrs["opacity"]),
+                                   ("scaling", "scaling", lrs["scaling"]), ("rotation", "rotation", lrs["rotation"]))]
+        self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)  # gaussian_model.py:262 with the fused step
+        self.max_radii2D = torch.zeros(P, device=xyz.device)
+
+    get_xyz = property(lambda s: s._xyz)
+
+    def prune(self, keep):  # gaussian_model.py:488-505
+        t, (self.max_radii2D,) = prune_optimizer(self.optimizer, keep, extra=(self.max_radii2D,))
+        self._xyz, self._features_dc, self._features_rest = t["xyz"], t["f_dc"], t["f_rest"]
+        self._opacity, self._scaling, self._rotation = t["opacity"], t["scaling"], t["rotation"]
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gaussians", type=int, default=200_000)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--quiet", action="store_true")
+    a = ap.parse_args(argv)
+    dev = torch.device("cuda:0")
+    P, H, W = a.gaussians, a.size, a.size
+    sc = make_scene(P, H, W, seed=0, opacity="trained", device=dev)
+    cam = Camera(sc["viewmatrix"], H, W)
+    sun = Camera(make_camera(2 * H, 2 * W, seed=5, device=dev), 2 * H, 2 * W)
+    cam2sun = torch.eye(3, device=dev)
+    cam2sun[:2, 2] = (sun.affine[2, :2] - cam.affine[2, :2]) / 350.0  # altitude-dependent shift between the two views
+    pipe = types.SimpleNamespace(debug=False, antialiasing=False, compute_cov3D_python=False, require_radii=True)
+    bg = sc["bg"]
+    U, V = torch.meshgrid(torch.linspace(-1, 1, W, device=dev), torch.linspace(-1, 1, H, device=dev), indexing="xy")
+
+    target_model = Gaussians(sc["means3D"], sc["colors"][:, :3], sc["opacities"].squeeze(1).clamp(1e-4, 1 - 1e-4),
+                             sc["scales"], sc["rotations"])
+    with torch.no_grad():
+        gt = render(cam, target_model, pipe, bg)["render"][:3].clone()
+
+    # the trainee: perturbed colours / opacities / positions, scales re-initialised from the 3-NN statistic
+    g = torch.Generator().manual_seed(1)
+    noise = lambda *s: torch.randn(*s, generator=g).to(dev)
+    dist2 = torch.clamp_min(distCUDA2(sc["means3D"]), 1e-7)  # gaussian_model.py:179-182
+    model = Gaussians(sc["means3D"] + 2e-4 * noise(P, 3), (sc["colors"][:, :3] + 0.2 * noise(P, 3)).clamp(0.02, 0.98),
+                      torch.full((P,), 0.3, device=dev), torch.sqrt(dist2)[:, None].repeat(1, 3), sc["rotations"])
+    first = last = None
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(1, a.iters + 1):
+        out = render(cam, model, pipe, bg)
+        img, altitude = out["render"][:3], out["render"][3]
+        sun_img = render(sun, model, pipe, bg)["render"]
+        sample, _ = resample(sun_img, cam2sun, torch.stack((U, V, altitude / 350.0), dim=-1))
+        loss, _ = photometric_loss(img, gt, 0.2)
+        loss = loss + 1e-4 * (sample[3] - altitude).clamp(-5, 5).abs().mean()
+        loss.backward()
+        model.optimizer.step()
+        model.optimizer.zero_grad(set_to_none=True)
+        with torch.no_grad():
+            model.max_radii2D = torch.maximum(model.max_radii2D, out["radii"].float())
+            if it % 50 == 0:  # train_pan.py:673-678
+                keep = model._opacity.squeeze() >= math.log(0.005 / 0.995)
+                if not bool(keep.all()):
+                    model.prune(keep)
+        if it == 1 or it % 25 == 0 or it == a.iters:
+            v = float(loss.detach())
+            first = v if first is None else first
+            last = v
+            if not a.quiet:
+                print(f"iter {it:4d}  loss {v:.5f}  gaussians {model._xyz.shape[0]}")
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if not a.quiet:
+        print(f"{a.iters} iterations in {dt:.2f} s ({dt / a.iters * 1e3:.2f} ms/iter, 2 renders + resample + loss + Adam each)")
+    return first, last, model._xyz.shape[0]
+
+
+if __name__ == "__main__":
+    main()
