@@ -58,6 +58,8 @@ def _f32(t, dev):
         return None
     if t.device != dev:
         raise RuntimeError(f"rasterizer input on {t.device}, expected {dev}")
+    if t.dtype == torch.float32 and t.is_contiguous():
+        return t  # the common case: only the data pointer is used, nothing to convert
     return t.detach().to(torch.float32).contiguous()
 
 
