@@ -85,27 +85,6 @@ __device__ inline void stage_rows3(const float* __restrict__ src, size_t row0, i
   }
 }
 
-// Can this Gaussian reach alpha >= 1/255 anywhere in the pixel block [x0,x1] x [y0,y1]?
-// alpha = o exp(-q/2), q(d) = a dx^2 + 2 b dx dy + c dy^2 (d = centre - pixel), so alpha >= 1/255 <=> q <= tau,
-// tau = 2 ln(255 o). The minimum of the convex q over the block is 0 if the centre is inside, otherwise it lies on
-// the edges that face the centre: minimise q along x = clamp(gx) and along y = clamp(gy), the free coordinate
-// clamped to the block. The continuous block contains the pixel centres, so q_min(block) <= q(pixel): dropping the
-// block when q_min > tau (plus a margin far above the fp32 rounding of the renderer's `power`) never drops a pixel
-// that would blend this Gaussian (forward.cu:374-376 skips alpha < 1/255). NaNs fail the comparison -> kept.
-// b_c = b/c and b_a = b/a are per-Gaussian constants (the unclamped minimiser on an edge).
-__device__ inline bool block_hit(float gx, float gy, float a, float b, float c, float b_c, float b_a, float tau_m,
-                                 float x0, float y0, float x1, float y1) {
-  const float cx = fminf(fmaxf(gx, x0), x1), cy = fminf(fmaxf(gy, y0), y1);
-  const float dxe = gx - cx, dye = gy - cy;
-  const float py = fminf(fmaxf(gy + b_c * dxe, y0), y1);  // edge x = cx, free y
-  const float dy1 = gy - py;
-  const float q1 = a * dxe * dxe + 2.f * b * dxe * dy1 + c * dy1 * dy1;
-  const float pxs = fminf(fmaxf(gx + b_a * dye, x0), x1);  // edge y = cy, free x
-  const float dx2 = gx - pxs;
-  const float q2 = a * dx2 * dx2 + 2.f * b * dx2 * dye + c * dye * dye;
-  return !(fminf(q1, q2) > tau_m);
-}
-
 constexpr float SH_C0 = 0.28209479177387814f;  // utils/sh_utils.py:25
 
 __device__ inline float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }

@@ -15,6 +15,6 @@ for f in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
     for k, v in agg.items():
         out.setdefault(k, {}).update({c: sum(x) / len(x) for c, x in v.items()})
 json.dump(out, open(os.path.join(dst, "pmc_mean_per_dispatch.json"), "w"), indent=1, sort_keys=True)
-for k in ("render_bwd_kernel", "render_fwd_kernel"):
+for k in [k for k in out if k.startswith("render_")]:
     if k in out:
         print(k, {c: f"{v:.3g}" for c, v in sorted(out[k].items())})
