@@ -258,7 +258,7 @@ int eogs_rast_forward_render(int P, int H, int W, int64_t R, const float* bg, un
   }
   { ProfScope ps(PS_BINNING, s); launch_binning(g, b, im, P, H, W, R, s); }
   LAUNCH_TRY(s, debug, "binning");
-  { ProfScope ps(PS_RENDER_FWD, s); launch_render_fwd(g, b, im, H, W, bg, out_color, out_invdepth, s); }
+  { ProfScope ps(PS_RENDER_FWD, s); launch_render_fwd(g, b, im, P, H, W, R, bg, out_color, out_invdepth, s); }
   LAUNCH_TRY(s, debug, "render_fwd");
   return EOGS_OK;
 }

@@ -334,7 +334,7 @@ void launch_scan_pblock(const GeomWS& g, int P, hipStream_t s);
 // part of binning that needs only the geometry workspace (queued by forward_prepare right after its sync)
 void launch_binning_head(const GeomWS& g, int P, int block, hipStream_t s);
 void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, hipStream_t s);
-void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, int W,
+void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R,
                        const float* bg, float* out_color, float* out_invdepth, hipStream_t s);
 void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, int W, int64_t R, const float* colors,
                        const float* out_color, const float* out_invdepth, const float* dL_dcolor,

@@ -296,7 +296,7 @@ __device__ inline void quad_append(uint8_t* sidx, int lane, bool hit, int pos, u
 }  // namespace
 
 template <int MACRO>
-__global__ __launch_bounds__(BLK) void render_fwd_quad_kernel(
+__global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(8, 8))) void render_fwd_quad_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx,
     const float4* __restrict__ packed, const float* __restrict__ bg,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
@@ -400,14 +400,16 @@ __global__ __launch_bounds__(BLK) void render_fwd_quad_kernel(
   }
 }
 
-// EOGS_QUAD: bit 0 = forward, bit 1 = backward use the quad sub-list kernels (tuning switch)
-static int quad_mode() {
-  static int mode = -1;
-  if (mode < 0) {
-    const char* e = getenv("EOGS_QUAD");
-    mode = e ? atoi(e) : 3;
-  }
-  return mode;
+// Quad sub-lists pay while footprints are small: the trip count falls to the longest sub-list (0.6 of the tile's list at
+// four listed tiles per Gaussian) against ~15 % more work per trip and ~170 instructions per chunk for the masks.
+// EOGS_QUAD_SWITCH=<listed tiles per Gaussian> overrides the crossover (0 disables the quad kernel).
+#define EOGS_QUAD_SWITCH_DEFAULT 8.0  // measured: -20 % render_fwd at 4.0 listed tiles per Gaussian, -13.5 % at 6.4
+static double quad_switch() {
+  static const double v = [] {
+    const char* e = getenv("EOGS_QUAD_SWITCH");
+    return e ? atof(e) : EOGS_QUAD_SWITCH_DEFAULT;
+  }();
+  return v;
 }
 
 static inline uint32_t render_grid(int ntiles) {
@@ -415,11 +417,11 @@ static inline uint32_t render_grid(int ntiles) {
   return ((groups + 7u) / 8u) * 8u;  // multiple of 8 for the XCD band mapping
 }
 
-void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, int W,
+void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R,
                        const float* bg, float* out_color, float* out_invdepth, hipStream_t s) {
   const int gsx = (W + SUBX - 1) / SUBX, gsy = (H + SUBY - 1) / SUBY, ntiles = gsx * gsy;
   auto* kern = b.block > 1 ? render_fwd_kernel<BLOCK_BIG> : render_fwd_kernel<1>;
-  if ((quad_mode() & 1) && (b.block == 1 || (quad_mode() & 4))) kern = b.block > 1 ? render_fwd_quad_kernel<BLOCK_BIG> : render_fwd_quad_kernel<1>;
+  if (b.block == 1 && (double)nr_slots(R) <= quad_switch() * (double)P) kern = render_fwd_quad_kernel<1>;
   hipLaunchKernelGGL(kern, dim3(render_grid(ntiles)), dim3(BLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H, gsx,
                      ntiles, (int)macro_grid_x(W, b.block), g.packed, bg, im.final_T, im.n_contrib, out_color, out_invdepth);
 }
@@ -648,242 +650,12 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
 }
 
 
-// ------------------------------------------------------------------------------------------------------
-// Backward with quad sub-lists (per-tile lists only)
-// ------------------------------------------------------------------------------------------------------
-// Same decomposition as render_fwd_quad_kernel: every quad (16 lanes, 4x4 pixels) walks its own sub-list of the chunk's
-// entries, so one trip of the pixel-parallel loop evaluates four DIFFERENT entries. A transposition round covers 8 trips:
-// lane (k = lane >> 3, q = (lane >> 1) & 3, h = lane & 1) owns trip k, quad q and two pixel rows of that quad (8 pixels,
-// the same u/v matrix layout as render_bwd_kernel because pixel index = lane in both phases), accumulates the six
-// moments and five colour sums in registers, merges the two halves with one DPP step and adds the 11 totals to the
-// ENTRY's accumulators in LDS (ds_add_f32: an entry is visited by up to four quads, in different trips). At the end of
-// the chunk lane i turns entry i's accumulated moments into the 48-byte record exactly as transpose_round does.
-namespace {
-
-#define QB 80    // bytes per quad sub-list in backward (64 entries + pipelined over-read)
-#define NACC 11  // accumulators per entry: M_1, M_dx, M_dy, M_dxdx, M_dxdy, M_dydy, five colour sums
-#define RB_DEAD 0xFFu
-
-__device__ inline void lds_add(float* p, float v) {  // ds_add_f32, result unused
-  (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-__device__ inline void transpose_round_quad(int nk, int lane, const uint8_t* rb, const float* slab, const float* s_u,
-                                            const float* s_v, const float* s_pix, float bx0, float by0, float* accb) {
-  const int k = lane >> 3, o = lane & 7, q = o >> 1, h = o & 1;
-  const uint32_t rbv = rb[k * 4 + q];
-  const bool live = k < nk && rbv != RB_DEAD;
-  const uint32_t idx = live ? rbv : 0u;
-  const float2 gxy = *reinterpret_cast<const float2*>(slab + idx * ENT);
-  const float gxr = gxy.x - (bx0 + (float)(4 * (q & 1)));  // centre relative to the quad's first column
-  const float dy0 = gxy.y - (by0 + (float)(4 * (q >> 1) + 2 * h)), dy1 = dy0 - 1.f;
-  float S0a = 0.f, Sxa = 0.f, Sxxa = 0.f, S0b = 0.f, Sxb = 0.f, Sxxb = 0.f;
-  float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f, c4 = 0.f;
-  const float* urow = s_u + uv_index(k, 8 * o);
-  const float* vrow = s_v + uv_index(k, 8 * o);
-  const float* prow = s_pix + (8 * o) * 8 + 4 * o;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    const float u = urow[i], v = vrow[i];
-    const float4 ga = *reinterpret_cast<const float4*>(prow + i * 8);
-    const float gb = prow[i * 8 + 4];
-    const float dx = gxr - (float)(i & 3);
-    const float t1 = v * dx;
-    if (i < 4) { S0a += v; Sxa += t1; Sxxa += t1 * dx; }
-    else { S0b += v; Sxb += t1; Sxxb += t1 * dx; }
-    c0 += u * ga.x; c1 += u * ga.y; c2 += u * ga.z; c3 += u * ga.w; c4 += u * gb;
-  }
-  float c[11] = {S0a + S0b, Sxa + Sxb, dy0 * S0a + dy1 * S0b, Sxxa + Sxxb, dy0 * Sxa + dy1 * Sxb,
-                 dy0 * dy0 * S0a + dy1 * dy1 * S0b, c0, c1, c2, c3, c4};
-  DPP_STEP11("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1");  // lane h = 1 += lane h = 0
-  if (live && h == 1) {
-    float* a = accb + idx * NACC;
-#pragma unroll
-    for (int t = 0; t < NACC; t++) lds_add(a + t, c[t]);
-  }
-}
-
-}  // namespace
-
-__global__ __launch_bounds__(BLK) void render_bwd_quad_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx,
-    const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib,
-    const float* __restrict__ out_color, const float* __restrict__ out_invdepth, const float* __restrict__ dL_dpix,
-    const float* __restrict__ dL_dinv, float* __restrict__ records, uint8_t* __restrict__ live_flag) {
-  __shared__ __attribute__((aligned(16))) float s_slab[BLK / 64][64 * ENT];
-  __shared__ __attribute__((aligned(16))) float s_acc[BLK / 64][64 * NACC];
-  __shared__ __attribute__((aligned(16))) float s_u[BLK / 64][UV_SIZE];
-  __shared__ __attribute__((aligned(16))) float s_v[BLK / 64][UV_SIZE];
-  __shared__ __attribute__((aligned(16))) float s_pix[BLK / 64][64 * 8 + 32];
-  __shared__ uint32_t s_slot[BLK / 64][64];
-  __shared__ __attribute__((aligned(16))) uint8_t s_idx[BLK / 64][4 * QB];
-  __shared__ __attribute__((aligned(16))) uint8_t s_rb[BLK / 64][KSURV * 4];
-  const int lane = threadIdx.x & 63;
-  const int tile = tile_of_wave();
-  if (tile >= ntiles) return;
-  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  float* slab = s_slab[w];
-  float* accb = s_acc[w];
-  float* su = s_u[w];
-  float* sv = s_v[w];
-  float* spix = s_pix[w];
-  uint32_t* sslot = s_slot[w];
-  uint8_t* sidx = s_idx[w];
-  uint8_t* rb = s_rb[w];
-  int ox, oy;
-  quad_pixel(lane, ox, oy);
-  const int tx0 = (tile % gsx) * SUBX, ty0 = (tile / gsx) * SUBY;
-  const int px = tx0 + ox, py = ty0 + oy;
-  const bool inside = px < W && py < H;
-  const uint32_t pix_id = (uint32_t)py * (uint32_t)W + (uint32_t)px;
-  const float pxf = (float)px, pyf = (float)py;
-  const uint2 range = ranges[tile];
-  const size_t HW = (size_t)H * W;
-  const bool have_inv = dL_dinv != nullptr;
-  const int myq = lane >> 4;
-  const uint8_t* myidx = sidx + myq * QB;
-  const unsigned long long myrow = 0xFFFFull << (16 * myq);
-
-  float g[NCH] = {0.f, 0.f, 0.f, 0.f, 0.f};
-  float ginv = 0.f, Dfinal = 0.f;
-  uint32_t ncontrib = 0;
-  if (inside) {
-    ncontrib = n_contrib[pix_id];
-#pragma unroll
-    for (int ch = 0; ch < NCH; ch++) {
-      g[ch] = dL_dpix[ch * HW + pix_id];
-      Dfinal += g[ch] * out_color[ch * HW + pix_id];
-    }
-    if (have_inv) {
-      ginv = dL_dinv[pix_id];
-      Dfinal += ginv * out_invdepth[pix_id];
-    }
-  }
-  {  // pixel gradients for the transposition rounds: 8 floats per pixel (pixel index = lane), +4 floats per 8 pixels
-    float* d = spix + lane * 8 + 4 * (lane >> 3);
-    *reinterpret_cast<float4*>(d) = make_float4(g[0], g[1], g[2], g[3]);
-    d[4] = g[4];
-  }
-#pragma unroll
-  for (int t = 0; t < NACC; t++) accb[t * 64 + lane] = 0.f;
-  for (int t = lane; t < 4 * QB / 4; t += 64) reinterpret_cast<uint32_t*>(sidx)[t] = 0u;  // over-read bytes: valid positions
-  const uint32_t tile_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(ncontrib));
-  const float kx = LN2 * 0.5f * W, ky = LN2 * 0.5f * H;
-  const float bx0 = (float)tx0, by0 = (float)ty0;
-  float T = 1.0f, Dacc = 0.f;
-
-  uint32_t jbase = 0;
-  Cand nxt = gather_cand<1>(peek_cand<1>(range.x + lane, range.y, keys, point_list), 0u, packed);
-  Peek pk = peek_cand<1>(range.x + 64 + lane, range.y, keys, point_list);
-  for (uint32_t c0 = range.x; c0 < range.y && jbase < tile_last; c0 += 64) {
-    wave_lds_sync();
-    int nq[4] = {0, 0, 0, 0};
-    {
-      const uint32_t qm = nxt.hit ? quad_mask(nxt, bx0, by0) : 0u;
-      // per-tile lists: the in-range entries are lanes 0..jn-1, parked at their own lane index
-      const bool listed = nxt.hit && jbase + (uint32_t)lane < tile_last;  // entries behind the last contributor are dead
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const bool in = listed && ((qm >> q) & 1u);
-        const unsigned long long bal = __builtin_amdgcn_ballot_w64(in);
-        if (in) sidx[q * QB + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (uint8_t)lane;
-        nq[q] = (int)__popcll(bal);
-      }
-    }
-    const int jn = park(slab, sslot, lane, nxt, 0);
-    nxt = gather_cand<1>(pk, 0u, packed);
-    pk = peek_cand<1>(c0 + 128 + lane, range.y, keys, point_list);
-    wave_lds_sync();
-    const int nmax = max(max(nq[0], nq[1]), max(nq[2], nq[3]));
-    const int nmine = myq == 0 ? nq[0] : (myq == 1 ? nq[1] : (myq == 2 ? nq[2] : nq[3]));
-    int k = 0;  // trips waiting in the current transposition round
-    auto grad = [&](const Ent& e, int pos, bool active) {
-      const float dx = e.q0.x - pxf, dy = e.q0.y - pyf;
-      const float p = (e.q0.z * dx - e.q0.w * dy) * dx + e.q1.x * dy * dy;
-      const float G = __builtin_amdgcn_exp2f(p);
-      const float alpha = fminf(e.q1.y * G, 0.99f);
-      const bool valid = active && (jbase + (uint32_t)pos < ncontrib) && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);
-      const unsigned long long vb = __builtin_amdgcn_ballot_w64(valid);
-      if (vb == 0ull) return;  // this trip reaches no pixel of the tile
-
-      float gc = g[0] * e.q1.z + g[1] * e.q1.w + g[2] * e.q2.x + g[3] * e.q2.y + g[4] * e.q2.z;
-      if (have_inv) gc += ginv * e.q2.w;
-      const float a_eff = valid ? alpha : 0.f;
-      const float G_eff = valid ? G : 0.f;
-      const float wgt = a_eff * T;
-      Dacc += gc * wgt;
-      const float one_m = 1.f - a_eff;
-      const float dLda = T * gc - (Dfinal - Dacc) * __builtin_amdgcn_rcpf(one_m);
-      T = T * one_m;
-      su[uv_index(k, lane)] = wgt;
-      sv[uv_index(k, lane)] = G_eff * dLda;  // v = G dL/dalpha
-      if ((lane & 15) == 0) rb[k * 4 + myq] = (vb & myrow) ? (uint8_t)pos : (uint8_t)RB_DEAD;
-      if (++k == KSURV) {
-        wave_lds_sync();
-        transpose_round_quad(KSURV, lane, rb, slab, su, sv, spix, bx0, by0, accb);
-        wave_lds_sync();
-        k = 0;
-      }
-    };
-    if (nmax > 0) {
-      int i0 = myidx[0], i1 = myidx[1];
-      Ent ea = fetch(slab, i0);
-      int j = 0;
-      for (; j + 1 < nmax; j += 2) {
-        const Ent eb = fetch(slab, i1);
-        const int i2 = myidx[j + 2];
-        grad(ea, i0, j < nmine);
-        ea = fetch(slab, i2);
-        const int i3 = myidx[j + 3];
-        grad(eb, i1, j + 1 < nmine);
-        i0 = i2;
-        i1 = i3;
-      }
-      if (j < nmax) grad(ea, i0, j < nmine);
-      if (k) {  // the chunk's last, partial round (the accumulators are per chunk)
-        wave_lds_sync();
-        transpose_round_quad(k, lane, rb, slab, su, sv, spix, bx0, by0, accb);
-      }
-      wave_lds_sync();
-      // entry `lane`: accumulated moments -> record (backward.cu:624-640, as in transpose_round)
-      if (lane < jn) {
-        float m[NACC];
-        bool any = false;
-        float* a = accb + lane * NACC;
-#pragma unroll
-        for (int t = 0; t < NACC; t++) {
-          m[t] = a[t];
-          any = any || m[t] != 0.f;
-        }
-        if (any) {
-#pragma unroll
-          for (int t = 0; t < NACC; t++) a[t] = 0.f;
-          const float4 q0 = *reinterpret_cast<const float4*>(slab + lane * ENT);
-          const float2 q1 = *reinterpret_cast<const float2*>(slab + lane * ENT + 4);
-          const float A = q0.z, B = q0.w, Cq = q1.x, op = q1.y;
-          const float m2x = op * kx * (2.f * A * m[1] - B * m[2]);
-          const float m2y = op * ky * (2.f * Cq * m[2] - B * m[1]);
-          const float ho = -0.5f * op;
-          const uint32_t slot = sslot[lane];
-          float4* dst = reinterpret_cast<float4*>(records + (size_t)slot * REC);
-          dst[0] = make_float4(m2x, m2y, ho * m[3], ho * m[4]);
-          dst[1] = make_float4(ho * m[5], m[0], m[6], m[7]);
-          dst[2] = make_float4(m[8], m[9], m[10], 0.f);
-          live_flag[slot] = 1;
-        }
-      }
-    }
-    jbase += (uint32_t)jn;
-  }
-}
-
 void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, int W, int64_t R, const float* colors,
                        const float* out_color, const float* out_invdepth, const float* dL_dcolor,
                        const float* dL_dinvdepth, hipStream_t s) {
   const int gsx = (W + SUBX - 1) / SUBX, gsy = (H + SUBY - 1) / SUBY, ntiles = gsx * gsy;
   (void)R;  // live flags are cleared once per forward (tile_ranges_kernel)
   auto* kern = b.block > 1 ? render_bwd_kernel<BLOCK_BIG> : render_bwd_kernel<1>;
-  if ((quad_mode() & 2) && b.block == 1) kern = render_bwd_quad_kernel;
   hipLaunchKernelGGL(kern, dim3(render_grid(ntiles)), dim3(BLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H, gsx,
                      ntiles, (int)macro_grid_x(W, b.block), g.packed, im.n_contrib, out_color, out_invdepth, dL_dcolor,
                      dL_dinvdepth, b.records, b.live);
