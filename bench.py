@@ -272,6 +272,78 @@ def resample_bench(abi, dev, H, W, iters=20):
     return out
 
 
+def shade_bench(abi, dev, H, W, iters=20):
+    """Extra: the per-pixel chain after the raw render — AffineCamera.render_pipeline
+    (scene/cameras/affine_cameras.py:303-348), Suncamera_L (loss/shadow.py:37-51) and Translucentshadows_L (:13-17) —
+    forward + backward on one H x W view: the reference's PyTorch ops on the same GPU vs eogs2_amd.shade."""
+    import types
+
+    from eogs2_amd import shade as S
+
+    torch.manual_seed(5)
+    raw = torch.rand(3, H, W, device=dev, requires_grad=True)
+    sample = torch.rand(3, H, W, device=dev)
+    alt = (torch.randn(H, W, device=dev) * 0.5).requires_grad_(True)
+    uv = (torch.rand(H, W, 2, device=dev) * 2.2 - 1.1)
+    gt = torch.rand(3, H, W, device=dev)
+    cam = types.SimpleNamespace(use_cc=True, use_exposure=False, use_shadow=True)
+    cam.color_correction = torch.nn.Conv2d(3, 3, 1, bias=True).to(dev)
+    cam.inshadow_color_correction = torch.nn.Parameter(torch.full((3, 1, 1), 0.05, device=dev))
+
+    def ref_ops():
+        cc = cam.color_correction(raw.unsqueeze(0))
+        shadow = torch.exp(0.4 * alt.clip(max=0.0))
+        shaded = (shadow * cc + (1 - shadow) * cam.inshadow_color_correction * cc).squeeze(0)
+        diff = raw - sample
+        vis = ((alt > -1e-2) * (uv.abs() < 1).all(-1)).detach()
+        l_alt = (alt.abs() * vis).sum() / vis.sum()
+        l_rgb = (diff.abs() * vis).sum() / vis.sum()
+        b = shadow.clip(0.05, 0.95)
+        l_ts = -(shadow * torch.log2(b) + (1 - shadow) * torch.log2(1 - b)).mean()
+        return (shaded - gt).abs().mean() + l_alt + l_rgb + 0.1 * l_ts
+
+    def fused():
+        out = S.render_pipeline(cam, raw, alt)
+        l_alt, l_rgb = S.suncamera_l(raw, sample, alt, uv)
+        return (out["final"] - gt).abs().mean() + l_alt + l_rgb + 0.1 * S.translucentshadows_l(out["shadowmap"])
+
+    res = {}
+    params = [raw, alt, cam.inshadow_color_correction, *cam.color_correction.parameters()]
+    for tag, fn in (("torch_ops_ms", ref_ops), ("fused_ms", fused)):
+        def run():
+            for q in params:
+                q.grad = None
+            v = fn()
+            v.backward()
+            return v
+        for _ in range(3):
+            v = run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            run()
+        torch.cuda.synchronize()
+        res[tag] = (time.perf_counter() - t0) / iters * 1e3
+        res["value_" + tag[:-3]] = float(v.detach())
+        if tag == "fused_ms":
+            abi.profile_reset()
+            abi.profile_enable(1)
+            for _ in range(5):
+                run()
+            abi.profile_enable(0)
+            res["kernels_ms"] = {k: ms / n for k, (ms, n) in abi.profile().items() if n and k.startswith(("shade_", "mloss_"))}
+    npx = H * W
+    k = res.get("kernels_ms", {})
+    # algorithmic bytes per pixel: shade fwd reads 16 (raw, alt_diff) writes 28 (cc, shaded, shadow); bwd reads 16 + 28
+    # upstream, writes 16
+    if "shade_fwd" in k:
+        res["roofline"] = {"shade_fwd": {"algorithmic_bytes": 44 * npx, "achieved_GBps": 44 * npx / (k["shade_fwd"] * 1e-3) / 1e9},
+                           "shade_bwd": {"algorithmic_bytes": 60 * npx, "achieved_GBps": 60 * npx / (k["shade_bwd"] * 1e-3) / 1e9}}
+    res["what"] = (f"{H}x{W} view: colour correction + shadow map + in-shadow tint, sun-camera masked L1 pair, translucent-shadow "
+                   "regulariser, fwd+bwd incl. the L1 on the shaded image (PyTorch in both variants)")
+    return res
+
+
 def optimizer_bench(abi, dev, P, iters=20):
     """Extra: the reference's optimizer step — torch.optim.Adam over six single-tensor groups
     (GS/scene/gaussian_model.py:228-262) — and its prune (`_prune_optimizer` + `prune_points`, :466-505: 21 boolean-mask
@@ -522,6 +594,7 @@ def main():
             line["photometric_loss"] = photometric_loss_bench(abi, dev, H, W)
             line["optimizer"] = optimizer_bench(abi, dev, P)
             line["resample"] = resample_bench(abi, dev, H, W)
+            line["shade"] = shade_bench(abi, dev, H, W)
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(P, H)
         print(json.dumps(line), flush=True)

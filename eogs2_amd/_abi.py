@@ -22,6 +22,8 @@ FLAG_DEBUG = 2
 FLAG_RAW_PARAMS = 4
 LOSS_L1 = 1
 LOSS_SSIM = 2
+MLOSS_SUN = 0
+MLOSS_RANDOM = 1
 
 _p = C.c_void_p
 _i = C.c_int
@@ -79,11 +81,20 @@ SIGNATURES = {
     # include/eogs_knn.h
     "eogs_knn_bytes": (_i, [_i, C.POINTER(_z)]),
     "eogs_knn_mean_dist2": (_i, [_i, _p, _p, _p, _z, _p]),
+    # include/eogs_shade.h
+    "eogs_shade_bytes": (_i, [_i, _i, C.POINTER(_z)]),
+    "eogs_shade_forward": (_i, [_i, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "eogs_shade_backward": (_i, [_i, _i] + [_p] * 10 + [_p, _z, _p]),
+    "eogs_mloss_forward": (_i, [_i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "eogs_mloss_backward": (_i, [_i, _i, _i] + [_p] * 9 + [_p]),
+    "eogs_tshadow_forward": (_i, [_i64, _p, _p, _p, _z, _p]),
+    "eogs_tshadow_backward": (_i, [_i64, _p, _p, _p, _p]),
 }
 # symbols only the HIP library exports (the CPU oracle of the loss is oracle/loss_oracle.py, not a C-ABI twin)
 HIP_ONLY = ("eogs_loss_bytes", "eogs_loss_forward", "eogs_loss_backward", "eogs_adam_step", "eogs_compact_bytes",
             "eogs_compact_plan", "eogs_compact_apply", "eogs_resample_forward", "eogs_resample_bytes", "eogs_resample_backward", "eogs_knn_bytes",
-            "eogs_knn_mean_dist2")
+            "eogs_knn_mean_dist2", "eogs_shade_bytes", "eogs_shade_forward", "eogs_shade_backward", "eogs_mloss_forward",
+            "eogs_mloss_backward", "eogs_tshadow_forward", "eogs_tshadow_backward")
 
 
 class AdamTensor(C.Structure):
@@ -124,7 +135,7 @@ class RastABI:
             raise RastError(code, self.cdll.eogs_rast_last_error().decode())
 
     def __getattr__(self, name):
-        short = name.startswith(("loss_", "adam_", "compact_", "resample_", "knn_"))
+        short = name.startswith(("loss_", "adam_", "compact_", "resample_", "knn_", "shade_", "mloss_", "tshadow_"))
         return getattr(self.cdll, ("eogs_" if short else "eogs_rast_") + name)
 
     def profile_slot_names(self):

@@ -56,9 +56,10 @@ int check_launch(hipStream_t s, bool debug, const char* what) {
 }
 // ---- optional per-kernel-group timing with hipEvents on the launch stream ----
 enum { PS_PREPROCESS, PS_DEPTH_SORT, PS_BINNING, PS_RENDER_FWD, PS_RENDER_BWD, PS_GAUSS_BWD, PS_LOSS_FWD, PS_LOSS_BWD, PS_ADAM,
-       PS_COMPACT, PS_RESAMPLE_FWD, PS_RESAMPLE_BWD, PS_KNN, PS_COUNT };
+       PS_COMPACT, PS_RESAMPLE_FWD, PS_RESAMPLE_BWD, PS_KNN, PS_SHADE_FWD, PS_SHADE_BWD, PS_MLOSS_FWD, PS_MLOSS_BWD, PS_COUNT };
 const char* const kSlotNames[PS_COUNT] = {"preprocess_fwd", "depth_sort", "binning", "render_fwd", "render_bwd", "gaussian_bwd",
-                                          "loss_fwd", "loss_bwd", "adam", "compact", "resample_fwd", "resample_bwd", "knn"};
+                                          "loss_fwd", "loss_bwd", "adam", "compact", "resample_fwd", "resample_bwd", "knn",
+                                          "shade_fwd", "shade_bwd", "mloss_fwd", "mloss_bwd"};
 struct Pending { int slot; hipEvent_t a, b; };
 // process-wide (autograd runs backward on its own thread), guarded by g_prof_mu
 std::mutex g_prof_mu;
@@ -541,6 +542,92 @@ int eogs_knn_mean_dist2(int P, const float* points, float* mean_dist2, void* ws,
   hipStream_t s = (hipStream_t)stream;
   { ProfScope ps(PS_KNN, s); launch_knn(w, P, points, mean_dist2, s); }
   LAUNCH_TRY(s, false, "knn");
+  return EOGS_OK;
+}
+
+// ---- include/eogs_shade.h ----
+int eogs_shade_bytes(int H, int W, size_t* bytes) {
+  g_err[0] = 0;
+  if (H <= 0 || W <= 0 || !bytes) return fail(EOGS_ERR_INVALID_ARG, "shade_bytes: bad argument");
+  *bytes = shade_ws_bytes();
+  return EOGS_OK;
+}
+
+int eogs_shade_forward(int H, int W, const float* raw, const float* alt_diff, const float* M, const float* inshadow,
+                       float* cc, float* shaded, float* shadow, void* stream) {
+  g_err[0] = 0;
+  if (H <= 0 || W <= 0) return fail(EOGS_ERR_INVALID_ARG, "shade_forward: bad sizes");
+  if (!raw || !M || !shaded) return fail(EOGS_ERR_INVALID_ARG, "shade_forward: NULL argument");
+  if ((alt_diff != nullptr) != (shadow != nullptr) || (alt_diff && !inshadow))
+    return fail(EOGS_ERR_INVALID_ARG, "shade_forward: alt_diff, inshadow and shadow go together");
+  hipStream_t s = (hipStream_t)stream;
+  { ProfScope ps(PS_SHADE_FWD, s); launch_shade_fwd(H, W, raw, alt_diff, M, inshadow, cc, shaded, shadow, s); }
+  LAUNCH_TRY(s, false, "shade_fwd");
+  return EOGS_OK;
+}
+
+int eogs_shade_backward(int H, int W, const float* raw, const float* alt_diff, const float* M, const float* inshadow,
+                        const float* g_shaded, const float* g_cc, const float* g_shadow, float* g_raw,
+                        float* g_alt_diff, float* g_params, void* ws, size_t ws_bytes, void* stream) {
+  g_err[0] = 0;
+  if (H <= 0 || W <= 0) return fail(EOGS_ERR_INVALID_ARG, "shade_backward: bad sizes");
+  if (!raw || !M || !g_shaded || !g_raw || !g_params || !ws) return fail(EOGS_ERR_INVALID_ARG, "shade_backward: NULL argument");
+  if ((alt_diff != nullptr) != (g_alt_diff != nullptr) || (alt_diff && !inshadow) || (!alt_diff && g_shadow))
+    return fail(EOGS_ERR_INVALID_ARG, "shade_backward: alt_diff, inshadow and g_alt_diff go together");
+  if (ws_bytes < shade_ws_bytes()) return fail(EOGS_ERR_WORKSPACE, "shade_backward: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  { ProfScope ps(PS_SHADE_BWD, s);
+    launch_shade_bwd(H, W, raw, alt_diff, M, inshadow, g_shaded, g_cc, g_shadow, g_raw, g_alt_diff, g_params, ws, s); }
+  LAUNCH_TRY(s, false, "shade_bwd");
+  return EOGS_OK;
+}
+
+int eogs_mloss_forward(int H, int W, int mode, const float* alt_diff, const float* rgb_a, const float* rgb_b,
+                       const float* uv, float* out, void* ws, size_t ws_bytes, void* stream) {
+  g_err[0] = 0;
+  if (H <= 0 || W <= 0 || (mode != EOGS_MLOSS_SUN && mode != EOGS_MLOSS_RANDOM))
+    return fail(EOGS_ERR_INVALID_ARG, "mloss_forward: bad sizes or mode");
+  if (!alt_diff || !rgb_a || !rgb_b || !uv || !out || !ws) return fail(EOGS_ERR_INVALID_ARG, "mloss_forward: NULL argument");
+  if (ws_bytes < shade_ws_bytes()) return fail(EOGS_ERR_WORKSPACE, "mloss_forward: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  { ProfScope ps(PS_MLOSS_FWD, s); launch_mloss_fwd(H, W, mode, alt_diff, rgb_a, rgb_b, uv, out, ws, s); }
+  LAUNCH_TRY(s, false, "mloss_fwd");
+  return EOGS_OK;
+}
+
+int eogs_mloss_backward(int H, int W, int mode, const float* alt_diff, const float* rgb_a, const float* rgb_b,
+                        const float* uv, const float* out, const float* upstream, float* g_alt_diff, float* g_rgb_a,
+                        float* g_rgb_b, void* stream) {
+  g_err[0] = 0;
+  if (H <= 0 || W <= 0 || (mode != EOGS_MLOSS_SUN && mode != EOGS_MLOSS_RANDOM))
+    return fail(EOGS_ERR_INVALID_ARG, "mloss_backward: bad sizes or mode");
+  if (!alt_diff || !rgb_a || !rgb_b || !uv || !out || !upstream || !g_alt_diff || !g_rgb_a)
+    return fail(EOGS_ERR_INVALID_ARG, "mloss_backward: NULL argument");
+  hipStream_t s = (hipStream_t)stream;
+  { ProfScope ps(PS_MLOSS_BWD, s);
+    launch_mloss_bwd(H, W, mode, alt_diff, rgb_a, rgb_b, uv, out, upstream, g_alt_diff, g_rgb_a, g_rgb_b, s); }
+  LAUNCH_TRY(s, false, "mloss_bwd");
+  return EOGS_OK;
+}
+
+int eogs_tshadow_forward(int64_t n, const float* a, float* out, void* ws, size_t ws_bytes, void* stream) {
+  g_err[0] = 0;
+  if (n <= 0) return fail(EOGS_ERR_INVALID_ARG, "tshadow_forward: bad size");
+  if (!a || !out || !ws) return fail(EOGS_ERR_INVALID_ARG, "tshadow_forward: NULL argument");
+  if (ws_bytes < shade_ws_bytes()) return fail(EOGS_ERR_WORKSPACE, "tshadow_forward: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  launch_tshadow_fwd(n, a, out, ws, s);
+  LAUNCH_TRY(s, false, "tshadow_fwd");
+  return EOGS_OK;
+}
+
+int eogs_tshadow_backward(int64_t n, const float* a, const float* upstream, float* g_a, void* stream) {
+  g_err[0] = 0;
+  if (n <= 0) return fail(EOGS_ERR_INVALID_ARG, "tshadow_backward: bad size");
+  if (!a || !upstream || !g_a) return fail(EOGS_ERR_INVALID_ARG, "tshadow_backward: NULL argument");
+  hipStream_t s = (hipStream_t)stream;
+  launch_tshadow_bwd(n, a, upstream, g_a, s);
+  LAUNCH_TRY(s, false, "tshadow_bwd");
   return EOGS_OK;
 }
 

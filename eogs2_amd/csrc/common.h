@@ -9,6 +9,7 @@
 #include "eogs_optim.h"
 #include "eogs_resample.h"
 #include "eogs_knn.h"
+#include "eogs_shade.h"
 
 #define NCH EOGS_RAST_CHANNELS  // 5 feature channels
 #define TILE EOGS_RAST_TILE     // 16x16 pixel tiles: the reference's binning granularity (tile rect, radii)
@@ -393,6 +394,20 @@ size_t resample_bwd_ws_bytes(int H, int W);
 void launch_resample_bwd(int C, int Hv, int Wv, int H, int W, int n_out, const float* vr, const float* uva,
                          const float* M, int fill_channel, const float* gs, const float* guv, float* gvr, float* guva,
                          void* ws, hipStream_t s);
+
+// ---- image chain after the raw render (shade.hip, include/eogs_shade.h) ----
+size_t shade_ws_bytes();
+void launch_shade_fwd(int H, int W, const float* raw, const float* alt_diff, const float* M, const float* inshadow, float* cc,
+                      float* shaded, float* shadow, hipStream_t s);
+void launch_shade_bwd(int H, int W, const float* raw, const float* alt_diff, const float* M, const float* inshadow,
+                      const float* g_shaded, const float* g_cc, const float* g_shadow, float* g_raw, float* g_alt,
+                      float* g_params, void* ws, hipStream_t s);
+void launch_mloss_fwd(int H, int W, int mode, const float* alt_diff, const float* a, const float* b, const float* uv, float* out,
+                      void* ws, hipStream_t s);
+void launch_mloss_bwd(int H, int W, int mode, const float* alt_diff, const float* a, const float* b, const float* uv,
+                      const float* out, const float* upstream, float* g_alt, float* g_a, float* g_b, hipStream_t s);
+void launch_tshadow_fwd(int64_t n, const float* a, float* out, void* ws, hipStream_t s);
+void launch_tshadow_bwd(int64_t n, const float* a, const float* upstream, float* g_a, hipStream_t s);
 
 // ---- 3-nearest-neighbour statistic (knn.hip, include/eogs_knn.h) ----
 struct KnnWS {

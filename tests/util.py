@@ -8,7 +8,7 @@ import torch
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 _ALL_NPZ = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-GOLDEN = [n for n in _ALL_NPZ if not n.startswith("loss_")]        # rasterizer cases (make_golden.py)
+GOLDEN = [n for n in _ALL_NPZ if not n.startswith(("loss_", "shade_"))]  # rasterizer cases (make_golden.py)
 GOLDEN_LOSS = [n for n in _ALL_NPZ if n.startswith("loss_")]       # photometric-loss cases (make_golden_loss.py)
 
 # north_star tolerance: "within 1e-4 rel".  Applied as |a-b| <= RTOL * max|b| per tensor (gradient sums are
