@@ -89,12 +89,14 @@ SIGNATURES = {
     "eogs_mloss_backward": (_i, [_i, _i, _i] + [_p] * 9 + [_p]),
     "eogs_tshadow_forward": (_i, [_i64, _p, _p, _p, _z, _p]),
     "eogs_tshadow_backward": (_i, [_i64, _p, _p, _p, _p]),
+    # include/eogs_tsdf.h
+    "eogs_tsdf_integrate": (_i, [_i, _i, _i, _p, _p, _p, _p, _f, _f, _i, _i, _p, _p, _p, _p, _p]),
 }
 # symbols only the HIP library exports (the CPU oracle of the loss is oracle/loss_oracle.py, not a C-ABI twin)
 HIP_ONLY = ("eogs_loss_bytes", "eogs_loss_forward", "eogs_loss_backward", "eogs_adam_step", "eogs_compact_bytes",
             "eogs_compact_plan", "eogs_compact_apply", "eogs_resample_forward", "eogs_resample_bytes", "eogs_resample_backward", "eogs_knn_bytes",
             "eogs_knn_mean_dist2", "eogs_shade_bytes", "eogs_shade_forward", "eogs_shade_backward", "eogs_mloss_forward",
-            "eogs_mloss_backward", "eogs_tshadow_forward", "eogs_tshadow_backward")
+            "eogs_mloss_backward", "eogs_tshadow_forward", "eogs_tshadow_backward", "eogs_tsdf_integrate")
 
 
 class AdamTensor(C.Structure):
@@ -135,7 +137,7 @@ class RastABI:
             raise RastError(code, self.cdll.eogs_rast_last_error().decode())
 
     def __getattr__(self, name):
-        short = name.startswith(("loss_", "adam_", "compact_", "resample_", "knn_", "shade_", "mloss_", "tshadow_"))
+        short = name.startswith(("loss_", "adam_", "compact_", "resample_", "knn_", "shade_", "mloss_", "tshadow_", "tsdf_"))
         return getattr(self.cdll, ("eogs_" if short else "eogs_rast_") + name)
 
     def profile_slot_names(self):

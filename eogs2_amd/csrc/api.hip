@@ -56,10 +56,10 @@ int check_launch(hipStream_t s, bool debug, const char* what) {
 }
 // ---- optional per-kernel-group timing with hipEvents on the launch stream ----
 enum { PS_PREPROCESS, PS_DEPTH_SORT, PS_BINNING, PS_RENDER_FWD, PS_RENDER_BWD, PS_GAUSS_BWD, PS_LOSS_FWD, PS_LOSS_BWD, PS_ADAM,
-       PS_COMPACT, PS_RESAMPLE_FWD, PS_RESAMPLE_BWD, PS_KNN, PS_SHADE_FWD, PS_SHADE_BWD, PS_MLOSS_FWD, PS_MLOSS_BWD, PS_COUNT };
+       PS_COMPACT, PS_RESAMPLE_FWD, PS_RESAMPLE_BWD, PS_KNN, PS_SHADE_FWD, PS_SHADE_BWD, PS_MLOSS_FWD, PS_MLOSS_BWD, PS_TSDF, PS_COUNT };
 const char* const kSlotNames[PS_COUNT] = {"preprocess_fwd", "depth_sort", "binning", "render_fwd", "render_bwd", "gaussian_bwd",
                                           "loss_fwd", "loss_bwd", "adam", "compact", "resample_fwd", "resample_bwd", "knn",
-                                          "shade_fwd", "shade_bwd", "mloss_fwd", "mloss_bwd"};
+                                          "shade_fwd", "shade_bwd", "mloss_fwd", "mloss_bwd", "tsdf"};
 struct Pending { int slot; hipEvent_t a, b; };
 // process-wide (autograd runs backward on its own thread), guarded by g_prof_mu
 std::mutex g_prof_mu;
@@ -628,6 +628,24 @@ int eogs_tshadow_backward(int64_t n, const float* a, const float* upstream, floa
   hipStream_t s = (hipStream_t)stream;
   launch_tshadow_bwd(n, a, upstream, g_a, s);
   LAUNCH_TRY(s, false, "tshadow_bwd");
+  return EOGS_OK;
+}
+
+// ---- include/eogs_tsdf.h ----
+int eogs_tsdf_integrate(int nx, int ny, int nz, const float* ax, const float* ay, const float* az, const float* affine,
+                        float model_scale, float trunc_margin, int H, int W, const float* altitude, const float* weight,
+                        float* tsdf_vol, float* weight_vol, void* stream) {
+  g_err[0] = 0;
+  if (nx < 0 || ny < 0 || nz < 0 || H <= 0 || W <= 0) return fail(EOGS_ERR_INVALID_ARG, "tsdf_integrate: bad sizes");
+  if ((size_t)nx * ny * nz == 0) return EOGS_OK;
+  if ((uint64_t)nx * ny * nz > ((uint64_t)1 << 40)) return fail(EOGS_ERR_OVERFLOW, "tsdf_integrate: volume too large");
+  if (!ax || !ay || !az || !affine || !altitude || !weight || !tsdf_vol || !weight_vol)
+    return fail(EOGS_ERR_INVALID_ARG, "tsdf_integrate: NULL argument");
+  if (!(model_scale != 0.f) || !(trunc_margin > 0.f)) return fail(EOGS_ERR_INVALID_ARG, "tsdf_integrate: bad scale or truncation");
+  hipStream_t s = (hipStream_t)stream;
+  { ProfScope ps(PS_TSDF, s);
+    launch_tsdf_integrate(nx, ny, nz, ax, ay, az, affine, model_scale, trunc_margin, H, W, altitude, weight, tsdf_vol, weight_vol, s); }
+  LAUNCH_TRY(s, false, "tsdf_integrate");
   return EOGS_OK;
 }
 

@@ -10,6 +10,7 @@
 #include "eogs_resample.h"
 #include "eogs_knn.h"
 #include "eogs_shade.h"
+#include "eogs_tsdf.h"
 
 #define NCH EOGS_RAST_CHANNELS  // 5 feature channels
 #define TILE EOGS_RAST_TILE     // 16x16 pixel tiles: the reference's binning granularity (tile rect, radii)
@@ -408,6 +409,11 @@ void launch_mloss_bwd(int H, int W, int mode, const float* alt_diff, const float
                       const float* out, const float* upstream, float* g_alt, float* g_a, float* g_b, hipStream_t s);
 void launch_tshadow_fwd(int64_t n, const float* a, float* out, void* ws, hipStream_t s);
 void launch_tshadow_bwd(int64_t n, const float* a, const float* upstream, float* g_a, hipStream_t s);
+
+// ---- TSDF integration (tsdf.hip, include/eogs_tsdf.h) ----
+void launch_tsdf_integrate(int nx, int ny, int nz, const float* ax, const float* ay, const float* az, const float* affine,
+                           float scale, float trunc, int H, int W, const float* alt, const float* wgt, float* tsdf,
+                           float* wvol, hipStream_t s);
 
 // ---- 3-nearest-neighbour statistic (knn.hip, include/eogs_knn.h) ----
 struct KnnWS {

@@ -10,12 +10,12 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols(headers=("eogs_rast.h", "eogs_loss.h", "eogs_optim.h", "eogs_resample.h", "eogs_knn.h", "eogs_shade.h")):
+def header_symbols(headers=("eogs_rast.h", "eogs_loss.h", "eogs_optim.h", "eogs_resample.h", "eogs_knn.h", "eogs_shade.h", "eogs_tsdf.h")):
     out = set()
     for h in headers:
         src = open(os.path.join(ROOT, "include", h)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-        out |= set(re.findall(r"\b(eogs_(?:rast|loss|adam|compact|resample|knn|shade|mloss|tshadow)_[a-z_0-9]+)\s*\(", src))
+        out |= set(re.findall(r"\b(eogs_(?:rast|loss|adam|compact|resample|knn|shade|mloss|tshadow|tsdf)_[a-z_0-9]+)\s*\(", src))
     return sorted(out)
 
 
