@@ -67,7 +67,7 @@ def measured_traffic(kernel, a):
         except Exception:
             continue
         for name, c in pm.items():
-            if name.startswith(kernel + "_kernel") and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            if name.startswith((kernel + "_kernel", kernel + "_quad_kernel")) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 return int((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024), os.path.relpath(d, ROOT)
     return None, None
 
@@ -91,7 +91,7 @@ def measured_valu(kernel, a):
         except Exception:
             continue
         for name, c in pm.items():
-            if name.startswith(kernel + "_kernel") and "SQ_INSTS_VALU" in c:
+            if name.startswith((kernel + "_kernel", kernel + "_quad_kernel")) and "SQ_INSTS_VALU" in c:
                 return float(c["SQ_INSTS_VALU"])
     return None
 
