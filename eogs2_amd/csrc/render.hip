@@ -53,6 +53,7 @@ namespace {
 // {k + 8(o&3) + 12(o>>2) + i}: 32 different banks for the 32 (k,o) pairs of a half-wave.
 #define UV_HALF 268
 #define UV_SIZE (2 * UV_HALF)
+#define UV_PITCH 576  // >= UV_SIZE, multiple of 64 dwords
 __device__ inline int uv_index(int k, int p) { return (p >> 5) * UV_HALF + k * 33 + (p & 31); }
 
 // ---- wave64 helpers ----
@@ -511,7 +512,9 @@ __device__ inline void transpose_round(int nsurv, int lane, const float* rb, con
 
 }  // namespace
 
-template <int MACRO>
+// HAVE_INV: an upstream gradient of the inverse-depth image exists (the reference always materialises a zero one,
+// renderer.py:101 never consumes invdepths; here the common case compiles the term away).
+template <int MACRO, bool HAVE_INV>
 __global__ __launch_bounds__(BLK) void render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx,
     const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib,
@@ -519,8 +522,8 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
     const float* __restrict__ dL_dinv, float* __restrict__ records, uint8_t* __restrict__ live_flag) {
   __shared__ __attribute__((aligned(16))) float s_slab[BLK / 64][64 * ENT];
   __shared__ __attribute__((aligned(16))) float s_round[BLK / 64][KSURV * 8];
-  __shared__ __attribute__((aligned(16))) float s_u[BLK / 64][UV_SIZE];
-  __shared__ __attribute__((aligned(16))) float s_v[BLK / 64][UV_SIZE];
+  // u and v matrices of a wave sit UV_PITCH floats (a multiple of 64 dwords) apart: one ds_write2st64_b32 stores both
+  __shared__ __attribute__((aligned(16))) float s_uv[BLK / 64][UV_PITCH + UV_SIZE];
   __shared__ __attribute__((aligned(16))) float s_pix[BLK / 64][64 * 8 + 32];
   __shared__ uint32_t s_slot[BLK / 64][64];
   const int lane = threadIdx.x & 63;
@@ -528,8 +531,8 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
   if (tile >= ntiles) return;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   float* slab = s_slab[w];
-  float* su = s_u[w];
-  float* sv = s_v[w];
+  float* su = s_uv[w];
+  float* sv = s_uv[w] + UV_PITCH;
   float* spix = s_pix[w];
   uint32_t* sslot = s_slot[w];
   float* rb = s_round[w];
@@ -542,7 +545,7 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
   const uint2 range = ranges[(fty / MACRO) * gmx + ftx / MACRO];  // the macro block's list
   const uint32_t sub = (uint32_t)((fty % MACRO) * MACRO + ftx % MACRO);
   const size_t HW = (size_t)H * W;
-  const bool have_inv = dL_dinv != nullptr;
+  constexpr bool have_inv = HAVE_INV;
 
   float g[NCH] = {0.f, 0.f, 0.f, 0.f, 0.f};
   float ginv = 0.f, Dfinal = 0.f;
@@ -569,6 +572,7 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
   const float kx = LN2 * 0.5f * W, ky = LN2 * 0.5f * H;  // d(pixel)/d(ndc) times the ln2 of the log2-domain conic
   const float bx0 = (float)tx0, by0 = (float)ty0;
   float T = 1.0f, Dacc = 0.f;
+  float* const uvlane = su + uv_index(0, lane);
 
   // the block's list is only walked until this tile's last contributor has been seen: entries behind it are dead
   // (never gathered, never written). Positions count the tile's own entries, exactly as in the forward kernel.
@@ -615,8 +619,9 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
       const float one_m = 1.f - a_eff;
       const float dLda = T * gc - (Dfinal - Dacc) * __builtin_amdgcn_rcpf(one_m);
       T = T * one_m;
-      su[uv_index(k, lane)] = wgt;
-      sv[uv_index(k, lane)] = G_eff * dLda;  // v = G dL/dalpha
+      float* const uv = uvlane + k * 33;  // = su + uv_index(k, lane); k is wave-uniform
+      uv[0] = wgt;
+      uv[UV_PITCH] = G_eff * dLda;  // v = G dL/dalpha
       kj |= (unsigned long long)j << (8 * k);
       if (++k == KSURV) {
         stash(kstashed, KSURV);
@@ -655,7 +660,8 @@ void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, 
                        const float* dL_dinvdepth, hipStream_t s) {
   const int gsx = (W + SUBX - 1) / SUBX, gsy = (H + SUBY - 1) / SUBY, ntiles = gsx * gsy;
   (void)R;  // live flags are cleared once per forward (tile_ranges_kernel)
-  auto* kern = b.block > 1 ? render_bwd_kernel<BLOCK_BIG> : render_bwd_kernel<1>;
+  auto* kern = b.block > 1 ? (dL_dinvdepth ? render_bwd_kernel<BLOCK_BIG, true> : render_bwd_kernel<BLOCK_BIG, false>)
+                           : (dL_dinvdepth ? render_bwd_kernel<1, true> : render_bwd_kernel<1, false>);
   hipLaunchKernelGGL(kern, dim3(render_grid(ntiles)), dim3(BLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H, gsx,
                      ntiles, (int)macro_grid_x(W, b.block), g.packed, im.n_contrib, out_color, out_invdepth, dL_dcolor,
                      dL_dinvdepth, b.records, b.live);
