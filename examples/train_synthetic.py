@@ -4,10 +4,14 @@
     python examples/train_synthetic.py [--gaussians 200000] [--size 512] [--iters 200]
 
 Per iteration: render the view through `eogs2_amd.render.render` (raw-parameter front end, §8 f1), render a sun-like
-virtual camera at twice the resolution and resample it onto the view (`eogs2_amd.resample`, §8 f2), photometric loss
-against a target image (`eogs2_amd.losses.photometric_loss`, §8 f2) plus an altitude-consistency term on the resample,
-`FusedAdam` step (§8 f3), transparent-Gaussian prune by stream compaction (`prune_optimizer`, §8 f3). The target is the
-render of the unperturbed scene, so the loss must fall. Initial scales come from `simple_knn._C.distCUDA2` (§8 f4).
+virtual camera at twice the resolution and resample it onto the view (`eogs2_amd.resample`, §8 f2), run the camera's
+render pipeline — learnable colour correction, shadow map from the altitude difference, in-shadow tint
+(`eogs2_amd.shade.render_pipeline`, §8 f2) —, photometric loss against a target image
+(`eogs2_amd.losses.photometric_loss`) plus the sun-camera consistency pair and the translucent-shadow regulariser
+(`eogs2_amd.shade.suncamera_l`, `translucentshadows_l`), `FusedAdam` step on the Gaussians and Adam on the camera
+parameters (§8 f3), transparent-Gaussian prune by stream compaction (`prune_optimizer`, §8 f3). The target is the shaded
+render of the unperturbed scene under an identity colour correction, so the loss must fall. Initial scales come from
+`simple_knn._C.distCUDA2` (§8 f4).
 """
 import argparse
 import math
@@ -24,6 +28,7 @@ from eogs2_amd.losses import photometric_loss  # noqa: E402
 from eogs2_amd.optim import FusedAdam, prune_optimizer  # noqa: E402
 from eogs2_amd.render import render  # noqa: E402
 from eogs2_amd.resample import resample  # noqa: E402
+from eogs2_amd.shade import render_pipeline, suncamera_l, translucentshadows_l  # noqa: E402
 from eogs2_amd.synthetic import make_camera, make_scene  # noqa: E402
 from simple_knn._C import distCUDA2  # noqa: E402
 
@@ -88,10 +93,32 @@ def main(argv=None):
     bg = sc["bg"]
     U, V = torch.meshgrid(torch.linspace(-1, 1, W, device=dev), torch.linspace(-1, 1, H, device=dev), indexing="xy")
 
+    def view(m, cc_cam):
+        """train_pan.py:279-330: view render, sun render resampled onto the view, camera render pipeline."""
+        out = render(cam, m, pipe, bg)
+        img, altitude = out["render"][:3], out["render"][3]
+        sun_img = render(sun, m, pipe, bg)["render"]
+        sample, sun_uv = resample(sun_img, cam2sun, torch.stack((U, V, altitude / 350.0), dim=-1))
+        sun_altitude_diff = altitude - sample[3]
+        shaded = render_pipeline(cc_cam, img, sun_altitude_diff)
+        return out, img, sample, sun_uv, sun_altitude_diff, shaded
+
+    def colour_camera(perturb):
+        c = types.SimpleNamespace(use_cc=True, use_exposure=False, use_shadow=True)
+        c.color_correction = torch.nn.Conv2d(3, 3, 1, bias=True).to(dev)  # affine_cameras.py:219-231
+        with torch.no_grad():
+            c.color_correction.weight.copy_((torch.eye(3) + perturb * torch.randn(3, 3, generator=gcam)).reshape(3, 3, 1, 1))
+            c.color_correction.bias.zero_()
+        c.inshadow_color_correction = torch.nn.Parameter(torch.full((3, 1, 1), 0.05, device=dev))
+        return c
+
+    gcam = torch.Generator().manual_seed(2)
     target_model = Gaussians(sc["means3D"], sc["colors"][:, :3], sc["opacities"].squeeze(1).clamp(1e-4, 1 - 1e-4),
                              sc["scales"], sc["rotations"])
     with torch.no_grad():
-        gt = render(cam, target_model, pipe, bg)["render"][:3].clone()
+        gt = view(target_model, colour_camera(0.0))[5]["final"].clone()
+    cc_cam = colour_camera(0.15)
+    camera_optimizer = torch.optim.Adam([*cc_cam.color_correction.parameters(), cc_cam.inshadow_color_correction], lr=2e-3)
 
     # the trainee: perturbed colours / opacities / positions, scales re-initialised from the 3-NN statistic
     g = torch.Generator().manual_seed(1)
@@ -103,15 +130,15 @@ def main(argv=None):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for it in range(1, a.iters + 1):
-        out = render(cam, model, pipe, bg)
-        img, altitude = out["render"][:3], out["render"][3]
-        sun_img = render(sun, model, pipe, bg)["render"]
-        sample, _ = resample(sun_img, cam2sun, torch.stack((U, V, altitude / 350.0), dim=-1))
-        loss, _ = photometric_loss(img, gt, 0.2)
-        loss = loss + 1e-4 * (sample[3] - altitude).clamp(-5, 5).abs().mean()
+        out, img, sample, sun_uv, sun_altitude_diff, shaded = view(model, cc_cam)
+        loss, _ = photometric_loss(shaded["final"], gt, 0.2)
+        L_sun_alt, L_sun_rgb = suncamera_l(img, sample[:3], sun_altitude_diff, sun_uv)
+        loss = loss + 1e-4 * L_sun_alt + 1e-3 * L_sun_rgb + 1e-3 * translucentshadows_l(shaded["shadowmap"])
         loss.backward()
         model.optimizer.step()
+        camera_optimizer.step()
         model.optimizer.zero_grad(set_to_none=True)
+        camera_optimizer.zero_grad(set_to_none=True)
         with torch.no_grad():
             model.max_radii2D = torch.maximum(model.max_radii2D, out["radii"].float())
             if it % 50 == 0:  # train_pan.py:673-678
@@ -127,7 +154,7 @@ def main(argv=None):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if not a.quiet:
-        print(f"{a.iters} iterations in {dt:.2f} s ({dt / a.iters * 1e3:.2f} ms/iter, 2 renders + resample + loss + Adam each)")
+        print(f"{a.iters} iterations in {dt:.2f} s ({dt / a.iters * 1e3:.2f} ms/iter, 2 renders + resample + render pipeline + losses + Adam each)")
     return first, last, model._xyz.shape[0]
 
 

@@ -1,4 +1,5 @@
-"""GPU: the end-to-end example (render -> resample -> loss -> FusedAdam -> prune, all on the HIP library) optimises."""
+"""GPU: the end-to-end example (render -> resample -> camera render pipeline -> losses -> FusedAdam -> prune, all on the
+HIP library) optimises."""
 import os
 import sys
 
