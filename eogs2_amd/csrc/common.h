@@ -22,7 +22,9 @@
 #define MASK_MAX_SUBTILES 64    // Gaussians whose 16-px rect spans <= 64 internal tiles carry an exact hit mask
 #define BLK 256                 // threads per workgroup everywhere (4 wave64)
 #define NFEAT 6                 // staged per-Gaussian features: 5 colours + 1/depth
-#define REC 12                  // floats per (tile,Gaussian) gradient record (48 B, 11 used)
+#ifndef REC
+#define REC 16                  // floats per (tile,Gaussian) gradient record: one whole 64-byte line (11 used)
+#endif
 
 // ---- misc[] slots (u32) in the geometry workspace ----
 #define MISC_TOTAL_LO 0  // sum of tiles_touched (u64, lo/hi)

@@ -451,9 +451,9 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
   for (int k = 0; k < 18; k++) vmsum[k] = 0.f;
 
   if (t < rows) {
-    float acc[REC];
+    float acc[12];
 #pragma unroll
-    for (int k = 0; k < REC; k++) acc[k] = 0.f;
+    for (int k = 0; k < 12; k++) acc[k] = 0.f;
     const bool visible = radii[idx] > 0;
     if (visible) {
       // fixed-order sum of this Gaussian's (tile,Gaussian) records: deterministic, no atomics
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             const uint32_t qq = have[u] ? q[u] : q[0];  // a valid address either way
-            ra[u] = r4[3 * qq]; rb[u] = r4[3 * qq + 1]; rc[u] = r4[3 * qq + 2];
+            ra[u] = r4[(REC / 4) * qq]; rb[u] = r4[(REC / 4) * qq + 1]; rc[u] = r4[(REC / 4) * qq + 2];
           }
 #pragma unroll
           for (int u = 0; u < 4; u++) {

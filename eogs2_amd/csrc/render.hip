@@ -29,7 +29,7 @@
 //     transposition through LDS: the pixel-parallel pass only produces two numbers per (pixel, Gaussian),
 //     u = alpha T and v = G dL/dalpha; every 8 surviving Gaussians the wave switches to lanes = (Gaussian,
 //     pixel row) and accumulates the six moments of v and the five colour sums of u serially in registers
-//     (see transpose_round). No cross-lane reduction tree, no atomics, and ONE 48-byte record per
+//     (see transpose_round). No cross-lane reduction tree, no atomics, and ONE record (11 floats in a 64-byte line) per
 //     (tile,Gaussian) pair written with plain stores by the only wave that owns the pair (plus a 1-byte live flag:
 //     pairs behind every pixel's last contributor are never gathered nor written); gaussian_bwd_kernel sums each
 //     Gaussian's live records in fixed order (bitwise reproducible gradients).
@@ -506,6 +506,7 @@ __device__ inline void transpose_round(int nsurv, int lane, const float* rb, con
     dst[0] = make_float4(m2x, m2y, ho * acc[3], ho * acc[4]);
     dst[1] = make_float4(ho * acc[5], acc[0], acc[6], acc[7]);
     dst[2] = make_float4(acc[8], acc[9], acc[10], 0.f);
+    if (REC == 16) dst[3] = make_float4(0.f, 0.f, 0.f, 0.f);  // whole 64-byte line: no partial-line write
     live_flag[slot] = 1;  // pairs that never get here keep the 0 of the memset and are skipped by gaussian_bwd
   }
 }
