@@ -134,4 +134,29 @@ def prune_optimizer(optimizer, mask, extra=()):
     return optimizable, out[i:]
 
 
-__all__ = ["FusedAdam", "compact_rows", "prune_optimizer"]
+def reset_opacity(optimizer, name="opacity", cap=0.01):
+    """`GaussianModel.reset_opacity` (gaussian_model.py:347-352) with `replace_tensor_to_optimizer` (:451-464): the
+    opacity logits are capped at logit(`cap`), both Adam moments of the group restart at zero, the group gets a new
+    Parameter. Runs every `opacity_reset_interval` = 3000 iterations (gs_config/train.yaml:104): two elementwise PyTorch
+    ops, not a kernel of this library. Returns {name: new nn.Parameter}."""
+    out = {}
+    for group in optimizer.param_groups:
+        if group["name"] != name:
+            continue
+        p = group["params"][0]
+        with torch.no_grad():
+            o = torch.min(torch.sigmoid(p), torch.ones_like(p) * cap)
+            new = torch.log(o / (1 - o))  # general_utils.inverse_sigmoid
+        st = optimizer.state.get(p, None)
+        if st is not None:
+            st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(new), torch.zeros_like(new)
+            del optimizer.state[p]
+        new_p = nn.Parameter(new.requires_grad_(True))
+        group["params"][0] = new_p
+        if st is not None:
+            optimizer.state[new_p] = st
+        out[name] = new_p
+    return out
+
+
+__all__ = ["FusedAdam", "compact_rows", "prune_optimizer", "reset_opacity"]

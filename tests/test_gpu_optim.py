@@ -95,3 +95,31 @@ def test_prune_optimizer_keeps_training_state(dev):
         p.grad = torch.ones_like(p)
     opt.step()
     assert all(int(opt.state[gr["params"][0]]["step"]) == 2 for gr in opt.param_groups)
+
+
+def test_reset_opacity_caps_logits_and_restarts_moments(dev):
+    """gaussian_model.py:347-352,451-464: opacities above 0.01 are capped, smaller ones kept, the group's Adam moments
+    restart at zero under a new Parameter, every other group is untouched, and the optimizer keeps stepping."""
+    from eogs2_amd.optim import FusedAdam, reset_opacity
+
+    P = 5_000
+    opt = FusedAdam(_groups(P, dev, seed=5), lr=0.0, eps=1e-15)
+    for gr in opt.param_groups:
+        gr["params"][0].grad = torch.ones_like(gr["params"][0])
+    opt.step()
+    others = {gr["name"]: gr["params"][0] for gr in opt.param_groups if gr["name"] != "opacity"}
+    old = next(gr["params"][0] for gr in opt.param_groups if gr["name"] == "opacity").detach().clone()
+    out = reset_opacity(opt)
+    new = next(gr["params"][0] for gr in opt.param_groups if gr["name"] == "opacity")
+    assert out["opacity"] is new and new.requires_grad and len(opt.state) == len(opt.param_groups)
+    expect = torch.min(torch.sigmoid(old), torch.full_like(old, 0.01))
+    assert torch.allclose(torch.sigmoid(new.detach()), expect, rtol=1e-5, atol=1e-8)
+    assert float(torch.sigmoid(new.detach()).max()) <= 0.01 * (1 + 1e-5)
+    st = opt.state[new]
+    assert float(st["exp_avg"].abs().max()) == 0.0 and float(st["exp_avg_sq"].abs().max()) == 0.0 and int(st["step"]) == 1
+    for gr in opt.param_groups:
+        if gr["name"] != "opacity":
+            assert gr["params"][0] is others[gr["name"]]
+        gr["params"][0].grad = torch.ones_like(gr["params"][0])
+    opt.step()
+    assert int(opt.state[new]["step"]) == 2
