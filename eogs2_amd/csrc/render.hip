@@ -656,13 +656,252 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
 }
 
 
-void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int H, int W, int64_t R, const float* colors,
+
+// ------------------------------------------------------------------------------------------------------
+// Backward with quad sub-lists (per-tile lists, small footprints)
+// ------------------------------------------------------------------------------------------------------
+// Same decomposition as render_fwd_quad_kernel: every quad (16 lanes, 4x4 pixels) walks its own sub-list of the chunk's
+// entries, so one trip of the pixel-parallel loop evaluates four DIFFERENT entries and the trip count falls to the longest
+// sub-list. A transposition round covers 8 trips: lane (k = lane >> 3, q = (lane >> 1) & 3, h = lane & 1) owns trip k,
+// quad q and two pixel rows of that quad (8 pixels; the u/v matrix layout of render_bwd_kernel carries over because the
+// pixel index is the lane in both phases), accumulates the six moments and five colour sums in registers and merges the
+// two halves with one DPP step. An entry is visited by up to four quads in different trips, and its partial sums must end
+// in ONE record: the (k, q) lanes park their 11 partials in a staging area (plain stores, aliasing the u matrix that has
+// just been consumed), and the entry's OWNER lane (lane i = entry i of the chunk, which knows from the sub-list build at
+// which trip each quad visits it) pulls them into 11 register accumulators, quads in fixed order. No LDS atomics (measured:
+// ds_add_f32 merges made this kernel 2x slower), bitwise reproducible, and the record is written once per
+// chunk by the owner exactly as transpose_round writes it.
+namespace {
+
+#define QB 80     // bytes per quad sub-list in backward (64 entries + pipelined over-read)
+#define STG 12    // floats per staged (trip, quad) partial: 11 used
+
+// Transposition of one round of `nk` trips (trips 8 r .. 8 r + nk - 1 of the chunk).
+__device__ inline void transpose_round_quad(int nk, int r, int lane, const uint8_t* sidx, const float* slab, float* s_u,
+                                            const float* s_v, const float* s_pix, float bx0, float by0) {
+  const int k = lane >> 3, o = lane & 7, q = o >> 1, h = o & 1;
+  const uint32_t idx = sidx[q * QB + 8 * r + k];  // the entry quad q evaluated in trip k (any staged byte is a valid position)
+  const float2 gxy = *reinterpret_cast<const float2*>(slab + idx * ENT);
+  const float gxr = gxy.x - (bx0 + (float)(4 * (q & 1)));  // centre relative to the quad's first column
+  const float dy0 = gxy.y - (by0 + (float)(4 * (q >> 1) + 2 * h)), dy1 = dy0 - 1.f;
+  float S0a = 0.f, Sxa = 0.f, Sxxa = 0.f, S0b = 0.f, Sxb = 0.f, Sxxb = 0.f;
+  float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f, c4 = 0.f;
+  const float* urow = s_u + uv_index(k, 8 * o);
+  const float* vrow = s_v + uv_index(k, 8 * o);
+  const float* prow = s_pix + (8 * o) * 8 + 4 * o;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const float u = urow[i], v = vrow[i];
+    const float4 ga = *reinterpret_cast<const float4*>(prow + i * 8);
+    const float gb = prow[i * 8 + 4];
+    const float dx = gxr - (float)(i & 3);
+    const float t1 = v * dx;
+    if (i < 4) { S0a += v; Sxa += t1; Sxxa += t1 * dx; }
+    else { S0b += v; Sxb += t1; Sxxb += t1 * dx; }
+    c0 += u * ga.x; c1 += u * ga.y; c2 += u * ga.z; c3 += u * ga.w; c4 += u * gb;
+  }
+  float c[11] = {S0a + S0b, Sxa + Sxb, dy0 * S0a + dy1 * S0b, Sxxa + Sxxb, dy0 * Sxa + dy1 * Sxb,
+                 dy0 * dy0 * S0a + dy1 * dy1 * S0b, c0, c1, c2, c3, c4};
+  DPP_STEP11("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1");  // lane h = 1 += lane h = 0
+  // every lane has read its u/v above (LDS instructions of a wave execute in order): the u matrix becomes the staging area
+  if (h == 1 && k < nk) {
+    float4* st = reinterpret_cast<float4*>(s_u + (k * 4 + q) * STG);
+    st[0] = make_float4(c[0], c[1], c[2], c[3]);
+    st[1] = make_float4(c[4], c[5], c[6], c[7]);
+    st[2] = make_float4(c[8], c[9], c[10], 0.f);
+  }
+}
+
+}  // namespace
+
+template <bool HAVE_INV>
+__global__ __launch_bounds__(BLK) void render_bwd_quad_kernel(
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx,
+    const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib,
+    const float* __restrict__ out_color, const float* __restrict__ out_invdepth, const float* __restrict__ dL_dpix,
+    const float* __restrict__ dL_dinv, float* __restrict__ records, uint8_t* __restrict__ live_flag) {
+  __shared__ __attribute__((aligned(16))) float s_slab[BLK / 64][64 * ENT];
+  __shared__ __attribute__((aligned(16))) float s_uv[BLK / 64][UV_PITCH + UV_SIZE];
+  __shared__ __attribute__((aligned(16))) float s_pix[BLK / 64][64 * 8 + 32];
+  __shared__ __attribute__((aligned(16))) uint8_t s_idx[BLK / 64][4 * QB];
+  static_assert(32 * STG <= UV_SIZE, "the staging area lives inside the u matrix");
+  const int lane = threadIdx.x & 63;
+  const int tile = tile_of_wave();
+  if (tile >= ntiles) return;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float* slab = s_slab[w];
+  float* su = s_uv[w];
+  float* sv = s_uv[w] + UV_PITCH;
+  float* spix = s_pix[w];
+  uint8_t* sidx = s_idx[w];
+  int ox, oy;
+  quad_pixel(lane, ox, oy);
+  const int tx0 = (tile % gsx) * SUBX, ty0 = (tile / gsx) * SUBY;
+  const int px = tx0 + ox, py = ty0 + oy;
+  const bool inside = px < W && py < H;
+  const uint32_t pix_id = (uint32_t)py * (uint32_t)W + (uint32_t)px;
+  const float pxf = (float)px, pyf = (float)py;
+  const uint2 range = ranges[tile];
+  const size_t HW = (size_t)H * W;
+  const int myq = lane >> 4;
+  const uint8_t* myidx = sidx + myq * QB;
+
+  float g[NCH] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  float ginv = 0.f, Dfinal = 0.f;
+  uint32_t ncontrib = 0;
+  if (inside) {
+    ncontrib = n_contrib[pix_id];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) {
+      g[ch] = dL_dpix[ch * HW + pix_id];
+      Dfinal += g[ch] * out_color[ch * HW + pix_id];
+    }
+    if (HAVE_INV) {
+      ginv = dL_dinv[pix_id];
+      Dfinal += ginv * out_invdepth[pix_id];
+    }
+  }
+  {  // pixel gradients for the transposition rounds: 8 floats per pixel (pixel index = lane), +4 floats per 8 pixels
+    float* d = spix + lane * 8 + 4 * (lane >> 3);
+    *reinterpret_cast<float4*>(d) = make_float4(g[0], g[1], g[2], g[3]);
+    d[4] = g[4];
+  }
+  for (int t = lane; t < 4 * QB / 4; t += 64) reinterpret_cast<uint32_t*>(sidx)[t] = 0u;  // over-read bytes: valid positions
+  const uint32_t tile_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(ncontrib));
+  const float kx = LN2 * 0.5f * W, ky = LN2 * 0.5f * H;
+  const float bx0 = (float)tx0, by0 = (float)ty0;
+  float T = 1.0f, Dacc = 0.f;
+  float* const uvlane = su + uv_index(0, lane);
+
+  uint32_t jbase = 0;
+  Cand nxt = gather_cand<1>(peek_cand<1>(range.x + lane, range.y, keys, point_list), 0u, packed);
+  Peek pk = peek_cand<1>(range.x + 64 + lane, range.y, keys, point_list);
+  for (uint32_t c0 = range.x; c0 < range.y && jbase < tile_last; c0 += 64) {
+    wave_lds_sync();
+    int nq[4];
+    uint32_t myranks = 0xFFFFFFFFu;  // byte q: the trip in which quad q evaluates this lane's entry (0xFF: never)
+    {
+      const uint32_t qm = nxt.hit ? quad_mask(nxt, bx0, by0) : 0u;
+      // per-tile lists: the in-range entries are lanes 0..jn-1, parked at their own lane index
+      const bool listed = nxt.hit && jbase + (uint32_t)lane < tile_last;  // entries behind the last contributor are dead
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const bool in = listed && ((qm >> q) & 1u);
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(in);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (in) {
+          sidx[q * QB + (int)rank] = (uint8_t)lane;
+          myranks = (myranks & ~(0xFFu << (8 * q))) | (rank << (8 * q));
+        }
+        nq[q] = (int)__popcll(bal);
+      }
+    }
+    const uint32_t cur_slot = nxt.slot;
+    const int jn = park(slab, nullptr, lane, nxt, 0);
+    nxt = gather_cand<1>(pk, 0u, packed);
+    pk = peek_cand<1>(c0 + 128 + lane, range.y, keys, point_list);
+    wave_lds_sync();
+    const int nmax = max(max(nq[0], nq[1]), max(nq[2], nq[3]));
+    const int nmine = myq == 0 ? nq[0] : (myq == 1 ? nq[1] : (myq == 2 ? nq[2] : nq[3]));
+    float acc[11];
+#pragma unroll
+    for (int t = 0; t < 11; t++) acc[t] = 0.f;
+
+    // one round: transposition of `nk` trips, then every owner lane pulls the partials of its entry
+    auto round = [&](int r, int nk) {
+      wave_lds_sync();
+      transpose_round_quad(nk, r, lane, sidx, slab, su, sv, spix, bx0, by0);
+      wave_lds_sync();
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t rk = (myranks >> (8 * q)) & 0xFFu;
+        const bool mine = rk != 0xFFu && (int)(rk >> 3) == r;
+        if (__builtin_amdgcn_ballot_w64(mine) == 0ull) continue;
+        if (mine) {
+          const float4* st = reinterpret_cast<const float4*>(su + ((rk & 7u) * 4u + (uint32_t)q) * STG);
+          const float4 a0 = st[0], a1 = st[1], a2 = st[2];
+          acc[0] += a0.x; acc[1] += a0.y; acc[2] += a0.z; acc[3] += a0.w;
+          acc[4] += a1.x; acc[5] += a1.y; acc[6] += a1.z; acc[7] += a1.w;
+          acc[8] += a2.x; acc[9] += a2.y; acc[10] += a2.z;
+        }
+      }
+      wave_lds_sync();  // the next trips overwrite the u matrix
+    };
+    auto grad = [&](const Ent& e, int pos, int j) {
+      const float dx = e.q0.x - pxf, dy = e.q0.y - pyf;
+      const float p = (e.q0.z * dx - e.q0.w * dy) * dx + e.q1.x * dy * dy;
+      const float G = __builtin_amdgcn_exp2f(p);
+      const float alpha = fminf(e.q1.y * G, 0.99f);
+      const bool valid = (j < nmine) && (jbase + (uint32_t)pos < ncontrib) && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);
+      float gc = g[0] * e.q1.z + g[1] * e.q1.w + g[2] * e.q2.x + g[3] * e.q2.y + g[4] * e.q2.z;
+      if (HAVE_INV) gc += ginv * e.q2.w;
+      const float a_eff = valid ? alpha : 0.f;
+      const float G_eff = valid ? G : 0.f;
+      const float wgt = a_eff * T;
+      Dacc += gc * wgt;
+      const float one_m = 1.f - a_eff;
+      const float dLda = T * gc - (Dfinal - Dacc) * __builtin_amdgcn_rcpf(one_m);
+      T = T * one_m;
+      float* const uv = uvlane + (j & 7) * 33;  // trip j is slot j & 7 of round j >> 3 (trips are never skipped)
+      uv[0] = wgt;
+      uv[UV_PITCH] = G_eff * dLda;  // v = G dL/dalpha
+      if ((j & 7) == 7) round(j >> 3, KSURV);
+    };
+    if (nmax > 0) {
+      int i0 = myidx[0], i1 = myidx[1];
+      Ent ea = fetch(slab, i0);
+      int j = 0;
+      for (; j + 1 < nmax; j += 2) {
+        const Ent eb = fetch(slab, i1);
+        const int i2 = myidx[j + 2];
+        grad(ea, i0, j);
+        ea = fetch(slab, i2);
+        const int i3 = myidx[j + 3];
+        grad(eb, i1, j + 1);
+        i0 = i2;
+        i1 = i3;
+      }
+      if (j < nmax) grad(ea, i0, j);
+      if (nmax & 7) round(nmax >> 3, nmax & 7);  // the chunk's last, partial round
+      // entry `lane`: accumulated moments -> record (backward.cu:624-640, as in transpose_round)
+      bool any = false;
+#pragma unroll
+      for (int t = 0; t < 11; t++) any = any || acc[t] != 0.f;
+      if (lane < jn && any) {
+        const float4 q0 = *reinterpret_cast<const float4*>(slab + lane * ENT);
+        const float2 q1 = *reinterpret_cast<const float2*>(slab + lane * ENT + 4);
+        const float A = q0.z, B = q0.w, Cq = q1.x, op = q1.y;
+        const float m2x = op * kx * (2.f * A * acc[1] - B * acc[2]);
+        const float m2y = op * ky * (2.f * Cq * acc[2] - B * acc[1]);
+        const float ho = -0.5f * op;
+        float4* dst = reinterpret_cast<float4*>(records + (size_t)cur_slot * REC);
+        dst[0] = make_float4(m2x, m2y, ho * acc[3], ho * acc[4]);
+        dst[1] = make_float4(ho * acc[5], acc[0], acc[6], acc[7]);
+        dst[2] = make_float4(acc[8], acc[9], acc[10], 0.f);
+        if (REC == 16) dst[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+        live_flag[cur_slot] = 1;
+      }
+    }
+    jbase += (uint32_t)jn;
+  }
+}
+
+static double quad_bwd_switch() {  // EOGS_QUAD_BWD_SWITCH=<listed tiles per Gaussian>, 0 disables the quad backward
+  static const double v = [] {
+    const char* e = getenv("EOGS_QUAD_BWD_SWITCH");
+    return e ? atof(e) : EOGS_QUAD_SWITCH_DEFAULT;
+  }();
+  return v;
+}
+
+void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, const float* colors,
                        const float* out_color, const float* out_invdepth, const float* dL_dcolor,
                        const float* dL_dinvdepth, hipStream_t s) {
   const int gsx = (W + SUBX - 1) / SUBX, gsy = (H + SUBY - 1) / SUBY, ntiles = gsx * gsy;
-  (void)R;  // live flags are cleared once per forward (tile_ranges_kernel)
   auto* kern = b.block > 1 ? (dL_dinvdepth ? render_bwd_kernel<BLOCK_BIG, true> : render_bwd_kernel<BLOCK_BIG, false>)
                            : (dL_dinvdepth ? render_bwd_kernel<1, true> : render_bwd_kernel<1, false>);
+  if (b.block == 1 && quad_bwd_switch() > 0.0 && (double)nr_slots(R) <= quad_bwd_switch() * (double)P)
+    kern = dL_dinvdepth ? render_bwd_quad_kernel<true> : render_bwd_quad_kernel<false>;
   hipLaunchKernelGGL(kern, dim3(render_grid(ntiles)), dim3(BLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H, gsx,
                      ntiles, (int)macro_grid_x(W, b.block), g.packed, im.n_contrib, out_color, out_invdepth, dL_dcolor,
                      dL_dinvdepth, b.records, b.live);
