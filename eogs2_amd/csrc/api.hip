@@ -207,7 +207,7 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
   const uint64_t entries_big = (uint64_t)g_pinned[MISC_MACRO_LO] | ((uint64_t)g_pinned[MISC_MACRO_HI] << 32);
   // List granularity of this forward (common.h "blocks"). Per-tile lists while footprints are small: every entry a
   // wave reads is one it uses. Lists per 32 x 32-pixel block once a Gaussian is listed in many tiles: the sort then
-  // moves 4-7x fewer entries, which outweighs the block-list scan in the render waves (measured crossover at about eight
+  // moves 4-7x fewer entries, which outweighs the block-list scan in the render waves (measured crossover at about nine
   // listed tiles per Gaussian: 1024^2 trained -8 %, 2048^2 trained -28 %, 1024^2 at opacity 0.01 +13 % if forced).
   // Block ids must fit the low half of the sort key.
   const bool big_fits = (uint64_t)macro_grid_x(W, BLOCK_BIG) * macro_grid_y(H, BLOCK_BIG) <= (1u << MACRO_KEY_BITS);
