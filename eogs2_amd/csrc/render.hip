@@ -147,6 +147,14 @@ __device__ inline int park(float* slab, uint32_t* sslot, int lane, const Cand& c
 struct Ent {
   float4 q0, q1, q2;
 };
+// p = (A dx - B dy) dx + C dy^2 with ONE fixed association and explicit fused steps, so that every kernel (forward and
+// backward, tile and quad variants, both unrolled copies of the entry loops) rounds it identically: left to
+// `fp contract(fast)`, the compiler picked different contractions in different copies, and a pixel within an ulp of the
+// alpha = 1/255 or p = 0 threshold could blend an entry in the forward and skip it in the backward.
+__device__ inline float power_of(const Ent& e, float dx, float dy) {
+  const float t = __builtin_fmaf(e.q0.z, dx, -(e.q0.w * dy));
+  return __builtin_fmaf(dy, e.q1.x * dy, dx * t);
+}
 __device__ inline Ent fetch(const float* slab, int j) {
   const float4* s = reinterpret_cast<const float4*>(slab + j * ENT);
   Ent e;
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(BLK) void render_fwd_kernel(
     // one list entry against this lane's pixel; returns nothing, all state is captured by reference
     auto blend = [&](const Ent& e, int j) {
       const float dx = e.q0.x - pxf, dy = e.q0.y - pyf;
-      const float p = (e.q0.z * dx - e.q0.w * dy) * dx + e.q1.x * dy * dy;
+      const float p = power_of(e, dx, dy);
       const float alpha = fminf(e.q1.y * __builtin_amdgcn_exp2f(p), 0.99f);
       bool valid = !done && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);
       const float test_T = T * (1.f - alpha);
@@ -357,7 +365,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // one entry of this lane's quad sub-list against the lane's pixel
     auto blend = [&](const Ent& e, int pos, bool active) {
       const float dx = e.q0.x - pxf, dy = e.q0.y - pyf;
-      const float p = (e.q0.z * dx - e.q0.w * dy) * dx + e.q1.x * dy * dy;
+      const float p = power_of(e, dx, dy);
       const float alpha = fminf(e.q1.y * __builtin_amdgcn_exp2f(p), 0.99f);
       bool valid = active && !done && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);
       const float test_T = T * (1.f - alpha);
@@ -603,7 +611,7 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
     };
     auto grad = [&](const Ent& e, int j) {
       const float dx = e.q0.x - pxf, dy = e.q0.y - pyf;
-      const float p = (e.q0.z * dx - e.q0.w * dy) * dx + e.q1.x * dy * dy;
+      const float p = power_of(e, dx, dy);
       const float G = __builtin_amdgcn_exp2f(p);
       const float alpha = fminf(e.q1.y * G, 0.99f);
       const bool valid = (jbase + (uint32_t)j < ncontrib) && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);
@@ -829,7 +837,7 @@ __global__ __launch_bounds__(BLK) void render_bwd_quad_kernel(
     };
     auto grad = [&](const Ent& e, int pos, int j) {
       const float dx = e.q0.x - pxf, dy = e.q0.y - pyf;
-      const float p = (e.q0.z * dx - e.q0.w * dy) * dx + e.q1.x * dy * dy;
+      const float p = power_of(e, dx, dy);
       const float G = __builtin_amdgcn_exp2f(p);
       const float alpha = fminf(e.q1.y * G, 0.99f);
       const bool valid = (j < nmine) && (jbase + (uint32_t)pos < ncontrib) && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);
