@@ -1,4 +1,5 @@
 #!/bin/bash
+# Tuning aid (on the GPU box, from the repo root): A/B of environment switches.
 # tools/ab3.sh "ENV1=a ENV2=b|ENV1=c" "bench args 1|bench args 2" -> one line per (env set, args) with all kernel groups
 IFS='|' read -ra ENVS <<< "$1"; IFS='|' read -ra ARGS <<< "$2"; OUT=gpurun_out/ab3.txt; : > $OUT
 for a in "${ARGS[@]}"; do
