@@ -13,7 +13,8 @@ Extra objects in the JSON line:
   pipeline      — the whole fwd+bwd: (432 P + 268 R + 64 HW) bytes / step time, same peak
   kernels_ms    — mean device ms per kernel group (HIP events inside the library)
   cpu_baseline  — the pure-PyTorch dense alpha-blend (oracle/torch_dense.py, fwd+bwd through autograd) on a
-                  bounded 1/64-area crop of the same workload, all host cores; rank 0, N=1 only
+                  bounded 1/64-area crop of the same workload, all host cores; rank 0, N=1 only; `scalar_c`: the
+                  single-threaded C restatement (oracle/rast_oracle.c) on the same crop
 """
 import argparse
 import json
@@ -497,11 +498,45 @@ def cpu_baseline(P_full, S_full):
         once()
         ts.append(time.perf_counter() - t0)
     t = sorted(ts)[len(ts) // 2]
-    return {
+    out = {
         "value": 1.0 / (t * frac), "unit": "views/s", "cores": torch.get_num_threads(), "kind": "port",
         "sample": f"1/{frac}-area crop of the workload ({P} Gaussians / {S}x{S}, same pixel density and footprint), "
                   f"dense PyTorch fwd+bwd via autograd, median of {len(ts)} = {t * 1e3:.0f} ms, scaled x{frac}",
     }
+    # second reference point: the scalar C restatement of the reference algorithm, one thread, same crop,
+    # driven through the same host wrapper over host pointers (checker library: never on the product path)
+    try:
+        import oracle
+        from eogs2_amd import GaussianRasterizer, _lib
+        from eogs2_amd.synthetic import settings_for
+
+        hip = _lib.get
+        _lib.get = oracle.abi
+        try:
+            rast = GaussianRasterizer(settings_for(sc, S, S))
+
+            def once_c():
+                lv = {k: sc[k].clone().requires_grad_(True) for k in ("means3D", "opacities", "colors", "scales", "rotations")}
+                m2 = torch.zeros(P, 3, requires_grad=True)
+                c, _, _ = rast(lv["means3D"], m2, lv["opacities"], colors_precomp=lv["colors"], scales=lv["scales"],
+                               rotations=lv["rotations"])
+                torch.autograd.backward([c], [sc["dL_dcolor"]])
+
+            once_c()
+            tc = []
+            t_end = time.perf_counter() + 8.0
+            while len(tc) < 9 and (time.perf_counter() < t_end or not tc):
+                t0 = time.perf_counter()
+                once_c()
+                tc.append(time.perf_counter() - t0)
+            tcm = sorted(tc)[len(tc) // 2]
+            out["scalar_c"] = {"value": 1.0 / (tcm * frac), "unit": "views/s", "cores": 1,
+                               "sample": f"oracle/rast_oracle.c fwd+bwd on the same crop, median of {len(tc)} = {tcm * 1e3:.0f} ms, scaled x{frac}"}
+        finally:
+            _lib.get = hip
+    except Exception as e:  # the checker library is optional for the bench line
+        out["scalar_c"] = {"error": str(e)[:200]}
+    return out
 
 
 def main():
