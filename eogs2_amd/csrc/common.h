@@ -34,6 +34,9 @@
 #define MISC_KEY_NMIN 5  // max of ~key = ~min depth key (zero-initialised like the rest of misc)
 #define MISC_MACRO_LO 6  // number of (macro block, Gaussian) list entries (u64, lo/hi)
 #define MISC_MACRO_HI 7
+#define MISC_OPW_LO 8    // sum over listed (tile, Gaussian) pairs of round(64 opacity) (u64, lo/hi): mean pair opacity
+#define MISC_OPW_HI 9
+#define MISC_READBACK 10 // words copied to the host by forward_prepare
 #define MISC_WORDS 64
 
 // ---- radix sort geometry ----
@@ -119,6 +122,7 @@ __device__ inline bool block_hit(float gx, float gy, float a, float b, float c, 
 // the mode from the two pair counts it reads back (api.hip) and hands it on inside num_rendered.
 #define BLOCK_BIG 4
 #define EOGS_BLOCK_SWITCH 9  // listed internal tiles per Gaussian (average) above which a forward uses BLOCK_BIG
+#define EOGS_DEPTH_SWITCH 115  // (pairs per tile) x (mean pair opacity) above which a forward uses BLOCK_BIG (api.hip)
 #define MACRO_KEY_BITS 16  // M > 1: block id in the low half of the key, sub-mask in the high half
 static_assert(BLOCK_BIG * BLOCK_BIG <= 16, "the sub-mask lives in the upper 16 bits of the sort key");
 
@@ -199,7 +203,7 @@ struct GeomWS {
                         //   lpre = exclusive prefix of `tiles` inside the Gaussian's preprocess workgroup (256 Gaussians)
   float4* bext;         // 2 x float4 = 32 bytes per Gaussian, written for BK_SPANS only: SpanParams
   uint4* sinfo;         // the same records in DEPTH order (gathered once by expand_count_kernel)
-  uint32_t* pbkey;      // per preprocess workgroup: {max depth key, max ~key, list entries} over its listed Gaussians
+  uint32_t* pbkey;      // per preprocess workgroup: {max depth key, max ~key, list entries, sum of tiles * round(64 opacity)}
   uint32_t* pblock;     // per preprocess workgroup: total, then (scan_pblock_kernel) exclusive prefix over workgroups.
                         // record slot of (Gaussian i, its q-th tile) = pblock[i/256] + lpre[i] + q: records are laid out
                         // in Gaussian-id order, so gaussian_bwd streams them
@@ -225,7 +229,7 @@ static inline GeomWS geom_layout(char* base, int P) {
   o = ws_carve(base, o, g.sinfo, n * 2);
   o = ws_carve(base, o, g.bext, n * 2);
   o = ws_carve(base, o, g.pblock, (size_t)ceil_div_u32(n, BLK) + 1);
-  o = ws_carve(base, o, g.pbkey, (size_t)ceil_div_u32(n, BLK) * 3);
+  o = ws_carve(base, o, g.pbkey, (size_t)ceil_div_u32(n, BLK) * 4);
   o = ws_carve(base, o, g.skeyA, n);
   o = ws_carve(base, o, g.skeyB, n);
   o = ws_carve(base, o, g.svalA, n);

@@ -133,6 +133,7 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
 
   const size_t idx = row0 + t;
   uint32_t my_tiles = 0, my_entries = 0, key_bits = 0, bkind = BK_RECT;
+  uint32_t op64 = 0;  // round(64 * opacity), for the mean pair opacity that picks the list granularity (api.hip)
   uint4 bi0 = make_uint4(0u, 0u, 0u, 0u);
   if (t < rows) {
     const float p[3] = {s_m[3 * t], s_m[3 * t + 1], s_m[3 * t + 2]};
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
         if (d < 0) atomicOr(&misc[MISC_ERR], 1u);
         const float op_in = RAW ? sigmoidf(opacities[idx]) : opacities[idx];
         const float ca = cz * det_inv, cb = -cy * det_inv, cc = cx * det_inv, op = op_in * hcs;
+        op64 = (uint32_t)(fminf(fmaxf(op, 0.f), 1.f) * 64.f + 0.5f);  // (NaN -> 0)
         // Internal SUBX x SUBY tiles: the reference's 16-px tile rect clipped to the image, intersected with the
         // bounding box of the ellipse alpha >= 1/255 (q <= tau  =>  |dx| <= sqrt(tau cov_xx), |dy| <= sqrt(tau cov_yy),
         // cov = conic^-1 = the 2D covariance incl. the 0.3 dilation). Pixels outside that box skip this Gaussian in
@@ -310,28 +312,32 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
   // range of the depth keys of listed Gaussians (lets the host drop sort passes whose digit is constant) and the
   // workgroup's pair count: plain stores, reduced by pblock_scan_kernel (same-address atomics from 16k waves cost
   // 0.36 ms here)
-  __shared__ uint32_t s_k[3][BLK / 64];
+  __shared__ uint32_t s_k[4][BLK / 64];
   uint32_t kmax = my_tiles ? key_bits : 0u, knmin = my_tiles ? ~key_bits : 0u, esum = my_tiles ? my_entries : 0u;
+  uint32_t osum = my_tiles * op64;  // <= 65536 tiles * 64 per Gaussian, 256 Gaussians per workgroup: fits 32 bits
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
     const uint32_t a = __shfl_xor(kmax, o, 64), b = __shfl_xor(knmin, o, 64);
     kmax = a > kmax ? a : kmax;
     knmin = b > knmin ? b : knmin;
     esum += __shfl_xor(esum, o, 64);
+    osum += __shfl_xor(osum, o, 64);
   }
-  if (lane == 0) { s_k[0][w] = kmax; s_k[1][w] = knmin; s_k[2][w] = esum; }
+  if (lane == 0) { s_k[0][w] = kmax; s_k[1][w] = knmin; s_k[2][w] = esum; s_k[3][w] = osum; }
   __syncthreads();
   if (t == 0) {
     pblock[blockIdx.x] = w0 + w1 + w2 + w3;
-    uint32_t a = s_k[0][0], b = s_k[1][0], e = s_k[2][0];
+    uint32_t a = s_k[0][0], b = s_k[1][0], e = s_k[2][0], ow = s_k[3][0];
     for (int i = 1; i < BLK / 64; i++) {
       a = s_k[0][i] > a ? s_k[0][i] : a;
       b = s_k[1][i] > b ? s_k[1][i] : b;
       e += s_k[2][i];
+      ow += s_k[3][i];
     }
-    pbkey[3 * blockIdx.x] = a;
-    pbkey[3 * blockIdx.x + 1] = b;
-    pbkey[3 * blockIdx.x + 2] = e;
+    pbkey[4 * blockIdx.x] = a;
+    pbkey[4 * blockIdx.x + 1] = b;
+    pbkey[4 * blockIdx.x + 2] = e;
+    pbkey[4 * blockIdx.x + 3] = ow;
   }
 }
 
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(BLK) void pblock_scan_kernel(uint32_t* __restrict__
                                                           uint32_t nblk, uint32_t* __restrict__ misc) {
   __shared__ uint32_t s_w[4];
   __shared__ uint32_t s_k[2][BLK / 64];
-  unsigned long long carry = 0ull, entries = 0ull;
+  unsigned long long carry = 0ull, entries = 0ull, opw = 0ull;
   uint32_t kmax = 0, knmin = 0;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (uint32_t b0 = 0; b0 < nblk; b0 += BLK * 16) {
@@ -352,10 +358,11 @@ __global__ __launch_bounds__(BLK) void pblock_scan_kernel(uint32_t* __restrict__
       v[k] = 0;
       if (i0 + k < nblk) {
         v[k] = pblock[i0 + k];
-        const uint32_t a = pbkey[3 * (i0 + k)], b = pbkey[3 * (i0 + k) + 1];
+        const uint32_t a = pbkey[4 * (i0 + k)], b = pbkey[4 * (i0 + k) + 1];
         kmax = a > kmax ? a : kmax;
         knmin = b > knmin ? b : knmin;
-        entries += pbkey[3 * (i0 + k) + 2];
+        entries += pbkey[4 * (i0 + k) + 2];
+        opw += pbkey[4 * (i0 + k) + 3];
       }
       sum += v[k];
     }
@@ -385,19 +392,25 @@ __global__ __launch_bounds__(BLK) void pblock_scan_kernel(uint32_t* __restrict__
     knmin = b > knmin ? b : knmin;
   }
   // total list entries: every thread holds a partial sum
-  __shared__ unsigned long long s_e[BLK / 64];
+  __shared__ unsigned long long s_e[BLK / 64], s_o[BLK / 64];
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) entries += __shfl_xor(entries, o, 64);
-  if (lane == 0) { s_k[0][w] = kmax; s_k[1][w] = knmin; s_e[w] = entries; }
+  for (int o = 32; o >= 1; o >>= 1) {
+    entries += __shfl_xor(entries, o, 64);
+    opw += __shfl_xor(opw, o, 64);
+  }
+  if (lane == 0) { s_k[0][w] = kmax; s_k[1][w] = knmin; s_e[w] = entries; s_o[w] = opw; }
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t a = s_k[0][0], b = s_k[1][0];
-    unsigned long long e = s_e[0];
+    unsigned long long e = s_e[0], ow = s_o[0];
     for (int i = 1; i < BLK / 64; i++) {
       a = s_k[0][i] > a ? s_k[0][i] : a;
       b = s_k[1][i] > b ? s_k[1][i] : b;
       e += s_e[i];
+      ow += s_o[i];
     }
+    misc[MISC_OPW_LO] = (uint32_t)ow;
+    misc[MISC_OPW_HI] = (uint32_t)(ow >> 32);
     misc[MISC_MACRO_LO] = (uint32_t)e;
     misc[MISC_MACRO_HI] = (uint32_t)(e >> 32);
     pblock[nblk] = (uint32_t)carry;
