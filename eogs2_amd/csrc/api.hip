@@ -449,6 +449,27 @@ int eogs_adam_step(int n, const eogs_adam_tensor* tensors, double beta1, double 
   return EOGS_OK;
 }
 
+int eogs_pack_columns(int64_t rows, int n, const eogs_pack_tensor* tensors, float* packed, int packed_cols, int unpack,
+                      void* stream) {
+  g_err[0] = 0;
+  if (rows < 0 || n < 0 || n > EOGS_PACK_MAX_TENSORS || packed_cols < 0 || packed_cols > 16)
+    return fail(EOGS_ERR_INVALID_ARG, "pack_columns: bad sizes");
+  if (rows == 0 || n == 0) return EOGS_OK;
+  if (!tensors || !packed) return fail(EOGS_ERR_INVALID_ARG, "pack_columns: NULL argument");
+  int total = 0;
+  for (int i = 0; i < n; i++) {
+    const eogs_pack_tensor& t = tensors[i];
+    if (!t.data || t.width <= 0 || t.col0 < 0 || t.ncols <= 0 || t.col0 + t.ncols > t.width)
+      return fail(EOGS_ERR_INVALID_ARG, "pack_columns: bad tensor descriptor");
+    total += t.ncols;
+  }
+  if (total != packed_cols) return fail(EOGS_ERR_INVALID_ARG, "pack_columns: packed_cols is not the sum of the column counts");
+  hipStream_t s = (hipStream_t)stream;
+  launch_pack_columns(rows, n, tensors, packed, packed_cols, unpack, s);
+  LAUNCH_TRY(s, false, "pack_columns");
+  return EOGS_OK;
+}
+
 int eogs_compact_bytes(int64_t n_rows, size_t* bytes) {
   if (n_rows < 0 || !bytes) return fail(EOGS_ERR_INVALID_ARG, "compact_bytes: bad argument");
   *bytes = compact_layout(nullptr, n_rows).bytes;

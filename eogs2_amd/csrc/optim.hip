@@ -144,7 +144,55 @@ __global__ __launch_bounds__(BLK) void compact_apply_kernel(CompactTable tab, co
   }
 }
 
+struct PackTable {
+  eogs_pack_tensor t[EOGS_PACK_MAX_TENSORS];
+  int n;
+};
+
+// One workgroup = 256 consecutive rows. A tensor's 256 x width block and the bucket's 256 x K block are both contiguous in
+// memory, so every global access is a contiguous run (lane = consecutive word); the column shuffle happens in LDS.
+// (One lane per row - 14 scalar stores 56 bytes apart per lane - ran at 0.093 ms for 1 M rows, slower than torch.cat.)
+#define PACK_MAX_COLS 16
+template <bool UNPACK>
+__global__ __launch_bounds__(BLK) void pack_columns_kernel(PackTable tab, int64_t rows, float* __restrict__ packed, int K) {
+  __shared__ float s_pk[BLK * PACK_MAX_COLS];
+  const int64_t row0 = (int64_t)blockIdx.x * BLK;
+  const int nrows = (int)((rows - row0) < (int64_t)BLK ? (rows - row0) : (int64_t)BLK);
+  float* pblk = packed + (size_t)row0 * K;
+  if (UNPACK) {
+    for (int e = threadIdx.x; e < nrows * K; e += BLK) s_pk[e] = pblk[e];
+    __syncthreads();
+  }
+  int o = 0;
+  for (int t = 0; t < tab.n; t++) {
+    const int wd = tab.t[t].width, c0 = tab.t[t].col0, nc = tab.t[t].ncols;
+    float* blk = tab.t[t].data + (size_t)row0 * wd;
+    for (int e = threadIdx.x; e < nrows * wd; e += BLK) {
+      const int r = e / wd, c = e - r * wd - c0;
+      if (c >= 0 && c < nc) {
+        if (UNPACK) blk[e] = s_pk[r * K + o + c];
+        else s_pk[r * K + o + c] = blk[e];
+      }
+    }
+    o += nc;
+  }
+  if (!UNPACK) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < nrows * K; e += BLK) pblk[e] = s_pk[e];
+  }
+}
+
 }  // namespace
+
+void launch_pack_columns(int64_t rows, int n, const eogs_pack_tensor* tensors, float* packed, int packed_cols, int unpack,
+                         hipStream_t s) {
+  PackTable tab;
+  tab.n = n;
+  for (int i = 0; i < n; i++) tab.t[i] = tensors[i];
+  const unsigned blocks = (unsigned)((rows + BLK - 1) / BLK);
+  if (unpack) hipLaunchKernelGGL(pack_columns_kernel<true>, dim3(blocks), dim3(BLK), 0, s, tab, rows, packed, packed_cols);
+  else hipLaunchKernelGGL(pack_columns_kernel<false>, dim3(blocks), dim3(BLK), 0, s, tab, rows, packed, packed_cols);
+}
 
 int launch_adam(int n, const eogs_adam_tensor* tensors, double beta1, double beta2, double eps, int64_t step, hipStream_t s) {
   AdamTable tab;

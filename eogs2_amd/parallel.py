@@ -13,6 +13,32 @@ import torch
 import torch.distributed as dist
 
 
+def _pack_hip(bucket, grads):
+    """One launch of eogs_pack_columns (include/eogs_optim.h) instead of torch.cat over strided column slices
+    (0.062 -> 0.03 ms for the 56 B/Gaussian bucket at 1 M Gaussians). False when the fast path does not apply."""
+    import ctypes
+
+    from . import _lib
+    from ._abi import PackTensor
+
+    if any(g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.ndim != 2 for g in grads):
+        return False
+    if len(grads) > 8 or bucket.flat.shape[1] > 16:
+        return False
+    abi = _lib.get()
+    if abi.device_type != "cuda":
+        return False
+    arr = (PackTensor * len(grads))()
+    for a, g, c in zip(arr, grads, bucket.cols):
+        lo, hi, _ = c.indices(g.shape[1])
+        a.data, a.width, a.col0, a.ncols = g.data_ptr(), g.shape[1], lo, hi - lo
+    with torch.cuda.device(bucket.flat.device):
+        stream = ctypes.c_void_p(torch.cuda.current_stream(bucket.flat.device).cuda_stream)
+        abi.check(abi.pack_columns(bucket.flat.shape[0], len(grads), ctypes.cast(arr, ctypes.c_void_p),
+                                   ctypes.c_void_p(bucket.flat.data_ptr()), bucket.flat.shape[1], 0, stream))
+    return True
+
+
 class GradBucket:
     """Packs selected gradient columns of several [P, k] parameters into one [P, K] fp32 buffer,
     all-reduces it once, and scatters the result back into the .grad tensors."""
@@ -41,7 +67,10 @@ class GradBucket:
         if any(pt.data_ptr() == self.flat.data_ptr() for pt in parts):
             # grads are already views of the bucket (second call without a new backward): nothing to pack
             return
-        torch.cat(parts, dim=1, out=self.flat)
+        if self.flat.is_cuda and not _pack_hip(self, [p.grad for p in self.params]):
+            torch.cat(parts, dim=1, out=self.flat)
+        elif not self.flat.is_cuda:
+            torch.cat(parts, dim=1, out=self.flat)  # CPU tensors (gloo tests)
 
     def unpack(self):
         """Parameters whose every column is in the bucket get a VIEW of it as .grad (no copy); partially bucketed

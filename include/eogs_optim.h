@@ -10,6 +10,9 @@
  *        Arithmetic = torch.optim.Adam (amsgrad off, no weight decay, maximize off), fp32:
  *            m <- b1 m + (1-b1) g;  v <- b2 v + (1-b2) g^2
  *            p <- p - (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+ *  - eogs_pack_columns: gathers column ranges of several row-major [P, k] gradient tensors side by side into ONE
+ *        row-major [P, K] bucket (or scatters it back) in one launch: the pack step of the view-sharded data-parallel
+ *        all-reduce (xyz 3 + f_dc 3 + opacity 1 + scaling 3 + rotation 4 = 14 floats = 56 B/Gaussian).
  *  - eogs_compact_*: stable stream compaction of the rows of many tensors by one keep-mask, replacing the
  *        `tensor[mask]` chain of prune_points / _prune_optimizer (gaussian_model.py:466-505: 6 parameters, their 12 Adam
  *        moments and 3 statistics = 21 boolean-mask gathers, each with its own nonzero + host sync).
@@ -43,6 +46,21 @@ typedef struct {
  * Tensors with numel == 0 are skipped. Asynchronous on `stream`. */
 int eogs_adam_step(int n, const eogs_adam_tensor* tensors, double beta1, double beta2, double eps, int64_t step,
                    void* stream);
+
+/* One tensor of a pack: `data` holds rows x width fp32 values; columns [col0, col0 + ncols) take part. */
+#define EOGS_PACK_MAX_TENSORS 8
+typedef struct {
+  float* data;
+  int width;
+  int col0;
+  int ncols;
+} eogs_pack_tensor;
+
+/* unpack == 0: packed[r][o_t + c] = tensors[t].data[r * width_t + col0_t + c]; unpack != 0: the reverse copy.
+ * o_t = sum of ncols of the tensors before t; packed_cols must equal the sum of all ncols (<= 16).
+ * `tensors` is a HOST array of n <= EOGS_PACK_MAX_TENSORS descriptors. Asynchronous on `stream`. */
+int eogs_pack_columns(int64_t rows, int n, const eogs_pack_tensor* tensors, float* packed, int packed_cols, int unpack,
+                      void* stream);
 
 /* Row compaction. Workspace: per-workgroup keep counts / offsets. */
 int eogs_compact_bytes(int64_t n_rows, size_t* bytes);

@@ -123,3 +123,47 @@ def test_reset_opacity_caps_logits_and_restarts_moments(dev):
         gr["params"][0].grad = torch.ones_like(gr["params"][0])
     opt.step()
     assert int(opt.state[new]["step"]) == 2
+
+
+def test_grad_bucket_pack_kernel_equals_cat(dev):
+    """eogs_pack_columns (the data-parallel bucket's pack step) against torch.cat over the same column slices, and the
+    unpack direction of the C-ABI against slicing."""
+    import ctypes
+
+    from eogs2_amd import _lib
+    from eogs2_amd._abi import PackTensor
+    from eogs2_amd.parallel import GradBucket
+
+    P = 70_001
+    g = torch.Generator().manual_seed(11)
+    widths, cols = (3, 5, 1, 3, 4), [slice(0, 3), slice(0, 3), slice(0, 1), slice(0, 3), slice(0, 4)]
+    params = [torch.zeros(P, w, device=dev, requires_grad=True) for w in widths]
+    for p in params:
+        p.grad = torch.randn(p.shape, generator=g).to(dev)
+    want = torch.cat([p.grad[:, c] for p, c in zip(params, cols)], dim=1)
+    b = GradBucket(params, cols=cols)
+    assert b.bytes_per_gaussian == 56
+    b.pack()
+    assert torch.equal(b.flat, want)
+    # a missing gradient falls back to the torch path (zeros for that tensor)
+    params[2].grad = None
+    b2 = GradBucket(params, cols=cols)
+    b2.pack()
+    want2 = want.clone()
+    want2[:, 6] = 0
+    assert torch.equal(b2.flat, want2)
+    # unpack direction of the C-ABI
+    abi = _lib.get()
+    outs = [torch.full((P, w), 7.0, device=dev) for w in widths]
+    arr = (PackTensor * 5)()
+    for a, o, c in zip(arr, outs, cols):
+        a.data, a.width, a.col0, a.ncols = o.data_ptr(), o.shape[1], c.start, c.stop - c.start
+    abi.check(abi.pack_columns(P, 5, ctypes.cast(arr, ctypes.c_void_p), ctypes.c_void_p(want.data_ptr()), 14, 1,
+                               ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    o = 0
+    for out, c, w in zip(outs, cols, widths):
+        n = c.stop - c.start
+        assert torch.equal(out[:, c], want[:, o:o + n])
+        if n < w:
+            assert torch.equal(out[:, n:], torch.full((P, w - n), 7.0, device=dev))  # other columns untouched
+        o += n
