@@ -62,8 +62,9 @@ def project(means3D, viewmatrix, H, W, means2D=None):
     if means2D is not None:
         ndc = ndc + means2D[:, :2]  # zero-valued leaf: its grad is dL/d(ndc), the reference's dL_dmeans2D
     size = torch.tensor([W, H], dtype=torch.float64, device=means3D.device)
-    pix = (((ndc.double() + 1.0) * size - 1.0) * 0.5).float()
-    depth = (200.0 - uva[:, 2].double()).float()
+    # narrowed to the working dtype like the reference (fp32); float64 inputs keep float64 (conditioning probes)
+    pix = (((ndc.double() + 1.0) * size - 1.0) * 0.5).to(means3D.dtype)
+    depth = (200.0 - uva[:, 2].double()).to(means3D.dtype)
     return pix, depth
 
 
@@ -87,7 +88,7 @@ def render_dense(
     else:
         Sigma = cov3d_full(scales, rotations, scale_modifier)
     if T_override is None:
-        s = torch.tensor([W / 2.0, H / 2.0], dtype=torch.float32, device=dev)
+        s = torch.tensor([W / 2.0, H / 2.0], dtype=means3D.dtype, device=dev)
         T = viewmatrix[:3, :2].t() * s[:, None]  # rows i: s_i * A[i,:]
     else:
         T = T_override
@@ -106,7 +107,7 @@ def render_dense(
         root = torch.sqrt(torch.clamp(mid * mid - det, min=0.1))
         radius = torch.ceil(3.0 * torch.sqrt(torch.maximum(mid + root, mid - root)))
         gx, gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
-        ri = radius.to(torch.int32).float()
+        ri = radius.to(torch.int32).to(means3D.dtype)
 
         def tdiv(v):  # truncating float->int division as in getRect
             return torch.trunc(v / TILE).to(torch.int64)
@@ -124,9 +125,9 @@ def render_dense(
 
     cy0, cx0, ch, cw = (0, 0, H, W) if crop is None else crop
     assert cy0 % TILE == 0 and cx0 % TILE == 0
-    out_color = torch.zeros(C, ch, cw, device=dev)
-    out_invd = torch.zeros(1, ch, cw, device=dev)
-    out_T = torch.ones(ch, cw, device=dev)
+    out_color = torch.zeros(C, ch, cw, device=dev, dtype=means3D.dtype)
+    out_invd = torch.zeros(1, ch, cw, device=dev, dtype=means3D.dtype)
+    out_T = torch.ones(ch, cw, device=dev, dtype=means3D.dtype)
     assert block % TILE == 0
     for by in range(cy0, min(cy0 + ch, H), block):
         for bx in range(cx0, min(cx0 + cw, W), block):
@@ -142,7 +143,7 @@ def render_dense(
                 out_color[:, oy[:, None], ox[None, :]] = bg[:, None, None].expand(C, ys.numel(), xs.numel())
                 continue
             PY, PX = torch.meshgrid(ys, xs, indexing="ij")
-            pxf, pyf = PX.reshape(-1).float(), PY.reshape(-1).float()
+            pxf, pyf = PX.reshape(-1).to(means3D.dtype), PY.reshape(-1).to(means3D.dtype)
             ptx, pty = (PX.reshape(-1) // TILE), (PY.reshape(-1) // TILE)
             dx = pix[ids, 0][:, None] - pxf[None, :]
             dy = pix[ids, 1][:, None] - pyf[None, :]
