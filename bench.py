@@ -44,7 +44,66 @@ def parse():
     ap.add_argument("--no-train-iter", action="store_true", help="skip the extra synthetic training-iteration measurement")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) and run the gradient all-reduce even with one rank (self-test)")
+    ap.add_argument("--ar-chunks", type=int, default=0,
+                    help="Gaussian ranges of the overlapped gradient exchange (eogs_rast_backward_range); 0 = pick the "
+                         "faster of 1 and 4 during warmup")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher self-test: ranks rendezvous over gloo, all-reduce one number and exit before any GPU call")
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(a, argv):
+    """`python3 bench.py --gpus N` without a launcher: this process starts the N ranks itself (one process per GPU,
+    LOCAL_RANK = GPU index) BEFORE anything touches the GPU here, forwards rank 0's JSON line, and exits with the worst
+    return code. The parent never initialises HIP: a process that did must not start other programs on this pool."""
+    import subprocess
+
+    port = _free_port()
+    threads = max(1, (os.cpu_count() or 8) // a.gpus)
+    procs = []
+    try:
+        for r in range(a.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                       EOGS_BENCH_CHILD="1")
+            env.setdefault("OMP_NUM_THREADS", str(threads))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                          stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+        out, _ = procs[0].communicate()
+        rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    except BaseException:
+        for p in procs:  # exactly the PIDs started above
+            if p.poll() is None:
+                p.kill()
+        raise
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    bad = [rc for rc in rcs if rc != 0]
+    if bad:
+        print(f"bench.py: rank return codes {rcs}", file=sys.stderr)
+        sys.exit(bad[0] if bad[0] > 0 else 1)
+
+
+def dry_run(a, rank, world):
+    """Stops before any GPU call: proves that the launcher's ranks find each other (gloo over 127.0.0.1)."""
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": a.gpus, "world_size": world, "ranks_seen": int(t.item()),
+                          "launcher": "self" if os.environ.get("EOGS_BENCH_CHILD") else "external"}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def measured_traffic(kernel, a):
@@ -63,14 +122,28 @@ def measured_traffic(kernel, a):
         return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
 
     for d in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_v*", "pmc_mean_per_dispatch.json")), key=ver, reverse=True):
+        if not _profile_is_current(d):
+            continue  # counters of other kernels: never replayed
         try:
             pm = json.load(open(d))
         except Exception:
             continue
         for name, c in pm.items():
-            if name.startswith((kernel + "_kernel", kernel + "_quad_kernel")) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            if name.startswith((kernel + "_kernel", kernel + "_quad_kernel", kernel + "_mfma_kernel")) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 return int((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024), os.path.relpath(d, ROOT)
     return None, None
+
+
+def _profile_is_current(pmc_json):
+    """A committed PMC profile counts only if it was taken on the kernel sources this process runs (meta.json written by
+    tools/prof_summary.py holds their sha256): traffic / instruction counts of older kernels are not printed."""
+    from eogs2_amd.build import source_hash
+
+    try:
+        meta = json.load(open(os.path.join(os.path.dirname(pmc_json), "meta.json")))
+    except Exception:
+        return False
+    return meta.get("kernel_source_sha256") == source_hash()
 
 
 def measured_valu(kernel, a):
@@ -87,12 +160,14 @@ def measured_valu(kernel, a):
         return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
 
     for d in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_v*", "pmc_mean_per_dispatch.json")), key=ver, reverse=True):
+        if not _profile_is_current(d):
+            continue
         try:
             pm = json.load(open(d))
         except Exception:
             continue
         for name, c in pm.items():
-            if name.startswith((kernel + "_kernel", kernel + "_quad_kernel")) and "SQ_INSTS_VALU" in c:
+            if name.startswith((kernel + "_kernel", kernel + "_quad_kernel", kernel + "_mfma_kernel")) and "SQ_INSTS_VALU" in c:
                 return float(c["SQ_INSTS_VALU"])
     return None
 
@@ -541,10 +616,18 @@ def cpu_baseline(P_full, S_full):
 
 def main():
     a = parse()
+    # read by the HSA runtime when it initialises: must be in the environment before the first torch.cuda call
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if a.gpus > 1 and "RANK" not in os.environ:
+        return launch_ranks(a, sys.argv[1:])  # no launcher around us: start the ranks, never touch the GPU here
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if a.dry_run:
+        return dry_run(a, rank, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -553,9 +636,6 @@ def main():
     if use_dist:
         import torch.distributed as dist
 
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from eogs2_amd import GaussianRasterizer, _lib
@@ -575,19 +655,25 @@ def main():
     params = {k: sc[k].clone().requires_grad_(True) for k in ("means3D", "colors", "opacities", "scales", "rotations")}
     means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
     dL = sc["dL_dcolor"]
-    bucket = GradBucket([params["means3D"], params["colors"], params["opacities"], params["scales"], params["rotations"]],
-                        cols=[slice(0, 3), slice(0, 3), slice(0, 1), slice(0, 3), slice(0, 4)])
+    names = ("means3D", "colors", "opacities", "scales", "rotations")
+    bucket = GradBucket([params[k] for k in names], cols=[slice(0, 3), slice(0, 3), slice(0, 1), slice(0, 3), slice(0, 4)],
+                        names=names, chunks=max(1, a.ar_chunks))
     rast = GaussianRasterizer(rs)
 
     def step():
-        for p in params.values():
-            p.grad = None
         means2D.grad = None
+        if use_dist:
+            # the exchange step: the backward writes the gradients into the bucket and starts the RCCL all-reduce of each
+            # Gaussian range as soon as it is computed; finish() waits and leaves the sums in every .grad
+            bucket.begin()
+        else:
+            for p in params.values():
+                p.grad = None
         color, radii, _ = rast(params["means3D"], means2D, params["opacities"], colors_precomp=params["colors"],
                                scales=params["scales"], rotations=params["rotations"])
         torch.autograd.backward([color], [dL])  # the loss gradient dL/dcolor is an input of the path
         if use_dist:
-            bucket.all_reduce()
+            bucket.finish()
         return color
 
     def fence():
@@ -601,6 +687,40 @@ def main():
     while time.perf_counter() - t_ramp < 1.5:
         step()
         torch.cuda.synchronize()
+    ramp_s = time.perf_counter() - t_ramp
+    exchange = None
+    if use_dist:
+        # who is really there: a SUM all-reduce of ones over RCCL
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        exchange = {"rccl_ranks": int(ones.item()), "bytes": int(bucket.flat.numel() * 4),
+                    "bytes_per_gaussian": bucket.bytes_per_gaussian, "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+        # the collective alone (not overlapped with anything), max over ranks
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            dist.all_reduce(bucket.flat)
+        fence()
+        tt = torch.tensor([(time.perf_counter() - t0) / 10], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        exchange["allreduce_ms"] = float(tt.item()) * 1e3
+        # ranges of the overlapped exchange: measured, not guessed (same choice on every rank: max over ranks)
+        cand = [a.ar_chunks] if a.ar_chunks > 0 else [1, 4]
+        tried = {}
+        for k in cand:
+            bucket.chunks = k
+            for _ in range(3):
+                step()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                step()
+            fence()
+            tt = torch.tensor([(time.perf_counter() - t0) / 10], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tried[str(k)] = float(tt.item()) * 1e3
+        bucket.chunks = int(min(tried, key=tried.get))
+        exchange.update(chunks=bucket.chunks, chunks_tried_ms_per_step=tried)
     for _ in range(a.warmup):
         step()
     fence()
@@ -691,7 +811,12 @@ def main():
                        "list_block_px": 32 if nr >= 0 and (nr >> 62) & 1 else 8,
                        "parallelism": f"view-dp{world}"},
             "roofline": roof, "pipeline": pipe, "kernels_ms": kern, "kernel_rooflines": per_kernel,
+            "ramp_s": ramp_s,  # untimed clock ramp before the contract's warmup (a fresh box starts at idle clocks)
         }
+        if exchange is not None:
+            line["exchange"] = exchange
+            line["rccl_ranks"] = exchange["rccl_ranks"]
+            line["allreduce_ms"] = exchange["allreduce_ms"]
         if world == 1 and not use_dist and not a.no_train_iter:
             line["train_iter"] = train_iteration(sc, P, H, W, dev, fused=False)
             line["train_iter_fused"] = train_iteration(sc, P, H, W, dev, fused=True)

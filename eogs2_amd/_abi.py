@@ -6,7 +6,7 @@ exports the same symbols over host pointers.
 """
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 EOGS_OK = 0
 ERR_NAMES = {
@@ -58,7 +58,19 @@ SIGNATURES = {
         + [_p] * 9  # 7 gradients + dL_dT_sum + dL_dvm_mean
         + [_p],  # stream
     ),
+    "eogs_rast_backward_range": (
+        _i,
+        [_i, _i, _i, _i64]
+        + [_p] * 7
+        + [_f, _p, _p, _p, _p, _u]
+        + [_p] * 4
+        + [_p, _z, _p, _z, _p, _z]
+        + [_p] * 9
+        + [_i, _i]  # p_begin, p_end
+        + [_p],
+    ),
     "eogs_rast_mark_visible": (_i, [_i, _p, _p, _p, _p, _p]),
+    "eogs_rast_path_info": (_i, [_i, _i64, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "eogs_rast_profile_enable": (_i, [_i]),
     "eogs_rast_profile_select": (_i, [_u]),
     "eogs_rast_profile_reset": (_i, []),
@@ -146,6 +158,12 @@ class RastABI:
     def __getattr__(self, name):
         short = name.startswith(("loss_", "adam_", "pack_", "compact_", "resample_", "knn_", "shade_", "mloss_", "tshadow_", "tsdf_"))
         return getattr(self.cdll, ("eogs_" if short else "eogs_rast_") + name)
+
+    def path_info(self, P, num_rendered):
+        """(list block in pixels, forward kernel variant, backward kernel variant) of a forward (include/eogs_rast.h)."""
+        b, f, w = _i(), _i(), _i()
+        self.check(self.cdll.eogs_rast_path_info(int(P), int(num_rendered), C.byref(b), C.byref(f), C.byref(w)))
+        return b.value, f.value, w.value
 
     def profile_slot_names(self):
         names = []

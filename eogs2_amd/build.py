@@ -18,6 +18,17 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+def source_hash():
+    """sha256 over the kernel sources (csrc/*.hip, csrc/*.h, include/*.h): identifies the kernel set a profile was taken on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def needs_build():
     if not os.path.exists(OUT):
         return True

@@ -94,23 +94,27 @@ void prof_drain() {  // caller holds g_prof_mu
   }
   g_npending = 0;
 }
+// The two events live in the scope object and the {slot, a, b} triple is queued only once both are recorded: forward
+// and autograd's backward run on different threads, and a drain triggered by another scope must never see (or recycle)
+// a half-recorded pair.
 struct ProfScope {
-  hipStream_t s; int idx = -1;
-  ProfScope(int slot, hipStream_t st) : s(st) {
+  hipStream_t s; int slot; bool on = false; hipEvent_t a{}, b{};
+  ProfScope(int slot_, hipStream_t st) : s(st), slot(slot_) {
     if (!g_prof_on.load(std::memory_order_relaxed) || !((g_prof_mask.load(std::memory_order_relaxed) >> slot) & 1u)) return;
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (g_npending == 4096) prof_drain();
-    Pending& p = g_pending[g_npending];
-    p.slot = slot;
-    if (!prof_get_event(&p.a)) return;
-    if (!prof_get_event(&p.b)) { prof_put_event(p.a); return; }
-    idx = g_npending++;
-    (void)hipEventRecord(p.a, s);
+    {
+      std::lock_guard<std::mutex> lk(g_prof_mu);
+      if (!prof_get_event(&a)) return;
+      if (!prof_get_event(&b)) { prof_put_event(a); return; }
+    }
+    on = true;
+    (void)hipEventRecord(a, s);
   }
   ~ProfScope() {
-    if (idx < 0) return;
+    if (!on) return;
+    (void)hipEventRecord(b, s);
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    (void)hipEventRecord(g_pending[idx].b, s);
+    if (g_npending == 4096) prof_drain();
+    g_pending[g_npending++] = Pending{slot, a, b};
   }
 };
 
@@ -278,18 +282,21 @@ int eogs_rast_forward_render(int P, int H, int W, int64_t R, const float* bg, un
   return EOGS_OK;
 }
 
-int eogs_rast_backward(int P, int H, int W, int64_t R, const float* bg, const float* means3D, const int* radii,
-                       const float* colors, const float* opacities, const float* scales, const float* rotations,
-                       float scale_modifier, const float* cov3D_precomp, const float* viewmatrix,
-                       const float* projmatrix, const float* alt_affine, unsigned flags, const float* out_color,
-                       const float* out_invdepth,
-                       const float* dL_dout_color, const float* dL_dout_invdepth, const void* geom, size_t geom_bytes,
-                       const void* binning, size_t binning_bytes, const void* image, size_t image_bytes,
-                       float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D,
-                       float* dL_dscales, float* dL_drotations, float* dL_dT_sum, float* dL_dvm_mean, void* stream) {
+int eogs_rast_backward_range(int P, int H, int W, int64_t R, const float* bg, const float* means3D, const int* radii,
+                             const float* colors, const float* opacities, const float* scales, const float* rotations,
+                             float scale_modifier, const float* cov3D_precomp, const float* viewmatrix,
+                             const float* projmatrix, const float* alt_affine, unsigned flags, const float* out_color,
+                             const float* out_invdepth,
+                             const float* dL_dout_color, const float* dL_dout_invdepth, const void* geom, size_t geom_bytes,
+                             const void* binning, size_t binning_bytes, const void* image, size_t image_bytes,
+                             float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D,
+                             float* dL_dscales, float* dL_drotations, float* dL_dT_sum, float* dL_dvm_mean, int p_begin,
+                             int p_end, void* stream) {
   (void)bg;
   g_err[0] = 0;
   if (P < 0 || H <= 0 || W <= 0 || R < 0) return fail(EOGS_ERR_INVALID_ARG, "backward: bad sizes");
+  if (p_begin < 0 || p_end < p_begin || p_end > P || (p_begin % BLK) != 0 || (p_end != P && (p_end % BLK) != 0))
+    return fail(EOGS_ERR_INVALID_ARG, "backward: the Gaussian range must lie in [0, P] with multiples of 256 as inner bounds");
   hipStream_t s = (hipStream_t)stream;
   const bool debug = flags & EOGS_FLAG_DEBUG;
   if (P == 0) {
@@ -323,7 +330,7 @@ int eogs_rast_backward(int P, int H, int W, int64_t R, const float* bg, const fl
   if ((size_t)(gb - (char*)geom) + g.bytes - 256 > geom_bytes || (size_t)(ib - (char*)image) + im.bytes - 256 > image_bytes)
     return fail(EOGS_ERR_WORKSPACE, "backward: workspace too small");
 
-  if (R > 0) {
+  if (R > 0 && p_begin == 0) {  // the per-pixel pass covers the whole image: once, with the first range
     { ProfScope ps(PS_RENDER_BWD, s); launch_render_bwd(g, b, im, P, H, W, R, colors, out_color, out_invdepth, dL_dout_color, dL_dout_invdepth, s); }
     LAUNCH_TRY(s, debug, "render_bwd");
   }
@@ -331,8 +338,33 @@ int eogs_rast_backward(int P, int H, int W, int64_t R, const float* bg, const fl
                  viewmatrix, projmatrix, radii, scale_modifier, (flags & EOGS_FLAG_ANTIALIASING) != 0,
                  dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, have_sr ? dL_dscales : nullptr,
                  have_sr ? dL_drotations : nullptr, dL_dT_sum, dL_dvm_mean, raw, alt_affine};
-  { ProfScope ps(PS_GAUSS_BWD, s); launch_gaussian_bwd(a, g, b, s); }
+  { ProfScope ps(PS_GAUSS_BWD, s); launch_gaussian_bwd(a, g, b, p_begin, p_end, s); }
   LAUNCH_TRY(s, debug, "gaussian_bwd");
+  return EOGS_OK;
+}
+
+int eogs_rast_backward(int P, int H, int W, int64_t R, const float* bg, const float* means3D, const int* radii,
+                       const float* colors, const float* opacities, const float* scales, const float* rotations,
+                       float scale_modifier, const float* cov3D_precomp, const float* viewmatrix,
+                       const float* projmatrix, const float* alt_affine, unsigned flags, const float* out_color,
+                       const float* out_invdepth,
+                       const float* dL_dout_color, const float* dL_dout_invdepth, const void* geom, size_t geom_bytes,
+                       const void* binning, size_t binning_bytes, const void* image, size_t image_bytes,
+                       float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D,
+                       float* dL_dscales, float* dL_drotations, float* dL_dT_sum, float* dL_dvm_mean, void* stream) {
+  return eogs_rast_backward_range(P, H, W, R, bg, means3D, radii, colors, opacities, scales, rotations, scale_modifier,
+                                  cov3D_precomp, viewmatrix, projmatrix, alt_affine, flags, out_color, out_invdepth,
+                                  dL_dout_color, dL_dout_invdepth, geom, geom_bytes, binning, binning_bytes, image,
+                                  image_bytes, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dscales,
+                                  dL_drotations, dL_dT_sum, dL_dvm_mean, 0, P < 0 ? 0 : P, stream);
+}
+
+int eogs_rast_path_info(int P, int64_t R, int* list_block_px, int* fwd_kernel, int* bwd_kernel) {
+  if (P < 0 || R < 0 || !list_block_px || !fwd_kernel || !bwd_kernel) return fail(EOGS_ERR_INVALID_ARG, "path_info: bad argument");
+  const int block = nr_block(R);
+  *list_block_px = block * SUBX;
+  *fwd_kernel = render_fwd_variant(block, R, P);
+  *bwd_kernel = render_bwd_variant(block, R, P);
   return EOGS_OK;
 }
 

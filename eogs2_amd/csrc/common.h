@@ -215,6 +215,7 @@ struct GeomWS {
   uint32_t* dtotal;     // per-digit totals [256]
   uint32_t* blocksum;   // expand: per-workgroup pair counts / offsets [nblkE + 1]
   uint32_t* misc;       // MISC_WORDS
+  float* vmpart;        // backward: per-workgroup partials of the 18 camera-gradient sums [ceil(P/256)][18]
   uint32_t nblkP, nblkE;
   size_t bytes;
 };
@@ -238,6 +239,7 @@ static inline GeomWS geom_layout(char* base, int P) {
   o = ws_carve(base, o, g.dtotal, 256);
   o = ws_carve(base, o, g.blocksum, (size_t)g.nblkE + 1);
   o = ws_carve(base, o, g.misc, MISC_WORDS);
+  o = ws_carve(base, o, g.vmpart, (size_t)ceil_div_u32(n, BLK) * 18);
   g.bytes = ws_align(o) + 256;  // slack so a base that is only 1-aligned still fits after rounding
   return g;
 }
@@ -347,6 +349,9 @@ void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, 
 void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, const float* colors,
                        const float* out_color, const float* out_invdepth, const float* dL_dcolor,
                        const float* dL_dinvdepth, hipStream_t s);
+// which render kernel a forward / backward runs: 0 = one list per tile, 1 = block lists, 2 = quad sub-lists (render.hip)
+int render_fwd_variant(int block, int64_t R, int P);
+int render_bwd_variant(int block, int64_t R, int P);
 struct GaussBwdArgs {
   int P, H, W;
   const float *means3D, *scales, *rotations, *cov3D_precomp, *opacities, *viewmatrix, *projmatrix;
@@ -358,7 +363,9 @@ struct GaussBwdArgs {
   bool raw;  // EOGS_FLAG_RAW_PARAMS
   const float* alt_affine;
 };
-void launch_gaussian_bwd(const GaussBwdArgs& a, const GeomWS& g, const BinWS& b, hipStream_t s);
+// per-Gaussian backward over rows [p_begin, p_end) (p_begin a multiple of BLK); the camera sums are finished by the call
+// whose p_end == P
+void launch_gaussian_bwd(const GaussBwdArgs& a, const GeomWS& g, const BinWS& b, int p_begin, int p_end, hipStream_t s);
 void launch_selftest(uint32_t* out, hipStream_t s);
 
 // ---- photometric loss (loss.hip, include/eogs_loss.h) ----

@@ -447,12 +447,13 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
     const uint8_t* __restrict__ live,
     float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscales,
-    float* __restrict__ dL_drotations, float* __restrict__ dL_dT_sum, float* __restrict__ dL_dvm_mean) {
+    float* __restrict__ dL_drotations, bool want_T, bool want_vm, float* __restrict__ vmpart, uint32_t blk0) {
   __shared__ float s_m[3 * BLK];
   __shared__ float s_s[3 * BLK];
   __shared__ float s_red[BLK / 64][18];
   const int t = threadIdx.x;
-  const size_t row0 = (size_t)blockIdx.x * BLK;
+  const uint32_t blk = blk0 + blockIdx.x;  // workgroup index over ALL Gaussians (the launch may cover a range of them)
+  const size_t row0 = (size_t)blk * BLK;
   const int rows = (int)(((size_t)P - row0) < (size_t)BLK ? ((size_t)P - row0) : (size_t)BLK);
   stage_rows3(means3D, row0, rows, s_m);
   if (scales) stage_rows3(scales, row0, rows, s_s);
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
       // fixed-order sum of this Gaussian's (tile,Gaussian) records: deterministic, no atomics
       const uint4 bi1 = binfo[2 * idx + 1];
       const uint32_t n = bi1.x;
-      const size_t s0 = (size_t)pblock[blockIdx.x] + bi1.y;  // Gaussian-id order: a wave reads one contiguous region
+      const size_t s0 = (size_t)pblock[blk] + bi1.y;  // Gaussian-id order: a wave reads one contiguous region
       const float4* r4 = reinterpret_cast<const float4*>(records + s0 * REC);
       // Two memory round trips instead of 2n dependent ones: first all live flags of this Gaussian (independent byte
       // loads -> a register bitmask), then the live records (independent loads driven by the mask). Dead pairs
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
         dcov[4] = 2 * T[0][2] * T[0][1] * dxx + (T[0][1] * T[1][2] + T[0][2] * T[1][1]) * dxy + 2 * T[1][1] * T[1][2] * dyy;
       }
       // ---- dL/dT (backward.cu:276-287), reduced over Gaussians instead of stored as [P,6] ----
-      if (dL_dT_sum) {
+      if (want_T) {
         const float V[3][3] = {{c6[0], c6[1], c6[2]}, {c6[1], c6[3], c6[4]}, {c6[2], c6[4], c6[5]}};
         float TV[2][3];
 #pragma unroll
@@ -662,7 +663,7 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
     }
     if (dL_drotations) reinterpret_cast<float4*>(dL_drotations)[idx] = make_float4(dq[0], dq[1], dq[2], dq[3]);
 
-    if (dL_dvm_mean) {  // means3D^T @ dL_dmeans2D and sum dL_dmeans2D (__init__.py:193-201); z column is zero
+    if (want_vm) {  // means3D^T @ dL_dmeans2D and sum dL_dmeans2D (__init__.py:193-201); z column is zero
 #pragma unroll
       for (int a = 0; a < 3; a++) {
         vmsum[6 + 3 * a + 0] = m[a] * gxn;
@@ -673,7 +674,9 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
     }
   }
 
-  if (dL_dT_sum || dL_dvm_mean) {  // wave-uniform: kernel arguments
+  // Camera sums (wrapper math of __init__.py:179-201): one row of 18 partials per workgroup, summed in fixed order by
+  // camera_sum_kernel — no atomics, so grad_viewmatrix is bitwise reproducible like every other gradient.
+  if (want_T || want_vm) {  // wave-uniform: kernel arguments
 #pragma unroll
     for (int k = 0; k < 18; k++) {
       float v = wave_sum(vmsum[k]);
@@ -681,30 +684,52 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
     }
     __syncthreads();
     if (t < 18) {
-      const float v = s_red[0][t] + s_red[1][t] + s_red[2][t] + s_red[3][t];
-      if (t < 6) {
-        if (dL_dT_sum) atomicAdd(&dL_dT_sum[t], v);
-      } else if (dL_dvm_mean) {
-        // vmsum[6..14] -> 3x3 (third column stays 0), vmsum[15..17] -> sum
-        const int k = t - 6;
-        if (k < 9) {
-          const int a = k / 3, c = k % 3;
-          if (c < 2) atomicAdd(&dL_dvm_mean[3 * a + c], v);
-        } else if (k - 9 < 2) {
-          atomicAdd(&dL_dvm_mean[9 + (k - 9)], v);
-        }
-      }
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < BLK / 64; w++) v += s_red[w][t];
+      vmpart[(size_t)blk * 18 + t] = v;
     }
   }
 }
 
-void launch_gaussian_bwd(const GaussBwdArgs& a, const GeomWS& g, const BinWS& b, hipStream_t s) {
-  if (a.dL_dT_sum) (void)hipMemsetAsync(a.dL_dT_sum, 0, 6 * sizeof(float), s);
-  if (a.dL_dvm_mean) (void)hipMemsetAsync(a.dL_dvm_mean, 0, 12 * sizeof(float), s);
-  const uint32_t nblk = ceil_div_u32((uint64_t)a.P, BLK);
+// Sums the per-workgroup camera partials [nblk][18] in a fixed order: thread t owns column t % 18 of the rows
+// r = t / 18 (mod 14), then 14 row-partials per column are added serially.
+__global__ __launch_bounds__(BLK) void camera_sum_kernel(const float* __restrict__ vmpart, uint32_t nblk,
+                                                         float* __restrict__ dL_dT_sum, float* __restrict__ dL_dvm_mean) {
+  __shared__ float s_p[14][18];
+  const int t = threadIdx.x;
+  if (t < 14 * 18) {
+    const int c = t % 18, r0 = t / 18;
+    float v = 0.f;
+    for (uint32_t r = r0; r < nblk; r += 14) v += vmpart[(size_t)r * 18 + c];
+    s_p[r0][c] = v;
+  }
+  __syncthreads();
+  if (t < 18) {
+    float v = 0.f;
+#pragma unroll
+    for (int r = 0; r < 14; r++) v += s_p[r][t];
+    if (t < 6) {
+      if (dL_dT_sum) dL_dT_sum[t] = v;
+    } else if (dL_dvm_mean) {
+      // columns 6..14 -> means3D^T @ dL_dmeans2D (3x3, third column stays 0), 15..17 -> sum dL_dmeans2D
+      const int k = t - 6;
+      if (k < 9) dL_dvm_mean[k] = (k % 3) < 2 ? v : 0.f;
+      else dL_dvm_mean[k] = (k - 9) < 2 ? v : 0.f;
+    }
+  }
+}
+
+void launch_gaussian_bwd(const GaussBwdArgs& a, const GeomWS& g, const BinWS& b, int p_begin, int p_end, hipStream_t s) {
+  const uint32_t nblk_all = ceil_div_u32((uint64_t)a.P, BLK);
+  const uint32_t blk0 = (uint32_t)p_begin / BLK, nblk = ceil_div_u32((uint64_t)(p_end - p_begin), BLK);
+  const bool want_T = a.dL_dT_sum != nullptr, want_vm = a.dL_dvm_mean != nullptr;
   auto* kern = a.raw ? gaussian_bwd_kernel<true> : gaussian_bwd_kernel<false>;
-  hipLaunchKernelGGL(kern, dim3(nblk), dim3(BLK), 0, s, a.P, a.H, a.W, a.means3D, a.scales, a.rotations,
-                     a.cov3D_precomp, a.opacities, a.viewmatrix, a.projmatrix, a.alt_affine, a.radii, a.scale_modifier,
-                     (int)a.antialiasing, g.binfo, g.pblock, b.records, b.live, a.dL_dmeans2D, a.dL_dcolors, a.dL_dopacity,
-                     a.dL_dmeans3D, a.dL_dcov3D, a.dL_dscales, a.dL_drotations, a.dL_dT_sum, a.dL_dvm_mean);
+  if (nblk)
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(BLK), 0, s, a.P, a.H, a.W, a.means3D, a.scales, a.rotations,
+                       a.cov3D_precomp, a.opacities, a.viewmatrix, a.projmatrix, a.alt_affine, a.radii, a.scale_modifier,
+                       (int)a.antialiasing, g.binfo, g.pblock, b.records, b.live, a.dL_dmeans2D, a.dL_dcolors, a.dL_dopacity,
+                       a.dL_dmeans3D, a.dL_dcov3D, a.dL_dscales, a.dL_drotations, want_T, want_vm, g.vmpart, blk0);
+  if ((want_T || want_vm) && p_end == a.P)
+    hipLaunchKernelGGL(camera_sum_kernel, dim3(1), dim3(BLK), 0, s, g.vmpart, nblk_all, a.dL_dT_sum, a.dL_dvm_mean);
 }

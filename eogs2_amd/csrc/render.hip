@@ -426,11 +426,16 @@ static inline uint32_t render_grid(int ntiles) {
   return ((groups + 7u) / 8u) * 8u;  // multiple of 8 for the XCD band mapping
 }
 
+int render_fwd_variant(int block, int64_t R, int P) {
+  if (block > 1) return 1;
+  return (double)nr_slots(R) <= quad_switch() * (double)P ? 2 : 0;
+}
+
 void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R,
                        const float* bg, float* out_color, float* out_invdepth, hipStream_t s) {
   const int gsx = (W + SUBX - 1) / SUBX, gsy = (H + SUBY - 1) / SUBY, ntiles = gsx * gsy;
-  auto* kern = b.block > 1 ? render_fwd_kernel<BLOCK_BIG> : render_fwd_kernel<1>;
-  if (b.block == 1 && (double)nr_slots(R) <= quad_switch() * (double)P) kern = render_fwd_quad_kernel<1>;
+  const int variant = render_fwd_variant(b.block, R, P);
+  auto* kern = variant == 1 ? render_fwd_kernel<BLOCK_BIG> : (variant == 2 ? render_fwd_quad_kernel<1> : render_fwd_kernel<1>);
   hipLaunchKernelGGL(kern, dim3(render_grid(ntiles)), dim3(BLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H, gsx,
                      ntiles, (int)macro_grid_x(W, b.block), g.packed, bg, im.final_T, im.n_contrib, out_color, out_invdepth);
 }
@@ -902,14 +907,19 @@ static double quad_bwd_switch() {  // EOGS_QUAD_BWD_SWITCH=<listed tiles per Gau
   return v;
 }
 
+int render_bwd_variant(int block, int64_t R, int P) {
+  if (block > 1) return 1;
+  return (quad_bwd_switch() > 0.0 && (double)nr_slots(R) <= quad_bwd_switch() * (double)P) ? 2 : 0;
+}
+
 void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, const float* colors,
                        const float* out_color, const float* out_invdepth, const float* dL_dcolor,
                        const float* dL_dinvdepth, hipStream_t s) {
   const int gsx = (W + SUBX - 1) / SUBX, gsy = (H + SUBY - 1) / SUBY, ntiles = gsx * gsy;
-  auto* kern = b.block > 1 ? (dL_dinvdepth ? render_bwd_kernel<BLOCK_BIG, true> : render_bwd_kernel<BLOCK_BIG, false>)
-                           : (dL_dinvdepth ? render_bwd_kernel<1, true> : render_bwd_kernel<1, false>);
-  if (b.block == 1 && quad_bwd_switch() > 0.0 && (double)nr_slots(R) <= quad_bwd_switch() * (double)P)
-    kern = dL_dinvdepth ? render_bwd_quad_kernel<true> : render_bwd_quad_kernel<false>;
+  const int variant = render_bwd_variant(b.block, R, P);
+  auto* kern = variant == 1 ? (dL_dinvdepth ? render_bwd_kernel<BLOCK_BIG, true> : render_bwd_kernel<BLOCK_BIG, false>)
+                            : (dL_dinvdepth ? render_bwd_kernel<1, true> : render_bwd_kernel<1, false>);
+  if (variant == 2) kern = dL_dinvdepth ? render_bwd_quad_kernel<true> : render_bwd_quad_kernel<false>;
   hipLaunchKernelGGL(kern, dim3(render_grid(ntiles)), dim3(BLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H, gsx,
                      ntiles, (int)macro_grid_x(W, b.block), g.packed, im.n_contrib, out_color, out_invdepth, dL_dcolor,
                      dL_dinvdepth, b.records, b.live);

@@ -3,95 +3,208 @@
 The reference is single-GPU (one view per optimizer step, GS/train_pan.py:252-257). Renders of different
 cameras are independent given the same Gaussians, so rank r renders view r with replicated parameters and
 the only exchange step is a SUM all-reduce of the Gaussian parameter gradients: 56 B/Gaussian
-(xyz 12 + f_dc 12 + opacity 4 + scaling 12 + rotation 16) in ONE contiguous bucket, i.e. one RCCL collective
-per step (`torch.distributed` backend "nccl" is RCCL on ROCm; over xGMI RCCL picks ring/tree/direct itself).
+(xyz 12 + f_dc 12 + opacity 4 + scaling 12 + rotation 16), i.e. one RCCL exchange per step
+(`torch.distributed` backend "nccl" is RCCL on ROCm; over xGMI RCCL picks ring/tree/direct itself).
 Densification statistics (GS/train_pan.py:683-690) are kept replica-identical with three tiny all-reduces.
+
+Layout of the exchange buffer: ONE flat fp32 allocation holding one contiguous `[P, k]` block per parameter,
+`[xyz | f_dc | opacity | scaling | rotation]`, each block 256-byte aligned. A block has exactly the layout of its
+parameter's gradient, so
+
+* the rasterizer's backward writes the gradients of full-width parameters straight into their blocks
+  (`BackwardPlan.alloc`), `p.grad` IS a view of the buffer (no pack, no unpack, and `FusedAdam` consumes the
+  views in place: they are contiguous), and
+* the whole buffer is reduced by one collective, or — `chunks` > 1 — the per-Gaussian backward runs over
+  ascending Gaussian ranges (`eogs_rast_backward_range`) and the rows of range i are all-reduced
+  (5 coalesced pieces, one per block) on RCCL's stream while range i+1 is being computed.
 
 One process per GPU; works unchanged on the gloo backend (CPU tests, world_size 2).
 """
 import torch
 import torch.distributed as dist
 
+from .rasterizer import BackwardPlan, set_backward_plan
 
-def _pack_hip(bucket, grads):
-    """One launch of eogs_pack_columns (include/eogs_optim.h) instead of torch.cat over strided column slices
-    (0.062 -> 0.03 ms for the 56 B/Gaussian bucket at 1 M Gaussians). False when the fast path does not apply."""
-    import ctypes
-
-    from . import _lib
-    from ._abi import PackTensor
-
-    if any(g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.ndim != 2 for g in grads):
-        return False
-    if len(grads) > 8 or bucket.flat.shape[1] > 16:
-        return False
-    abi = _lib.get()
-    if abi.device_type != "cuda":
-        return False
-    arr = (PackTensor * len(grads))()
-    for a, g, c in zip(arr, grads, bucket.cols):
-        lo, hi, _ = c.indices(g.shape[1])
-        a.data, a.width, a.col0, a.ncols = g.data_ptr(), g.shape[1], lo, hi - lo
-    with torch.cuda.device(bucket.flat.device):
-        stream = ctypes.c_void_p(torch.cuda.current_stream(bucket.flat.device).cuda_stream)
-        abi.check(abi.pack_columns(bucket.flat.shape[0], len(grads), ctypes.cast(arr, ctypes.c_void_p),
-                                   ctypes.c_void_p(bucket.flat.data_ptr()), bucket.flat.shape[1], 0, stream))
-    return True
+_ALIGN = 64  # floats: every block starts on a 256-byte boundary (the kernels store float4 rows)
 
 
-class GradBucket:
-    """Packs selected gradient columns of several [P, k] parameters into one [P, K] fp32 buffer,
-    all-reduces it once, and scatters the result back into the .grad tensors."""
+def _dist_on(group=None):
+    return dist.is_available() and dist.is_initialized()
 
-    def __init__(self, params, cols=None):
+
+class GradBucket(BackwardPlan):
+    """The exchange buffer of the Gaussian parameter gradients.
+
+    params: [P, k] leaf tensors.  cols: per parameter, the slice of its columns that are model parameters (default:
+    all; `colors_precomp` carries f_dc in columns 0:3, the altitude / constant channels stay rank-local).
+    names: per parameter, the name of the rasterizer gradient it receives ("means3D", "colors", "opacities",
+    "scales", "rotations") — needed only for the overlapped path (`begin()` ... backward ... `finish()`).
+
+    Two ways to use it, both ending with every `p.grad` holding the all-reduced sum:
+
+    * `all_reduce()` after any number of backward passes: gradients that are not already views of the buffer are
+      copied into their blocks, one collective, full-width parameters get the block back as `.grad` (a view).
+    * `begin()` before the step's ONLY rasterizer backward, `finish()` after it: the backward writes into the buffer
+      and the collectives are started from inside it, range by range (see the module docstring).
+    """
+
+    def __init__(self, params, cols=None, names=None, chunks=1, group=None):
         self.params = list(params)
-        self.cols = list(cols) if cols is not None else [slice(0, p.shape[1]) for p in self.params]
         P = self.params[0].shape[0]
-        assert all(p.shape[0] == P for p in self.params)
-        self.widths = [len(range(*c.indices(p.shape[1]))) for p, c in zip(self.params, self.cols)]
-        self.flat = torch.zeros(P, sum(self.widths), dtype=torch.float32, device=self.params[0].device)
+        assert all(p.ndim >= 2 and p.shape[0] == P for p in self.params)
+        self.P = P
+        rowlen = [p.numel() // max(P, 1) if P else int(torch.tensor(p.shape[1:]).prod()) for p in self.params]
+        self.cols = list(cols) if cols is not None else [slice(0, n) for n in rowlen]
+        self.names = list(names) if names is not None else [None] * len(self.params)
+        self.chunks = max(1, int(chunks))
+        self.group = group
+        self.rowlen = rowlen
+        self.widths = [len(range(*c.indices(n))) for n, c in zip(rowlen, self.cols)]
+        # a column subset is only meaningful for [P, k] parameters (colors_precomp); [P, 1, 3] etc. go in whole
+        assert all(w == n or p.ndim == 2 for w, n, p in zip(self.widths, rowlen, self.params))
+        self.offsets, o = [], 0
+        for w in self.widths:
+            self.offsets.append(o)
+            o = (o + P * w + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.flat = torch.zeros(o, dtype=torch.float32, device=self.params[0].device)
+        self._works = []
+        self._armed = False      # begin() called, backward not yet seen
+        self._consumed = False   # the armed backward ran through this plan
+        self._placed = [False] * len(self.params)   # block i was written directly by the backward
+        self._partial = {}       # i -> the backward's gradient tensor whose bucket columns must be copied back
+        self.exchanges = 0       # collectives issued so far (diagnostics)
 
+    # ---- layout ----
     @property
     def bytes_per_gaussian(self):
         return 4 * sum(self.widths)
 
     def _full(self, i):
-        return self.widths[i] == self.params[i].shape[1]
+        return self.widths[i] == self.rowlen[i]
 
+    def block(self, i, p0=0, p1=None):
+        """Rows [p0, p1) of block i as a contiguous [rows, width] view of the buffer."""
+        p1 = self.P if p1 is None else p1
+        w, o = self.widths[i], self.offsets[i]
+        return self.flat[o + p0 * w:o + p1 * w].view(p1 - p0, w)
+
+    def _is_block(self, g, i):
+        b = self.block(i)
+        return g is not None and g.data_ptr() == b.data_ptr() and g.numel() == b.numel() and g.is_contiguous()
+
+    # ---- synchronous path ----
     def pack(self):
-        """One fused concatenation kernel: grads (or zeros) -> the contiguous [P, K] bucket."""
-        parts = []
-        for p, c in zip(self.params, self.cols):
-            g = p.grad if p.grad is not None else torch.zeros_like(p)
-            parts.append(g[:, c])
-        if any(pt.data_ptr() == self.flat.data_ptr() for pt in parts):
-            # grads are already views of the bucket (second call without a new backward): nothing to pack
-            return
-        if self.flat.is_cuda and not _pack_hip(self, [p.grad for p in self.params]):
-            torch.cat(parts, dim=1, out=self.flat)
-        elif not self.flat.is_cuda:
-            torch.cat(parts, dim=1, out=self.flat)  # CPU tensors (gloo tests)
+        """Brings every block up to date with its parameter's .grad. Decided per parameter: a gradient that already IS
+        the block (a previous unpack / the overlapped path handed it out, and autograd accumulated into it in place) is
+        left alone, everything else is copied (zeros for a missing gradient)."""
+        for i, (p, c) in enumerate(zip(self.params, self.cols)):
+            g = p.grad
+            if self._is_block(g, i):
+                continue
+            b = self.block(i)
+            if g is None:
+                b.zero_()
+            else:
+                b.copy_(g[:, c] if not self._full(i) else g.reshape(b.shape))
 
     def unpack(self):
-        """Parameters whose every column is in the bucket get a VIEW of it as .grad (no copy); partially bucketed
-        ones (colors_precomp: only the f_dc columns are parameters) get their columns copied back."""
-        o = 0
-        for i, (p, c, w) in enumerate(zip(self.params, self.cols, self.widths)):
+        """Full-width parameters get a VIEW of their block as .grad (no copy); partially bucketed ones
+        (colors_precomp: only the f_dc columns are parameters) get their columns copied back."""
+        for i, (p, c) in enumerate(zip(self.params, self.cols)):
             if self._full(i):
-                p.grad = self.flat[:, o:o + w]
+                if not self._is_block(p.grad, i):
+                    p.grad = self.block(i).view(p.shape)
             else:
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
-                p.grad[:, c].copy_(self.flat[:, o:o + w])
-            o += w
+                p.grad[:, c].copy_(self.block(i))
 
-    def all_reduce(self, group=None, average=False):
+    def all_reduce(self, average=False):
         self.pack()
-        if dist.is_available() and dist.is_initialized():
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        if _dist_on():
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.exchanges += 1
             if average:
-                self.flat.div_(dist.get_world_size(group))
+                self.flat.div_(dist.get_world_size(self.group))
         self.unpack()
+
+    # ---- overlapped path: BackwardPlan ----
+    def begin(self):
+        """Arms the bucket for the step's only rasterizer backward: gradients are cleared (set to None) and the next
+        backward writes into / exchanges from this buffer."""
+        for p in self.params:
+            p.grad = None
+        self._works, self._partial = [], {}
+        self._placed = [False] * len(self.params)
+        self._armed, self._consumed = True, False
+        set_backward_plan(self)
+
+    def alloc(self, name, shape, device):
+        self._consumed = True
+        for i, n in enumerate(self.names):
+            if n == name and self._full(i) and tuple(shape) == (self.P, self.widths[i]) and device == self.flat.device:
+                self._placed[i] = True
+                return self.block(i)  # a fresh view each time: autograd may adopt it as .grad without a copy
+        return None
+
+    def on_chunk(self, i, p0, p1, grads):
+        self._consumed = True
+        views = []
+        for k, (n, c) in enumerate(zip(self.names, self.cols)):
+            b = self.block(k, p0, p1)
+            if not self._placed[k]:
+                g = grads.get(n) if n is not None else None
+                if g is None:
+                    b.zero_()
+                else:
+                    b.copy_(g[p0:p1, c] if not self._full(k) else g[p0:p1].reshape(b.shape))
+                    self._partial[k] = g
+            views.append(b.view(-1))
+        if not _dist_on():
+            return
+        whole = p0 == 0 and p1 == self.P
+        if whole:
+            self._works.append(dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            try:  # one grouped launch for the five pieces of this range
+                with dist._coalescing_manager(group=self.group, async_ops=True) as cm:
+                    for v in views:
+                        dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
+                self._works.append(cm)
+            except (AttributeError, RuntimeError, ValueError):
+                for v in views:
+                    self._works.append(dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.exchanges += 1
+
+    def finish(self, average=False):
+        """Waits for the exchanges started by the backward and leaves the all-reduced sums in every .grad. If the
+        backward did not run through the plan (no rasterizer backward, or P == 0), falls back to `all_reduce()`."""
+        if not self._armed:
+            raise RuntimeError("GradBucket.finish() without begin()")
+        self._armed = False
+        leftover = set_backward_plan(None)
+        if leftover is not None and leftover is not self:
+            set_backward_plan(leftover)  # someone else's plan: not ours to drop
+        if not self._consumed:
+            return self.all_reduce(average=average)
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if average and _dist_on():
+            self.flat.div_(dist.get_world_size(self.group))
+        for i, (p, c) in enumerate(zip(self.params, self.cols)):
+            if self._full(i):
+                if not self._is_block(p.grad, i):
+                    # autograd kept its own tensor (it copied, or a second contribution arrived): the reduced block wins
+                    # only when it holds everything p.grad was built from, which begin()'s contract guarantees
+                    p.grad = self.block(i).view(p.shape)
+            else:
+                g = p.grad if p.grad is not None else self._partial.get(i)
+                if g is None:
+                    g = torch.zeros_like(p)
+                g[:, c].copy_(self.block(i))
+                p.grad = g
+        self._partial = {}
 
 
 def all_reduce_densification_stats(xyz_gradient_accum, denom, max_radii2D, group=None):

@@ -17,6 +17,7 @@ arithmetic step runs in the HIP library reached through `_lib.get()`. There is n
 CPU fallback; a missing library raises.
 """
 import ctypes
+import threading
 from typing import NamedTuple
 
 import torch
@@ -195,6 +196,55 @@ def _run_forward(rs, viewmat, means3D, colors, opacities, scales, rotations, cov
     return num_rendered, color, radii, invdepths, geom, binning, img
 
 
+class BackwardPlan:
+    """How the next backward hands over its per-Gaussian gradients (used by eogs2_amd.parallel.GradBucket).
+
+    `alloc(name, shape, device)` may return the tensor a gradient is written into (name in "means3D", "colors",
+    "opacities", "scales", "rotations"; None -> torch.empty). With `chunks` > 1 the per-Gaussian pass runs over that
+    many ascending Gaussian ranges (eogs_rast_backward_range) and `on_chunk(i, p0, p1, grads)` is called right after
+    range i has been queued on the stream — the caller starts its collective on those rows while the next range
+    computes. A plan is consumed by ONE backward."""
+
+    chunks = 1
+
+    def alloc(self, name, shape, device):
+        return None
+
+    def on_chunk(self, i, p0, p1, grads):
+        pass
+
+
+_plan_lock = threading.Lock()
+_plan = None
+
+
+def set_backward_plan(plan):
+    """Installs `plan` for the next rasterizer backward on any thread (autograd runs backward on its own thread);
+    None removes it. Returns the previous plan."""
+    global _plan
+    with _plan_lock:
+        old, _plan = _plan, plan
+    return old
+
+
+def _take_plan():
+    global _plan
+    with _plan_lock:
+        plan, _plan = _plan, None
+    return plan
+
+
+def chunk_ranges(P, chunks):
+    """Ascending Gaussian ranges covering [0, P) whose inner bounds are multiples of 256 (the per-Gaussian workgroup)."""
+    chunks = max(1, min(int(chunks), (P + 255) // 256))
+    per = ((P + chunks - 1) // chunks + 255) // 256 * 256
+    out, p0 = [], 0
+    while p0 < P:
+        out.append((p0, min(P, p0 + per)))
+        p0 += per
+    return out or [(0, 0)]
+
+
 def _run_backward(rs, num_rendered, grad_out_color, grad_out_depth, means3D, colors, opacities, scales, rotations,
                   cov3Ds_precomp, radii, geom, binning, img, color, invdepths, want_vm, alt_affine=None, raw=False):
     """Marshalling of DGR/rasterize_points.cu:133-224 over the C-ABI (P > 0).
@@ -202,6 +252,7 @@ def _run_backward(rs, num_rendered, grad_out_color, grad_out_depth, means3D, col
     Returns (d_means2D, d_colors, d_opacity[P,1], d_means3D, d_cov3D|None, d_scales|None, d_rot|None, grad_viewmatrix|None).
     """
     abi = _backend()
+    plan = _take_plan()
     dev = means3D.device
     P = means3D.shape[0]
     H, W = int(rs.image_height), int(rs.image_width)
@@ -218,29 +269,44 @@ def _run_backward(rs, num_rendered, grad_out_color, grad_out_depth, means3D, col
         g_depth = _f32(grad_out_depth, dev)
         have_sr = scales is not None and scales.numel() != 0
 
+        def out(name, shape):  # a data-parallel plan may place a gradient inside its exchange buffer
+            t = plan.alloc(name, shape, dev) if plan is not None else None
+            if t is None:
+                return torch.empty(shape, **f32)
+            if tuple(t.shape) != tuple(shape) or t.dtype != torch.float32 or t.device != dev or not t.is_contiguous():
+                raise RuntimeError(f"backward plan: bad buffer for {name}")
+            return t
+
         d_means2D = torch.empty((P, 3), **f32)
-        d_colors = torch.empty((P, 3 if raw else NUM_CHANNELS), **f32)
-        d_opacity = torch.empty((P, 1), **f32)
-        d_means3D = torch.empty((P, 3), **f32)
+        d_colors = out("colors", (P, 3 if raw else NUM_CHANNELS))
+        d_opacity = out("opacities", (P, 1))
+        d_means3D = out("means3D", (P, 3))
         d_cov3D = None if raw else torch.empty((P, 6), **f32)
-        d_scales = torch.empty((P, 3), **f32) if have_sr else None
-        d_rot = torch.empty((P, 4), **f32) if have_sr else None
+        d_scales = out("scales", (P, 3)) if have_sr else None
+        d_rot = out("rotations", (P, 4)) if have_sr else None
         dT_sum = torch.empty((6,), **f32) if want_vm else None
         dvm_mean = torch.empty((12,), **f32) if want_vm else None
 
-        abi.check(
-            abi.backward(
-                P, H, W, num_rendered,
-                _ptr(_f32(rs.bg, dev)), _ptr(_f32(means3D, dev)), _ptr(radii), _ptr(_f32(colors, dev)),
-                _ptr(_f32(opacities, dev)), _ptr(_f32(scales, dev)), _ptr(_f32(rotations, dev)),
-                float(rs.scale_modifier), _ptr(_f32(cov3Ds_precomp, dev)),
-                _ptr(_f32(rs.viewmatrix, dev)), _ptr(_f32(rs.projmatrix, dev)), _ptr(_f32(alt_affine, dev)), flags,
-                _ptr(color), _ptr(invdepths), _ptr(g_color), _ptr(g_depth),
-                _ptr(geom), geom.numel(), _ptr(binning), binning.numel(), _ptr(img), img.numel(),
-                _ptr(d_means2D), _ptr(d_colors), _ptr(d_opacity), _ptr(d_means3D), _ptr(d_cov3D),
-                _ptr(d_scales), _ptr(d_rot), _ptr(dT_sum), _ptr(dvm_mean), cx.stream,
-            )
+        grads = {"means3D": d_means3D, "colors": d_colors, "opacities": d_opacity, "scales": d_scales, "rotations": d_rot}
+        args = (
+            P, H, W, num_rendered,
+            _ptr(_f32(rs.bg, dev)), _ptr(_f32(means3D, dev)), _ptr(radii), _ptr(_f32(colors, dev)),
+            _ptr(_f32(opacities, dev)), _ptr(_f32(scales, dev)), _ptr(_f32(rotations, dev)),
+            float(rs.scale_modifier), _ptr(_f32(cov3Ds_precomp, dev)),
+            _ptr(_f32(rs.viewmatrix, dev)), _ptr(_f32(rs.projmatrix, dev)), _ptr(_f32(alt_affine, dev)), flags,
+            _ptr(color), _ptr(invdepths), _ptr(g_color), _ptr(g_depth),
+            _ptr(geom), geom.numel(), _ptr(binning), binning.numel(), _ptr(img), img.numel(),
+            _ptr(d_means2D), _ptr(d_colors), _ptr(d_opacity), _ptr(d_means3D), _ptr(d_cov3D),
+            _ptr(d_scales), _ptr(d_rot), _ptr(dT_sum), _ptr(dvm_mean),
         )
+        if plan is None or plan.chunks <= 1:
+            abi.check(abi.backward(*args, cx.stream))
+            if plan is not None:
+                plan.on_chunk(0, 0, P, grads)
+        else:
+            for i, (p0, p1) in enumerate(chunk_ranges(P, plan.chunks)):
+                abi.check(abi.backward_range(*args, p0, p1, cx.stream))
+                plan.on_chunk(i, p0, p1, grads)
 
         if want_vm:
             # DGR/diff_gaussian_rasterization/__init__.py:174-202, on the reduced sums.
@@ -391,4 +457,7 @@ __all__ = [
     "rasterize_gaussians",
     "RastError",
     "NUM_CHANNELS",
+    "BackwardPlan",
+    "set_backward_plan",
+    "chunk_ranges",
 ]

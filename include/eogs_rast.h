@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EOGS_RAST_ABI_VERSION 3
+#define EOGS_RAST_ABI_VERSION 4
 #define EOGS_RAST_CHANNELS 5 /* DGR/cuda_rasterizer/config.h:15 NUM_CHANNELS */
 #define EOGS_RAST_TILE 16    /* DGR/cuda_rasterizer/config.h:16-17 BLOCK_X/BLOCK_Y */
 
@@ -139,6 +139,29 @@ int eogs_rast_backward(
     float* dL_dmeans3D, float* dL_dcov3D, float* dL_dscales, float* dL_drotations,
     float* dL_dT_sum, float* dL_dvm_mean, void* stream);
 
+/* Backward over a range of Gaussians: the same computation as eogs_rast_backward, split so that a data-parallel
+ * caller can hand finished gradient rows to the collective while later rows are still being computed
+ * (the exchange step of view-sharded training; the reference is single-GPU,
+ * src/gaussiansplatting/train_pan.py:252-257). Arguments as eogs_rast_backward; the gradient pointers are the
+ * FULL arrays (row 0). A call with p_begin == 0 first runs the per-pixel pass (BACKWARD::render) for the whole
+ * image; every call then runs the per-Gaussian pass (computeCov2DCUDA + BACKWARD::preprocessCUDA) for rows
+ * [p_begin, p_end) only. The caller covers [0, P) with ascending, adjacent ranges on ONE stream; p_begin must be a
+ * multiple of 256. dL_dT_sum / dL_dvm_mean are valid after the call whose p_end == P.
+ * eogs_rast_backward(...) == eogs_rast_backward_range(..., 0, P), bit for bit. */
+int eogs_rast_backward_range(
+    int P, int H, int W, int64_t num_rendered,
+    const float* bg, const float* means3D, const int* radii, const float* colors,
+    const float* opacities, const float* scales, const float* rotations,
+    float scale_modifier, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* alt_affine, unsigned flags,
+    const float* out_color, const float* out_invdepth,
+    const float* dL_dout_color, const float* dL_dout_invdepth,
+    const void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes,
+    const void* image, size_t image_bytes,
+    float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity,
+    float* dL_dmeans3D, float* dL_dcov3D, float* dL_dscales, float* dL_drotations,
+    float* dL_dT_sum, float* dL_dvm_mean, int p_begin, int p_end, void* stream);
+
 /* Replaces CudaRasterizer::Rasterizer::markVisible (DGR/cuda_rasterizer/rasterizer_impl.cu:141-153).
  * The reference predicate has its culling commented out (DGR/cuda_rasterizer/auxiliary.h:151-176),
  * so every Gaussian is reported visible: present[i] = 1. */
@@ -158,6 +181,13 @@ int eogs_rast_profile_select(unsigned slot_mask);
 int eogs_rast_profile_reset(void);
 int eogs_rast_profile_slots(void);
 int eogs_rast_profile_get(int slot, double* total_ms, int64_t* launches, const char** name);
+/* Which kernels a (P, num_rendered) pair selects — the library picks list granularity and render kernel per forward
+ * (DESIGN.md §2.3, §2.5); tests use this to record that every kernel was compared with the oracle.
+ *   *list_block_px  8 (per-tile lists) or 32 (block lists)
+ *   *fwd_kernel / *bwd_kernel  0 = one list per tile (render_*_kernel<1>), 1 = block lists (render_*_kernel<4>),
+ *                              2 = quad sub-lists (render_*_quad_kernel)
+ * The oracle reports 16 / -1 / -1 (the reference's 16-px tiles, no kernel variants). */
+int eogs_rast_path_info(int P, int64_t num_rendered, int* list_block_px, int* fwd_kernel, int* bwd_kernel);
 /* Runs the library's wave64 primitive self-test (DPP reduction, readlane broadcast) on `stream` and returns,
  * after synchronising, a bit mask of failing primitives in *failed (0 = all good). scratch: >= 4 device bytes. */
 int eogs_rast_selftest(void* scratch, unsigned* failed, void* stream);

@@ -818,6 +818,63 @@ int eogs_rast_backward(
   return rc;
 }
 
+/* Range form of the backward (include/eogs_rast.h): the checker evaluates the whole backward into temporaries and copies
+ * rows [p_begin, p_end) out — K times the work for K ranges, which only ever run at test sizes. */
+int eogs_rast_backward_range(
+    int P, int H, int W, int64_t R,
+    const float* bg, const float* means3D, const int* radii, const float* colors,
+    const float* opacities, const float* scales, const float* rotations,
+    float scale_modifier, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* alt_affine, unsigned flags,
+    const float* out_color, const float* out_invdepth,
+    const float* dL_dout_color, const float* dL_dout_invdepth,
+    const void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes,
+    const void* image, size_t image_bytes,
+    float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity,
+    float* dL_dmeans3D, float* dL_dcov3D, float* dL_dscales, float* dL_drotations,
+    float* dL_dT_sum, float* dL_dvm_mean, int p_begin, int p_end, void* stream) {
+  if (P < 0 || p_begin < 0 || p_end < p_begin || p_end > P || (p_begin % 256) != 0 || (p_end != P && (p_end % 256) != 0))
+    return fail(EOGS_ERR_INVALID_ARG, "backward: the Gaussian range must lie in [0, P] with multiples of 256 as inner bounds");
+  if (p_begin == 0 && p_end == P)
+    return eogs_rast_backward(P, H, W, R, bg, means3D, radii, colors, opacities, scales, rotations, scale_modifier,
+                              cov3D_precomp, viewmatrix, projmatrix, alt_affine, flags, out_color, out_invdepth,
+                              dL_dout_color, dL_dout_invdepth, geom, geom_bytes, binning, binning_bytes, image,
+                              image_bytes, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dscales,
+                              dL_drotations, dL_dT_sum, dL_dvm_mean, stream);
+  const size_t n = (size_t)P, ncol = (flags & EOGS_FLAG_RAW_PARAMS) ? 3 : C_;
+  const size_t w[7] = {3, ncol, 1, 3, 6, 3, 4};
+  float* dst[7] = {dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dscales, dL_drotations};
+  float* tmp[7] = {0};
+  int rc = EOGS_OK;
+  for (int k = 0; k < 7; k++)
+    if (dst[k] && !(tmp[k] = (float*)malloc(n * w[k] * 4 + 4))) rc = fail(EOGS_ERR_DEVICE, "backward: out of host memory");
+  float tsum[6], vsum[12];
+  if (rc == EOGS_OK)
+    rc = eogs_rast_backward(P, H, W, R, bg, means3D, radii, colors, opacities, scales, rotations, scale_modifier,
+                            cov3D_precomp, viewmatrix, projmatrix, alt_affine, flags, out_color, out_invdepth,
+                            dL_dout_color, dL_dout_invdepth, geom, geom_bytes, binning, binning_bytes, image, image_bytes,
+                            tmp[0], tmp[1], tmp[2], tmp[3], tmp[4], tmp[5], tmp[6], dL_dT_sum ? tsum : NULL,
+                            dL_dvm_mean ? vsum : NULL, stream);
+  if (rc == EOGS_OK) {
+    for (int k = 0; k < 7; k++)
+      if (dst[k]) memcpy(dst[k] + (size_t)p_begin * w[k], tmp[k] + (size_t)p_begin * w[k], (size_t)(p_end - p_begin) * w[k] * 4);
+    if (p_end == P) {
+      if (dL_dT_sum) memcpy(dL_dT_sum, tsum, sizeof tsum);
+      if (dL_dvm_mean) memcpy(dL_dvm_mean, vsum, sizeof vsum);
+    }
+  }
+  for (int k = 0; k < 7; k++) free(tmp[k]);
+  return rc;
+}
+
+/* The checker has one path: the reference's 16-px tiles. */
+int eogs_rast_path_info(int P, int64_t num_rendered, int* list_block_px, int* fwd_kernel, int* bwd_kernel) {
+  (void)P; (void)num_rendered;
+  if (!list_block_px || !fwd_kernel || !bwd_kernel) return fail(EOGS_ERR_INVALID_ARG, "path_info: bad argument");
+  *list_block_px = TILE; *fwd_kernel = -1; *bwd_kernel = -1;
+  return EOGS_OK;
+}
+
 /* checkFrustum (rasterizer_impl.cu:54-66): in_frustum's culling is commented out and the function
  * falls off its end (auxiliary.h:151-176); the intended value is "visible". */
 int eogs_rast_mark_visible(int P, const float* means3D, const float* viewmatrix,

@@ -35,6 +35,34 @@ def _view_grads(view):
     return params, radii
 
 
+def _overlapped_step(view, chunks, params=None):
+    """One data-parallel step the way bench.py runs it: begin() arms the bucket, the backward writes into it and starts
+    the exchange range by range (eogs_rast_backward_range; the checker library implements the same entry point),
+    finish() waits."""
+    import oracle
+    from eogs2_amd import GaussianRasterizer, _lib
+    from eogs2_amd.parallel import GradBucket
+    from eogs2_amd.synthetic import make_camera, make_scene, settings_for
+
+    product_get = _lib.get
+    _lib.get = oracle.abi  # test-only checker backend (CPU tensors)
+    try:
+        sc = make_scene(P, H, W, seed=0, opacity="trained", scale_mult=3.0)
+        sc["viewmatrix"] = make_camera(H, W, seed=view)
+        if params is None:
+            params = {k: sc[k].clone().requires_grad_(True) for k in NAMES}
+        bucket = GradBucket([params[k] for k in NAMES], cols=COLS, names=NAMES, chunks=chunks)
+        bucket.begin()
+        color, _, _ = GaussianRasterizer(settings_for(sc, H, W))(
+            params["means3D"], torch.zeros(P, 3), params["opacities"], colors_precomp=params["colors"],
+            scales=params["scales"], rotations=params["rotations"])
+        (color * sc["dL_dcolor"]).sum().backward()
+        bucket.finish()
+    finally:
+        _lib.get = product_get
+    return params, bucket
+
+
 def _worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -46,9 +74,26 @@ def _worker(rank, world, port, out_dir):
     bucket = GradBucket([params[k] for k in NAMES], cols=COLS)
     assert bucket.bytes_per_gaussian == 56
     bucket.all_reduce()
+    # the overlapped exchange, whole and in two Gaussian ranges: same sums, and full-width gradients live in the bucket
+    ov = {}
+    for chunks in (1, 2):
+        p2, b2 = _overlapped_step(rank, chunks)
+        assert b2.exchanges == chunks
+        for i, k in enumerate(NAMES):
+            assert b2._is_block(p2[k].grad, i) == (k != "colors"), k
+        ov[chunks] = {k: p2[k].grad.clone() for k in NAMES}
+    # gradient accumulation over two steps with zero_grad(set_to_none=False): the gradients are views of the bucket by
+    # then, autograd accumulates into them in place, and pack() must still refresh the partially bucketed parameter
+    for k in NAMES:
+        params[k].grad.zero_()
+    params2, _ = _view_grads(rank)
+    for k in NAMES:
+        params[k].grad += params2[k].grad
+    bucket.all_reduce()
+    second = {k: params[k].grad.clone() for k in NAMES}
     acc, den, mr = torch.full((P, 1), float(rank + 1)), torch.ones(P, 1), radii.float()
     all_reduce_densification_stats(acc, den, mr)
-    torch.save({"grads": {k: params[k].grad for k in NAMES}, "acc": acc, "den": den, "mr": mr, "radii": radii},
+    torch.save({"grads": second, "ov": ov, "acc": acc, "den": den, "mr": mr, "radii": radii},
                os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -63,13 +108,39 @@ def test_two_rank_grad_allreduce(tmp_path):
     for k, c in zip(NAMES, COLS):
         expect = sum(s[0][k].grad for s in singles)
         for r in range(world):
-            got = outs[r]["grads"][k]
-            assert torch.allclose(got[:, c], expect[:, c], rtol=1e-6, atol=1e-9), (k, r)
-            # columns outside the bucket (altitude / constant feature channels) stay rank-local
-            if k == "colors":
-                assert torch.equal(got[:, 3:], singles[r][0][k].grad[:, 3:])
+            for got in (outs[r]["grads"][k], outs[r]["ov"][1][k], outs[r]["ov"][2][k]):
+                assert torch.allclose(got[:, c], expect[:, c], rtol=1e-6, atol=1e-9), (k, r)
+                # columns outside the bucket (altitude / constant feature channels) stay rank-local
+                if k == "colors":
+                    assert torch.equal(got[:, 3:], singles[r][0][k].grad[:, 3:])
+            assert torch.equal(outs[r]["ov"][1][k], outs[r]["ov"][2][k]), k  # ranges change nothing, bit for bit
     for r in range(world):
         assert torch.equal(outs[r]["acc"], torch.full((P, 1), 3.0))
         assert torch.equal(outs[r]["den"], torch.full((P, 1), 2.0))
         assert torch.equal(outs[r]["mr"], torch.maximum(singles[0][1], singles[1][1]).float())
     assert torch.equal(outs[0]["grads"]["means3D"], outs[1]["grads"]["means3D"])
+
+
+def test_bench_launcher_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2` with no launcher around it: the parent starts two ranks before any GPU call and
+    forwards rank 0's line (--dry-run stops the ranks after a gloo rendezvous + all-reduce, so this runs without a GPU)."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line == {"dry_run": True, "n_gpus": 2, "world_size": 2, "ranks_seen": 2, "launcher": "self"}
+
+
+def test_chunk_ranges():
+    from eogs2_amd.rasterizer import chunk_ranges
+
+    for P in (0, 1, 255, 256, 257, 1000, 1 << 20, (1 << 20) + 3):
+        for k in (1, 2, 4, 7, 64):
+            r = chunk_ranges(P, k)
+            assert r[0][0] == 0 and r[-1][1] == P and len(r) <= max(k, 1)
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            assert all(p0 % 256 == 0 for p0, _ in r) and all(p1 % 256 == 0 for _, p1 in r[:-1])

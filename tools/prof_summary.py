@@ -15,6 +15,12 @@ for f in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
     for k, v in agg.items():
         out.setdefault(k, {}).update({c: sum(x) / len(x) for c, x in v.items()})
 json.dump(out, open(os.path.join(dst, "pmc_mean_per_dispatch.json"), "w"), indent=1, sort_keys=True)
+# which kernels these numbers belong to: bench.py only replays counter-derived figures (HBM traffic, VALU instructions)
+# from a profile whose kernel sources are the ones it is running
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from eogs2_amd.build import source_hash  # noqa: E402
+
+json.dump({"kernel_source_sha256": source_hash()}, open(os.path.join(dst, "meta.json"), "w"))
 for k in [k for k in out if k.startswith("render_")]:
     if k in out:
         print(k, {c: f"{v:.3g}" for c, v in sorted(out[k].items())})
