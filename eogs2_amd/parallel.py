@@ -32,6 +32,29 @@ def _dist_on(group=None):
     return dist.is_available() and dist.is_initialized()
 
 
+def _copy_cols(block, g, cols, to_block):
+    """block [rows, w] (contiguous) <-> columns `cols` of g [rows, k]: one launch of eogs_pack_columns
+    (include/eogs_optim.h) on the GPU; plain tensor indexing for CPU tensors (gloo tests)."""
+    lo, hi, _ = cols.indices(g.shape[1])
+    if block.is_cuda and g.is_contiguous() and g.dtype == torch.float32 and block.shape[0] > 0:
+        import ctypes
+
+        from . import _lib
+        from ._abi import PackTensor
+
+        abi = _lib.get()
+        arr = (PackTensor * 1)()
+        arr[0].data, arr[0].width, arr[0].col0, arr[0].ncols = g.data_ptr(), g.shape[1], lo, hi - lo
+        with torch.cuda.device(block.device):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(block.device).cuda_stream)
+            abi.check(abi.pack_columns(block.shape[0], 1, ctypes.cast(arr, ctypes.c_void_p), ctypes.c_void_p(block.data_ptr()),
+                                       hi - lo, 0 if to_block else 1, stream))
+    elif to_block:
+        block.copy_(g[:, cols])
+    else:
+        g[:, cols].copy_(block)
+
+
 class GradBucket(BackwardPlan):
     """The exchange buffer of the Gaussian parameter gradients.
 
@@ -104,8 +127,10 @@ class GradBucket(BackwardPlan):
             b = self.block(i)
             if g is None:
                 b.zero_()
+            elif self._full(i):
+                b.copy_(g.reshape(b.shape))
             else:
-                b.copy_(g[:, c] if not self._full(i) else g.reshape(b.shape))
+                _copy_cols(b, g, c, True)
 
     def unpack(self):
         """Full-width parameters get a VIEW of their block as .grad (no copy); partially bucketed ones
@@ -117,7 +142,7 @@ class GradBucket(BackwardPlan):
             else:
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
-                p.grad[:, c].copy_(self.block(i))
+                _copy_cols(self.block(i), p.grad, c, False)
 
     def all_reduce(self, average=False):
         self.pack()
@@ -156,8 +181,10 @@ class GradBucket(BackwardPlan):
                 g = grads.get(n) if n is not None else None
                 if g is None:
                     b.zero_()
+                elif self._full(k):
+                    b.copy_(g[p0:p1].reshape(b.shape))
                 else:
-                    b.copy_(g[p0:p1, c] if not self._full(k) else g[p0:p1].reshape(b.shape))
+                    _copy_cols(b, g[p0:p1], c, True)
                     self._partial[k] = g
             views.append(b.view(-1))
         if not _dist_on():
@@ -202,7 +229,7 @@ class GradBucket(BackwardPlan):
                 g = p.grad if p.grad is not None else self._partial.get(i)
                 if g is None:
                     g = torch.zeros_like(p)
-                g[:, c].copy_(self.block(i))
+                _copy_cols(self.block(i), g, c, False)
                 p.grad = g
         self._partial = {}
 

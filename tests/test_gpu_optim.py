@@ -126,8 +126,8 @@ def test_reset_opacity_caps_logits_and_restarts_moments(dev):
 
 
 def test_grad_bucket_pack_kernel_equals_cat(dev):
-    """eogs_pack_columns (the data-parallel bucket's pack step) against torch.cat over the same column slices, and the
-    unpack direction of the C-ABI against slicing."""
+    """The data-parallel bucket's blocks against torch.cat over the same column slices (the partially bucketed colour
+    block goes through eogs_pack_columns), and both directions of that C-ABI call against slicing."""
     import ctypes
 
     from eogs2_amd import _lib
@@ -141,17 +141,24 @@ def test_grad_bucket_pack_kernel_equals_cat(dev):
     for p in params:
         p.grad = torch.randn(p.shape, generator=g).to(dev)
     want = torch.cat([p.grad[:, c] for p, c in zip(params, cols)], dim=1)
+    # the bucket: one contiguous [P, k] block per parameter (the colour block is filled by eogs_pack_columns)
     b = GradBucket(params, cols=cols)
     assert b.bytes_per_gaussian == 56
     b.pack()
-    assert torch.equal(b.flat, want)
-    # a missing gradient falls back to the torch path (zeros for that tensor)
+    o = 0
+    for i, c in enumerate(cols):
+        n = c.stop - c.start
+        assert torch.equal(b.block(i), want[:, o:o + n]), i
+        o += n
+    b.unpack()  # no process group: the sums are the gradients themselves
+    for i, (p, c) in enumerate(zip(params, cols)):
+        assert b._is_block(p.grad, i) == (i != 1)
+    assert torch.equal(torch.cat([p.grad[:, c] for p, c in zip(params, cols)], dim=1), want)
+    # a missing gradient counts as zeros
     params[2].grad = None
     b2 = GradBucket(params, cols=cols)
     b2.pack()
-    want2 = want.clone()
-    want2[:, 6] = 0
-    assert torch.equal(b2.flat, want2)
+    assert float(b2.block(2).abs().max()) == 0.0 and torch.equal(b2.block(4), want[:, 10:14])
     # unpack direction of the C-ABI
     abi = _lib.get()
     outs = [torch.full((P, w), 7.0, device=dev) for w in widths]
