@@ -181,8 +181,11 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
   HIP_TRY(hipMemsetAsync(g.misc, 0, MISC_WORDS * sizeof(uint32_t), s));
   FwdPrepArgs a{P, H, W, means3D, scales, rotations, cov3D_precomp, opacities, colors, viewmatrix, scale_modifier,
                 (flags & EOGS_FLAG_ANTIALIASING) != 0, radii, raw, alt_affine};
-  { ProfScope ps(PS_PREPROCESS, s); launch_preprocess_fwd(a, g, s); launch_scan_pblock(g, P, s); }
+  { ProfScope ps(PS_PREPROCESS, s); launch_preprocess_fwd(a, g, s); }
   LAUNCH_TRY(s, debug, "preprocess_fwd");
+  // pass 0's histogram of the depth sort, with the scan of the pair counts riding along as one extra workgroup
+  { ProfScope ps(PS_DEPTH_SORT, s); launch_depth_sort_head(g, P, s); }
+  LAUNCH_TRY(s, debug, "depth_sort_head");
   // The pair count is read back on a side stream that waits only for the two kernels above, so the host wakes up
   // while the caller's stream is still busy with the depth sort (which does not depend on num_rendered) and has the
   // rest of the forward queued before the GPU runs dry.
@@ -191,18 +194,20 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
   HIP_TRY(hipEventRecord(sd->ev, s));
   HIP_TRY(hipStreamWaitEvent(sd->stream, sd->ev, 0));
   HIP_TRY(hipMemcpyAsync(g_pinned, g.misc, MISC_READBACK * sizeof(uint32_t), hipMemcpyDeviceToHost, sd->stream));
-  { ProfScope ps(PS_DEPTH_SORT, s); launch_depth_sort(g, P, 0, 3, s); }
+  { ProfScope ps(PS_DEPTH_SORT, s); launch_depth_sort(g, P, 0, 3, s, true); }
   LAUNCH_TRY(s, debug, "depth_sort");
   HIP_TRY(hipStreamSynchronize(sd->stream));
+  const uint32_t* sorted_ids = g.svalA;  // after an even number of depth-sort passes
   {
     // Fourth pass (bits 24..31) only if the listed Gaussians' keys differ there. EOGS altitudes span far less than
     // a factor of two around 200 - altitude, so they normally share sign, exponent-high bits: one digit, no pass.
     const uint32_t kmax = g_pinned[MISC_KEY_MAX], kmin = ~g_pinned[MISC_KEY_NMIN];
-    ProfScope ps(PS_DEPTH_SORT, s);
     if (kmax != 0 && ((kmax ^ kmin) >> 24) == 0) {
-      // three passes left the order in buffer B; unlisted Gaussians (key 0xFFFFFFFF) may sit anywhere: they emit nothing
-      HIP_TRY(hipMemcpyAsync(g.svalA, g.svalB, (size_t)P * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+      // three passes left the order in buffer B (binning reads it from there); unlisted Gaussians (key 0xFFFFFFFF) may sit
+      // anywhere: they emit nothing
+      sorted_ids = g.svalB;
     } else {
+      ProfScope ps(PS_DEPTH_SORT, s);
       launch_depth_sort(g, P, 3, 4, s);
     }
   }
@@ -239,7 +244,7 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
   // chunk scan only touch the geometry workspace
   if (total) {
     ProfScope ps(PS_BINNING, s);
-    launch_binning_head(g, P, block, s);
+    launch_binning_head(g, P, block, sorted_ids, s);
   }
   LAUNCH_TRY(s, debug, "binning_head");
   if (g_pinned[MISC_ERR] & 1u) return fail(EOGS_ERR_ALTITUDE, "Point is too high: altitude > 200");

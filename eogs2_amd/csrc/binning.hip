@@ -58,10 +58,101 @@ __device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, uint32_t& 
 
 }  // namespace
 
+// Single workgroup: exclusive scan of the per-workgroup pair counts (-> record slots in Gaussian-id order), their
+// 64-bit total (= num_rendered) and the key range, written to misc[] for the host readback.
+
+__device__ inline void pblock_scan_body(uint32_t* __restrict__ pblock, const uint32_t* __restrict__ pbkey, uint32_t nblk,
+                                        uint32_t* __restrict__ misc) {
+  __shared__ uint32_t s_w[4];
+  __shared__ uint32_t s_k[2][BLK / 64];
+  unsigned long long carry = 0ull, entries = 0ull, opw = 0ull;
+  uint32_t kmax = 0, knmin = 0;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (uint32_t b0 = 0; b0 < nblk; b0 += BLK * 16) {
+    const uint32_t i0 = b0 + threadIdx.x * 16;
+    uint32_t v[16], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      v[k] = 0;
+      if (i0 + k < nblk) {
+        v[k] = pblock[i0 + k];
+        const uint32_t a = pbkey[4 * (i0 + k)], b = pbkey[4 * (i0 + k) + 1];
+        kmax = a > kmax ? a : kmax;
+        knmin = b > knmin ? b : knmin;
+        entries += pbkey[4 * (i0 + k) + 2];
+        opw += pbkey[4 * (i0 + k) + 3];
+      }
+      sum += v[k];
+    }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t nb = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += nb;
+    }
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    const uint32_t w0 = s_w[0], w1 = s_w[1], w2 = s_w[2], w3 = s_w[3];
+    const uint32_t pre = (w > 0 ? w0 : 0u) + (w > 1 ? w1 : 0u) + (w > 2 ? w2 : 0u);
+    __syncthreads();
+    uint32_t run = (uint32_t)carry + pre + inc - sum;  // slots are u32: the host rejects totals >= 2^31
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      if (i0 + k < nblk) pblock[i0 + k] = run;
+      run += v[k];
+    }
+    carry += (unsigned long long)w0 + w1 + w2 + w3;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const uint32_t a = __shfl_xor(kmax, o, 64), b = __shfl_xor(knmin, o, 64);
+    kmax = a > kmax ? a : kmax;
+    knmin = b > knmin ? b : knmin;
+  }
+  // total list entries: every thread holds a partial sum
+  __shared__ unsigned long long s_e[BLK / 64], s_o[BLK / 64];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    entries += __shfl_xor(entries, o, 64);
+    opw += __shfl_xor(opw, o, 64);
+  }
+  if (lane == 0) { s_k[0][w] = kmax; s_k[1][w] = knmin; s_e[w] = entries; s_o[w] = opw; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t a = s_k[0][0], b = s_k[1][0];
+    unsigned long long e = s_e[0], ow = s_o[0];
+    for (int i = 1; i < BLK / 64; i++) {
+      a = s_k[0][i] > a ? s_k[0][i] : a;
+      b = s_k[1][i] > b ? s_k[1][i] : b;
+      e += s_e[i];
+      ow += s_o[i];
+    }
+    misc[MISC_OPW_LO] = (uint32_t)ow;
+    misc[MISC_OPW_HI] = (uint32_t)(ow >> 32);
+    misc[MISC_MACRO_LO] = (uint32_t)e;
+    misc[MISC_MACRO_HI] = (uint32_t)(e >> 32);
+    pblock[nblk] = (uint32_t)carry;
+    misc[MISC_TOTAL_LO] = (uint32_t)carry;
+    misc[MISC_TOTAL_HI] = (uint32_t)(carry >> 32);
+    misc[MISC_KEY_MAX] = a;
+    misc[MISC_KEY_NMIN] = b;
+  }
+}
+
+
 // ---- radix pass, kernel 1: per-workgroup digit histogram, written digit-major hist[d][blk] ----
+// The first pass of the depth sort runs one extra workgroup (blockIdx.x == nblk, `pblock` non-NULL) that does the
+// single-workgroup scan of the preprocess pair counts beside the histogram workgroups: one launch less on the forward's
+// critical path (a dependent single-workgroup kernel costs ~7 us however little it does).
 template <int ITEMS>
 __global__ __launch_bounds__(BLK) void radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift,
-                                                         uint32_t mask, uint32_t* __restrict__ hist, uint32_t nblk) {
+                                                         uint32_t mask, uint32_t* __restrict__ hist, uint32_t nblk,
+                                                         uint32_t* __restrict__ pblock, const uint32_t* __restrict__ pbkey,
+                                                         uint32_t npb, uint32_t* __restrict__ misc) {
+  if (blockIdx.x == nblk) {  // (only launched when pblock != NULL)
+    pblock_scan_body(pblock, pbkey, npb, misc);
+    return;
+  }
   __shared__ uint32_t h[256];
   const int t = threadIdx.x;
   h[t] = 0;
@@ -186,11 +277,17 @@ __global__ __launch_bounds__(BLK) void radix_scatter_kernel(const uint32_t* __re
   }
 }
 
+template <int ITEMS>
+static void radix_hist(const uint32_t* kin, uint32_t n, int shift, int nbits, uint32_t* hist, uint32_t nblk, hipStream_t s) {
+  hipLaunchKernelGGL((radix_hist_kernel<ITEMS>), dim3(nblk), dim3(BLK), 0, s, kin, n, shift, (1u << nbits) - 1u, hist, nblk,
+                     (uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, (uint32_t*)nullptr);
+}
+
 template <int ITEMS, typename VT>
 static void radix_pass(const uint32_t* kin, const VT* vin, uint32_t* kout, VT* vout, uint32_t n, int shift,
-                       int nbits, uint32_t* hist, uint32_t nblk, uint32_t* dtotal, hipStream_t s) {
+                       int nbits, uint32_t* hist, uint32_t nblk, uint32_t* dtotal, hipStream_t s, bool hist_done = false) {
   const uint32_t mask = (1u << nbits) - 1u;
-  hipLaunchKernelGGL((radix_hist_kernel<ITEMS>), dim3(nblk), dim3(BLK), 0, s, kin, n, shift, mask, hist, nblk);
+  if (!hist_done) radix_hist<ITEMS>(kin, n, shift, nbits, hist, nblk, s);
   hipLaunchKernelGGL(radix_rowscan_kernel, dim3(mask + 1), dim3(BLK), 0, s, hist, nblk, dtotal);
   hipLaunchKernelGGL((radix_scatter_kernel<ITEMS, VT>), dim3(nblk), dim3(BLK), 0, s, kin, vin, kout, vout, n, shift, nbits,
                      hist, nblk, dtotal);
@@ -198,12 +295,20 @@ static void radix_pass(const uint32_t* kin, const VT* vin, uint32_t* kout, VT* v
 
 // Depth sort: stable 8-bit passes over the depth bits, ping-ponging A -> B -> A ...; after an even number of passes
 // the ids in depth order are in svalA.
-void launch_depth_sort(const GeomWS& g, int P, int first, int last, hipStream_t s) {
+void launch_depth_sort(const GeomWS& g, int P, int first, int last, hipStream_t s, bool first_hist_done) {
   for (int pass = first; pass < last; pass++) {
     const bool a2b = (pass & 1) == 0;
     radix_pass<SORTP_ITEMS, uint32_t>(a2b ? g.skeyA : g.skeyB, a2b ? g.svalA : g.svalB, a2b ? g.skeyB : g.skeyA,
-                                      a2b ? g.svalB : g.svalA, (uint32_t)P, 8 * pass, 8, g.hist, g.nblkP, g.dtotal, s);
+                                      a2b ? g.svalB : g.svalA, (uint32_t)P, 8 * pass, 8, g.hist, g.nblkP, g.dtotal, s,
+                                      first_hist_done && pass == first);
   }
+}
+
+// Histogram of the depth sort's pass 0 + (one extra workgroup) the scan of the preprocess pair counts, whose totals the
+// host reads back: forward_prepare records its readback event right after this launch.
+void launch_depth_sort_head(const GeomWS& g, int P, hipStream_t s) {
+  hipLaunchKernelGGL((radix_hist_kernel<SORTP_ITEMS>), dim3(g.nblkP + 1), dim3(BLK), 0, s, g.skeyA, (uint32_t)P, 0, 255u, g.hist,
+                     g.nblkP, g.pblock, g.pbkey, ceil_div_u32((uint64_t)P, BLK), g.misc);
 }
 
 void launch_sort_u32(uint32_t* keyA, uint32_t* valA, uint32_t* keyB, uint32_t* valB, uint32_t n, int passes, uint32_t* hist,
@@ -573,9 +678,11 @@ __global__ __launch_bounds__(BLK) void tile_ranges_kernel(const uint32_t* __rest
   if (i == R - 1) ranges[cur].y = R;
 }
 
-void launch_binning_head(const GeomWS& g, int P, int block, hipStream_t s) {
-  hipLaunchKernelGGL(expand_count_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.svalA, g.binfo, (uint32_t)P, (int)(block > 1),
+void launch_binning_head(const GeomWS& g, int P, int block, const uint32_t* sorted_ids, hipStream_t s) {
+  hipLaunchKernelGGL(expand_count_kernel, dim3(g.nblkE), dim3(BLK), 0, s, sorted_ids, g.binfo, (uint32_t)P, (int)(block > 1),
                      g.sinfo, g.blocksum);
+  // (Folding this scan into the emission kernels through per-group sums was measured: the 4096 atomicAdds on 64 addresses
+  // cost expand_count 14 us, three times what the scan kernel takes.)
   launch_small_scan(g.blocksum, g.nblkE, s);
 }
 
@@ -594,8 +701,8 @@ void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int
     hipLaunchKernelGGL(expand_kernel<BLOCK_BIG>, dim3(g.nblkE), dim3(BLK), 0, s, g.sinfo, g.bext, g.pblock, g.blocksum,
                        (uint32_t)P, gmx, nblocks, b.tkeyA, b.tvalA, im.ranges);
   else  // per-tile lists: the specialised walker (set bits / spans directly, cursors carried across LDS windows)
-    hipLaunchKernelGGL(expand_fine_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.sinfo, g.bext, g.pblock, g.blocksum, (uint32_t)P,
-                       gmx, macro_grid_y(H, 1), b.tkeyA, b.tvalA, im.ranges);
+    hipLaunchKernelGGL(expand_fine_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.sinfo, g.bext, g.pblock, g.blocksum,
+                       (uint32_t)P, gmx, macro_grid_y(H, 1), b.tkeyA, b.tvalA, im.ranges);
   uint32_t *ka = b.tkeyA, *kb = b.tkeyB;
   uint2 *va = b.tvalA, *vb = b.tvalB;
   int shift = 0;

@@ -23,8 +23,13 @@
 #define BLK 256                 // threads per workgroup everywhere (4 wave64)
 #define NFEAT 6                 // staged per-Gaussian features: 5 colours + 1/depth
 #ifndef REC
-#define REC 16                  // floats per (tile,Gaussian) gradient record: one whole 64-byte line (11 used)
-#endif
+#define REC 16                  // floats per (tile,Gaussian) gradient record: one whole 64-byte line, four 16-byte quarters
+#endif                          //   [0..3]   dL/dmean2D.x, .y (NDC units), dL/dconic.a, dL/dopacity
+                                //   [4..7]   dL/dconic.b, -, -, -
+                                //   [8..11]  dL/dconic.c, dL/dcolour0, -, -
+                                //   [12..15] dL/dcolour1..4
+                                // (the quarters are what the four lane groups of the MFMA reduction each finish, render.hip)
+static_assert(REC == 16, "record quarters");
 
 // ---- misc[] slots (u32) in the geometry workspace ----
 #define MISC_TOTAL_LO 0  // sum of tiles_touched (u64, lo/hi)
@@ -338,11 +343,13 @@ struct FwdPrepArgs {
 };
 void launch_preprocess_fwd(const FwdPrepArgs& a, const GeomWS& g, hipStream_t s);
 // passes [first, last) of the 4-pass depth sort (8 bits each); pass p reads buffer A if p is even, B if odd
-void launch_depth_sort(const GeomWS& g, int P, int first, int last, hipStream_t s);
+void launch_depth_sort(const GeomWS& g, int P, int first, int last, hipStream_t s, bool first_hist_done = false);
+// pass 0's histogram + the scan of the preprocess pair counts (totals for the host readback) in one launch
+void launch_depth_sort_head(const GeomWS& g, int P, hipStream_t s);
 void launch_small_scan(uint32_t* data, uint32_t n, hipStream_t s);
-void launch_scan_pblock(const GeomWS& g, int P, hipStream_t s);
-// part of binning that needs only the geometry workspace (queued by forward_prepare right after its sync)
-void launch_binning_head(const GeomWS& g, int P, int block, hipStream_t s);
+// part of binning that needs only the geometry workspace (queued by forward_prepare right after its sync);
+// sorted_ids: the depth-ordered Gaussian ids (svalA or svalB, whichever the last depth-sort pass wrote)
+void launch_binning_head(const GeomWS& g, int P, int block, const uint32_t* sorted_ids, hipStream_t s);
 void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, hipStream_t s);
 void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R,
                        const float* bg, float* out_color, float* out_invdepth, hipStream_t s);

@@ -341,86 +341,6 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
   }
 }
 
-// Single workgroup: exclusive scan of the per-workgroup pair counts (-> record slots in Gaussian-id order), their
-// 64-bit total (= num_rendered) and the key range, written to misc[] for the host readback.
-__global__ __launch_bounds__(BLK) void pblock_scan_kernel(uint32_t* __restrict__ pblock, const uint32_t* __restrict__ pbkey,
-                                                          uint32_t nblk, uint32_t* __restrict__ misc) {
-  __shared__ uint32_t s_w[4];
-  __shared__ uint32_t s_k[2][BLK / 64];
-  unsigned long long carry = 0ull, entries = 0ull, opw = 0ull;
-  uint32_t kmax = 0, knmin = 0;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (uint32_t b0 = 0; b0 < nblk; b0 += BLK * 16) {
-    const uint32_t i0 = b0 + threadIdx.x * 16;
-    uint32_t v[16], sum = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      v[k] = 0;
-      if (i0 + k < nblk) {
-        v[k] = pblock[i0 + k];
-        const uint32_t a = pbkey[4 * (i0 + k)], b = pbkey[4 * (i0 + k) + 1];
-        kmax = a > kmax ? a : kmax;
-        knmin = b > knmin ? b : knmin;
-        entries += pbkey[4 * (i0 + k) + 2];
-        opw += pbkey[4 * (i0 + k) + 3];
-      }
-      sum += v[k];
-    }
-    uint32_t inc = sum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t nb = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += nb;
-    }
-    if (lane == 63) s_w[w] = inc;
-    __syncthreads();
-    const uint32_t w0 = s_w[0], w1 = s_w[1], w2 = s_w[2], w3 = s_w[3];
-    const uint32_t pre = (w > 0 ? w0 : 0u) + (w > 1 ? w1 : 0u) + (w > 2 ? w2 : 0u);
-    __syncthreads();
-    uint32_t run = (uint32_t)carry + pre + inc - sum;  // slots are u32: the host rejects totals >= 2^31
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      if (i0 + k < nblk) pblock[i0 + k] = run;
-      run += v[k];
-    }
-    carry += (unsigned long long)w0 + w1 + w2 + w3;
-  }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    const uint32_t a = __shfl_xor(kmax, o, 64), b = __shfl_xor(knmin, o, 64);
-    kmax = a > kmax ? a : kmax;
-    knmin = b > knmin ? b : knmin;
-  }
-  // total list entries: every thread holds a partial sum
-  __shared__ unsigned long long s_e[BLK / 64], s_o[BLK / 64];
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    entries += __shfl_xor(entries, o, 64);
-    opw += __shfl_xor(opw, o, 64);
-  }
-  if (lane == 0) { s_k[0][w] = kmax; s_k[1][w] = knmin; s_e[w] = entries; s_o[w] = opw; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t a = s_k[0][0], b = s_k[1][0];
-    unsigned long long e = s_e[0], ow = s_o[0];
-    for (int i = 1; i < BLK / 64; i++) {
-      a = s_k[0][i] > a ? s_k[0][i] : a;
-      b = s_k[1][i] > b ? s_k[1][i] : b;
-      e += s_e[i];
-      ow += s_o[i];
-    }
-    misc[MISC_OPW_LO] = (uint32_t)ow;
-    misc[MISC_OPW_HI] = (uint32_t)(ow >> 32);
-    misc[MISC_MACRO_LO] = (uint32_t)e;
-    misc[MISC_MACRO_HI] = (uint32_t)(e >> 32);
-    pblock[nblk] = (uint32_t)carry;
-    misc[MISC_TOTAL_LO] = (uint32_t)carry;
-    misc[MISC_TOTAL_HI] = (uint32_t)(carry >> 32);
-    misc[MISC_KEY_MAX] = a;
-    misc[MISC_KEY_NMIN] = b;
-  }
-}
-
 void launch_preprocess_fwd(const FwdPrepArgs& a, const GeomWS& g, hipStream_t s) {
   const int gx = (a.W + TILE - 1) / TILE, gy = (a.H + TILE - 1) / TILE;
   const uint32_t nblk = ceil_div_u32((uint64_t)a.P, BLK);
@@ -430,9 +350,6 @@ void launch_preprocess_fwd(const FwdPrepArgs& a, const GeomWS& g, hipStream_t s)
                      (int)a.antialiasing, a.radii, g.packed, g.binfo, g.bext, g.pblock, g.pbkey, g.skeyA, g.svalA, g.misc);
 }
 
-void launch_scan_pblock(const GeomWS& g, int P, hipStream_t s) {
-  hipLaunchKernelGGL(pblock_scan_kernel, dim3(1), dim3(BLK), 0, s, g.pblock, g.pbkey, ceil_div_u32((uint64_t)P, BLK), g.misc);
-}
 
 // ------------------------------------------------------------------------------------------------------
 // Backward, per Gaussian.
@@ -492,18 +409,24 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
             q[u] = have[u] ? q0 + (uint32_t)__builtin_ctz(m) : q0;
             m &= m - 1u;  // (0 & anything stays 0)
           }
-          float4 ra[4], rb[4], rc[4];
+          float4 ra[4], rd[4];
+          float rb[4];
+          float2 rc[4];
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             const uint32_t qq = have[u] ? q[u] : q[0];  // a valid address either way
-            ra[u] = r4[(REC / 4) * qq]; rb[u] = r4[(REC / 4) * qq + 1]; rc[u] = r4[(REC / 4) * qq + 2];
+            ra[u] = r4[(REC / 4) * qq];
+            rb[u] = reinterpret_cast<const float*>(r4 + (REC / 4) * qq + 1)[0];
+            rc[u] = reinterpret_cast<const float2*>(r4 + (REC / 4) * qq + 2)[0];
+            rd[u] = r4[(REC / 4) * qq + 3];
           }
 #pragma unroll
           for (int u = 0; u < 4; u++) {
-            if (have[u]) {
-              acc[0] += ra[u].x; acc[1] += ra[u].y; acc[2] += ra[u].z; acc[3] += ra[u].w;
-              acc[4] += rb[u].x; acc[5] += rb[u].y; acc[6] += rb[u].z; acc[7] += rb[u].w;
-              acc[8] += rc[u].x; acc[9] += rc[u].y; acc[10] += rc[u].z;
+            if (have[u]) {  // record line (common.h REC) -> acc: 0,1 mean2D  2,3,4 conic  5 opacity  6..10 colour
+              acc[0] += ra[u].x; acc[1] += ra[u].y; acc[2] += ra[u].z; acc[5] += ra[u].w;
+              acc[3] += rb[u];
+              acc[4] += rc[u].x; acc[6] += rc[u].y;
+              acc[7] += rd[u].x; acc[8] += rd[u].y; acc[9] += rd[u].z; acc[10] += rd[u].w;
             }
           }
         }

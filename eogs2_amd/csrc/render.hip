@@ -428,7 +428,7 @@ static inline uint32_t render_grid(int ntiles) {
 
 int render_fwd_variant(int block, int64_t R, int P) {
   if (block > 1) return 1;
-  return (double)nr_slots(R) <= quad_switch() * (double)P ? 2 : 0;
+  return (quad_switch() > 0.0 && (double)nr_slots(R) <= quad_switch() * (double)P) ? 2 : 0;
 }
 
 void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R,
@@ -515,11 +515,11 @@ __device__ inline void transpose_round(int nsurv, int lane, const float* rb, con
     const float m2y = op * ky * (2.f * Cq * acc[2] - B * acc[1]);  // -c = 2C/log2e
     const float ho = -0.5f * op;
     const uint32_t slot = __float_as_uint(q1.z);
-    float4* dst = reinterpret_cast<float4*>(records + (size_t)slot * REC);
-    dst[0] = make_float4(m2x, m2y, ho * acc[3], ho * acc[4]);
-    dst[1] = make_float4(ho * acc[5], acc[0], acc[6], acc[7]);
-    dst[2] = make_float4(acc[8], acc[9], acc[10], 0.f);
-    if (REC == 16) dst[3] = make_float4(0.f, 0.f, 0.f, 0.f);  // whole 64-byte line: no partial-line write
+    float4* dst = reinterpret_cast<float4*>(records + (size_t)slot * REC);  // layout: common.h REC
+    dst[0] = make_float4(m2x, m2y, ho * acc[3], acc[0]);
+    dst[1] = make_float4(ho * acc[4], 0.f, 0.f, 0.f);
+    dst[2] = make_float4(ho * acc[5], acc[6], 0.f, 0.f);
+    dst[3] = make_float4(acc[7], acc[8], acc[9], acc[10]);  // whole 64-byte line: no partial-line write
     live_flag[slot] = 1;  // pairs that never get here keep the 0 of the memset and are skipped by gaussian_bwd
   }
 }
@@ -887,16 +887,265 @@ __global__ __launch_bounds__(BLK) void render_bwd_quad_kernel(
         const float m2x = op * kx * (2.f * A * acc[1] - B * acc[2]);
         const float m2y = op * ky * (2.f * Cq * acc[2] - B * acc[1]);
         const float ho = -0.5f * op;
-        float4* dst = reinterpret_cast<float4*>(records + (size_t)cur_slot * REC);
-        dst[0] = make_float4(m2x, m2y, ho * acc[3], ho * acc[4]);
-        dst[1] = make_float4(ho * acc[5], acc[0], acc[6], acc[7]);
-        dst[2] = make_float4(acc[8], acc[9], acc[10], 0.f);
-        if (REC == 16) dst[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4* dst = reinterpret_cast<float4*>(records + (size_t)cur_slot * REC);  // layout: common.h REC
+        dst[0] = make_float4(m2x, m2y, ho * acc[3], acc[0]);
+        dst[1] = make_float4(ho * acc[4], 0.f, 0.f, 0.f);
+        dst[2] = make_float4(ho * acc[5], acc[6], 0.f, 0.f);
+        dst[3] = make_float4(acc[7], acc[8], acc[9], acc[10]);
         live_flag[cur_slot] = 1;
       }
     }
     jbase += (uint32_t)jn;
   }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Backward with quad sub-lists, pixel reduction on the matrix pipe
+// ------------------------------------------------------------------------------------------------------
+// Same pixel-parallel pass as render_bwd_quad_kernel (every quad walks its own sub-list), but the reduction over pixels
+// — per (tile, Gaussian) six moments of v = G dL/dalpha and five colour sums of u = alpha T — is ONE dense product
+//     D[m][n] = sum_p A[m][p] * B[p][n],   p = 64 pixels (x 2: v-part and u-part),  n = 16 consecutive list entries,
+// evaluated by v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate: bit for bit a k-ordered fmaf chain, MI355X_MICROARCH.md).
+// north_star ruled MFMA out on the premise that the path is bandwidth-bound; the counters say the render backward is
+// VALU/LDS-latency-bound (profiles/r01_v15: 78 % VALU-active, 8.7 % of HBM peak), and this contraction was ~45 % of its
+// VALU instructions (transposition FMAs, DPP merges, staging + owner pull). Deviation recorded in DESIGN.md §2.6.
+//   * rows of B are indexed by list ENTRY, not by trip: a quad that evaluates entry e in any trip stores u, v at
+//     [e - 16 w][pixel]; entries a quad never visits keep zeros. The four quads' partial sums therefore merge inside the
+//     accumulator — no staging area, no owner pull, no DPP;
+//   * A is constant per lane: rows {1,x,y,x^2 | 1,x,y,xy | 1,y,y^2,-} (tile-local pixel coordinates, v-part) and the five
+//     upstream colour gradients of the pixel (u-part); the duplicated rows put everything a lane needs for its four
+//     outputs into that lane: lane (n, g) finishes outputs 4g..4g+3 of entry n (moments are shifted from the tile origin to
+//     the Gaussian centre: sum v (gx - x) = gx S0 - Sx, ...) and stores its 16-byte quarter of the record line;
+//   * per window: 8 ds_read_b128 + 32 MFMA + 8 zeroing stores per lane instead of ~200 VALU + 3 LDS round trips per 8 trips.
+namespace {
+
+#define MW 16            // list entries per window = MFMA N
+#define MRS 68           // row stride of the window matrices in floats (17 x 16 B: the b128 operand reads of 16 rows spread over all banks)
+#define MUV (MW * MRS)   // floats per matrix = 17 x 64 dwords: u and v of a pixel go out in one ds_write2st64_b32
+#define QBM 96           // bytes per quad sub-list (64 entries + the pipelined over-read past a window's trips)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+}  // namespace
+
+template <bool HAVE_INV>
+__global__ __launch_bounds__(BLK) void render_bwd_mfma_kernel(
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx,
+    const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib,
+    const float* __restrict__ out_color, const float* __restrict__ out_invdepth, const float* __restrict__ dL_dpix,
+    const float* __restrict__ dL_dinv, float* __restrict__ records, uint8_t* __restrict__ live_flag) {
+  __shared__ __attribute__((aligned(16))) float s_slab[BLK / 64][64 * ENT];
+  __shared__ __attribute__((aligned(16))) float s_uv[BLK / 64][2 * MUV];
+  __shared__ uint32_t s_slot[BLK / 64][64];
+  __shared__ __attribute__((aligned(16))) uint8_t s_idx[BLK / 64][4 * QBM];
+  static_assert(6 * 64 <= 2 * MUV, "the colour-gradient staging lives inside the window matrices");
+  const int lane = threadIdx.x & 63;
+  const int tile = tile_of_wave();
+  if (tile >= ntiles) return;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float* slab = s_slab[w];
+  float* su = s_uv[w];
+  uint32_t* sslot = s_slot[w];
+  uint8_t* sidx = s_idx[w];
+  int ox, oy;
+  quad_pixel(lane, ox, oy);
+  const int tx0 = (tile % gsx) * SUBX, ty0 = (tile / gsx) * SUBY;
+  const int px = tx0 + ox, py = ty0 + oy;
+  const bool inside = px < W && py < H;
+  const uint32_t pix_id = (uint32_t)py * (uint32_t)W + (uint32_t)px;
+  const float pxf = (float)px, pyf = (float)py;
+  const uint2 range = ranges[tile];
+  const size_t HW = (size_t)H * W;
+  const int myq = lane >> 4;
+  const uint8_t* myidx = sidx + myq * QBM;
+
+  float g[NCH] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  float ginv = 0.f, Dfinal = 0.f;
+  uint32_t ncontrib = 0;
+  if (inside) {
+    ncontrib = n_contrib[pix_id];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) {
+      g[ch] = dL_dpix[ch * HW + pix_id];
+      Dfinal += g[ch] * out_color[ch * HW + pix_id];
+    }
+    if (HAVE_INV) {
+      ginv = dL_dinv[pix_id];
+      Dfinal += ginv * out_invdepth[pix_id];
+    }
+  }
+  // ---- A operands. MFMA lane (m = lane & 15, kk = lane >> 4), k-step (j, i): pixel = lane 16 j + 4 kk + i of the pixel
+  //      pass, i.e. tile-local (x, y) = (4 (j & 1) + i, 4 (j >> 1) + kk) (quad_pixel) ----
+  const int mrow = lane & 15, kk = lane >> 4;
+  float Au[16], Av[16];
+  {
+    // u-part: rows 11..15 carry the pixel's upstream gradient of colour channel 0..4 (0 elsewhere); staged once through LDS
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) su[ch * 64 + lane] = g[ch];
+    su[NCH * 64 + lane] = 0.f;
+    wave_lds_sync();
+    const float* src = su + (mrow >= 11 ? mrow - 11 : NCH) * 64 + 4 * kk;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float4 t = *reinterpret_cast<const float4*>(src + 16 * j);
+      Au[4 * j] = t.x; Au[4 * j + 1] = t.y; Au[4 * j + 2] = t.z; Au[4 * j + 3] = t.w;
+    }
+    wave_lds_sync();
+    // v-part: rows 0..10 = {1, x, y, x^2 | 1, x, y, x y | 1, y, y^2}
+    const int ex = (mrow == 1 || mrow == 5 || mrow == 7) ? 1 : (mrow == 3 ? 2 : 0);
+    const int ey = (mrow == 2 || mrow == 6 || mrow == 7 || mrow == 9) ? 1 : (mrow == 10 ? 2 : 0);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const float x = (float)(4 * (j & 1) + i), y = (float)(4 * (j >> 1) + kk);
+        const float fx = ex == 0 ? 1.f : (ex == 1 ? x : x * x), fy = ey == 0 ? 1.f : (ey == 1 ? y : y * y);
+        Av[4 * j + i] = mrow < 11 ? fx * fy : 0.f;
+      }
+  }
+  // the window matrices start (and are handed back by every window) all zero; sub-list bytes: valid slab positions
+  for (int t = lane; t < 2 * MUV / 4; t += 64) reinterpret_cast<float4*>(su)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = lane; t < 4 * QBM / 4; t += 64) reinterpret_cast<uint32_t*>(sidx)[t] = 0u;
+  const uint32_t tile_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(ncontrib));
+  const float kx = LN2 * 0.5f * W, ky = LN2 * 0.5f * H;
+  const float bx0 = (float)tx0, by0 = (float)ty0;
+  float T = 1.0f, Dacc = 0.f;
+  float* const uvlane = su + lane;
+  const float* const opnd = su + mrow * MRS + 4 * kk;  // this lane's B operands: row = entry, 4 pixels per quad
+
+  uint32_t jbase = 0;
+  Cand nxt = gather_cand<1>(peek_cand<1>(range.x + lane, range.y, keys, point_list), 0u, packed);
+  Peek pk = peek_cand<1>(range.x + 64 + lane, range.y, keys, point_list);
+  for (uint32_t c0 = range.x; c0 < range.y && jbase < tile_last; c0 += 64) {
+    wave_lds_sync();
+    unsigned long long bal[4];
+    {
+      const uint32_t qm = nxt.hit ? quad_mask(nxt, bx0, by0) : 0u;
+      // per-tile lists: the in-range entries are lanes 0..jn-1, parked at their own lane index
+      const bool listed = nxt.hit && jbase + (uint32_t)lane < tile_last;  // entries behind the last contributor are dead
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const bool in = listed && ((qm >> q) & 1u);
+        bal[q] = __builtin_amdgcn_ballot_w64(in);
+        if (in) {
+          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[q] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[q], 0u));
+          sidx[q * QBM + (int)rank] = (uint8_t)lane;
+        }
+      }
+    }
+    const unsigned long long mybal = myq == 0 ? bal[0] : (myq == 1 ? bal[1] : (myq == 2 ? bal[2] : bal[3]));
+    sslot[lane] = nxt.slot;
+    const int jn = park(slab, nullptr, lane, nxt, 0);
+    nxt = gather_cand<1>(pk, 0u, packed);
+    pk = peek_cand<1>(c0 + 128 + lane, range.y, keys, point_list);
+    wave_lds_sync();
+
+    for (int wdw = 0; wdw < 64 / MW; wdw++) {
+      const unsigned long long wm = 0xFFFFull << (MW * wdw);
+      const int ntr = max(max((int)__popcll(bal[0] & wm), (int)__popcll(bal[1] & wm)),
+                          max((int)__popcll(bal[2] & wm), (int)__popcll(bal[3] & wm)));
+      if (ntr == 0) continue;  // wave-uniform: no quad lists any entry of this window
+      const int start = (int)__popcll(mybal & ((1ull << (MW * wdw)) - 1ull));  // my quad's sub-list entries before this window
+      const int cnt = (int)__popcll(mybal & wm);
+      const int row0 = MW * wdw;
+      // ---- pixel pass over this window's sub-list segments ----
+      auto grad = [&](const Ent& e, int pos, int t) {
+        const float dx = e.q0.x - pxf, dy = e.q0.y - pyf;
+        const float p = power_of(e, dx, dy);
+        const float G = __builtin_amdgcn_exp2f(p);
+        const float alpha = fminf(e.q1.y * G, 0.99f);
+        const bool act = t < cnt;
+        const bool valid = act && (jbase + (uint32_t)pos < ncontrib) && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);
+        float gc = g[0] * e.q1.z + g[1] * e.q1.w + g[2] * e.q2.x + g[3] * e.q2.y + g[4] * e.q2.z;
+        if (HAVE_INV) gc += ginv * e.q2.w;
+        const float a_eff = valid ? alpha : 0.f;
+        const float G_eff = valid ? G : 0.f;
+        const float wgt = a_eff * T;
+        Dacc += gc * wgt;
+        const float one_m = 1.f - a_eff;
+        const float dLda = T * gc - (Dfinal - Dacc) * __builtin_amdgcn_rcpf(one_m);
+        T = T * one_m;
+        if (act) {  // row = the entry's place in the window; quads whose segment is exhausted store nothing
+          float* const uv = uvlane + (pos - row0) * MRS;
+          uv[0] = wgt;
+          uv[MUV] = G_eff * dLda;  // v = G dL/dalpha
+        }
+      };
+      {
+        const uint8_t* wi = myidx + start;
+        int i0 = wi[0], i1 = wi[1];
+        Ent ea = fetch(slab, i0);
+        int t = 0;
+        for (; t + 1 < ntr; t += 2) {
+          const Ent eb = fetch(slab, i1);
+          const int i2 = wi[t + 2];
+          grad(ea, i0, t);
+          ea = fetch(slab, i2);
+          const int i3 = wi[t + 3];
+          grad(eb, i1, t + 1);
+          i0 = i2;
+          i1 = i3;
+        }
+        if (t < ntr) grad(ea, i0, t);
+      }
+      wave_lds_sync();
+      // ---- reduction over pixels: 32 MFMA, two accumulators (dependent-accumulator latency 40 cycles vs 32 issue) ----
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float4 bu = *reinterpret_cast<const float4*>(opnd + 16 * j);
+        const float4 bv = *reinterpret_cast<const float4*>(opnd + MUV + 16 * j);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Av[4 * j + 0], bv.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Av[4 * j + 1], bv.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Av[4 * j + 2], bv.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Av[4 * j + 3], bv.w, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Au[4 * j + 0], bu.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Au[4 * j + 1], bu.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Au[4 * j + 2], bu.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Au[4 * j + 3], bu.w, acc1, 0, 0, 0);
+      }
+      // hand the matrices back all zero (LDS instructions of a wave execute in order: these follow the reads above)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        *reinterpret_cast<float4*>(const_cast<float*>(opnd) + 16 * j) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(const_cast<float*>(opnd) + MUV + 16 * j) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      const float a0 = acc0[0] + acc1[0], a1 = acc0[1] + acc1[1], a2 = acc0[2] + acc1[2], a3 = acc0[3] + acc1[3];
+      // ---- lane (n = mrow, g = kk): outputs 4g..4g+3 of entry row0 + n -> its quarter of the record line ----
+      const unsigned long long nzb = __builtin_amdgcn_ballot_w64(a0 != 0.f || a1 != 0.f || a2 != 0.f || a3 != 0.f);
+      const uint32_t any16 = (uint32_t)(nzb | (nzb >> 16) | (nzb >> 32) | (nzb >> 48)) & 0xFFFFu;
+      if ((any16 >> mrow) & 1u) {  // entries no pixel blends leave no record (their live flag stays 0)
+        const int e = row0 + mrow;
+        const float4 q0 = *reinterpret_cast<const float4*>(slab + e * ENT);      // gx gy A B
+        const float2 q1 = *reinterpret_cast<const float2*>(slab + e * ENT + 4);  // C op
+        const uint32_t slot = sslot[e];
+        const float gxr = q0.x - bx0, gyr = q0.y - by0;  // centre relative to the tile origin
+        const float ho = -0.5f * q1.y;
+        float4 out;
+        if (kk == 0) {         // S0 Sx Sy Sxx
+          const float Sdx = gxr * a0 - a1, Sdy = gyr * a0 - a2;
+          const float Sdxdx = gxr * (Sdx - a1) + a3;
+          out = make_float4(q1.y * kx * (2.f * q0.z * Sdx - q0.w * Sdy), q1.y * ky * (2.f * q1.x * Sdy - q0.w * Sdx), ho * Sdxdx, a0);
+          live_flag[slot] = 1;
+        } else if (kk == 1) {  // S0 Sx Sy Sxy
+          out = make_float4(ho * (gxr * (gyr * a0 - a2) - gyr * a1 + a3), 0.f, 0.f, 0.f);
+        } else if (kk == 2) {  // S0 Sy Syy c0
+          out = make_float4(ho * (gyr * ((gyr * a0 - a1) - a1) + a2), a3, 0.f, 0.f);
+        } else {               // c1 c2 c3 c4
+          out = make_float4(a0, a1, a2, a3);
+        }
+        reinterpret_cast<float4*>(records + (size_t)slot * REC)[kk] = out;
+      }
+    }
+    jbase += (uint32_t)jn;
+  }
+}
+
+static int bwd_mfma_on() {  // EOGS_BWD_MFMA=0 falls back to the VALU transposition (render_bwd_quad_kernel)
+  static const int v = [] {
+    const char* e = getenv("EOGS_BWD_MFMA");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
 }
 
 static double quad_bwd_switch() {  // EOGS_QUAD_BWD_SWITCH=<listed tiles per Gaussian>, 0 disables the quad backward
@@ -909,7 +1158,8 @@ static double quad_bwd_switch() {  // EOGS_QUAD_BWD_SWITCH=<listed tiles per Gau
 
 int render_bwd_variant(int block, int64_t R, int P) {
   if (block > 1) return 1;
-  return (quad_bwd_switch() > 0.0 && (double)nr_slots(R) <= quad_bwd_switch() * (double)P) ? 2 : 0;
+  if (!(quad_bwd_switch() > 0.0 && (double)nr_slots(R) <= quad_bwd_switch() * (double)P)) return 0;
+  return bwd_mfma_on() ? 3 : 2;
 }
 
 void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, const float* colors,
@@ -920,6 +1170,7 @@ void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, 
   auto* kern = variant == 1 ? (dL_dinvdepth ? render_bwd_kernel<BLOCK_BIG, true> : render_bwd_kernel<BLOCK_BIG, false>)
                             : (dL_dinvdepth ? render_bwd_kernel<1, true> : render_bwd_kernel<1, false>);
   if (variant == 2) kern = dL_dinvdepth ? render_bwd_quad_kernel<true> : render_bwd_quad_kernel<false>;
+  if (variant == 3) kern = dL_dinvdepth ? render_bwd_mfma_kernel<true> : render_bwd_mfma_kernel<false>;
   hipLaunchKernelGGL(kern, dim3(render_grid(ntiles)), dim3(BLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H, gsx,
                      ntiles, (int)macro_grid_x(W, b.block), g.packed, im.n_contrib, out_color, out_invdepth, dL_dcolor,
                      dL_dinvdepth, b.records, b.live);

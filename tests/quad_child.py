@@ -28,7 +28,7 @@ def main(out_path, P, H, W, opacity, invdepth):
         g = torch.Generator().manual_seed(9)
         case["dL_dinvdepth"] = (torch.randn((1, int(H), int(W)), generator=g) / (int(H) * int(W))).numpy()
     got = run_case(case, torch.device("cuda:0"), GaussianRasterizer, GaussianRasterizationSettings)
-    np.savez(out_path, **{k: v.detach().cpu().numpy() for k, v in got.items()})
+    np.savez(out_path, **{k: v.detach().cpu().numpy() for k, v in got.items() if not k.startswith('_')})
 
 
 if __name__ == "__main__":

@@ -19,7 +19,7 @@ def test_wrapper_over_oracle_matches_golden(name, oracle_backend):
     out = run_case(case, torch.device("cpu"), GaussianRasterizer, GaussianRasterizationSettings)
     assert np.array_equal(out["out_radii"].numpy(), case["out_radii"])
     for k, v in out.items():
-        if k == "out_radii":
+        if k == "out_radii" or k.startswith("_"):
             continue
         ref = case[k]
         got = v.numpy()

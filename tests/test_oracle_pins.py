@@ -102,3 +102,24 @@ def test_oracle_altitude_trap(oracle_backend):
     with pytest.raises(RastError, match="too high"):
         GaussianRasterizer(rs)(sc["means3D"], torch.zeros(50, 3), sc["opacities"], colors_precomp=sc["colors"],
                                scales=sc["scales"], rotations=sc["rotations"])
+
+
+def test_config1_plumbing_1k_128(oracle_backend):
+    """BASELINE.json configs[0] / SURVEY.md 8d config 1: 1 k synthetic Gaussians, 128 x 128, seed 0, CPU only — the
+    pure-PyTorch alpha-blend forward equals the restatement reached through the drop-in API
+    (`diff_gaussian_rasterization.GaussianRasterizer`, here routed to the checker library) to 1e-5 absolute."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+
+    P, H, W = 1000, 128, 128
+    sc = make_scene(P, H, W, seed=0)
+    rs = settings_for(sc, H, W)
+    assert isinstance(rs, GaussianRasterizationSettings)
+    with torch.no_grad():
+        color, radii, invd = GaussianRasterizer(rs)(sc["means3D"], torch.zeros(P, 3), sc["opacities"],
+                                                    colors_precomp=sc["colors"], scales=sc["scales"], rotations=sc["rotations"])
+        c2, r2, i2 = render_dense(sc["means3D"], sc["opacities"], sc["colors"], sc["bg"], sc["viewmatrix"], H, W,
+                                  scales=sc["scales"], rotations=sc["rotations"])
+    assert torch.equal(radii, r2) and int((radii > 0).sum()) == P
+    assert float((color - c2).abs().max()) <= 1e-5
+    assert float((invd - i2).abs().max()) <= 1e-5
+    assert float((color[:3] - sc["bg"][:3, None, None]).abs().max()) > 1e-3  # something was blended

@@ -81,6 +81,9 @@ def run_case(case, device, rasterizer_mod, settings_cls):
     if "dL_dinvdepth" in case:
         loss = loss + (invd * t("dL_dinvdepth")).sum()
     out = dict(out_color=color.detach(), out_radii=radii, out_invdepth=invd.detach())
+    nr = getattr(color.grad_fn, "num_rendered", None)
+    if nr is not None:
+        out["_num_rendered"] = int(nr)  # the library's opaque token: tells which kernels ran (eogs_rast_path_info)
     if P:
         loss.backward()
         out.update(g_means3D=means3D.grad, g_means2D=means2D.grad, g_opacities=opac.grad, g_colors=colors.grad,
