@@ -580,14 +580,17 @@ def cpu_baseline(P_full, S_full):
             ts.append(time.perf_counter() - t0)
         return sorted(ts)[len(ts) // 2], len(ts), P, S
 
-    t64, n64, P64, S64 = dense_crop(64, 12.0, 15)
-    t16, n16, P16, S16 = dense_crop(16, 10.0, 5)
+    t64, n64, P64, S64 = dense_crop(64, 8.0, 11)
+    t16, n16, P16, S16 = dense_crop(16, 12.0, 7)
+    # Scaling by area is NOT linear for the dense PyTorch path: the larger crop amortises per-op overhead over bigger
+    # tensors (measured on the GPU box: x16 of the 1/16 crop is about half of x64 of the 1/64 crop), so the reported value
+    # comes from the larger crop and the smaller one is kept beside it.
     out = {
-        "value": 1.0 / (t64 * 64), "unit": "views/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": f"1/64-area crop of the workload ({P64} Gaussians / {S64}x{S64}, same pixel density and footprint), "
-                  f"dense PyTorch fwd+bwd via autograd, median of {n64} = {t64 * 1e3:.0f} ms, scaled x64",
-        "linearity": {"sample": f"1/16-area crop ({P16} Gaussians / {S16}x{S16}), median of {n16} = {t16 * 1e3:.0f} ms, scaled x16",
-                      "value": 1.0 / (t16 * 16), "ratio_to_x64_estimate": (t16 * 16) / (t64 * 64)},
+        "value": 1.0 / (t16 * 16), "unit": "views/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"1/16-area crop of the workload ({P16} Gaussians / {S16}x{S16}, same pixel density and footprint), "
+                  f"dense PyTorch fwd+bwd via autograd, median of {n16} = {t16 * 1e3:.0f} ms, scaled x16",
+        "smaller_crop": {"sample": f"1/64-area crop ({P64} Gaussians / {S64}x{S64}), median of {n64} = {t64 * 1e3:.0f} ms, scaled x64",
+                         "value": 1.0 / (t64 * 64), "x16_over_x64_time_estimate": (t16 * 16) / (t64 * 64)},
     }
     # second reference point: the scalar C restatement of the reference algorithm, one thread, on the FULL
     # workload, driven through the same host wrapper over host pointers (checker library: never on the product path)

@@ -259,7 +259,8 @@ __global__ __launch_bounds__(BLK) void render_fwd_kernel(
 // Trip count = the longest sub-list (~0.6 of the tile's list at 1M Gaussians / 1024^2), list traffic from HBM unchanged.
 namespace {
 
-#define QCAP 128  // bytes per quad sub-list (>= FWD_CAP, + room for the pipelined over-read)
+#define QCAP 112  // bytes per quad sub-list (>= FWD_CAP + 2: padding and the pipelined over-read); with the dummy slab entry
+                  // the forward wave stays at 5104 B of LDS: 32 waves per CU
 
 __device__ inline void quad_pixel(int lane, int& ox, int& oy) {
   const int q = lane >> 4, r = lane & 15;
@@ -310,7 +311,9 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const float4* __restrict__ packed, const float* __restrict__ bg,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
     float* __restrict__ out_invdepth) {
-  __shared__ __attribute__((aligned(16))) float s_slab[BLK / 64][FWD_CAP * ENT];
+  // slab position FWD_CAP holds a DUMMY entry (opacity 0: alpha = 0 fails the 1/255 test at every pixel); sub-lists
+  // shorter than the longest one are padded with it, so the hot loop needs no "is my quad still active" test
+  __shared__ __attribute__((aligned(16))) float s_slab[BLK / 64][(FWD_CAP + 1) * ENT];
   __shared__ __attribute__((aligned(16))) uint8_t s_idx[BLK / 64][4 * QCAP];
   const int lane = threadIdx.x & 63;
   const int tile = tile_of_wave();
@@ -318,6 +321,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   float* slab = s_slab[w];
   uint8_t* sidx = s_idx[w];
+  if (lane < ENT) slab[FWD_CAP * ENT + lane] = 0.f;
   int ox, oy;
   quad_pixel(lane, ox, oy);
   const int tx0 = (tile % gsx) * SUBX, ty0 = (tile / gsx) * SUBY;
@@ -332,7 +336,8 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   const int myq = lane >> 4;
   const uint8_t* myidx = sidx + myq * QCAP;
   // stale bytes are read (never used) by the pipelined loop: make them valid slab positions
-  reinterpret_cast<uint64_t*>(sidx)[lane] = 0ull;
+  if (lane < 4 * QCAP / 8) reinterpret_cast<uint64_t*>(sidx)[lane] = 0ull;
+  static_assert((4 * QCAP) % 8 == 0 && 4 * QCAP / 8 <= 64 && QCAP >= FWD_CAP + 2, "sub-list sizing");
 
   float T = 1.0f;
   uint32_t last_contributor = 0;
@@ -361,13 +366,17 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // a block's list holds the entries of all its internal tiles: keep appending until the inner loop is worth entering
     if (fill < FWD_MIN && c0 + 64 < range.y) continue;
     const int nmax = max(max(nq[0], nq[1]), max(nq[2], nq[3]));
-    const int nmine = myq == 0 ? nq[0] : (myq == 1 ? nq[1] : (myq == 2 ? nq[2] : nq[3]));
+    // pad the shorter sub-lists up to nmax (+1 for the pipelined over-read) with the dummy entry
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (lane <= nmax - nq[q]) sidx[q * QCAP + nq[q] + lane] = (uint8_t)FWD_CAP;
+    wave_lds_sync();
     // one entry of this lane's quad sub-list against the lane's pixel
-    auto blend = [&](const Ent& e, int pos, bool active) {
+    auto blend = [&](const Ent& e, int pos) {
       const float dx = e.q0.x - pxf, dy = e.q0.y - pyf;
       const float p = power_of(e, dx, dy);
       const float alpha = fminf(e.q1.y * __builtin_amdgcn_exp2f(p), 0.99f);
-      bool valid = active && !done && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);
+      bool valid = !done && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);
       const float test_T = T * (1.f - alpha);
       const bool term = valid && test_T < 0.0001f;  // this Gaussian is NOT blended; the pixel is finished
       done = done || term;
@@ -387,14 +396,14 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     for (; j + 1 < nmax; j += 2) {
       const Ent eb = fetch(slab, i1);
       const int i2 = myidx[j + 2];
-      blend(ea, i0, j < nmine);
+      blend(ea, i0);
       ea = fetch(slab, i2);
       const int i3 = myidx[j + 3];
-      blend(eb, i1, j + 1 < nmine);
+      blend(eb, i1);
       i0 = i2;
       i1 = i3;
     }
-    if (j < nmax) blend(ea, i0, j < nmine);
+    if (j < nmax) blend(ea, i0);
     jbase += (uint32_t)fill;
     fill = 0;
     nq[0] = nq[1] = nq[2] = nq[3] = 0;
@@ -728,12 +737,13 @@ __device__ inline void transpose_round_quad(int nk, int r, int lane, const uint8
 }  // namespace
 
 template <bool HAVE_INV>
-__global__ __launch_bounds__(BLK) void render_bwd_quad_kernel(
+__global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 4))) void render_bwd_quad_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx,
     const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ out_color, const float* __restrict__ out_invdepth, const float* __restrict__ dL_dpix,
     const float* __restrict__ dL_dinv, float* __restrict__ records, uint8_t* __restrict__ live_flag) {
-  __shared__ __attribute__((aligned(16))) float s_slab[BLK / 64][64 * ENT];
+  // slab position 64 holds a DUMMY entry (opacity 0 -> alpha = 0 -> never valid): shorter sub-lists are padded with it
+  __shared__ __attribute__((aligned(16))) float s_slab[BLK / 64][65 * ENT];
   __shared__ __attribute__((aligned(16))) float s_uv[BLK / 64][UV_PITCH + UV_SIZE];
   __shared__ __attribute__((aligned(16))) float s_pix[BLK / 64][64 * 8 + 32];
   __shared__ __attribute__((aligned(16))) uint8_t s_idx[BLK / 64][4 * QB];
@@ -780,6 +790,7 @@ __global__ __launch_bounds__(BLK) void render_bwd_quad_kernel(
     d[4] = g[4];
   }
   for (int t = lane; t < 4 * QB / 4; t += 64) reinterpret_cast<uint32_t*>(sidx)[t] = 0u;  // over-read bytes: valid positions
+  if (lane < ENT) slab[64 * ENT + lane] = 0.f;
   const uint32_t tile_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(ncontrib));
   const float kx = LN2 * 0.5f * W, ky = LN2 * 0.5f * H;
   const float bx0 = (float)tx0, by0 = (float)ty0;
@@ -815,7 +826,17 @@ __global__ __launch_bounds__(BLK) void render_bwd_quad_kernel(
     pk = peek_cand<1>(c0 + 128 + lane, range.y, keys, point_list);
     wave_lds_sync();
     const int nmax = max(max(nq[0], nq[1]), max(nq[2], nq[3]));
-    const int nmine = myq == 0 ? nq[0] : (myq == 1 ? nq[1] : (myq == 2 ? nq[2] : nq[3]));
+    // pad the shorter sub-lists up to the next multiple of 8 trips with the dummy entry (transposition rounds read the
+    // entry of every (trip, quad) of a round, and the hot loop then needs no "is my quad still active" test)
+    {
+      const int npad = (nmax + 7) & ~7;
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (lane < npad + 2 - nq[q]) sidx[q * QB + nq[q] + lane] = (uint8_t)64;
+      wave_lds_sync();
+    }
+    // contributing list positions of this pixel, relative to the chunk
+    const int nc_rel = (int)min(ncontrib - min(ncontrib, jbase), 64u);
     float acc[11];
 #pragma unroll
     for (int t = 0; t < 11; t++) acc[t] = 0.f;
@@ -845,7 +866,7 @@ __global__ __launch_bounds__(BLK) void render_bwd_quad_kernel(
       const float p = power_of(e, dx, dy);
       const float G = __builtin_amdgcn_exp2f(p);
       const float alpha = fminf(e.q1.y * G, 0.99f);
-      const bool valid = (j < nmine) && (jbase + (uint32_t)pos < ncontrib) && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);
+      const bool valid = (pos < nc_rel) && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);  // (the dummy: alpha = 0)
       float gc = g[0] * e.q1.z + g[1] * e.q1.w + g[2] * e.q2.x + g[3] * e.q2.y + g[4] * e.q2.z;
       if (HAVE_INV) gc += ginv * e.q2.w;
       const float a_eff = valid ? alpha : 0.f;
