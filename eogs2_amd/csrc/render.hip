@@ -205,22 +205,26 @@ __global__ __launch_bounds__(BLK) void render_fwd_kernel(
     const int n = fill;
     fill = 0;
     // one list entry against this lane's pixel; returns nothing, all state is captured by reference
+    int last_pos = -1;  // slab position of this pixel's last blended entry in this batch
     auto blend = [&](const Ent& e, int j) {
       const float dx = e.q0.x - pxf, dy = e.q0.y - pyf;
       const float p = power_of(e, dx, dy);
       const float alpha = fminf(e.q1.y * __builtin_amdgcn_exp2f(p), 0.99f);
       bool valid = !done && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);
       const float test_T = T * (1.f - alpha);
-      const bool term = valid && test_T < 0.0001f;  // this Gaussian is NOT blended; the pixel is finished
-      done = done || term;
-      valid = valid && !term;
-      if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;
+      // test_T >= 0 and finite: its bits order like the value, and ONE compare serves `stop` and `!stop`
+      const bool stop = valid && __float_as_uint(test_T) < __float_as_uint(0.0001f);
+      done = done || stop;    // this Gaussian is NOT blended; the pixel is finished
+      valid = valid != stop;  // (stop implies valid)
       const float wgt = valid ? alpha * T : 0.f;
+      // wave-uniform skip of entries no pixel blends; wgt > 0 <=> valid (alpha >= 1/255, T >= 1e-4), and a ballot of a
+      // COMPARE is the compare's own lane mask (a ballot of a boolean costs a v_cndmask + v_cmp)
+      if (__builtin_amdgcn_ballot_w64(wgt > 0.f) == 0ull) return;
       C[0] += e.q1.z * wgt; C[1] += e.q1.w * wgt;
       C[2] += e.q2.x * wgt; C[3] += e.q2.y * wgt; C[4] += e.q2.z * wgt;
       invd += e.q2.w * wgt;
       T = valid ? test_T : T;
-      last_contributor = valid ? jbase + (uint32_t)j + 1u : last_contributor;
+      last_pos = valid ? j : last_pos;
     };
     // software pipeline over two register sets: each entry's broadcast read is issued one entry ahead of its use
     // and lands directly in the set that has just been consumed (no register rotation)
@@ -233,6 +237,7 @@ __global__ __launch_bounds__(BLK) void render_fwd_kernel(
       blend(eb, j + 1);
     }
     if (j < n) blend(ea, j);
+    if (last_pos >= 0) last_contributor = jbase + (uint32_t)last_pos + 1u;
     jbase += (uint32_t)n;
   }
   if (inside) {
@@ -372,22 +377,26 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       if (lane <= nmax - nq[q]) sidx[q * QCAP + nq[q] + lane] = (uint8_t)FWD_CAP;
     wave_lds_sync();
     // one entry of this lane's quad sub-list against the lane's pixel
+    // Every trip evaluates four different entries, each picked because it reaches its quad: a trip in which no pixel of
+    // the wave blends is rare, so there is no wave-uniform early-out here (the ballot it needs costs two VALU
+    // instructions per trip). test_T >= 0 and finite, so its bits order like the value: ONE integer compare serves both
+    // `term` and `!term` (the float compare is emitted twice, once per polarity, for NaN's sake).
+    int last_pos = -1;  // slab position of this pixel's last blended entry in this batch
     auto blend = [&](const Ent& e, int pos) {
       const float dx = e.q0.x - pxf, dy = e.q0.y - pyf;
       const float p = power_of(e, dx, dy);
       const float alpha = fminf(e.q1.y * __builtin_amdgcn_exp2f(p), 0.99f);
       bool valid = !done && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);
       const float test_T = T * (1.f - alpha);
-      const bool term = valid && test_T < 0.0001f;  // this Gaussian is NOT blended; the pixel is finished
-      done = done || term;
-      valid = valid && !term;
-      if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;
+      const bool stop = valid && __float_as_uint(test_T) < __float_as_uint(0.0001f);
+      done = done || stop;    // this Gaussian is NOT blended; the pixel is finished
+      valid = valid != stop;  // (stop implies valid: one mask xor instead of a second compare)
       const float wgt = valid ? alpha * T : 0.f;
       C[0] += e.q1.z * wgt; C[1] += e.q1.w * wgt;
       C[2] += e.q2.x * wgt; C[3] += e.q2.y * wgt; C[4] += e.q2.z * wgt;
       invd += e.q2.w * wgt;
       T = valid ? test_T : T;
-      last_contributor = valid ? jbase + (uint32_t)pos + 1u : last_contributor;
+      last_pos = valid ? pos : last_pos;
     };
     // software pipeline: sub-list bytes two trips ahead, entry reads one trip ahead, two register sets
     int i0 = myidx[0], i1 = myidx[1];
@@ -404,6 +413,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       i1 = i3;
     }
     if (j < nmax) blend(ea, i0);
+    if (last_pos >= 0) last_contributor = jbase + (uint32_t)last_pos + 1u;
     jbase += (uint32_t)fill;
     fill = 0;
     nq[0] = nq[1] = nq[2] = nq[3] = 0;
@@ -623,13 +633,15 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
         *reinterpret_cast<float4*>(rb + lane * 8 + 4) = make_float4(b.x, b.y, __uint_as_float(sslot[jk]), 0.f);
       }
     };
+    const int nc_rel = (int)min(ncontrib - min(ncontrib, jbase), 64u);  // contributing list positions, chunk-relative
     auto grad = [&](const Ent& e, int j) {
       const float dx = e.q0.x - pxf, dy = e.q0.y - pyf;
       const float p = power_of(e, dx, dy);
       const float G = __builtin_amdgcn_exp2f(p);
       const float alpha = fminf(e.q1.y * G, 0.99f);
-      const bool valid = (jbase + (uint32_t)j < ncontrib) && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);
-      if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;  // wave-uniform skip: this entry reaches no pixel of the tile
+      const bool valid = (j < nc_rel) && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);
+      // wave-uniform skip: this entry reaches no pixel of the tile (a_eff > 0 <=> valid; the ballot of a compare is free)
+      if (__builtin_amdgcn_ballot_w64((valid ? alpha : 0.f) > 0.f) == 0ull) return;
 
       float gc = g[0] * e.q1.z + g[1] * e.q1.w + g[2] * e.q2.x + g[3] * e.q2.y + g[4] * e.q2.z;
       if (have_inv) gc += ginv * e.q2.w;
