@@ -746,9 +746,68 @@ __device__ inline void transpose_round_quad(int nk, int r, int lane, const uint8
   }
 }
 
+// ---- transposition of a round on the matrix pipe (RED = 1) ----
+// The u / v matrices keep their trip-indexed rows (8 trips per round, row stride URS floats, v behind u at UV_PITCH), but
+// the sums over a quad's 16 pixels are taken by v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate: a k-ordered fmaf chain):
+// D_q[m][n] = sum_p A[m][p] B_q[p][n], n = trip, p = the quad's pixels, A rows {1, x, y, x^2, x y, y^2} in TILE-LOCAL pixel
+// coordinates for the v-part and the pixel's five upstream colour gradients for the u-part (constant per lane, in
+// registers). Lane (n, g) then holds rows 4g..4g+3 of trip n for each quad and parks them in the staging area exactly where
+// the VALU transposition puts its partials; the owner pull is unchanged. Moments arrive relative to the tile origin and
+// are shifted to the Gaussian centre once per entry, when the owner forms the record.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define URS 72  // row stride (18 x 16 B): the b128 operand reads of 8 rows x 2 k-slices of a lane group hit 16 different
+                // 16-byte bank slots, and the pixel-parallel stores (lane = pixel) 32 consecutive banks per half-wave
+static_assert(8 * URS <= UV_PITCH, "u rows fit below the v matrix");
+
+__device__ inline void mfma_round_quad(int nk, int lane, float* s_u, const float (&fxv)[8], const float (&fyv)[2],
+                                       const float* au_row) {
+  const int n = lane & 15, kk = lane >> 4;
+  const float* op = s_u + (n & 7) * URS + 4 * kk;  // (columns 8..15 duplicate trips 0..7: harmless, never stored)
+  // two quads at a time (register pressure: the kernel must stay at 128 VGPRs for 4 waves/SIMD); their two accumulator
+  // chains are issued alternately: dependent-accumulator latency 40 cycles, issue interval 32
+  f32x4 res[4];
+#pragma unroll
+  for (int qp = 0; qp < 4; qp += 2) {
+    float4 bv[2], bu[2], au4[2];
+#pragma unroll
+    for (int d = 0; d < 2; d++) {
+      bv[d] = *reinterpret_cast<const float4*>(op + UV_PITCH + 16 * (qp + d));
+      bu[d] = *reinterpret_cast<const float4*>(op + 16 * (qp + d));
+      au4[d] = *reinterpret_cast<const float4*>(au_row + 16 * (qp + d));  // u-part A operands: re-read per round
+    }
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int d = 0; d < 2; d++) {
+        const float b = i == 0 ? bv[d].x : (i == 1 ? bv[d].y : (i == 2 ? bv[d].z : bv[d].w));
+        // v-part A operand of k-step (quad qp + d, column i): fx(x) fy(y), x = 4 ((qp + d) & 1) + i, y = 4 ((qp + d) >> 1) + kk
+        const float a = fxv[4 * ((qp + d) & 1) + i] * fyv[(qp + d) >> 1];
+        acc[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[d], 0, 0, 0);
+      }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int d = 0; d < 2; d++) {
+        const float b = i == 0 ? bu[d].x : (i == 1 ? bu[d].y : (i == 2 ? bu[d].z : bu[d].w));
+        const float a = i == 0 ? au4[d].x : (i == 1 ? au4[d].y : (i == 2 ? au4[d].z : au4[d].w));
+        acc[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[d], 0, 0, 0);
+      }
+    res[qp] = acc[0];
+    res[qp + 1] = acc[1];
+  }
+  // rows 0..3 {S0 Sx Sy Sxx} | 4..7 {Sxy Syy c0 c1} | 8..11 {c2 c3 c4 -}: the staging record of (trip n, quad q).
+  // (All operand reads above were issued before these stores: the staging area aliases the u rows.)
+  if (n < nk && kk < 3) {
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      *reinterpret_cast<float4*>(s_u + (n * 4 + q) * STG + 4 * kk) = make_float4(res[q][0], res[q][1], res[q][2], res[q][3]);
+  }
+}
+
 }  // namespace
 
-template <bool HAVE_INV>
+template <bool HAVE_INV, int RED>
 __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 4))) void render_bwd_quad_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx,
     const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib,
@@ -756,10 +815,12 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const float* __restrict__ dL_dinv, float* __restrict__ records, uint8_t* __restrict__ live_flag) {
   // slab position 64 holds a DUMMY entry (opacity 0 -> alpha = 0 -> never valid): shorter sub-lists are padded with it
   __shared__ __attribute__((aligned(16))) float s_slab[BLK / 64][65 * ENT];
-  __shared__ __attribute__((aligned(16))) float s_uv[BLK / 64][UV_PITCH + UV_SIZE];
-  __shared__ __attribute__((aligned(16))) float s_pix[BLK / 64][64 * 8 + 32];
+  __shared__ __attribute__((aligned(16))) float s_uv[BLK / 64][RED ? 2 * UV_PITCH : UV_PITCH + UV_SIZE];
+  // RED = 0: 8 floats per pixel (+ padding) for the VALU transposition; RED = 1: [channel 0..4 | zero row][pixel], the
+  // u-part A operands of the MFMA transposition
+  __shared__ __attribute__((aligned(16))) float s_pix[BLK / 64][RED ? 6 * 64 : 64 * 8 + 32];
   __shared__ __attribute__((aligned(16))) uint8_t s_idx[BLK / 64][4 * QB];
-  static_assert(32 * STG <= UV_SIZE, "the staging area lives inside the u matrix");
+  static_assert(32 * STG <= UV_SIZE && 32 * STG <= 8 * URS, "the staging area lives inside the u matrix");
   const int lane = threadIdx.x & 63;
   const int tile = tile_of_wave();
   if (tile >= ntiles) return;
@@ -796,7 +857,28 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       Dfinal += ginv * out_invdepth[pix_id];
     }
   }
-  {  // pixel gradients for the transposition rounds: 8 floats per pixel (pixel index = lane), +4 floats per 8 pixels
+  // RED = 1: this lane's v-part A operands, factored: A = fx(x) fy(y) (x: 8 tile columns; y: 2 rows for this lane's kk)
+  float fxv[8], fyv[2];
+  const float* au_row = spix;
+  if (RED) {
+    // MFMA lane (m = lane & 15, kk = lane >> 4), k-step (q, i): pixel = lane 16 q + 4 kk + i of the pixel pass, i.e.
+    // tile-local (x, y) = (4 (q & 1) + i, 4 (q >> 1) + kk). Rows 0..5: v-part {1, x, y, x^2, x y, y^2}; rows 6..10:
+    // u-part, the pixel's upstream gradient of colour channel 0..4 (kept in LDS, [channel | zero row][pixel]); 11..15: zero.
+    const int mrow = lane & 15, kk = lane >> 4;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) spix[ch * 64 + lane] = g[ch];
+    spix[NCH * 64 + lane] = 0.f;
+    au_row = spix + ((mrow >= 6 && mrow <= 10) ? mrow - 6 : NCH) * 64 + 4 * kk;
+    const int ex = (mrow == 1 || mrow == 4) ? 1 : (mrow == 3 ? 2 : 0);
+    const int ey = (mrow == 2 || mrow == 4) ? 1 : (mrow == 5 ? 2 : 0);
+#pragma unroll
+    for (int x = 0; x < 8; x++) fxv[x] = mrow < 6 ? (ex == 0 ? 1.f : (ex == 1 ? (float)x : (float)(x * x))) : 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const float y = (float)(4 * h + kk);
+      fyv[h] = ey == 0 ? 1.f : (ey == 1 ? y : y * y);
+    }
+  } else {  // pixel gradients for the transposition rounds: 8 floats per pixel (pixel index = lane), +4 floats per 8 pixels
     float* d = spix + lane * 8 + 4 * (lane >> 3);
     *reinterpret_cast<float4*>(d) = make_float4(g[0], g[1], g[2], g[3]);
     d[4] = g[4];
@@ -807,7 +889,8 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const float kx = LN2 * 0.5f * W, ky = LN2 * 0.5f * H;
   const float bx0 = (float)tx0, by0 = (float)ty0;
   float T = 1.0f, Dacc = 0.f;
-  float* const uvlane = su + uv_index(0, lane);
+  float* const uvlane = RED ? su + lane : su + uv_index(0, lane);
+  constexpr int ROWF = RED ? URS : 33;  // floats between the u/v rows of consecutive trips of a round
 
   uint32_t jbase = 0;
   Cand nxt = gather_cand<1>(peek_cand<1>(range.x + lane, range.y, keys, point_list), 0u, packed);
@@ -856,7 +939,8 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // one round: transposition of `nk` trips, then every owner lane pulls the partials of its entry
     auto round = [&](int r, int nk) {
       wave_lds_sync();
-      transpose_round_quad(nk, r, lane, sidx, slab, su, sv, spix, bx0, by0);
+      if (RED) mfma_round_quad(nk, lane, su, fxv, fyv, au_row);
+      else transpose_round_quad(nk, r, lane, sidx, slab, su, sv, spix, bx0, by0);
       wave_lds_sync();
 #pragma unroll
       for (int q = 0; q < 4; q++) {
@@ -888,7 +972,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       const float one_m = 1.f - a_eff;
       const float dLda = T * gc - (Dfinal - Dacc) * __builtin_amdgcn_rcpf(one_m);
       T = T * one_m;
-      float* const uv = uvlane + (j & 7) * 33;  // trip j is slot j & 7 of round j >> 3 (trips are never skipped)
+      float* const uv = uvlane + (j & 7) * ROWF;  // trip j is slot j & 7 of round j >> 3 (trips are never skipped)
       uv[0] = wgt;
       uv[UV_PITCH] = G_eff * dLda;  // v = G dL/dalpha
       if ((j & 7) == 7) round(j >> 3, KSURV);
@@ -917,6 +1001,16 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const float4 q0 = *reinterpret_cast<const float4*>(slab + lane * ENT);
         const float2 q1 = *reinterpret_cast<const float2*>(slab + lane * ENT + 4);
         const float A = q0.z, B = q0.w, Cq = q1.x, op = q1.y;
+        if (RED) {  // moments about the tile origin -> about the Gaussian centre: sum v (gx - x) = gx S0 - Sx, ...
+          const float gxr = q0.x - bx0, gyr = q0.y - by0;
+          const float S0 = acc[0], Sx = acc[1], Sy = acc[2], Sxx = acc[3], Sxy = acc[4], Syy = acc[5];
+          const float Sdx = gxr * S0 - Sx, Sdy = gyr * S0 - Sy;
+          acc[1] = Sdx;
+          acc[2] = Sdy;
+          acc[3] = gxr * (Sdx - Sx) + Sxx;
+          acc[4] = gxr * Sdy - gyr * Sx + Sxy;
+          acc[5] = gyr * (Sdy - Sy) + Syy;
+        }
         const float m2x = op * kx * (2.f * A * acc[1] - B * acc[2]);
         const float m2y = op * ky * (2.f * Cq * acc[2] - B * acc[1]);
         const float ho = -0.5f * op;
@@ -956,7 +1050,6 @@ namespace {
 #define MRS 68           // row stride of the window matrices in floats (17 x 16 B: the b128 operand reads of 16 rows spread over all banks)
 #define MUV (MW * MRS)   // floats per matrix = 17 x 64 dwords: u and v of a pixel go out in one ds_write2st64_b32
 #define QBM 96           // bytes per quad sub-list (64 entries + the pipelined over-read past a window's trips)
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 }  // namespace
 
@@ -1173,7 +1266,7 @@ __global__ __launch_bounds__(BLK) void render_bwd_mfma_kernel(
   }
 }
 
-static int bwd_mfma_on() {  // EOGS_BWD_MFMA=0 falls back to the VALU transposition (render_bwd_quad_kernel)
+static int bwd_mfma_on() {  // EOGS_BWD_MFMA: 0 = VALU transposition, 1 = entry-indexed MFMA kernel (2.6), 2 = trip-indexed MFMA transposition
   static const int v = [] {
     const char* e = getenv("EOGS_BWD_MFMA");
     return e ? atoi(e) : 0;
@@ -1192,7 +1285,7 @@ static double quad_bwd_switch() {  // EOGS_QUAD_BWD_SWITCH=<listed tiles per Gau
 int render_bwd_variant(int block, int64_t R, int P) {
   if (block > 1) return 1;
   if (!(quad_bwd_switch() > 0.0 && (double)nr_slots(R) <= quad_bwd_switch() * (double)P)) return 0;
-  return bwd_mfma_on() ? 3 : 2;
+  return bwd_mfma_on() == 1 ? 3 : (bwd_mfma_on() == 2 ? 4 : 2);
 }
 
 void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, const float* colors,
@@ -1202,8 +1295,9 @@ void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, 
   const int variant = render_bwd_variant(b.block, R, P);
   auto* kern = variant == 1 ? (dL_dinvdepth ? render_bwd_kernel<BLOCK_BIG, true> : render_bwd_kernel<BLOCK_BIG, false>)
                             : (dL_dinvdepth ? render_bwd_kernel<1, true> : render_bwd_kernel<1, false>);
-  if (variant == 2) kern = dL_dinvdepth ? render_bwd_quad_kernel<true> : render_bwd_quad_kernel<false>;
+  if (variant == 2) kern = dL_dinvdepth ? render_bwd_quad_kernel<true, 0> : render_bwd_quad_kernel<false, 0>;
   if (variant == 3) kern = dL_dinvdepth ? render_bwd_mfma_kernel<true> : render_bwd_mfma_kernel<false>;
+  if (variant == 4) kern = dL_dinvdepth ? render_bwd_quad_kernel<true, 1> : render_bwd_quad_kernel<false, 1>;
   hipLaunchKernelGGL(kern, dim3(render_grid(ntiles)), dim3(BLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H, gsx,
                      ntiles, (int)macro_grid_x(W, b.block), g.packed, im.n_contrib, out_color, out_invdepth, dL_dcolor,
                      dL_dinvdepth, b.records, b.live);

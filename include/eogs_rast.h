@@ -185,7 +185,8 @@ int eogs_rast_profile_get(int slot, double* total_ms, int64_t* launches, const c
  * (DESIGN.md §2.3, §2.5); tests use this to record that every kernel was compared with the oracle.
  *   *list_block_px  8 (per-tile lists) or 32 (block lists)
  *   *fwd_kernel / *bwd_kernel  0 = one list per tile (render_*_kernel<1>), 1 = block lists (render_*_kernel<4>),
- *                              2 = quad sub-lists (render_*_quad_kernel)
+ *                              2 = quad sub-lists (render_*_quad_kernel); backward only: 3 = quad sub-lists with the
+ *                              entry-indexed MFMA reduction, 4 = quad sub-lists with the MFMA transposition
  * The oracle reports 16 / -1 / -1 (the reference's 16-px tiles, no kernel variants). */
 int eogs_rast_path_info(int P, int64_t num_rendered, int* list_block_px, int* fwd_kernel, int* bwd_kernel);
 /* Runs the library's wave64 primitive self-test (DPP reduction, readlane broadcast) on `stream` and returns,

@@ -28,8 +28,10 @@ FORCED = {  # (the default switches run in-process: tests/test_gpu_parity.py, sa
              "EOGS_BWD_MFMA": "0"},
     "quad_mfma": {"EOGS_BLOCK_SWITCH": "1000", "EOGS_DEPTH_SWITCH": "0", "EOGS_QUAD_SWITCH": "1000",
                   "EOGS_QUAD_BWD_SWITCH": "1000", "EOGS_BWD_MFMA": "1"},
+    "quad_mfma_t": {"EOGS_BLOCK_SWITCH": "1000", "EOGS_DEPTH_SWITCH": "0", "EOGS_QUAD_SWITCH": "1000",
+                    "EOGS_QUAD_BWD_SWITCH": "1000", "EOGS_BWD_MFMA": "2"},
 }
-KERNEL_NAMES = {0: "tile", 1: "block", 2: "quad", 3: "quad_mfma"}
+KERNEL_NAMES = {0: "tile", 1: "block", 2: "quad", 3: "quad_mfma", 4: "quad_mfma_t"}
 
 
 @pytest.fixture(scope="module")
@@ -95,11 +97,13 @@ def test_every_kernel_path_matches_oracle(dev, case_dir, tmp_path):
             assert all(p == (8, 2, 2) for p in paths), report[tag]
         if tag == "quad_mfma":
             assert all(p == (8, 2, 3) for p in paths), report[tag]
+        if tag == "quad_mfma_t":
+            assert all(p == (8, 2, 4) for p in paths), report[tag]
         seen_fwd |= {p[1] for p in paths}
         seen_bwd |= {p[2] for p in paths}
     print("kernel paths compared with the oracle:", json.dumps(report))
     assert seen_fwd == {0, 1, 2}, report
-    assert seen_bwd == {0, 1, 2, 3}, report
+    assert seen_bwd == {0, 1, 2, 3, 4}, report
 
 
 def _full_size_case(P, H, W, seed, opacity, **kw):
