@@ -222,18 +222,35 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
           my_tiles = 0;
         } else if (sw * sh <= MASK_MAX_SUBTILES) {
           kind = BK_MASK;
-          const float b_c = cb / cc, b_a = cb / ca;
           // (a rect of at most 64 tiles spans at most ceil(64/BLOCK_BIG)+1 blocks in a row: block bits fit 64 bits)
           const int bx0 = sx0 / BLOCK_BIG, by0 = sy0 / BLOCK_BIG, bw = (sx1 - 1) / BLOCK_BIG - bx0 + 1;
           unsigned long long blocks = 0ull;  // blocks (BLOCK_BIG x BLOCK_BIG tiles) with at least one listed tile
-          for (int sy = sy0; sy < sy1; sy++)
-            for (int sx = sx0; sx < sx1; sx++) {
-              const float bx = (float)(sx * SUBX), by = (float)(sy * SUBY);
-              if (block_hit(px, py, ca, cb, cc, b_c, b_a, tau_m, bx, by, bx + (SUBX - 1), by + (SUBY - 1))) {
-                m |= 1ull << ((sy - sy0) * sw + (sx - sx0));
-                blocks |= 1ull << ((sy / BLOCK_BIG - by0) * bw + (sx / BLOCK_BIG - bx0));
+          if (tau_m >= 0.f && tau_m < 3.0e38f && ca * cc - cb * cb > 0.f) {
+            // one closed-form column span per tile ROW (common.h row_span: the ellipse cut by the row band is convex) instead
+            // of one block test per TILE: the wave runs max-over-lanes iterations, and a footprint has far fewer rows (<= 8)
+            // than tiles (<= 64)
+            const SpanParams spm = span_params(px, py, ca, cb, cc, tau_m);
+            for (int sy = sy0; sy < sy1; sy++) {
+              int c0, c1;
+              row_span(spm, sy, sx0, sx1, c0, c1);
+              if (c1 > c0) {
+                const unsigned long long run = (c1 - c0 >= 64 ? ~0ull : ((1ull << (c1 - c0)) - 1ull)) << (c0 - sx0);
+                m |= run << ((sy - sy0) * sw);
+                const int b0 = c0 / BLOCK_BIG - bx0, b1 = (c1 - 1) / BLOCK_BIG - bx0;  // block columns [b0, b1]
+                blocks |= (((1ull << (b1 - b0 + 1)) - 1ull) << b0) << ((sy / BLOCK_BIG - by0) * bw);
               }
             }
+          } else {  // degenerate conic / threshold: the per-tile test (keeps NaNs: they fail every comparison)
+            const float b_c = cb / cc, b_a = cb / ca;
+            for (int sy = sy0; sy < sy1; sy++)
+              for (int sx = sx0; sx < sx1; sx++) {
+                const float bx = (float)(sx * SUBX), by = (float)(sy * SUBY);
+                if (block_hit(px, py, ca, cb, cc, b_c, b_a, tau_m, bx, by, bx + (SUBX - 1), by + (SUBY - 1))) {
+                  m |= 1ull << ((sy - sy0) * sw + (sx - sx0));
+                  blocks |= 1ull << ((sy / BLOCK_BIG - by0) * bw + (sx / BLOCK_BIG - bx0));
+                }
+              }
+          }
           my_tiles = (uint32_t)__popcll(m);
           my_entries = (uint32_t)__popcll(blocks);
         } else if (tau_m >= 0.f && tau_m < 3.0e38f && ca * cc - cb * cb > 0.f) {
