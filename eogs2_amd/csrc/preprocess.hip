@@ -399,6 +399,8 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
   for (int k = 0; k < 18; k++) vmsum[k] = 0.f;
 
   if (t < rows) {
+    // (Summing the records in double was measured: 0.109 -> 0.130 ms, and no accuracy gained — the residual error of
+    // extreme footprints comes from the per-pixel pass)
     float acc[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) acc[k] = 0.f;

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "librast_oracle.so")
 def build(force=False):
     src = os.path.join(_HERE, "rast_oracle.c")
     hdr = os.path.join(_HERE, "..", "include", "eogs_rast.h")
-    stale = (not os.path.exists(LIB_PATH)) or any(
+    stale = (not os.path.exists(LIB_PATH)) or (not os.path.exists(os.path.join(_HERE, "librast_oracle_fma.so"))) or any(
         os.path.getmtime(p) > os.path.getmtime(LIB_PATH) for p in (src, hdr)
     )
     if force or stale:
@@ -22,6 +22,26 @@ def build(force=False):
 
 
 _abi = None
+_abi_fma = None
+
+
+def abi_fma():
+    """RastABI over the FMA-contracted build of the same restatement (None if the host CPU has no FMA or the build is
+    missing): a second valid fp32 rounding, used by the tests to measure rounding-level instability."""
+    global _abi_fma
+    if _abi_fma is None:
+        path = os.path.join(_HERE, "librast_oracle_fma.so")
+        build()
+        try:
+            has_fma = "fma" in open("/proc/cpuinfo").read()
+        except OSError:
+            has_fma = False
+        if not has_fma or not os.path.exists(path):
+            return None
+        from eogs2_amd._abi import RastABI
+
+        _abi_fma = RastABI(path)
+    return _abi_fma
 
 
 def abi():

@@ -44,6 +44,15 @@
 
 static __thread char g_err[256];
 
+/* The per-Gaussian sums of BACKWARD::renderCUDA are fp32 atomicAdds in the reference (backward.cu:598-640), in an order that
+ * changes from run to run; the restatement accumulates them in double (the order-independent value the fp32 sums scatter
+ * around). For the tests' sensitivity attribution (tests/parity_cases.py) the accumulation can be switched to fp32 in
+ * pixel order — one of the orders the reference itself can produce — so that the size of the summation-order effect is
+ * measured rather than assumed. Test infrastructure only; not part of include/eogs_rast.h. */
+static int g_acc_float = 0;
+int eogs_oracle_accum_float(int on) { const int old = g_acc_float; g_acc_float = on != 0; return old; }
+#define ACC(a, term) do { if (g_acc_float) (a) = (double)((float)(a) + (float)(term)); else (a) += (double)(term); } while (0)
+
 static int fail(int code, const char* msg) {
   snprintf(g_err, sizeof g_err, "%s", msg);
   return code;
@@ -519,14 +528,14 @@ static int backward_activated(
           last_color[ch] = c;
           const float dL_dchannel = dL_dpixel[ch];
           dL_dalpha += (c - accum_rec[ch]) * dL_dchannel;
-          acc_color[(size_t)id * C_ + ch] += (double)(dchannel_dcolor * dL_dchannel);
+          ACC(acc_color[(size_t)id * C_ + ch], dchannel_dcolor * dL_dchannel);
         }
         if (dL_dout_invdepth) {
           const float invd = 1.f / g.depths[id];
           accum_invdepth_rec = last_alpha * last_invdepth + (1.f - last_alpha) * accum_invdepth_rec;
           last_invdepth = invd;
           dL_dalpha += (invd - accum_invdepth_rec) * dL_invdepth;
-          acc_invd[id] += (double)(dchannel_dcolor * dL_invdepth);
+          ACC(acc_invd[id], dchannel_dcolor * dL_invdepth);
         }
         dL_dalpha *= T;
         last_alpha = alpha;
@@ -536,12 +545,12 @@ static int backward_activated(
         const float gdx = G * dx, gdy = G * dy;
         const float dG_ddelx = -gdx * co[0] - gdy * co[1];
         const float dG_ddely = -gdy * co[2] - gdx * co[1];
-        acc_mean2D[2 * (size_t)id] += (double)(dL_dG * dG_ddelx * ddelx_dx);
-        acc_mean2D[2 * (size_t)id + 1] += (double)(dL_dG * dG_ddely * ddely_dy);
-        acc_conic[3 * (size_t)id] += (double)(-0.5f * gdx * dx * dL_dG);
-        acc_conic[3 * (size_t)id + 1] += (double)(-0.5f * gdx * dy * dL_dG);
-        acc_conic[3 * (size_t)id + 2] += (double)(-0.5f * gdy * dy * dL_dG);
-        acc_opac[id] += (double)(G * dL_dalpha);
+        ACC(acc_mean2D[2 * (size_t)id], dL_dG * dG_ddelx * ddelx_dx);
+        ACC(acc_mean2D[2 * (size_t)id + 1], dL_dG * dG_ddely * ddely_dy);
+        ACC(acc_conic[3 * (size_t)id], -0.5f * gdx * dx * dL_dG);
+        ACC(acc_conic[3 * (size_t)id + 1], -0.5f * gdx * dy * dL_dG);
+        ACC(acc_conic[3 * (size_t)id + 2], -0.5f * gdy * dy * dL_dG);
+        ACC(acc_opac[id], G * dL_dalpha);
       }
     }
 

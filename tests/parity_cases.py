@@ -187,7 +187,7 @@ def threshold_map(case):
     return near, touched
 
 
-def oracle_run(case):
+def oracle_run(case, backend=None):
     """The case through the same host wrapper over the CPU oracle (checker library; tests only)."""
     import oracle
     from util import run_case
@@ -195,7 +195,7 @@ def oracle_run(case):
     from eogs2_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib
 
     hip = _lib.get
-    _lib.get = oracle.abi
+    _lib.get = backend or oracle.abi
     try:
         ref = run_case(case, torch.device("cpu"), GaussianRasterizer, GaussianRasterizationSettings)
     finally:
@@ -213,12 +213,36 @@ def sensitivity_map(case, base=None):
     ORACLE's own output moves by more than the tolerance under such a perturbation (cancelling sums in the covariance
     backward of strongly anisotropic Gaussians, backward.cu:239-394; or a pair sitting on a threshold), two correct
     fp32 implementations cannot be expected to agree to the tolerance, and the movement bounds by how much."""
+    import oracle
+
     base = base if base is not None else oracle_run(case)
     out = {k: np.zeros_like(np.asarray(v), dtype=np.float64) for k, v in base.items() if k != "out_radii"}
+    # the summation order of the per-Gaussian sums: fp32 atomicAdds in the reference (backward.cu:598-640, order changes run
+    # to run), fp32 per-tile records here, double in the restatement. One evaluation with fp32 accumulation in pixel order
+    # (an order the reference itself can produce) measures how far that moves each output.
+    lib = oracle.abi().cdll
+    lib.eogs_oracle_accum_float(1)
+    try:
+        res = oracle_run(case)
+    finally:
+        lib.eogs_oracle_accum_float(0)
+    for k in out:
+        out[k] = np.maximum(out[k], np.abs(np.asarray(res[k], dtype=np.float64) - np.asarray(base[k], dtype=np.float64)))
+    # rounding alone: the same restatement built with fused multiply-adds (oracle/Makefile). Expressions of the reference
+    # that cancel (`denom - c_xx * c_yy` = -c_xy^2 computed from two rounded products, backward.cu:239-251) are numerically
+    # unstable rather than ill-conditioned: an input perturbation moves both products together and does not show it, a
+    # second valid rounding does.
+    fma = oracle.abi_fma()
+    if fma is not None:
+        res = oracle_run(case, backend=lambda: fma)
+        for k in out:
+            out[k] = np.maximum(out[k], np.abs(np.asarray(res[k], dtype=np.float64) - np.asarray(base[k], dtype=np.float64)))
     for draw in range(SENS_DRAWS):
         g = np.random.default_rng(1000 + draw)
         pert = dict(case)
-        for k in ("means3D", "scales", "rotations", "opacities", "colors", "cov3D_precomp"):
+        # the Gaussians' parameters (each moves all of a Gaussian's pixel terms together) AND the upstream gradient (moves
+        # every pixel's term independently: what the rounding of the individual terms of a cancelling per-Gaussian sum does)
+        for k in ("means3D", "scales", "rotations", "opacities", "colors", "cov3D_precomp", "dL_dcolor", "dL_dinvdepth"):
             if k in case:
                 v = np.asarray(case[k])
                 pert[k] = (v * (1.0 + SENS_ULPS * ULP * g.standard_normal(v.shape))).astype(np.float32)
@@ -265,7 +289,7 @@ class Attribution:
         return torch.from_numpy(self._sens[key])
 
 
-def check_close(got, ref, what, rtol, attribution=None, kind=None, flip_rtol=5e-2, key=None, sens_rtol=1e-1):
+def check_close(got, ref, what, rtol, attribution=None, kind=None, flip_rtol=5e-2, key=None, sens_rtol=1e-1, flip_abs=0.0):
     """|got - ref| <= rtol * max|ref| elementwise; elements beyond it must be attributed — to a threshold pixel (kind
     "image": the pixel is a near-threshold pixel; kind "gaussian": the row's Gaussian is touched by one; bounded by
     flip_rtol), or, failing that, to the oracle's own sensitivity: the element moves by at least err / SENS_FACTOR when
@@ -313,7 +337,10 @@ def check_close(got, ref, what, rtol, attribution=None, kind=None, flip_rtol=5e-
         f"ill-conditioned (max unexplained err {float(err[unexplained].max()):.3e}, rtol {rtol:g}, scale {scale:.3e})")
     flipped = bad & ok
     if bool(flipped.any()):
-        assert float(err[flipped].max()) <= flip_rtol, f"{what}: attributed flip of {float(err[flipped].max()):.3e} exceeds {flip_rtol:g}"
+        # a flipped blend decision moves a pixel by one contribution alpha T |c| <= |c|_max / 255 (flip_abs, absolute): in a
+        # faint image (few low-opacity Gaussians) that can be several per cent of the image's own scale
+        lim = max(flip_rtol, flip_abs / scale)
+        assert float(err[flipped].max()) <= lim, f"{what}: attributed flip of {float(err[flipped].max()):.3e} exceeds {lim:.3g}"
     return float(err.max()), nbad
 
 
@@ -344,8 +371,15 @@ def compare(out, ref, name, case, stats=None, cache=None):
             assert err <= lim, f"{name}:{k}: {err:.3e} of the magnitude sum (limit {lim:g})"
             continue
         grad = k.startswith("g_")
+        flip_abs = 0.0
+        if k == "out_color":    # one blended / skipped Gaussian at alpha ~ 1/255: |c|_max / 255 (+ a few per cent)
+            flip_abs = 1.05 / 255.0 * float(np.abs(np.asarray(case["colors"])).max()) if np.asarray(case["colors"]).size else 0.0
+        elif k == "out_invdepth" and np.asarray(case["means3D"]).size:
+            vm = np.asarray(case["viewmatrix"], dtype=np.float64)
+            depth = 200.0 - (np.asarray(case["means3D"], dtype=np.float64) @ vm[:3, 2] + vm[3, 2])
+            flip_abs = 1.05 / 255.0 / float(depth[depth > 0].min()) if (depth > 0).any() else 0.0
         _, n = check_close(v, r, f"{name}:{k}", GRAD_RTOL.get(name, RTOL) if grad else RTOL, att,
-                           "gaussian" if grad else "image", flip_rtol=5e-2 if grad else 2e-2, key=k)
+                           "gaussian" if grad else "image", flip_rtol=5e-2 if grad else 2e-2, key=k, flip_abs=flip_abs)
         flips += n
     if stats is not None:
         stats[name] = flips
