@@ -311,7 +311,8 @@ int eogs_rast_backward_range(int P, int H, int W, int64_t R, const float* bg, co
   }
   const bool raw = (flags & EOGS_FLAG_RAW_PARAMS) != 0;
   if (!means3D || !radii || !opacities || !viewmatrix || !projmatrix || !dL_dout_color || !out_color || !geom ||
-      !image || !dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || (!raw && (!colors || !dL_dcov3D)))
+      !image || !dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || (!raw && !colors) ||
+      (cov3D_precomp && !dL_dcov3D))
     return fail(EOGS_ERR_INVALID_ARG, "backward: NULL argument");
   if (dL_dout_invdepth && !out_invdepth) return fail(EOGS_ERR_INVALID_ARG, "backward: out_invdepth required with dL_dout_invdepth");
   const bool have_sr = scales && rotations;

@@ -281,7 +281,7 @@ def _run_backward(rs, num_rendered, grad_out_color, grad_out_depth, means3D, col
         d_colors = out("colors", (P, 3 if raw else NUM_CHANNELS))
         d_opacity = out("opacities", (P, 1))
         d_means3D = out("means3D", (P, 3))
-        d_cov3D = None if raw else torch.empty((P, 6), **f32)
+        d_cov3D = None if (raw or have_sr) else torch.empty((P, 6), **f32)  # only returned for cov3D_precomp inputs
         d_scales = out("scales", (P, 3)) if have_sr else None
         d_rot = out("rotations", (P, 4)) if have_sr else None
         dT_sum = torch.empty((6,), **f32) if want_vm else None

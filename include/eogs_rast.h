@@ -117,7 +117,8 @@ int eogs_rast_forward_render(
  *   dL_dout_color  f32[5,H,W];  dL_dout_invdepth f32[H,W] or NULL
  *   dL_dmeans2D f32[P,3] (NDC units, z = 0)  dL_dcolors f32[P,5]  dL_dopacity f32[P]
  *   dL_dmeans3D f32[P,3]  dL_dcov3D f32[P,6]  dL_dscales f32[P,3]  dL_drotations f32[P,4]
- *     (dL_dscales/dL_drotations may be NULL when cov3D_precomp is used)
+ *     (dL_dscales/dL_drotations may be NULL when cov3D_precomp is used; dL_dcov3D may be NULL when scales/rotations are
+ *     used: the reference always materialises it, DGR/rasterize_points.cu:167, and its wrapper then discards it)
  *   dL_dT_sum  f32[6] or NULL: sum over Gaussians of dL/dT (2x3, row-major), T = diag(W/2,H/2)·A[0:2,:],
  *     i.e. the reduction the reference wrapper performs on its [P,6] dL_dT tensor
  *     (DGR/diff_gaussian_rasterization/__init__.py:179-190) under the intended 6*idx layout

@@ -775,12 +775,19 @@ int eogs_rast_backward(
     float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity,
     float* dL_dmeans3D, float* dL_dcov3D, float* dL_dscales, float* dL_drotations,
     float* dL_dT_sum, float* dL_dvm_mean, void* stream) {
-  if (!(flags & EOGS_FLAG_RAW_PARAMS) || P <= 0)
-    return backward_activated(P, H, W, R, bg, means3D, radii, colors, opacities, scales, rotations, scale_modifier,
-                              cov3D_precomp, viewmatrix, projmatrix, flags, out_color, out_invdepth, dL_dout_color,
-                              dL_dout_invdepth, geom, geom_bytes, binning, binning_bytes, image, image_bytes,
-                              dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dscales,
-                              dL_drotations, dL_dT_sum, dL_dvm_mean, stream);
+  if (!(flags & EOGS_FLAG_RAW_PARAMS) || P <= 0) {
+    /* dL_dcov3D may be NULL when scales / rotations are given (the wrapper discards it then): computed into a temporary */
+    float* d_cov = dL_dcov3D;
+    if (!d_cov && P > 0 && scales && rotations && !(d_cov = (float*)malloc((size_t)P * 6 * 4)))
+      return fail(EOGS_ERR_DEVICE, "backward: out of host memory");
+    const int rc0 = backward_activated(P, H, W, R, bg, means3D, radii, colors, opacities, scales, rotations, scale_modifier,
+                                       cov3D_precomp, viewmatrix, projmatrix, flags, out_color, out_invdepth, dL_dout_color,
+                                       dL_dout_invdepth, geom, geom_bytes, binning, binning_bytes, image, image_bytes,
+                                       dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, d_cov, dL_dscales,
+                                       dL_drotations, dL_dT_sum, dL_dvm_mean, stream);
+    if (d_cov != dL_dcov3D) free(d_cov);
+    return rc0;
+  }
   g_err[0] = 0;
   if (!means3D || !scales || !rotations || cov3D_precomp || !opacities || !alt_affine || !dL_dcolors ||
       !dL_dopacity || !dL_dmeans3D || !dL_dscales || !dL_drotations || !geom)
