@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--ar-chunks", type=int, default=0,
                     help="Gaussian ranges of the overlapped gradient exchange (eogs_rast_backward_range); 0 = pick the "
                          "faster of 1 and 4 during warmup")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="collective backend; gloo + --share-gpu rehearses the N-rank path on a one-GPU box (not a measurement)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher self-test: ranks rendezvous over gloo, all-reduce one number and exit before any GPU call")
     return ap.parse_args()
@@ -636,14 +639,17 @@ def main():
     if a.dry_run:
         return dry_run(a, rank, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", 0 if a.share_gpu else local_rank)
     torch.cuda.set_device(dev)
     dist = None
     use_dist = world > 1 or a.force_dist
     if use_dist:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from eogs2_amd import GaussianRasterizer, _lib
     from eogs2_amd.parallel import GradBucket
@@ -667,9 +673,9 @@ def main():
                         names=names, chunks=max(1, a.ar_chunks))
     rast = GaussianRasterizer(rs)
 
-    def step():
+    def step(exchange=True):
         means2D.grad = None
-        if use_dist:
+        if use_dist and exchange:
             # the exchange step: the backward writes the gradients into the bucket and starts the RCCL all-reduce of each
             # Gaussian range as soon as it is computed; finish() waits and leaves the sums in every .grad
             bucket.begin()
@@ -679,7 +685,7 @@ def main():
         color, radii, _ = rast(params["means3D"], means2D, params["opacities"], colors_precomp=params["colors"],
                                scales=params["scales"], rotations=params["rotations"])
         torch.autograd.backward([color], [dL])  # the loss gradient dL/dcolor is an input of the path
-        if use_dist:
+        if use_dist and exchange:
             bucket.finish()
         return color
 
@@ -690,9 +696,10 @@ def main():
 
     # Initialisation, before the contract's warmup: a fresh box starts at idle clocks and the first ~1 s of work runs
     # 20-40 % slow (measured: 1.29-1.54 ms/step in the first 25 ms of GPU time against 1.07 afterwards).
+    # (The ramp is timed, so ranks run different numbers of steps: no collective inside it.)
     t_ramp = time.perf_counter()
     while time.perf_counter() - t_ramp < 1.5:
-        step()
+        step(exchange=False)
         torch.cuda.synchronize()
     ramp_s = time.perf_counter() - t_ramp
     exchange = None
@@ -826,6 +833,7 @@ def main():
             "ramp_s": ramp_s,  # untimed clock ramp before the contract's warmup (a fresh box starts at idle clocks)
         }
         if exchange is not None:
+            exchange["backend"] = a.backend + (" (rehearsal: ranks share one GPU)" if a.share_gpu else "")
             line["exchange"] = exchange
             line["rccl_ranks"] = exchange["rccl_ranks"]
             line["allreduce_ms"] = exchange["allreduce_ms"]

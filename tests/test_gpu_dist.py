@@ -1,0 +1,30 @@
+"""GPU (MI355X, one card): rehearsal of the N-rank data-parallel bench path. RCCL refuses two ranks on one device, so the
+ranks share cuda:0 and exchange over gloo (`--backend gloo --share-gpu`): not a measurement, but everything else is the
+code the driver's `--gpus N` run executes — bench.py starting its own ranks, the overlapped gradient exchange driven by
+the rasterizer's backward (eogs_rast_backward_range), the warmup measurement of the number of ranges, the JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_rank_bench_rehearsal():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
+                        "--steps", "4", "--warmup", "1", "--gaussians", "30000", "--size", "160"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["parallelism"] == "view-dp2"
+    ex = line["exchange"]
+    assert ex["rccl_ranks"] == 2 and ex["bytes_per_gaussian"] == 56 and ex["chunks"] in (1, 4)
+    assert set(ex["chunks_tried_ms_per_step"]) == {"1", "4"}
+    assert line["value"] > 0 and line["ms_per_step"] > 0
