@@ -8,6 +8,9 @@
 * `compact_rows(mask, tensors)` — every `tensor[mask]` of `prune_points` / `_prune_optimizer`
   (gaussian_model.py:466-505) in one scan + one gather launch and a single host sync.
 * `prune_optimizer(optimizer, mask, extra=())` — `_prune_optimizer` + the statistics of `prune_points`, on top of it.
+* `densify_and_clone` / `densify_and_split` / `cat_tensors_to_optimizer` — the clone / split densification of
+  gaussian_model.py:507-660 (off by default in the reference, `only_prune: True`): every boolean-mask gather of a step in
+  one scan + one gather, the random draw left to `torch.normal` so that it is the reference's own.
 
 No CPU / eager fallback: arithmetic only in the HIP library.
 """
@@ -134,6 +137,116 @@ def prune_optimizer(optimizer, mask, extra=()):
     return optimizable, out[i:]
 
 
+def _groups(optimizer):
+    plan = []
+    for group in optimizer.param_groups:
+        assert len(group["params"]) == 1
+        p = group["params"][0]
+        plan.append((group, p, optimizer.state.get(p, None)))
+    return plan
+
+
+def _install(optimizer, plan, new_tensors):
+    """Replaces every group's parameter (and moments) by the given tensors: `replace_tensor_to_optimizer` /
+    `cat_tensors_to_optimizer` / `_prune_optimizer` all end this way (gaussian_model.py:451-540)."""
+    out, i = {}, 0
+    for group, p, st in plan:
+        new_p = nn.Parameter(new_tensors[i].requires_grad_(True))
+        i += 1
+        if st is not None:
+            st["exp_avg"], st["exp_avg_sq"] = new_tensors[i], new_tensors[i + 1]
+            i += 2
+            del optimizer.state[p]
+            optimizer.state[new_p] = st
+        group["params"][0] = new_p
+        out[group["name"]] = new_p
+    return out
+
+
+def cat_tensors_to_optimizer(optimizer, tensors_dict):
+    """`GaussianModel.cat_tensors_to_optimizer` (gaussian_model.py:507-538): appends rows to every group's parameter and
+    zero rows to its Adam moments. Returns {group name: new nn.Parameter}."""
+    plan = _groups(optimizer)
+    new = []
+    for group, p, st in plan:
+        ext = tensors_dict[group["name"]]
+        new.append(torch.cat((p.data, ext), dim=0))
+        if st is not None:
+            new.append(torch.cat((st["exp_avg"], torch.zeros_like(ext)), dim=0))
+            new.append(torch.cat((st["exp_avg_sq"], torch.zeros_like(ext)), dim=0))
+    return _install(optimizer, plan, new)
+
+
+def _selected_rows(optimizer, mask, names, extra=()):
+    """{name: rows of that group's parameter where mask} + the same rows of `extra`: ONE scan + ONE gather launch and one
+    host sync for all of them (the reference indexes each tensor with the boolean mask: a nonzero + gather + sync each)."""
+    by_name = {g["name"]: g["params"][0] for g in optimizer.param_groups}
+    rows = compact_rows(mask, [by_name[n].data for n in names] + list(extra))
+    return dict(zip(names, rows[:len(names)])), rows[len(names):]
+
+
+def build_rotation(r):
+    """utils/general_utils.py:82-105 (quaternion normalised here, unlike the rasterizer's computeCov3D)."""
+    q = r / torch.sqrt(r[:, 0] * r[:, 0] + r[:, 1] * r[:, 1] + r[:, 2] * r[:, 2] + r[:, 3] * r[:, 3])[:, None]
+    rr, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.zeros((q.size(0), 3, 3), device=r.device)
+    R[:, 0, 0] = 1 - 2 * (y * y + z * z)
+    R[:, 0, 1] = 2 * (x * y - rr * z)
+    R[:, 0, 2] = 2 * (x * z + rr * y)
+    R[:, 1, 0] = 2 * (x * y + rr * z)
+    R[:, 1, 1] = 1 - 2 * (x * x + z * z)
+    R[:, 1, 2] = 2 * (y * z - rr * x)
+    R[:, 2, 0] = 2 * (x * z - rr * y)
+    R[:, 2, 1] = 2 * (y * z + rr * x)
+    R[:, 2, 2] = 1 - 2 * (x * x + y * y)
+    return R
+
+
+GROUPS = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+
+
+def densify_and_clone(optimizer, selected_pts_mask, tmp_radii=None):
+    """`GaussianModel.densify_and_clone` + `densification_postfix` (gaussian_model.py:625-660, 540-571) on the
+    optimizer's groups: the selected Gaussians are appended once more (zero moments for the copies). The caller computes
+    `selected_pts_mask` exactly as the reference (gradient norm >= threshold & max scaling <= percent_dense * extent) and
+    resets the three statistics to zeros of the new size. Returns ({name: new Parameter}, new tmp_radii or None)."""
+    names = [g["name"] for g in optimizer.param_groups]
+    rows, extra = _selected_rows(optimizer, selected_pts_mask, names, () if tmp_radii is None else (tmp_radii,))
+    params = cat_tensors_to_optimizer(optimizer, rows)
+    return params, (torch.cat((tmp_radii, extra[0])) if tmp_radii is not None else None)
+
+
+def densify_and_split(optimizer, selected_pts_mask, N=2, tmp_radii=None):
+    """`GaussianModel.densify_and_split` (gaussian_model.py:573-623) on the optimizer's groups: every selected Gaussian is
+    replaced by N samples of itself (positions drawn from it with `torch.normal`, scales divided by 0.8 N) and then
+    pruned. The random draw is `torch.normal(mean=zeros, std=stds)` as in the reference, so the same generator state gives
+    the same samples. Activations as the reference's model: scaling = exp(_scaling), its inverse log.
+    Returns ({name: new Parameter}, new tmp_radii or None, keep mask over the intermediate [old ++ new] rows)."""
+    names = [g["name"] for g in optimizer.param_groups]
+    sel, extra = _selected_rows(optimizer, selected_pts_mask, names, () if tmp_radii is None else (tmp_radii,))
+    scaling = torch.exp(sel["scaling"])
+    stds = scaling.repeat(N, 1)
+    means = torch.zeros((stds.size(0), 3), device=stds.device)
+    samples = torch.normal(mean=means, std=stds)
+    rots = build_rotation(sel["rotation"]).repeat(N, 1, 1)
+    new = {
+        "xyz": torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + sel["xyz"].repeat(N, 1),
+        "scaling": torch.log(scaling.repeat(N, 1) / (0.8 * N)),
+        "rotation": sel["rotation"].repeat(N, 1),
+        "opacity": sel["opacity"].repeat(N, 1),
+    }
+    for n in names:
+        if n not in new:  # f_dc [K,1,3], f_rest [K,M,3], anything else a model carries per Gaussian
+            new[n] = sel[n].repeat(N, *([1] * (sel[n].ndim - 1)))
+    cat_tensors_to_optimizer(optimizer, new)
+    radii = torch.cat((tmp_radii, extra[0].repeat(N))) if tmp_radii is not None else None
+    # prune the originals (prune_filter = cat(selected, zeros(N K)), gaussian_model.py:616-623): one compaction
+    n_new = N * int(sel["xyz"].shape[0])
+    keep = torch.cat((~selected_pts_mask, torch.ones(n_new, dtype=torch.bool, device=selected_pts_mask.device)))
+    params, _ = prune_optimizer(optimizer, keep)
+    return params, radii, keep
+
+
 def reset_opacity(optimizer, name="opacity", cap=0.01):
     """`GaussianModel.reset_opacity` (gaussian_model.py:347-352) with `replace_tensor_to_optimizer` (:451-464): the
     opacity logits are capped at logit(`cap`), both Adam moments of the group restart at zero, the group gets a new
@@ -159,4 +272,5 @@ def reset_opacity(optimizer, name="opacity", cap=0.01):
     return out
 
 
-__all__ = ["FusedAdam", "compact_rows", "prune_optimizer", "reset_opacity"]
+__all__ = ["FusedAdam", "compact_rows", "prune_optimizer", "reset_opacity", "cat_tensors_to_optimizer", "densify_and_clone",
+           "densify_and_split", "build_rotation"]

@@ -174,3 +174,66 @@ def test_grad_bucket_pack_kernel_equals_cat(dev):
         if n < w:
             assert torch.equal(out[:, n:], torch.full((P, w - n), 7.0, device=dev))  # other columns untouched
         o += n
+
+
+def _reference_densify(opt, mask, split, N, tmp_radii):
+    """gaussian_model.py:507-660 in plain PyTorch ops (boolean-mask indexing, torch.cat), on this optimizer."""
+    from eogs2_amd.optim import build_rotation
+
+    par = {g["name"]: g["params"][0] for g in opt.param_groups}
+    if split:
+        stds = torch.exp(par["scaling"])[mask].repeat(N, 1)
+        samples = torch.normal(mean=torch.zeros((stds.size(0), 3), device=stds.device), std=stds)
+        rots = build_rotation(par["rotation"][mask]).repeat(N, 1, 1)
+        new = {"xyz": torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + par["xyz"][mask].repeat(N, 1),
+               "scaling": torch.log(torch.exp(par["scaling"])[mask].repeat(N, 1) / (0.8 * N)),
+               "rotation": par["rotation"][mask].repeat(N, 1), "f_dc": par["f_dc"][mask].repeat(N, 1, 1),
+               "f_rest": par["f_rest"][mask].repeat(N, 1, 1), "opacity": par["opacity"][mask].repeat(N, 1)}
+        radii = torch.cat((tmp_radii, tmp_radii[mask].repeat(N)))
+    else:
+        new = {n: par[n][mask] for n in par}
+        radii = torch.cat((tmp_radii, tmp_radii[mask]))
+    out = {}
+    for g in opt.param_groups:  # cat_tensors_to_optimizer
+        p, ext = g["params"][0], new[g["name"]]
+        st = opt.state[p]
+        out[g["name"]] = (torch.cat((p.data, ext)), torch.cat((st["exp_avg"], torch.zeros_like(ext))),
+                          torch.cat((st["exp_avg_sq"], torch.zeros_like(ext))))
+    if split:  # prune_points(cat(mask, zeros))
+        keep = ~torch.cat((mask, torch.zeros(N * int(mask.sum()), dtype=torch.bool, device=mask.device)))
+        out = {n: tuple(t[keep] for t in v) for n, v in out.items()}
+    return out, radii
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_densify_clone_and_split_match_reference_ops(dev, split):
+    """Clone / split densification (gaussian_model.py:573-660; off by default in the reference) through the compaction
+    primitives: same tensors, same moments, same random draw as the reference's op sequence."""
+    from eogs2_amd.optim import FusedAdam, densify_and_clone, densify_and_split
+
+    P, N = 20_000, 2
+    opt = FusedAdam(_groups(P, dev, seed=5), lr=0.0, eps=1e-15)
+    g = torch.Generator().manual_seed(6)
+    for gr in opt.param_groups:
+        gr["params"][0].grad = torch.randn(gr["params"][0].shape, generator=g).to(dev)
+    opt.step()
+    mask = (torch.rand(P, generator=g) < 0.15).to(dev)
+    radii = torch.rand(P, generator=g).to(dev)
+    torch.manual_seed(123)
+    want, want_radii = _reference_densify(opt, mask, split, N, radii)
+    torch.manual_seed(123)
+    if split:
+        params, got_radii, keep = densify_and_split(opt, mask, N=N, tmp_radii=radii)
+        assert int(keep.sum()) == P - int(mask.sum()) + N * int(mask.sum())
+    else:
+        params, got_radii = densify_and_clone(opt, mask, tmp_radii=radii)
+    assert torch.equal(got_radii, want_radii)
+    for gr in opt.param_groups:
+        p = gr["params"][0]
+        st = opt.state[p]
+        w = want[gr["name"]]
+        assert params[gr["name"]] is p and p.requires_grad and tuple(p.shape) == tuple(w[0].shape)
+        assert torch.equal(p.detach(), w[0]) and torch.equal(st["exp_avg"], w[1]) and torch.equal(st["exp_avg_sq"], w[2])
+        p.grad = torch.ones_like(p)
+    opt.step()  # training goes on over the new rows
+    assert all(int(opt.state[gr["params"][0]]["step"]) == 2 for gr in opt.param_groups)
