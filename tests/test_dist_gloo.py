@@ -121,18 +121,19 @@ def test_two_rank_grad_allreduce(tmp_path):
     assert torch.equal(outs[0]["grads"]["means3D"], outs[1]["grads"]["means3D"])
 
 
-def test_bench_launcher_starts_its_own_ranks():
-    """`python3 bench.py --gpus 2` with no launcher around it: the parent starts two ranks before any GPU call and
+@pytest.mark.parametrize("n", [2, 4])
+def test_bench_launcher_starts_its_own_ranks(n):
+    """`python3 bench.py --gpus N` with no launcher around it: the parent starts N ranks before any GPU call and
     forwards rank 0's line (--dry-run stops the ranks after a gloo rendezvous + all-reduce, so this runs without a GPU)."""
     import json
     import subprocess
 
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--dry-run"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line == {"dry_run": True, "n_gpus": 2, "world_size": 2, "ranks_seen": 2, "launcher": "self"}
+    assert line == {"dry_run": True, "n_gpus": n, "world_size": n, "ranks_seen": n, "launcher": "self"}
 
 
 def test_chunk_ranges():
