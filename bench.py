@@ -80,8 +80,27 @@ def launch_ranks(a, argv):
             env.setdefault("OMP_NUM_THREADS", str(threads))
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
                                           stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
-        out, _ = procs[0].communicate()
-        rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+        # rank 0's stdout is drained by a thread; the ranks are polled, and if one of them dies the others (which would wait
+        # for it inside a collective forever) are ended: exactly the PIDs started above, nothing by pattern
+        import threading
+
+        chunks = []
+        reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+        reader.start()
+        while True:
+            rcs = [p.poll() for p in procs]
+            if all(rc is not None for rc in rcs):
+                break
+            if any(rc not in (None, 0) for rc in rcs):
+                time.sleep(2.0)  # let the failing rank's traceback reach stderr
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+                rcs = [p.wait() for p in procs]
+                break
+            time.sleep(0.2)
+        reader.join(timeout=10)
+        out = "".join(chunks)
     except BaseException:
         for p in procs:  # exactly the PIDs started above
             if p.poll() is None:

@@ -145,3 +145,21 @@ def test_chunk_ranges():
             assert r[0][0] == 0 and r[-1][1] == P and len(r) <= max(k, 1)
             assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
             assert all(p0 % 256 == 0 for p0, _ in r) and all(p1 % 256 == 0 for _, p1 in r[:-1])
+
+
+def test_bench_launcher_ends_all_ranks_when_one_dies(tmp_path, monkeypatch):
+    """A rank that dies must not leave the others waiting inside a rendezvous / collective: the launcher polls its
+    children and ends the ones it started (by PID)."""
+    import time
+    import types
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys, time\nsys.exit(7) if os.environ.get('RANK') == '1' else time.sleep(600)\n")
+    monkeypatch.setattr(bench, "__file__", str(script))
+    t0 = time.time()
+    with pytest.raises(SystemExit) as e:
+        bench.launch_ranks(types.SimpleNamespace(gpus=2), [])
+    assert e.value.code != 0 and time.time() - t0 < 60
