@@ -51,6 +51,13 @@ static __thread char g_err[256];
  * measured rather than assumed. Test infrastructure only; not part of include/eogs_rast.h. */
 static int g_acc_float = 0;
 int eogs_oracle_accum_float(int on) { const int old = g_acc_float; g_acc_float = on != 0; return old; }
+/* Diagnostic (tools/suffix_probe.py): evaluate dL/dalpha the way the HIP path does — front to back, the sum
+ * behind a Gaussian obtained by subtracting the running prefix from the rendered total,
+ *   dL/dalpha_j = T_j (g.c_j) - (D_final - D_j) / (1 - alpha_j),   D_final = sum_ch g_ch out_ch,
+ * in fp32 — instead of the reference's back-to-front recursion. Algebraically identical; used to measure how much of a
+ * HIP-vs-oracle difference is this formulation. Needs forward's out_color (out_invdepth with an invdepth gradient). */
+static int g_suffix_by_subtraction = 0;
+int eogs_oracle_suffix_by_subtraction(int on) { const int old = g_suffix_by_subtraction; g_suffix_by_subtraction = on != 0; return old; }
 #define ACC(a, term) do { if (g_acc_float) (a) = (double)((float)(a) + (float)(term)); else (a) += (double)(term); } while (0)
 
 static int fail(int code, const char* msg) {
@@ -453,7 +460,7 @@ static int backward_activated(
     float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity,
     float* dL_dmeans3D, float* dL_dcov3D, float* dL_dscales, float* dL_drotations,
     float* dL_dT_sum, float* dL_dvm_mean, void* stream) {
-  (void)out_color; (void)out_invdepth; (void)stream;
+  (void)stream;
   g_err[0] = 0;
   if (P < 0 || H <= 0 || W <= 0 || R < 0) return fail(EOGS_ERR_INVALID_ARG, "backward: bad sizes");
   if (dL_dT_sum) memset(dL_dT_sum, 0, 6 * 4);
@@ -507,6 +514,29 @@ static int backward_activated(
       float bg_dot_dpixel = 0;
       for (int ch = 0; ch < C_; ch++) bg_dot_dpixel += bg[ch] * dL_dpixel[ch];
 
+      float* alt = NULL; /* diagnostic: dL/dalpha per list entry in the front-to-back formulation */
+      if (g_suffix_by_subtraction && out_color && last_contributor > 0) {
+        alt = (float*)calloc(r1 - r0, 4);
+        float Dfinal = 0.f, Dacc = 0.f, Tf = 1.0f;
+        for (int ch = 0; ch < C_; ch++) Dfinal += dL_dpixel[ch] * out_color[ch * HW + pix_id];
+        if (dL_dout_invdepth && out_invdepth) Dfinal += dL_invdepth * out_invdepth[pix_id];
+        for (uint32_t k = r0; alt && k < r1 && k - r0 < last_contributor; k++) {
+          const uint32_t id = b.values[k];
+          const float dx = g.means2D[2 * (size_t)id] - pixfx, dy = g.means2D[2 * (size_t)id + 1] - pixfy;
+          const float* co = g.conic_opacity + 4 * (size_t)id;
+          const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+          if (power > 0.0f) continue;
+          const float alpha = fminf(0.99f, co[3] * expf(power));
+          if (alpha < 1.0f / 255.0f) continue;
+          float gc = 0.f;
+          for (int ch = 0; ch < C_; ch++) gc += dL_dpixel[ch] * colors[(size_t)id * C_ + ch];
+          if (dL_dout_invdepth) gc += dL_invdepth * (1.f / g.depths[id]);
+          Dacc += gc * (alpha * Tf);
+          alt[k - r0] = Tf * gc - (Dfinal - Dacc) / (1.f - alpha);
+          Tf *= (1.f - alpha);
+        }
+      }
+
       for (uint32_t k = r1; k-- > r0;) {
         contributor--;
         if (contributor >= last_contributor) continue;
@@ -540,6 +570,7 @@ static int backward_activated(
         dL_dalpha *= T;
         last_alpha = alpha;
         dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+        if (alt) dL_dalpha = alt[k - r0];
 
         const float dL_dG = co[3] * dL_dalpha;
         const float gdx = G * dx, gdy = G * dy;
@@ -552,6 +583,7 @@ static int backward_activated(
         ACC(acc_conic[3 * (size_t)id + 2], -0.5f * gdy * dy * dL_dG);
         ACC(acc_opac[id], G * dL_dalpha);
       }
+      free(alt);
     }
 
   /* outputs zero-initialised like rasterize_points.cu:163-174 */
