@@ -38,6 +38,14 @@
 
 #pragma clang fp contract(fast)
 
+// Threads per render workgroup. A workgroup is nothing but RBLK / 64 independent tiles (no barriers, no shared data), and its
+// LDS and wave slots are only released when its LAST wave ends: with four tiles of uneven list length per workgroup the
+// average occupancy was 2.7 of 4 waves per SIMD in the backward (SQ_WAVE_CYCLES), so one tile = one wave = one workgroup
+// (render_bwd 0.355 -> 0.329 ms, render_fwd 0.151 -> 0.144 ms). LDS addresses also become compile-time constants.
+#ifndef EOGS_RENDER_BLK
+#define EOGS_RENDER_BLK 64
+#endif
+#define RBLK EOGS_RENDER_BLK
 static_assert(SUBX == 8 && SUBY == 8 && PPL == 1, "render kernels are written for 8x8 internal tiles, one pixel per lane");
 
 namespace {
@@ -79,7 +87,7 @@ __device__ inline int tile_of_wave() {
   const int per = gridDim.x >> 3;
   const int grp = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   // the wave index is uniform across the wave: tell the compiler, so tile, list range and loop control live in SGPRs
-  return grp * (BLK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  return grp * (RBLK / 64) + (RBLK == 64 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
 }
 
 // One list entry as gathered by a lane: the Gaussian's 64-byte render record written by preprocess_fwd_kernel
@@ -165,16 +173,16 @@ __device__ inline Ent fetch(const float* slab, int j) {
 }  // namespace
 
 template <int MACRO>
-__global__ __launch_bounds__(BLK) void render_fwd_kernel(
+__global__ __launch_bounds__(RBLK) void render_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx,
     const float4* __restrict__ packed, const float* __restrict__ bg,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
     float* __restrict__ out_invdepth) {
-  __shared__ __attribute__((aligned(16))) float s_slab[BLK / 64][FWD_CAP * ENT];
+  __shared__ __attribute__((aligned(16))) float s_slab[RBLK / 64][FWD_CAP * ENT];
   const int lane = threadIdx.x & 63;
   const int tile = tile_of_wave();
   if (tile >= ntiles) return;  // wave-uniform; waves never synchronise with each other
-  float* slab = s_slab[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+  float* slab = s_slab[RBLK == 64 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
   const int px = (tile % gsx) * SUBX + (lane & 7), py = (tile / gsx) * SUBY + (lane >> 3);
   const bool inside = px < W && py < H;
   const uint32_t pix_id = (uint32_t)py * (uint32_t)W + (uint32_t)px;
@@ -311,19 +319,19 @@ __device__ inline void quad_append(uint8_t* sidx, int lane, bool hit, int pos, u
 }  // namespace
 
 template <int MACRO>
-__global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(8, 8))) void render_fwd_quad_kernel(
+__global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(8, 8))) void render_fwd_quad_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx,
     const float4* __restrict__ packed, const float* __restrict__ bg,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
     float* __restrict__ out_invdepth) {
   // slab position FWD_CAP holds a DUMMY entry (opacity 0: alpha = 0 fails the 1/255 test at every pixel); sub-lists
   // shorter than the longest one are padded with it, so the hot loop needs no "is my quad still active" test
-  __shared__ __attribute__((aligned(16))) float s_slab[BLK / 64][(FWD_CAP + 1) * ENT];
-  __shared__ __attribute__((aligned(16))) uint8_t s_idx[BLK / 64][4 * QCAP];
+  __shared__ __attribute__((aligned(16))) float s_slab[RBLK / 64][(FWD_CAP + 1) * ENT];
+  __shared__ __attribute__((aligned(16))) uint8_t s_idx[RBLK / 64][4 * QCAP];
   const int lane = threadIdx.x & 63;
   const int tile = tile_of_wave();
   if (tile >= ntiles) return;  // wave-uniform; waves never synchronise with each other
-  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int w = RBLK == 64 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   float* slab = s_slab[w];
   uint8_t* sidx = s_idx[w];
   if (lane < ENT) slab[FWD_CAP * ENT + lane] = 0.f;
@@ -441,7 +449,7 @@ static double quad_switch() {
 }
 
 static inline uint32_t render_grid(int ntiles) {
-  const uint32_t groups = ceil_div_u32((uint64_t)ntiles, BLK / 64);
+  const uint32_t groups = ceil_div_u32((uint64_t)ntiles, RBLK / 64);
   return ((groups + 7u) / 8u) * 8u;  // multiple of 8 for the XCD band mapping
 }
 
@@ -455,7 +463,7 @@ void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, 
   const int gsx = (W + SUBX - 1) / SUBX, gsy = (H + SUBY - 1) / SUBY, ntiles = gsx * gsy;
   const int variant = render_fwd_variant(b.block, R, P);
   auto* kern = variant == 1 ? render_fwd_kernel<BLOCK_BIG> : (variant == 2 ? render_fwd_quad_kernel<1> : render_fwd_kernel<1>);
-  hipLaunchKernelGGL(kern, dim3(render_grid(ntiles)), dim3(BLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H, gsx,
+  hipLaunchKernelGGL(kern, dim3(render_grid(ntiles)), dim3(RBLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H, gsx,
                      ntiles, (int)macro_grid_x(W, b.block), g.packed, bg, im.final_T, im.n_contrib, out_color, out_invdepth);
 }
 
@@ -548,21 +556,21 @@ __device__ inline void transpose_round(int nsurv, int lane, const float* rb, con
 // HAVE_INV: an upstream gradient of the inverse-depth image exists (the reference always materialises a zero one,
 // renderer.py:101 never consumes invdepths; here the common case compiles the term away).
 template <int MACRO, bool HAVE_INV>
-__global__ __launch_bounds__(BLK) void render_bwd_kernel(
+__global__ __launch_bounds__(RBLK) void render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx,
     const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ out_color, const float* __restrict__ out_invdepth, const float* __restrict__ dL_dpix,
     const float* __restrict__ dL_dinv, float* __restrict__ records, uint8_t* __restrict__ live_flag) {
-  __shared__ __attribute__((aligned(16))) float s_slab[BLK / 64][64 * ENT];
-  __shared__ __attribute__((aligned(16))) float s_round[BLK / 64][KSURV * 8];
+  __shared__ __attribute__((aligned(16))) float s_slab[RBLK / 64][64 * ENT];
+  __shared__ __attribute__((aligned(16))) float s_round[RBLK / 64][KSURV * 8];
   // u and v matrices of a wave sit UV_PITCH floats (a multiple of 64 dwords) apart: one ds_write2st64_b32 stores both
-  __shared__ __attribute__((aligned(16))) float s_uv[BLK / 64][UV_PITCH + UV_SIZE];
-  __shared__ __attribute__((aligned(16))) float s_pix[BLK / 64][64 * 8 + 32];
-  __shared__ uint32_t s_slot[BLK / 64][64];
+  __shared__ __attribute__((aligned(16))) float s_uv[RBLK / 64][UV_PITCH + UV_SIZE];
+  __shared__ __attribute__((aligned(16))) float s_pix[RBLK / 64][64 * 8 + 32];
+  __shared__ uint32_t s_slot[RBLK / 64][64];
   const int lane = threadIdx.x & 63;
   const int tile = tile_of_wave();
   if (tile >= ntiles) return;
-  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int w = RBLK == 64 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   float* slab = s_slab[w];
   float* su = s_uv[w];
   float* sv = s_uv[w] + UV_PITCH;
@@ -707,27 +715,31 @@ __global__ __launch_bounds__(BLK) void render_bwd_kernel(
 // chunk by the owner exactly as transpose_round writes it.
 namespace {
 
-#define QB 80     // bytes per quad sub-list in backward (64 entries + pipelined over-read)
+#define QB 68     // entries per quad sub-list in backward (64 + pipelined over-read); an entry is the BYTE OFFSET of its slab
+                  // entry (position * 48) as a full dword: the hot loop's ds_read needs no address arithmetic or extraction
+#define PIXB 296  // pixel gradients for the VALU transposition: channels 0..3 as one float4 per pixel (+1 float4 per 8 pixels
+                  // against bank conflicts) in floats [0, 288), channel 4 at PIXB + pixel + (pixel >> 3)
 #define STG 12    // floats per staged (trip, quad) partial: 11 used
 
 // Transposition of one round of `nk` trips (trips 8 r .. 8 r + nk - 1 of the chunk).
-__device__ inline void transpose_round_quad(int nk, int r, int lane, const uint8_t* sidx, const float* slab, float* s_u,
+__device__ inline void transpose_round_quad(int nk, int r, int lane, const uint32_t* sidx, const float* slab, float* s_u,
                                             const float* s_v, const float* s_pix, float bx0, float by0) {
   const int k = lane >> 3, o = lane & 7, q = o >> 1, h = o & 1;
-  const uint32_t idx = sidx[q * QB + 8 * r + k];  // the entry quad q evaluated in trip k (any staged byte is a valid position)
-  const float2 gxy = *reinterpret_cast<const float2*>(slab + idx * ENT);
+  const uint32_t off = sidx[q * QB + 8 * r + k];  // the entry quad q evaluated in trip k (any staged value is a valid offset)
+  const float2 gxy = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(slab) + off);
   const float gxr = gxy.x - (bx0 + (float)(4 * (q & 1)));  // centre relative to the quad's first column
   const float dy0 = gxy.y - (by0 + (float)(4 * (q >> 1) + 2 * h)), dy1 = dy0 - 1.f;
   float S0a = 0.f, Sxa = 0.f, Sxxa = 0.f, S0b = 0.f, Sxb = 0.f, Sxxb = 0.f;
   float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f, c4 = 0.f;
   const float* urow = s_u + uv_index(k, 8 * o);
   const float* vrow = s_v + uv_index(k, 8 * o);
-  const float* prow = s_pix + (8 * o) * 8 + 4 * o;
+  const float* pa = s_pix + (8 * o) * 4 + 4 * o;
+  const float* pb = s_pix + PIXB + 8 * o + o;
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     const float u = urow[i], v = vrow[i];
-    const float4 ga = *reinterpret_cast<const float4*>(prow + i * 8);
-    const float gb = prow[i * 8 + 4];
+    const float4 ga = *reinterpret_cast<const float4*>(pa + i * 4);
+    const float gb = pb[i];
     const float dx = gxr - (float)(i & 3);
     const float t1 = v * dx;
     if (i < 4) { S0a += v; Sxa += t1; Sxxa += t1 * dx; }
@@ -808,28 +820,29 @@ __device__ inline void mfma_round_quad(int nk, int lane, float* s_u, const float
 }  // namespace
 
 template <bool HAVE_INV, int RED>
-__global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 4))) void render_bwd_quad_kernel(
+__global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(4, 4))) void render_bwd_quad_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx,
     const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ out_color, const float* __restrict__ out_invdepth, const float* __restrict__ dL_dpix,
     const float* __restrict__ dL_dinv, float* __restrict__ records, uint8_t* __restrict__ live_flag) {
   // slab position 64 holds a DUMMY entry (opacity 0 -> alpha = 0 -> never valid): shorter sub-lists are padded with it
-  __shared__ __attribute__((aligned(16))) float s_slab[BLK / 64][65 * ENT];
-  __shared__ __attribute__((aligned(16))) float s_uv[BLK / 64][RED ? 2 * UV_PITCH : UV_PITCH + UV_SIZE];
+  __shared__ __attribute__((aligned(16))) float s_slab[RBLK / 64][65 * ENT];
+  __shared__ __attribute__((aligned(16))) float s_uv[RBLK / 64][RED ? 2 * UV_PITCH : UV_PITCH + UV_SIZE];
   // RED = 0: 8 floats per pixel (+ padding) for the VALU transposition; RED = 1: [channel 0..4 | zero row][pixel], the
   // u-part A operands of the MFMA transposition
-  __shared__ __attribute__((aligned(16))) float s_pix[BLK / 64][RED ? 6 * 64 : 64 * 8 + 32];
-  __shared__ __attribute__((aligned(16))) uint8_t s_idx[BLK / 64][4 * QB];
+  __shared__ __attribute__((aligned(16))) float s_pix[RBLK / 64][6 * 64];
+  __shared__ __attribute__((aligned(16))) uint32_t s_idx[RBLK / 64][4 * QB];
+  static_assert(PIXB + 72 <= 6 * 64, "both pixel-gradient planes fit");
   static_assert(32 * STG <= UV_SIZE && 32 * STG <= 8 * URS, "the staging area lives inside the u matrix");
   const int lane = threadIdx.x & 63;
   const int tile = tile_of_wave();
   if (tile >= ntiles) return;
-  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int w = RBLK == 64 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   float* slab = s_slab[w];
   float* su = s_uv[w];
   float* sv = s_uv[w] + UV_PITCH;
   float* spix = s_pix[w];
-  uint8_t* sidx = s_idx[w];
+  uint32_t* sidx = s_idx[w];
   int ox, oy;
   quad_pixel(lane, ox, oy);
   const int tx0 = (tile % gsx) * SUBX, ty0 = (tile / gsx) * SUBY;
@@ -840,7 +853,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const uint2 range = ranges[tile];
   const size_t HW = (size_t)H * W;
   const int myq = lane >> 4;
-  const uint8_t* myidx = sidx + myq * QB;
+  const uint32_t* myidx = sidx + myq * QB;
 
   float g[NCH] = {0.f, 0.f, 0.f, 0.f, 0.f};
   float ginv = 0.f, Dfinal = 0.f;
@@ -878,12 +891,11 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       const float y = (float)(4 * h + kk);
       fyv[h] = ey == 0 ? 1.f : (ey == 1 ? y : y * y);
     }
-  } else {  // pixel gradients for the transposition rounds: 8 floats per pixel (pixel index = lane), +4 floats per 8 pixels
-    float* d = spix + lane * 8 + 4 * (lane >> 3);
-    *reinterpret_cast<float4*>(d) = make_float4(g[0], g[1], g[2], g[3]);
-    d[4] = g[4];
+  } else {  // pixel gradients for the transposition rounds (pixel index = lane): see PIXB
+    *reinterpret_cast<float4*>(spix + lane * 4 + 4 * (lane >> 3)) = make_float4(g[0], g[1], g[2], g[3]);
+    spix[PIXB + lane + (lane >> 3)] = g[4];
   }
-  for (int t = lane; t < 4 * QB / 4; t += 64) reinterpret_cast<uint32_t*>(sidx)[t] = 0u;  // over-read bytes: valid positions
+  for (int t = lane; t < 4 * QB; t += 64) sidx[t] = 0u;  // over-read entries: valid offsets
   if (lane < ENT) slab[64 * ENT + lane] = 0.f;
   const uint32_t tile_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(ncontrib));
   const float kx = LN2 * 0.5f * W, ky = LN2 * 0.5f * H;
@@ -891,6 +903,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   float T = 1.0f, Dacc = 0.f;
   float* const uvlane = RED ? su + lane : su + uv_index(0, lane);
   constexpr int ROWF = RED ? URS : 33;  // floats between the u/v rows of consecutive trips of a round
+  float* const vlane = uvlane + UV_PITCH;
 
   uint32_t jbase = 0;
   Cand nxt = gather_cand<1>(peek_cand<1>(range.x + lane, range.y, keys, point_list), 0u, packed);
@@ -909,7 +922,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(in);
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
         if (in) {
-          sidx[q * QB + (int)rank] = (uint8_t)lane;
+          sidx[q * QB + (int)rank] = (uint32_t)(lane * (4 * ENT));
           myranks = (myranks & ~(0xFFu << (8 * q))) | (rank << (8 * q));
         }
         nq[q] = (int)__popcll(bal);
@@ -927,11 +940,11 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       const int npad = (nmax + 7) & ~7;
 #pragma unroll
       for (int q = 0; q < 4; q++)
-        if (lane < npad + 2 - nq[q]) sidx[q * QB + nq[q] + lane] = (uint8_t)64;
+        if (lane < npad + 2 - nq[q]) sidx[q * QB + nq[q] + lane] = (uint32_t)(64 * 4 * ENT);
       wave_lds_sync();
     }
-    // contributing list positions of this pixel, relative to the chunk
-    const int nc_rel = (int)min(ncontrib - min(ncontrib, jbase), 64u);
+    // contributing list positions of this pixel, relative to the chunk, as a slab byte offset
+    const uint32_t nc_off = min(ncontrib - min(ncontrib, jbase), 64u) * (uint32_t)(4 * ENT);
     float acc[11];
 #pragma unroll
     for (int t = 0; t < 11; t++) acc[t] = 0.f;
@@ -944,10 +957,8 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       wave_lds_sync();
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const uint32_t rk = (myranks >> (8 * q)) & 0xFFu;
-        const bool mine = rk != 0xFFu && (int)(rk >> 3) == r;
-        if (__builtin_amdgcn_ballot_w64(mine) == 0ull) continue;
-        if (mine) {
+        const uint32_t rk = myranks >> (8 * q);  // bits 7..3: the round of quad q's trip (31: never), bits 2..0: its slot
+        if (((rk >> 3) & 31u) == (uint32_t)r) {
           const float4* st = reinterpret_cast<const float4*>(su + ((rk & 7u) * 4u + (uint32_t)q) * STG);
           const float4 a0 = st[0], a1 = st[1], a2 = st[2];
           acc[0] += a0.x; acc[1] += a0.y; acc[2] += a0.z; acc[3] += a0.w;
@@ -957,12 +968,19 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       }
       wave_lds_sync();  // the next trips overwrite the u matrix
     };
-    auto grad = [&](const Ent& e, int pos, int j) {
+    auto fetch_off = [&](uint32_t off) {
+      const float4* e4 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(slab) + off);
+      Ent e;
+      e.q0 = e4[0]; e.q1 = e4[1]; e.q2 = e4[2];
+      return e;
+    };
+    // one (pixel, entry) evaluation; `slot` = trip & 7 selects the row of the u/v matrices
+    auto grad = [&](const Ent& e, uint32_t off, int slot) {
       const float dx = e.q0.x - pxf, dy = e.q0.y - pyf;
       const float p = power_of(e, dx, dy);
       const float G = __builtin_amdgcn_exp2f(p);
       const float alpha = fminf(e.q1.y * G, 0.99f);
-      const bool valid = (pos < nc_rel) && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);  // (the dummy: alpha = 0)
+      const bool valid = (off < nc_off) && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);  // (the dummy: alpha = 0)
       float gc = g[0] * e.q1.z + g[1] * e.q1.w + g[2] * e.q2.x + g[3] * e.q2.y + g[4] * e.q2.z;
       if (HAVE_INV) gc += ginv * e.q2.w;
       const float a_eff = valid ? alpha : 0.f;
@@ -972,27 +990,47 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       const float one_m = 1.f - a_eff;
       const float dLda = T * gc - (Dfinal - Dacc) * __builtin_amdgcn_rcpf(one_m);
       T = T * one_m;
-      float* const uv = uvlane + (j & 7) * ROWF;  // trip j is slot j & 7 of round j >> 3 (trips are never skipped)
-      uv[0] = wgt;
-      uv[UV_PITCH] = G_eff * dLda;  // v = G dL/dalpha
-      if ((j & 7) == 7) round(j >> 3, KSURV);
+      uvlane[slot * ROWF] = wgt;
+      vlane[slot * ROWF] = G_eff * dLda;  // v = G dL/dalpha
     };
     if (nmax > 0) {
-      int i0 = myidx[0], i1 = myidx[1];
-      Ent ea = fetch(slab, i0);
-      int j = 0;
-      for (; j + 1 < nmax; j += 2) {
-        const Ent eb = fetch(slab, i1);
-        const int i2 = myidx[j + 2];
-        grad(ea, i0, j);
-        ea = fetch(slab, i2);
-        const int i3 = myidx[j + 3];
-        grad(eb, i1, j + 1);
-        i0 = i2;
-        i1 = i3;
+      // trips are never skipped: trip j is slot j & 7 of round j >> 3. Full rounds are unrolled (slots, sub-list reads and u/v
+      // rows at immediate offsets); the entry of trip j + 1 and the sub-list element of trip j + 2 are in flight during trip j
+      uint32_t o0 = myidx[0], o1 = myidx[1];
+      Ent ea = fetch_off(o0);
+      const int nfull = nmax >> 3;
+      for (int r = 0; r < nfull; r++) {
+        const uint32_t* ip = myidx + 8 * r;
+#pragma unroll
+        for (int t = 0; t < 8; t += 2) {
+          const Ent eb = fetch_off(o1);
+          const uint32_t o2 = ip[t + 2];
+          grad(ea, o0, t);
+          ea = fetch_off(o2);
+          const uint32_t o3 = ip[t + 3];
+          grad(eb, o1, t + 1);
+          o0 = o2;
+          o1 = o3;
+        }
+        round(r, KSURV);
       }
-      if (j < nmax) grad(ea, i0, j);
-      if (nmax & 7) round(nmax >> 3, nmax & 7);  // the chunk's last, partial round
+      const int rem = nmax & 7;
+      if (rem) {  // the chunk's last, partial round
+        const uint32_t* ip = myidx + 8 * nfull;
+        int t = 0;
+        for (; t + 1 < rem; t += 2) {
+          const Ent eb = fetch_off(o1);
+          const uint32_t o2 = ip[t + 2];
+          grad(ea, o0, t);
+          ea = fetch_off(o2);
+          const uint32_t o3 = ip[t + 3];
+          grad(eb, o1, t + 1);
+          o0 = o2;
+          o1 = o3;
+        }
+        if (t < rem) grad(ea, o0, t);
+        round(nfull, rem);
+      }
       // entry `lane`: accumulated moments -> record (backward.cu:624-640, as in transpose_round)
       bool any = false;
 #pragma unroll
@@ -1054,20 +1092,20 @@ namespace {
 }  // namespace
 
 template <bool HAVE_INV>
-__global__ __launch_bounds__(BLK) void render_bwd_mfma_kernel(
+__global__ __launch_bounds__(RBLK) void render_bwd_mfma_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx,
     const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ out_color, const float* __restrict__ out_invdepth, const float* __restrict__ dL_dpix,
     const float* __restrict__ dL_dinv, float* __restrict__ records, uint8_t* __restrict__ live_flag) {
-  __shared__ __attribute__((aligned(16))) float s_slab[BLK / 64][64 * ENT];
-  __shared__ __attribute__((aligned(16))) float s_uv[BLK / 64][2 * MUV];
-  __shared__ uint32_t s_slot[BLK / 64][64];
-  __shared__ __attribute__((aligned(16))) uint8_t s_idx[BLK / 64][4 * QBM];
+  __shared__ __attribute__((aligned(16))) float s_slab[RBLK / 64][64 * ENT];
+  __shared__ __attribute__((aligned(16))) float s_uv[RBLK / 64][2 * MUV];
+  __shared__ uint32_t s_slot[RBLK / 64][64];
+  __shared__ __attribute__((aligned(16))) uint8_t s_idx[RBLK / 64][4 * QBM];
   static_assert(6 * 64 <= 2 * MUV, "the colour-gradient staging lives inside the window matrices");
   const int lane = threadIdx.x & 63;
   const int tile = tile_of_wave();
   if (tile >= ntiles) return;
-  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int w = RBLK == 64 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   float* slab = s_slab[w];
   float* su = s_uv[w];
   uint32_t* sslot = s_slot[w];
@@ -1298,7 +1336,7 @@ void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, 
   if (variant == 2) kern = dL_dinvdepth ? render_bwd_quad_kernel<true, 0> : render_bwd_quad_kernel<false, 0>;
   if (variant == 3) kern = dL_dinvdepth ? render_bwd_mfma_kernel<true> : render_bwd_mfma_kernel<false>;
   if (variant == 4) kern = dL_dinvdepth ? render_bwd_quad_kernel<true, 1> : render_bwd_quad_kernel<false, 1>;
-  hipLaunchKernelGGL(kern, dim3(render_grid(ntiles)), dim3(BLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H, gsx,
+  hipLaunchKernelGGL(kern, dim3(render_grid(ntiles)), dim3(RBLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H, gsx,
                      ntiles, (int)macro_grid_x(W, b.block), g.packed, im.n_contrib, out_color, out_invdepth, dL_dcolor,
                      dL_dinvdepth, b.records, b.live);
 }
