@@ -819,6 +819,20 @@ __device__ inline void mfma_round_quad(int nk, int lane, float* s_u, const float
 
 }  // namespace
 
+// -DEOGS_BWD_PHASES: where a wave of render_bwd_quad_kernel spends its residency (s_memtime at the phase boundaries, summed
+// over all waves into g_bwd_phase[]; read with eogs_debug_bwd_phases). Diagnostics only: every sample waits for the wave's
+// outstanding LDS operations, so the instrumented kernel is a few per cent slower and its prefetches are less effective.
+#ifdef EOGS_BWD_PHASES
+#define PHASE_TILES 65536
+__device__ unsigned long long g_bwd_phase[PHASE_TILES][6];  // per tile (wave): no same-address atomics
+#define PHASE_DECL unsigned long long ph_t = __builtin_readcyclecounter(), ph_acc[6] = {0, 0, 0, 0, 0, 0}
+#define PHASE(i) do { const unsigned long long ph_n = __builtin_readcyclecounter(); ph_acc[i] += ph_n - ph_t; ph_t = ph_n; } while (0)
+#define PHASE_FLUSH do { if (lane == 0 && tile < PHASE_TILES) { for (int i = 0; i < 6; i++) g_bwd_phase[tile][i] += ph_acc[i]; g_bwd_phase[tile][5] += 1ull; } } while (0)
+#else
+#define PHASE_DECL
+#define PHASE(i)
+#define PHASE_FLUSH
+#endif
 template <bool HAVE_INV, int RED>
 __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(4, 4))) void render_bwd_quad_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx,
@@ -905,6 +919,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
   constexpr int ROWF = RED ? URS : 33;  // floats between the u/v rows of consecutive trips of a round
   float* const vlane = uvlane + UV_PITCH;
 
+  PHASE_DECL;
   uint32_t jbase = 0;
   Cand nxt = gather_cand<1>(peek_cand<1>(range.x + lane, range.y, keys, point_list), 0u, packed);
   Peek pk = peek_cand<1>(range.x + 64 + lane, range.y, keys, point_list);
@@ -951,10 +966,12 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 
     // one round: transposition of `nk` trips, then every owner lane pulls the partials of its entry
     auto round = [&](int r, int nk) {
+      PHASE(1);
       wave_lds_sync();
       if (RED) mfma_round_quad(nk, lane, su, fxv, fyv, au_row);
       else transpose_round_quad(nk, r, lane, sidx, slab, su, sv, spix, bx0, by0);
       wave_lds_sync();
+      PHASE(2);
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const uint32_t rk = myranks >> (8 * q);  // bits 7..3: the round of quad q's trip (31: never), bits 2..0: its slot
@@ -967,6 +984,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         }
       }
       wave_lds_sync();  // the next trips overwrite the u matrix
+      PHASE(3);
     };
     auto fetch_off = [&](uint32_t off) {
       const float4* e4 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(slab) + off);
@@ -993,6 +1011,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
       uvlane[slot * ROWF] = wgt;
       vlane[slot * ROWF] = G_eff * dLda;  // v = G dL/dalpha
     };
+    PHASE(0);
     if (nmax > 0) {
       // trips are never skipped: trip j is slot j & 7 of round j >> 3. Full rounds are unrolled (slots, sub-list reads and u/v
       // rows at immediate offsets); the entry of trip j + 1 and the sub-list element of trip j + 2 are in flight during trip j
@@ -1061,7 +1080,9 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
       }
     }
     jbase += (uint32_t)jn;
+    PHASE(4);
   }
+  PHASE_FLUSH;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1340,6 +1361,24 @@ void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, 
                      ntiles, (int)macro_grid_x(W, b.block), g.packed, im.n_contrib, out_color, out_invdepth, dL_dcolor,
                      dL_dinvdepth, b.records, b.live);
 }
+
+#ifdef EOGS_BWD_PHASES
+extern "C" int eogs_debug_bwd_phases(unsigned long long* out8, int reset) {
+  static unsigned long long host[PHASE_TILES][6];
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_bwd_phase), sizeof(host)) != hipSuccess) return -1;
+  for (int i = 0; i < 8; i++) out8[i] = 0;
+  for (int t = 0; t < PHASE_TILES; t++) {
+    for (int i = 0; i < 5; i++) out8[i] += host[t][i];
+    out8[7] += host[t][5];  // waves
+  }
+  if (reset) {
+    void* dptr = nullptr;
+    if (hipGetSymbolAddress(&dptr, HIP_SYMBOL(g_bwd_phase)) != hipSuccess) return -1;
+    if (hipMemset(dptr, 0, sizeof(host)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 // ---- self test of the wave64 primitives (diagnostics) ----
 __global__ void selftest_kernel(uint32_t* out) {
