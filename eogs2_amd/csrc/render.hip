@@ -272,8 +272,14 @@ __global__ __launch_bounds__(RBLK) void render_fwd_kernel(
 // Trip count = the longest sub-list (~0.6 of the tile's list at 1M Gaussians / 1024^2), list traffic from HBM unchanged.
 namespace {
 
-#define QCAP 112  // bytes per quad sub-list (>= FWD_CAP + 2: padding and the pipelined over-read); with the dummy slab entry
-                  // the forward wave stays at 5104 B of LDS: 32 waves per CU
+#define FQ_CAP 64  // slab entries of the quad forward: per-tile lists only, a chunk is processed as soon as it is parked
+#define QCAP 68   // dwords per quad sub-list (>= FQ_CAP + 3: padding and the pipelined over-read); with the dummy slab entry
+                  // the forward wave needs 4208 B of LDS: 32 waves per CU
+// Waves per SIMD the quad forward is compiled for: at 8 (64 VGPRs) the two entry register sets spill (48 B of scratch per lane,
+// written and re-read every chunk) and the kernel takes 0.142 ms; at 6 (76 VGPRs, no scratch) 0.132 ms; 5 the same, 4 slower.
+#ifndef EOGS_FW
+#define EOGS_FW 6
+#endif
 
 __device__ inline void quad_pixel(int lane, int& ox, int& oy) {
   const int q = lane >> 4, r = lane & 15;
@@ -301,16 +307,16 @@ __device__ inline uint32_t quad_mask(const Cand& c, float bx0, float by0) {
   return m;
 }
 
-// Appends the slab positions of this chunk's hit entries to the four sub-lists. `pos` = the lane's slab position (valid
-// where c.hit), qm = its quad mask. nq[] are wave-uniform counts.
-__device__ inline void quad_append(uint8_t* sidx, int lane, bool hit, int pos, uint32_t qm, int (&nq)[4]) {
+// Appends this chunk's hit entries to the four sub-lists, as the BYTE OFFSETS of their slab entries (the hot loop's ds_read
+// takes them as they come). `pos` = the lane's slab position (valid where c.hit), qm = its quad mask. nq[] are wave-uniform.
+__device__ inline void quad_append(uint32_t* sidx, int lane, bool hit, int pos, uint32_t qm, int (&nq)[4]) {
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const bool in = hit && ((qm >> q) & 1u);
     const unsigned long long bal = __builtin_amdgcn_ballot_w64(in);
     if (in) {
       const int rank = nq[q] + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-      sidx[q * QCAP + rank] = (uint8_t)pos;
+      sidx[q * QCAP + rank] = (uint32_t)(pos * (4 * ENT));
     }
     nq[q] += (int)__popcll(bal);
   }
@@ -319,22 +325,23 @@ __device__ inline void quad_append(uint8_t* sidx, int lane, bool hit, int pos, u
 }  // namespace
 
 template <int MACRO>
-__global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(8, 8))) void render_fwd_quad_kernel(
+__global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_FW, EOGS_FW))) void render_fwd_quad_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx,
     const float4* __restrict__ packed, const float* __restrict__ bg,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
     float* __restrict__ out_invdepth) {
-  // slab position FWD_CAP holds a DUMMY entry (opacity 0: alpha = 0 fails the 1/255 test at every pixel); sub-lists
+  static_assert(MACRO == 1, "quad sub-lists run on per-tile lists: every chunk of 64 list entries is processed at once");
+  // slab position FQ_CAP holds a DUMMY entry (opacity 0: alpha = 0 fails the 1/255 test at every pixel); sub-lists
   // shorter than the longest one are padded with it, so the hot loop needs no "is my quad still active" test
-  __shared__ __attribute__((aligned(16))) float s_slab[RBLK / 64][(FWD_CAP + 1) * ENT];
-  __shared__ __attribute__((aligned(16))) uint8_t s_idx[RBLK / 64][4 * QCAP];
+  __shared__ __attribute__((aligned(16))) float s_slab[RBLK / 64][(FQ_CAP + 1) * ENT];
+  __shared__ __attribute__((aligned(16))) uint32_t s_idx[RBLK / 64][4 * QCAP];
   const int lane = threadIdx.x & 63;
   const int tile = tile_of_wave();
   if (tile >= ntiles) return;  // wave-uniform; waves never synchronise with each other
   const int w = RBLK == 64 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   float* slab = s_slab[w];
-  uint8_t* sidx = s_idx[w];
-  if (lane < ENT) slab[FWD_CAP * ENT + lane] = 0.f;
+  uint32_t* sidx = s_idx[w];
+  if (lane < ENT) slab[FQ_CAP * ENT + lane] = 0.f;
   int ox, oy;
   quad_pixel(lane, ox, oy);
   const int tx0 = (tile % gsx) * SUBX, ty0 = (tile / gsx) * SUBY;
@@ -343,14 +350,12 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
   const uint32_t pix_id = (uint32_t)py * (uint32_t)W + (uint32_t)px;
   const float pxf = (float)px, pyf = (float)py;
   const float bx0 = (float)tx0, by0 = (float)ty0;
-  const int ftx = tile % gsx, fty = tile / gsx;
-  const uint2 range = ranges[(fty / MACRO) * gmx + ftx / MACRO];  // the macro block's list
-  const uint32_t sub = (uint32_t)((fty % MACRO) * MACRO + ftx % MACRO);
+  const uint2 range = ranges[tile];
   const int myq = lane >> 4;
-  const uint8_t* myidx = sidx + myq * QCAP;
-  // stale bytes are read (never used) by the pipelined loop: make them valid slab positions
-  if (lane < 4 * QCAP / 8) reinterpret_cast<uint64_t*>(sidx)[lane] = 0ull;
-  static_assert((4 * QCAP) % 8 == 0 && 4 * QCAP / 8 <= 64 && QCAP >= FWD_CAP + 2, "sub-list sizing");
+  const uint32_t* myidx = sidx + myq * QCAP;
+  // stale elements are read (never used) by the pipelined loop: make them valid slab offsets
+  for (int t = lane; t < 4 * QCAP; t += 64) sidx[t] = 0u;
+  static_assert(QCAP >= FQ_CAP + 3, "sub-list sizing");
 
   float T = 1.0f;
   uint32_t last_contributor = 0;
@@ -359,38 +364,40 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
   bool done = !inside;
 
   uint32_t jbase = 0;  // entries of THIS tile processed so far: list positions are counted over the tile's own entries
-  int fill = 0;        // entries waiting in the slab
-  int nq[4] = {0, 0, 0, 0};
-  Cand nxt = gather_cand<MACRO>(peek_cand<MACRO>(range.x + lane, range.y, keys, point_list), sub, packed);
-  Peek pk = peek_cand<MACRO>(range.x + 64 + lane, range.y, keys, point_list);
+  Cand nxt = gather_cand<1>(peek_cand<1>(range.x + lane, range.y, keys, point_list), 0u, packed);
+  Peek pk = peek_cand<1>(range.x + 64 + lane, range.y, keys, point_list);
   for (uint32_t c0 = range.x; c0 < range.y; c0 += 64) {
     wave_lds_sync();  // previous chunk's reads are done
+    int nq[4] = {0, 0, 0, 0};
     {
+      // per-tile lists: the in-range entries are lanes 0..fill-1, parked at their own lane index
       const uint32_t qm = nxt.hit ? quad_mask(nxt, bx0, by0) : 0u;
-      const unsigned long long hm = __builtin_amdgcn_ballot_w64(nxt.hit);
-      const int pos = fill + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0u));
-      quad_append(sidx, lane, nxt.hit, pos, qm, nq);
-      fill += park(slab, nullptr, lane, nxt, fill);
+      quad_append(sidx, lane, nxt.hit, lane, qm, nq);
     }
-    nxt = gather_cand<MACRO>(pk, sub, packed);                                  // chunk c0+64: in flight during this chunk
-    pk = peek_cand<MACRO>(c0 + 128 + lane, range.y, keys, point_list);  // chunk c0+128
+    const int fill = park(slab, nullptr, lane, nxt, 0);
+    nxt = gather_cand<1>(pk, 0u, packed);                           // chunk c0+64: in flight during this chunk
+    pk = peek_cand<1>(c0 + 128 + lane, range.y, keys, point_list);  // chunk c0+128
     wave_lds_sync();
     if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;  // every pixel of the tile has terminated
-    // a block's list holds the entries of all its internal tiles: keep appending until the inner loop is worth entering
-    if (fill < FWD_MIN && c0 + 64 < range.y) continue;
     const int nmax = max(max(nq[0], nq[1]), max(nq[2], nq[3]));
-    // pad the shorter sub-lists up to nmax (+1 for the pipelined over-read) with the dummy entry
+    // pad the shorter sub-lists up to nmax (+2 for the pipelined over-read) with the dummy entry
 #pragma unroll
     for (int q = 0; q < 4; q++)
-      if (lane <= nmax - nq[q]) sidx[q * QCAP + nq[q] + lane] = (uint8_t)FWD_CAP;
+      if (lane <= nmax + 1 - nq[q]) sidx[q * QCAP + nq[q] + lane] = (uint32_t)(FQ_CAP * 4 * ENT);
     wave_lds_sync();
     // one entry of this lane's quad sub-list against the lane's pixel
     // Every trip evaluates four different entries, each picked because it reaches its quad: a trip in which no pixel of
     // the wave blends is rare, so there is no wave-uniform early-out here (the ballot it needs costs two VALU
     // instructions per trip). test_T >= 0 and finite, so its bits order like the value: ONE integer compare serves both
     // `term` and `!term` (the float compare is emitted twice, once per polarity, for NaN's sake).
-    int last_pos = -1;  // slab position of this pixel's last blended entry in this batch
-    auto blend = [&](const Ent& e, int pos) {
+    uint32_t last_off = 0xFFFFFFFFu;  // slab byte offset of this pixel's last blended entry in this chunk
+    auto fetch_off = [&](uint32_t off) {
+      const float4* e4 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(slab) + off);
+      Ent e;
+      e.q0 = e4[0]; e.q1 = e4[1]; e.q2 = e4[2];
+      return e;
+    };
+    auto blend = [&](const Ent& e, uint32_t off) {
       const float dx = e.q0.x - pxf, dy = e.q0.y - pyf;
       const float p = power_of(e, dx, dy);
       const float alpha = fminf(e.q1.y * __builtin_amdgcn_exp2f(p), 0.99f);
@@ -404,27 +411,45 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
       C[2] += e.q2.x * wgt; C[3] += e.q2.y * wgt; C[4] += e.q2.z * wgt;
       invd += e.q2.w * wgt;
       T = valid ? test_T : T;
-      last_pos = valid ? pos : last_pos;
+      last_off = valid ? off : last_off;
     };
-    // software pipeline: sub-list bytes two trips ahead, entry reads one trip ahead, two register sets
-    int i0 = myidx[0], i1 = myidx[1];
-    Ent ea = fetch(slab, i0);
-    int j = 0;
-    for (; j + 1 < nmax; j += 2) {
-      const Ent eb = fetch(slab, i1);
-      const int i2 = myidx[j + 2];
-      blend(ea, i0);
-      ea = fetch(slab, i2);
-      const int i3 = myidx[j + 3];
-      blend(eb, i1);
-      i0 = i2;
-      i1 = i3;
+    // software pipeline: sub-list elements two trips ahead, entry reads one trip ahead, two register sets; groups of eight
+    // trips are unrolled so that the sub-list reads sit at immediate offsets (four elements per ds_read2_b64)
+    uint32_t o0 = myidx[0], o1 = myidx[1];
+    Ent ea = fetch_off(o0);
+    const int ngrp = nmax >> 3;
+    for (int gi = 0; gi < ngrp; gi++) {
+      const uint32_t* ip = myidx + 8 * gi;
+#pragma unroll
+      for (int t = 0; t < 8; t += 2) {
+        const Ent eb = fetch_off(o1);
+        const uint32_t o2 = ip[t + 2];
+        blend(ea, o0);
+        ea = fetch_off(o2);
+        const uint32_t o3 = ip[t + 3];
+        blend(eb, o1);
+        o0 = o2;
+        o1 = o3;
+      }
     }
-    if (j < nmax) blend(ea, i0);
-    if (last_pos >= 0) last_contributor = jbase + (uint32_t)last_pos + 1u;
+    {
+      const int rem = nmax & 7;
+      const uint32_t* ip = myidx + 8 * ngrp;
+      int t = 0;
+      for (; t + 1 < rem; t += 2) {
+        const Ent eb = fetch_off(o1);
+        const uint32_t o2 = ip[t + 2];
+        blend(ea, o0);
+        ea = fetch_off(o2);
+        const uint32_t o3 = ip[t + 3];
+        blend(eb, o1);
+        o0 = o2;
+        o1 = o3;
+      }
+      if (t < rem) blend(ea, o0);
+    }
+    if (last_off != 0xFFFFFFFFu) last_contributor = jbase + last_off / (uint32_t)(4 * ENT) + 1u;
     jbase += (uint32_t)fill;
-    fill = 0;
-    nq[0] = nq[1] = nq[2] = nq[3] = 0;
   }
   if (inside) {
     const size_t HW = (size_t)H * W;
