@@ -157,15 +157,22 @@ def measured_traffic(kernel, a):
 
 
 def _profile_is_current(pmc_json):
-    """A committed PMC profile counts only if it was taken on the kernel sources this process runs (meta.json written by
-    tools/prof_summary.py holds their sha256): traffic / instruction counts of older kernels are not printed."""
+    """A committed PMC profile counts only if it was taken (1) on the kernel sources this process runs (meta.json written by
+    tools/prof_summary.py holds their sha256): traffic / instruction counts of older kernels are not printed — and (2) on
+    the DEFAULT workload: directories with a workload suffix (r02_v19_trained: other opacities run other kernels,
+    r02_v19_lds: other counters) or a non-empty BENCH_ARGS in their meta.json are never replayed."""
+    import re
+
     from eogs2_amd.build import source_hash
 
+    d = os.path.dirname(pmc_json)
+    if not re.fullmatch(r"r\d+_v\d+", os.path.basename(d)):
+        return False
     try:
-        meta = json.load(open(os.path.join(os.path.dirname(pmc_json), "meta.json")))
+        meta = json.load(open(os.path.join(d, "meta.json")))
     except Exception:
         return False
-    return meta.get("kernel_source_sha256") == source_hash()
+    return meta.get("kernel_source_sha256") == source_hash() and not meta.get("bench_args", "").strip()
 
 
 def measured_valu(kernel, a):

@@ -20,7 +20,7 @@ json.dump(out, open(os.path.join(dst, "pmc_mean_per_dispatch.json"), "w"), inden
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eogs2_amd.build import source_hash  # noqa: E402
 
-json.dump({"kernel_source_sha256": source_hash()}, open(os.path.join(dst, "meta.json"), "w"))
+json.dump({"kernel_source_sha256": source_hash(), "bench_args": os.environ.get("BENCH_ARGS", "")}, open(os.path.join(dst, "meta.json"), "w"))
 for k in [k for k in out if k.startswith("render_")]:
     if k in out:
         print(k, {c: f"{v:.3g}" for c, v in sorted(out[k].items())})
