@@ -249,3 +249,32 @@ def shard_views(num_views, rank=None, world=None):
     rank = dist.get_rank() if rank is None else rank
     world = dist.get_world_size() if world is None else world
     return list(range(rank, num_views, world))
+
+
+# Iteration-counted knobs of the reference's optimisation config (gs_config/train.yaml:87-116) that fire after a number of VIEWS
+_PER_VIEW_INTERVALS = ("iterations", "position_lr_max_steps", "densify_from_iter", "densify_until_iter",
+                       "densification_interval", "opacity_reset_interval", "iterend_opacity_reset_interval",
+                       "color_reset_iterations")
+_LEARNING_RATES = ("position_lr_init", "position_lr_final", "feature_lr", "opacity_lr", "scaling_lr", "rotation_lr")
+
+
+def view_sharded_schedule(opt, world=None):
+    """The "equal views seen" protocol for training with `world` views per optimizer step: returns a copy of the
+    optimisation settings `opt` (a dict with the reference's key names) in which every interval counted in iterations is
+    divided by `world` (at least 1), every learning rate is multiplied by sqrt(world), plus `grad_average: True` — the
+    exchanged gradient is the mean over the views (`GradBucket.all_reduce(average=True)` / `finish(average=True)`).
+    world == 1 returns the settings unchanged. Keys that are absent stay absent; values of 0 or below (disabled) are kept."""
+    import math
+
+    world = (dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1) if world is None else int(world)
+    out = dict(opt)
+    out["grad_average"] = world > 1
+    if world <= 1:
+        return out
+    for k in _PER_VIEW_INTERVALS:
+        if k in out and out[k] is not None and out[k] > 0:
+            out[k] = max(1, int(round(out[k] / world)))
+    for k in _LEARNING_RATES:
+        if k in out and out[k] is not None:
+            out[k] = out[k] * math.sqrt(world)
+    return out

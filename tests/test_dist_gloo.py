@@ -163,3 +163,25 @@ def test_bench_launcher_ends_all_ranks_when_one_dies(tmp_path, monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.launch_ranks(types.SimpleNamespace(gpus=2), [])
     assert e.value.code != 0 and time.time() - t0 < 60
+
+
+def test_view_sharded_schedule():
+    """The batch-N protocol of DESIGN.md 7: same number of views before every scheduled event, sqrt(N) learning rates."""
+    import math
+
+    sys.path.insert(0, ROOT)
+    from eogs2_amd.parallel import view_sharded_schedule
+
+    opt = {"iterations": 10000, "position_lr_init": 1.6e-4, "position_lr_final": 1.6e-6, "position_lr_max_steps": 30000,
+           "feature_lr": 0.0025, "densify_from_iter": 500, "densification_interval": 100, "opacity_reset_interval": 3000,
+           "iterend_opacity_reset_interval": 999999999, "lambda_dssim": 0.2, "percent_dense": 0.01, "only_prune": True,
+           "densify_until_iter": -1}
+    assert view_sharded_schedule(opt, 1) == dict(opt, grad_average=False)
+    s8 = view_sharded_schedule(opt, 8)
+    assert (s8["iterations"], s8["densify_from_iter"], s8["densification_interval"], s8["opacity_reset_interval"],
+            s8["position_lr_max_steps"]) == (1250, 62, 12, 375, 3750)
+    assert s8["densify_until_iter"] == -1 and s8["lambda_dssim"] == 0.2 and s8["only_prune"] is True and s8["grad_average"]
+    assert math.isclose(s8["position_lr_init"], 1.6e-4 * math.sqrt(8)) and math.isclose(s8["feature_lr"], 0.0025 * math.sqrt(8))
+    # views seen before each event differ from the reference's by less than one step's worth of views
+    for k in ("iterations", "densify_from_iter", "densification_interval", "opacity_reset_interval"):
+        assert abs(s8[k] * 8 - opt[k]) < 8, k
