@@ -23,7 +23,8 @@
 #define BLK 256                 // threads per workgroup everywhere (4 wave64)
 #define NFEAT 6                 // staged per-Gaussian features: 5 colours + 1/depth
 #ifndef REC
-#define REC 16                  // floats per (tile,Gaussian) gradient record: one whole 64-byte line, four 16-byte quarters
+#define REC 16                  // floats per (tile,Gaussian) gradient record slot: one 64-byte line, four 16-byte quarters, of which
+                                // only the 44 bytes below are written and read
 #endif                          //   [0..3]   dL/dmean2D.x, .y (NDC units), dL/dconic.a, dL/dopacity
                                 //   [4..7]   dL/dconic.b, -, -, -
                                 //   [8..11]  dL/dconic.c, dL/dcolour0, -, -

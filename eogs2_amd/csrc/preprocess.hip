@@ -292,10 +292,10 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
 #pragma unroll
             for (int k = 0; k < NCH; k++) f[k] = colors[NCH * idx + k];
           }
+          // three of the line's four 16-byte quarters: the fourth is never read, and not writing it is 14 % of this kernel
           packed[4 * idx + 0] = make_float4(px, py, ca * (-0.5f * L2E), cb * L2E);
           packed[4 * idx + 1] = make_float4(cc * (-0.5f * L2E), op, f[0], f[1]);
           packed[4 * idx + 2] = make_float4(f[2], f[3], f[4], 1.f / d);
-          packed[4 * idx + 3] = make_float4(0.f, 0.f, 0.f, 0.f);
           // internal-tile rect [sx0,sx1) x [sy0,sy1) (16 bits each) + hit mask relative to it (0 = every tile)
           bi0 = make_uint4((uint32_t)sx0 | ((uint32_t)sx1 << 16), (uint32_t)sy0 | ((uint32_t)sy1 << 16), (uint32_t)m,
                            (uint32_t)(m >> 32));
