@@ -23,14 +23,12 @@
 #define BLK 256                 // threads per workgroup everywhere (4 wave64)
 #define NFEAT 6                 // staged per-Gaussian features: 5 colours + 1/depth
 #ifndef REC
-#define REC 16                  // floats per (tile,Gaussian) gradient record slot: one 64-byte line, four 16-byte quarters, of which
-                                // only the 44 bytes below are written and read
+#define REC 12                  // floats per (tile,Gaussian) gradient record: 48 bytes, three 16-byte quarters, 11 floats used
 #endif                          //   [0..3]   dL/dmean2D.x, .y (NDC units), dL/dconic.a, dL/dopacity
-                                //   [4..7]   dL/dconic.b, -, -, -
-                                //   [8..11]  dL/dconic.c, dL/dcolour0, -, -
-                                //   [12..15] dL/dcolour1..4
-                                // (the quarters are what the four lane groups of the MFMA reduction each finish, render.hip)
-static_assert(REC == 16, "record quarters");
+                                //   [4..7]   dL/dconic.b, dL/dconic.c, dL/dcolour0, dL/dcolour1
+                                //   [8..11]  dL/dcolour2..4, -
+                                // (64-byte slots with zero padding in rounds 1-2: a quarter of the backward's record traffic)
+static_assert(REC == 12, "record quarters");
 
 // ---- misc[] slots (u32) in the geometry workspace ----
 #define MISC_TOTAL_LO 0  // sum of tiles_touched (u64, lo/hi)

@@ -428,24 +428,21 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
             q[u] = have[u] ? q0 + (uint32_t)__builtin_ctz(m) : q0;
             m &= m - 1u;  // (0 & anything stays 0)
           }
-          float4 ra[4], rd[4];
-          float rb[4];
-          float2 rc[4];
+          float4 ra[4], rb[4];
+          float3 rc[4];
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             const uint32_t qq = have[u] ? q[u] : q[0];  // a valid address either way
             ra[u] = r4[(REC / 4) * qq];
-            rb[u] = reinterpret_cast<const float*>(r4 + (REC / 4) * qq + 1)[0];
-            rc[u] = reinterpret_cast<const float2*>(r4 + (REC / 4) * qq + 2)[0];
-            rd[u] = r4[(REC / 4) * qq + 3];
+            rb[u] = r4[(REC / 4) * qq + 1];
+            rc[u] = reinterpret_cast<const float3*>(r4 + (REC / 4) * qq + 2)[0];
           }
 #pragma unroll
           for (int u = 0; u < 4; u++) {
-            if (have[u]) {  // record line (common.h REC) -> acc: 0,1 mean2D  2,3,4 conic  5 opacity  6..10 colour
+            if (have[u]) {  // record (common.h REC) -> acc: 0,1 mean2D  2,3,4 conic  5 opacity  6..10 colour
               acc[0] += ra[u].x; acc[1] += ra[u].y; acc[2] += ra[u].z; acc[5] += ra[u].w;
-              acc[3] += rb[u];
-              acc[4] += rc[u].x; acc[6] += rc[u].y;
-              acc[7] += rd[u].x; acc[8] += rd[u].y; acc[9] += rd[u].z; acc[10] += rd[u].w;
+              acc[3] += rb[u].x; acc[4] += rb[u].y; acc[6] += rb[u].z; acc[7] += rb[u].w;
+              acc[8] += rc[u].x; acc[9] += rc[u].y; acc[10] += rc[u].z;
             }
           }
         }

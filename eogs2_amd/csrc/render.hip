@@ -568,10 +568,9 @@ __device__ inline void transpose_round(int nsurv, int lane, const float* rb, con
     const float ho = -0.5f * op;
     const uint32_t slot = __float_as_uint(q1.z);
     float4* dst = reinterpret_cast<float4*>(records + (size_t)slot * REC);  // layout: common.h REC
-    dst[0] = make_float4(m2x, m2y, ho * acc[3], acc[0]);  // the 44 bytes gaussian_bwd reads, no padding
-    reinterpret_cast<float*>(dst + 1)[0] = ho * acc[4];
-    reinterpret_cast<float2*>(dst + 2)[0] = make_float2(ho * acc[5], acc[6]);
-    dst[3] = make_float4(acc[7], acc[8], acc[9], acc[10]);
+    dst[0] = make_float4(m2x, m2y, ho * acc[3], acc[0]);
+    dst[1] = make_float4(ho * acc[4], ho * acc[5], acc[6], acc[7]);
+    reinterpret_cast<float3*>(dst + 2)[0] = make_float3(acc[8], acc[9], acc[10]);
     live_flag[slot] = 1;  // pairs that never get here keep the 0 of the memset and are skipped by gaussian_bwd
   }
 }
@@ -1098,12 +1097,9 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         const float m2y = op * ky * (2.f * Cq * acc[2] - B * acc[1]);
         const float ho = -0.5f * op;
         float4* dst = reinterpret_cast<float4*>(records + (size_t)cur_slot * REC);  // layout: common.h REC
-        // only the 44 bytes gaussian_bwd reads (whole-line stores with zero padding were measured again in round 2: render_bwd
-        // +3.4 %, gaussian_bwd +1.4 %)
         dst[0] = make_float4(m2x, m2y, ho * acc[3], acc[0]);
-        reinterpret_cast<float*>(dst + 1)[0] = ho * acc[4];
-        reinterpret_cast<float2*>(dst + 2)[0] = make_float2(ho * acc[5], acc[6]);
-        dst[3] = make_float4(acc[7], acc[8], acc[9], acc[10]);
+        dst[1] = make_float4(ho * acc[4], ho * acc[5], acc[6], acc[7]);
+        reinterpret_cast<float3*>(dst + 2)[0] = make_float3(acc[8], acc[9], acc[10]);
         live_flag[cur_slot] = 1;
       }
     }
@@ -1346,10 +1342,14 @@ __global__ __launch_bounds__(RBLK) void render_bwd_mfma_kernel(
         } else {               // c1 c2 c3 c4
           out = make_float4(a0, a1, a2, a3);
         }
-        float4* const dq = reinterpret_cast<float4*>(records + (size_t)slot * REC) + kk;  // only the bytes gaussian_bwd reads
-        if (kk == 1) reinterpret_cast<float*>(dq)[0] = out.x;
-        else if (kk == 2) reinterpret_cast<float2*>(dq)[0] = make_float2(out.x, out.y);
-        else *dq = out;
+        float* const rec = records + (size_t)slot * REC;  // every lane group stores its own pieces of the 48-byte record
+        if (kk == 0) *reinterpret_cast<float4*>(rec) = out;
+        else if (kk == 1) rec[4] = out.x;
+        else if (kk == 2) { rec[5] = out.x; rec[6] = out.y; }  // (8-byte store: misaligned at float 5)
+        else {
+          rec[7] = out.x;
+          *reinterpret_cast<float3*>(rec + 8) = make_float3(out.y, out.z, out.w);
+        }
       }
     }
     jbase += (uint32_t)jn;
