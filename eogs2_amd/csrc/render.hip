@@ -29,7 +29,7 @@
 //     transposition through LDS: the pixel-parallel pass only produces two numbers per (pixel, Gaussian),
 //     u = alpha T and v = G dL/dalpha; every 8 surviving Gaussians the wave switches to lanes = (Gaussian,
 //     pixel row) and accumulates the six moments of v and the five colour sums of u serially in registers
-//     (see transpose_round). No cross-lane reduction tree, no atomics, and ONE record (11 floats in a 64-byte line) per
+//     (see transpose_round). No cross-lane reduction tree, no atomics, and ONE record (11 floats in 48 bytes) per
 //     (tile,Gaussian) pair written with plain stores by the only wave that owns the pair (plus a 1-byte live flag:
 //     pairs behind every pixel's last contributor are never gathered nor written); gaussian_bwd_kernel sums each
 //     Gaussian's live records in fixed order (bitwise reproducible gradients).
