@@ -377,7 +377,9 @@ __global__ __launch_bounds__(BLK) void expand_count_kernel(const uint32_t* __res
 // Gaussians with at most EXPAND_LANE_MAX tiles are walked by their own lane into an LDS window (tile id + owner lane),
 // FINE_STAGE pairs per round, and streamed out with consecutive lanes writing consecutive addresses; larger ones
 // are emitted by the whole wave, one after the other, straight to their (reserved) global positions.
-#define FINE_STAGE 6144     // pairs per LDS window (24 KB of tile ids + 12 KB of owner lanes)
+#ifndef FINE_STAGE
+#define FINE_STAGE 3072     // pairs per LDS window (12 KB of tile ids + 6 KB of owner lanes: 7 workgroups per CU; 6144 held the
+#endif                      // kernel at 3 per CU: binning -4 us at 4 and at 8.7 listed tiles per Gaussian; 1024 costs rounds at 8.7)
 struct FineItem {
   uint32_t id, c, pos0, rbase, sx0, sy0, sw, sh;
   unsigned long long m;
@@ -541,7 +543,7 @@ __global__ __launch_bounds__(BLK) void expand_fine_kernel(const uint4* __restric
 // code preprocess counted with. Output position = depth-order offset (exclusive scan of the entry counts).
 // Gaussians with at most EXPAND_LANE_MAX entries are walked by their own lane into an LDS window and streamed out with
 // consecutive lanes writing consecutive addresses; larger ones are emitted by the whole wave, one macro row per lane.
-#define EXPAND_STAGE 4096     // entries per LDS window (16 KB keys + 16 KB slots + 8 KB owner lanes)
+#define EXPAND_STAGE 4096     // entries per LDS window (16 KB keys + 16 KB slots + 8 KB owner lanes; 2048 / 1024 measured: no better)
 struct ExpandItem {
   uint32_t id, c, pos0, rbase, sx0, sy0, sx1, sy1, kind;
   unsigned long long m;
