@@ -663,21 +663,37 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint4* __restrict__ s
 
 // ---- block ranges from the sorted keys (identifyTileRanges, rasterizer_impl.cu:116-138) ----
 // With per-tile lists (one record slot per entry) it also clears the backward's per-record live flags.
+// Four consecutive keys per thread (one 16-byte load, one 4-byte store of cleared flags).
 __global__ __launch_bounds__(BLK) void tile_ranges_kernel(const uint32_t* __restrict__ skeys, uint32_t R, uint32_t kmask,
                                                           uint2* __restrict__ ranges, uint8_t* __restrict__ live) {
-  const uint32_t i = blockIdx.x * BLK + threadIdx.x;
-  if (i >= R) return;
-  if (live) live[i] = 0;
-  const uint32_t cur = skeys[i] & kmask;
-  if (i == 0) ranges[cur].x = 0;
-  else {
-    const uint32_t prev = skeys[i - 1] & kmask;
-    if (cur != prev) {
+  const uint32_t i0 = (blockIdx.x * BLK + threadIdx.x) * 4u;
+  if (i0 >= R) return;
+  uint32_t k[4];
+  if (i0 + 4u <= R) {
+    const uint4 v = *reinterpret_cast<const uint4*>(skeys + i0);
+    k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w;
+    if (live) *reinterpret_cast<uint32_t*>(live + i0) = 0u;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      k[j] = i0 + j < R ? skeys[i0 + j] : 0u;
+      if (live && i0 + j < R) live[i0 + j] = 0;
+    }
+  }
+  uint32_t prev = i0 ? skeys[i0 - 1] & kmask : 0u;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t i = i0 + j;
+    if (i >= R) break;
+    const uint32_t cur = k[j] & kmask;
+    if (i == 0) ranges[cur].x = 0;
+    else if (cur != prev) {
       ranges[prev].y = i;
       ranges[cur].x = i;
     }
+    if (i == R - 1) ranges[cur].y = R;
+    prev = cur;
   }
-  if (i == R - 1) ranges[cur].y = R;
 }
 
 void launch_binning_head(const GeomWS& g, int P, int block, const uint32_t* sorted_ids, hipStream_t s) {
@@ -718,6 +734,6 @@ void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int
     uint32_t* tk = ka; ka = kb; kb = tk;
     uint2* tv = va; va = vb; vb = tv;
   }
-  hipLaunchKernelGGL(tile_ranges_kernel, dim3(ceil_div_u32((uint64_t)Re, BLK)), dim3(BLK), 0, s, b.sorted_keys, Re,
+  hipLaunchKernelGGL(tile_ranges_kernel, dim3(ceil_div_u32((uint64_t)Re, BLK * 4)), dim3(BLK), 0, s, b.sorted_keys, Re,
                      M > 1 ? (1u << MACRO_KEY_BITS) - 1u : 0xFFFFFFFFu, im.ranges, M > 1 ? (uint8_t*)nullptr : b.live);
 }
