@@ -178,7 +178,7 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
   const bool debug = flags & EOGS_FLAG_DEBUG;
   if (!g_pinned) HIP_TRY(hipHostMalloc((void**)&g_pinned, MISC_WORDS * sizeof(uint32_t), hipHostMallocDefault));
 
-  HIP_TRY(hipMemsetAsync(g.misc, 0, MISC_WORDS * sizeof(uint32_t), s));
+  // (g.misc needs no clearing: the pair-count scan writes every word the host reads, the error flag included)
   FwdPrepArgs a{P, H, W, means3D, scales, rotations, cov3D_precomp, opacities, colors, viewmatrix, scale_modifier,
                 (flags & EOGS_FLAG_ANTIALIASING) != 0, radii, raw, alt_affine};
   { ProfScope ps(PS_PREPROCESS, s); launch_preprocess_fwd(a, g, s); }

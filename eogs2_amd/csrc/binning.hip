@@ -66,7 +66,7 @@ __device__ inline void pblock_scan_body(uint32_t* __restrict__ pblock, const uin
   __shared__ uint32_t s_w[4];
   __shared__ uint32_t s_k[2][BLK / 64];
   unsigned long long carry = 0ull, entries = 0ull, opw = 0ull;
-  uint32_t kmax = 0, knmin = 0;
+  uint32_t kmax = 0, knmin = 0, err = 0;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (uint32_t b0 = 0; b0 < nblk; b0 += BLK * 16) {
     const uint32_t i0 = b0 + threadIdx.x * 16;
@@ -80,7 +80,9 @@ __device__ inline void pblock_scan_body(uint32_t* __restrict__ pblock, const uin
         kmax = a > kmax ? a : kmax;
         knmin = b > knmin ? b : knmin;
         entries += pbkey[4 * (i0 + k) + 2];
-        opw += pbkey[4 * (i0 + k) + 3];
+        const uint32_t ow = pbkey[4 * (i0 + k) + 3];  // bit 31: error flag of the workgroup
+        opw += ow & 0x7FFFFFFFu;
+        err |= ow >> 31;
       }
       sum += v[k];
     }
@@ -115,18 +117,23 @@ __device__ inline void pblock_scan_body(uint32_t* __restrict__ pblock, const uin
   for (int o = 32; o >= 1; o >>= 1) {
     entries += __shfl_xor(entries, o, 64);
     opw += __shfl_xor(opw, o, 64);
+    err |= __shfl_xor(err, o, 64);
   }
-  if (lane == 0) { s_k[0][w] = kmax; s_k[1][w] = knmin; s_e[w] = entries; s_o[w] = opw; }
+  __shared__ uint32_t s_err[BLK / 64];
+  if (lane == 0) { s_k[0][w] = kmax; s_k[1][w] = knmin; s_e[w] = entries; s_o[w] = opw; s_err[w] = err; }
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t a = s_k[0][0], b = s_k[1][0];
     unsigned long long e = s_e[0], ow = s_o[0];
+    uint32_t er = s_err[0];
     for (int i = 1; i < BLK / 64; i++) {
       a = s_k[0][i] > a ? s_k[0][i] : a;
       b = s_k[1][i] > b ? s_k[1][i] : b;
       e += s_e[i];
       ow += s_o[i];
+      er |= s_err[i];
     }
+    misc[MISC_ERR] = er;  // every readback word is written here: the workspace needs no clearing
     misc[MISC_OPW_LO] = (uint32_t)ow;
     misc[MISC_OPW_HI] = (uint32_t)(ow >> 32);
     misc[MISC_MACRO_LO] = (uint32_t)e;

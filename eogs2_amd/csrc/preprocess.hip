@@ -132,7 +132,7 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
   __syncthreads();
 
   const size_t idx = row0 + t;
-  uint32_t my_tiles = 0, my_entries = 0, key_bits = 0, bkind = BK_RECT;
+  uint32_t my_tiles = 0, my_entries = 0, key_bits = 0, bkind = BK_RECT, my_err = 0;
   uint32_t op64 = 0;  // round(64 * opacity), for the mean pair opacity that picks the list granularity (api.hip)
   uint4 bi0 = make_uint4(0u, 0u, 0u, 0u);
   if (t < rows) {
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
       if (area != 0) {
         radius = r;
         const float d = (float)(200.0 - (double)pv[2]);  // forward.cu:267
-        if (d < 0) atomicOr(&misc[MISC_ERR], 1u);
+        if (d < 0) my_err = 0x80000000u;  // altitude > 200: reported through the workgroup's partials (no zero-initialised word)
         const float op_in = RAW ? sigmoidf(opacities[idx]) : opacities[idx];
         const float ca = cz * det_inv, cb = -cy * det_inv, cc = cx * det_inv, op = op_in * hcs;
         op64 = (uint32_t)(fminf(fmaxf(op, 0.f), 1.f) * 64.f + 0.5f);  // (NaN -> 0)
@@ -329,9 +329,9 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
   // range of the depth keys of listed Gaussians (lets the host drop sort passes whose digit is constant) and the
   // workgroup's pair count: plain stores, reduced by pblock_scan_kernel (same-address atomics from 16k waves cost
   // 0.36 ms here)
-  __shared__ uint32_t s_k[4][BLK / 64];
+  __shared__ uint32_t s_k[5][BLK / 64];
   uint32_t kmax = my_tiles ? key_bits : 0u, knmin = my_tiles ? ~key_bits : 0u, esum = my_tiles ? my_entries : 0u;
-  uint32_t osum = my_tiles * op64;  // <= 65536 tiles * 64 per Gaussian, 256 Gaussians per workgroup: fits 32 bits
+  uint32_t osum = my_tiles * op64;  // <= 65536 tiles * 64 per Gaussian, 256 Gaussians per workgroup: below 2^31
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
     const uint32_t a = __shfl_xor(kmax, o, 64), b = __shfl_xor(knmin, o, 64);
@@ -339,22 +339,24 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
     knmin = b > knmin ? b : knmin;
     esum += __shfl_xor(esum, o, 64);
     osum += __shfl_xor(osum, o, 64);
+    my_err |= __shfl_xor(my_err, o, 64);
   }
-  if (lane == 0) { s_k[0][w] = kmax; s_k[1][w] = knmin; s_k[2][w] = esum; s_k[3][w] = osum; }
+  if (lane == 0) { s_k[0][w] = kmax; s_k[1][w] = knmin; s_k[2][w] = esum; s_k[3][w] = osum; s_k[4][w] = my_err; }
   __syncthreads();
   if (t == 0) {
     pblock[blockIdx.x] = w0 + w1 + w2 + w3;
-    uint32_t a = s_k[0][0], b = s_k[1][0], e = s_k[2][0], ow = s_k[3][0];
+    uint32_t a = s_k[0][0], b = s_k[1][0], e = s_k[2][0], ow = s_k[3][0], er = s_k[4][0];
     for (int i = 1; i < BLK / 64; i++) {
       a = s_k[0][i] > a ? s_k[0][i] : a;
       b = s_k[1][i] > b ? s_k[1][i] : b;
       e += s_k[2][i];
       ow += s_k[3][i];
+      er |= s_k[4][i];
     }
     pbkey[4 * blockIdx.x] = a;
     pbkey[4 * blockIdx.x + 1] = b;
     pbkey[4 * blockIdx.x + 2] = e;
-    pbkey[4 * blockIdx.x + 3] = ow;
+    pbkey[4 * blockIdx.x + 3] = ow | er;  // bit 31: the workgroup's error flag (EOGS_ERR_ALTITUDE), summed out by the scan
   }
 }
 
