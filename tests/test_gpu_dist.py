@@ -28,3 +28,22 @@ def test_two_rank_bench_rehearsal():
     assert ex["rccl_ranks"] == 2 and ex["bytes_per_gaussian"] == 56 and ex["chunks"] in (1, 4)
     assert set(ex["chunks_tried_ms_per_step"]) == {"1", "4"}
     assert line["value"] > 0 and line["ms_per_step"] > 0
+
+
+def test_two_rank_bench_under_torchrun():
+    """The driver's own launch style for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...` — bench.py is then a rank (RANK / LOCAL_RANK / WORLD_SIZE from the
+    launcher) and must not start ranks of its own; rank 0 prints the one JSON line."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    port = 29600 + os.getpid() % 300
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "4", "--warmup", "1",
+                        "--gaussians", "30000", "--size", "160"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # one line, from rank 0
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["exchange"]["rccl_ranks"] == 2 and line["config"]["parallelism"] == "view-dp2"
