@@ -69,6 +69,8 @@ class _Model:
 def test_render_entry_point_fused_vs_reference_ops(oracle_backend):
     """`render()` with the reference's signature: the fused path and the reference's op sequence give the same
     image, radii and gradients — including the learnable last row of the view matrix (learn_wv_only_lastparam)."""
+    from util import render_unfused
+
     from eogs2_amd.render import render
 
     H, W, P = 40, 56, 200
@@ -78,7 +80,7 @@ def test_render_entry_point_fused_vs_reference_ops(oracle_backend):
     res = {}
     for fused in (True, False):
         cam, pc = _Cam(scene["viewmatrix"], H, W), _Model(raw)
-        out = render(cam, pc, pipe, scene["bg"], fused=fused)
+        out = render(cam, pc, pipe, scene["bg"]) if fused else render_unfused(cam, pc, pipe, scene["bg"])
         assert set(out) == {"render", "viewspace_points", "visibility_filter", "radii"}
         (out["render"] * scene["dL_dcolor"]).sum().backward()
         res[fused] = dict(render=out["render"].detach(), radii=out["radii"], vsp=out["viewspace_points"].grad,
@@ -88,3 +90,20 @@ def test_render_entry_point_fused_vs_reference_ops(oracle_backend):
     for k in res[True]:
         if k != "radii":
             assert_close(res[True][k], res[False][k], k, rtol=2e-5)
+
+
+def test_render_entry_point_delegates_what_it_does_not_fuse(oracle_backend):
+    """Inputs outside the raw-parameter path go to the caller's own render (or raise): nothing is re-implemented."""
+    from eogs2_amd.render import fusable, render
+
+    scene = make_scene(10, 16, 16, seed=1)
+    raw, _ = raw_params_from_scene(scene)
+    cam, pc = _Cam(scene["viewmatrix"], 16, 16), _Model(raw)
+    pipe = types.SimpleNamespace(debug=False, antialiasing=False, compute_cov3D_python=True, require_radii=True)
+    assert not fusable(cam, pipe) and not fusable(cam, types.SimpleNamespace(compute_cov3D_python=False), torch.zeros(10, 5))
+    with pytest.raises(NotImplementedError):
+        render(cam, pc, pipe, scene["bg"])
+    seen = []
+    assert render(cam, pc, pipe, scene["bg"], 2.0, fallback=lambda *a: seen.append(a) or "theirs") == "theirs"
+    assert seen[0][:5] == (cam, pc, pipe, scene["bg"], 2.0) and len(seen[0]) == 8
+

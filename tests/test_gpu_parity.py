@@ -425,11 +425,11 @@ def test_fused_matches_oracle(dev, monkeypatch):
 
 
 def test_render_entry_point(dev):
-    """eogs2_amd.render.render (the reference's renderer.py signature): fused and reference-op paths agree on the GPU."""
+    """eogs2_amd.render.render (the reference's renderer.py signature): the fused path agrees with the unfused ops + drop-in rasterizer built in the test."""
     import types
 
     from test_fused_cpu import _Cam, _Model
-    from util import raw_params_from_scene
+    from util import raw_params_from_scene, render_unfused
 
     from eogs2_amd.render import render
     from eogs2_amd.synthetic import make_scene
@@ -443,7 +443,7 @@ def test_render_entry_point(dev):
         cam, pc = _Cam(scene["viewmatrix"], H, W), _Model(raw)
         cam.last_row = cam.last_row.detach().to(dev).requires_grad_(True)
         cam.camera_center = cam.camera_center.to(dev)
-        out = render(cam, pc, pipe, scene["bg"], fused=fused)
+        out = render(cam, pc, pipe, scene["bg"]) if fused else render_unfused(cam, pc, pipe, scene["bg"])
         (out["render"] * scene["dL_dcolor"]).sum().backward()
         res[fused] = dict(render=out["render"].detach(), vsp=out["viewspace_points"].grad, last_row=cam.last_row.grad,
                           **{k: v.grad for k, v in pc.params().items()})

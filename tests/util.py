@@ -151,3 +151,23 @@ def run_raw(raw, alt_affine, scene, H, W, antialiasing, fused, dL_dinvdepth=None
                g_viewmatrix=vm.grad)
     out.update({"g_" + k: v.grad for k, v in leaves.items()})
     return out
+
+
+def render_unfused(cam, pc, pipe, bg):
+    """The unfused counterpart of `eogs2_amd.render.render` for tests: activations and the [rgb, altitude, 1] features as
+    PyTorch ops (what gaussian_model.py:109-137 / renderer.py:88-96 compute), then the drop-in GaussianRasterizer."""
+    import math
+
+    from eogs2_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+    vm = cam.world_view_transform.clone()
+    vm[3] = vm[3] + cam.last_row
+    rs = GaussianRasterizationSettings(int(cam.image_height), int(cam.image_width), math.tan(0.5), math.tan(0.5), bg, 1.0,
+                                       vm, vm, 0, cam.camera_center, False, pipe.debug, pipe.antialiasing)
+    vsp = torch.zeros_like(pc._xyz, requires_grad=True)
+    alt = cam.ECEF_to_UVA(pc._xyz)[:, 2:3]
+    feats = torch.cat([pc._features_dc.squeeze(1) * SH_C0 + 0.5, alt, torch.ones_like(alt)], dim=1)
+    img, radii, _ = GaussianRasterizer(rs)(means3D=pc._xyz, means2D=vsp, colors_precomp=feats, opacities=pc.get_opacity,
+                                           scales=pc.get_scaling, rotations=pc.get_rotation)
+    return {"render": img, "viewspace_points": vsp, "radii": radii, "visibility_filter": torch.nonzero(radii > 0)}
+
