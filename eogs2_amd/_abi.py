@@ -6,7 +6,7 @@ exports the same symbols over host pointers.
 """
 import ctypes as C
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 EOGS_OK = 0
 ERR_NAMES = {
@@ -40,13 +40,14 @@ SIGNATURES = {
     "eogs_rast_geom_bytes": (_i, [_i, C.POINTER(_z)]),
     "eogs_rast_image_bytes": (_i, [_i, _i, C.POINTER(_z)]),
     "eogs_rast_binning_bytes": (_i, [_i, _i, _i, _i64, C.POINTER(_z)]),
+    "eogs_rast_scratch_bytes": (_i, [_i, _i, _i, C.POINTER(_z)]),
     "eogs_rast_forward_prepare": (
         _i,
-        [_i, _i, _i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _u, _p, _p, _z, C.POINTER(_i64), _p],
+        [_i, _i, _i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _u, _p, _p, _z, _p, _z, C.POINTER(_i64), _p],
     ),
     "eogs_rast_forward_render": (
         _i,
-        [_i, _i, _i, _i64, _p, _u, _p, _z, _p, _z, _p, _z, _p, _p, _p],
+        [_i, _i, _i, _i64, _p, _u, _p, _z, _p, _z, _p, _z, _p, _z, _p, _p, _p],
     ),
     "eogs_rast_backward": (
         _i,

@@ -148,12 +148,18 @@ int eogs_rast_binning_bytes(int P, int H, int W, int64_t R, size_t* bytes) {
   *bytes = bin_layout(nullptr, H, W, R).bytes;
   return EOGS_OK;
 }
+int eogs_rast_scratch_bytes(int P, int H, int W, size_t* bytes) {
+  (void)H; (void)W;
+  if (P < 0 || !bytes) return fail(EOGS_ERR_INVALID_ARG, "scratch_bytes: bad argument");
+  *bytes = sort_layout(nullptr, ent_cap(P)).bytes;
+  return EOGS_OK;
+}
 
 int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const float* scales, const float* rotations,
                               const float* cov3D_precomp, const float* opacities, const float* colors,
                               float scale_modifier, const float* viewmatrix, const float* projmatrix,
                               const float* alt_affine, unsigned flags, int* radii, void* geom,
-                              size_t geom_bytes, int64_t* num_rendered, void* stream) {
+                              size_t geom_bytes, void* scratch, size_t scratch_bytes, int64_t* num_rendered, void* stream) {
   (void)projmatrix;
   g_err[0] = 0;
   if (P < 0 || H <= 0 || W <= 0 || !num_rendered) return fail(EOGS_ERR_INVALID_ARG, "forward_prepare: bad sizes");
@@ -161,6 +167,8 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
   if (P == 0) return EOGS_OK;
   if (((W + TILE - 1) / TILE) > 32767 || ((H + TILE - 1) / TILE) > 32767)
     return fail(EOGS_ERR_INVALID_ARG, "forward_prepare: image too large for 16-bit internal tile coordinates");
+  if ((uint64_t)macro_grid_x(W, BLOCK_BIG) * macro_grid_y(H, BLOCK_BIG) > MAX_BLOCKS)
+    return fail(EOGS_ERR_INVALID_ARG, "forward_prepare: image too large (more than 65536 blocks of 32 x 32 pixels)");
   if (!means3D || !opacities || !viewmatrix || !radii || !geom) return fail(EOGS_ERR_INVALID_ARG, "forward_prepare: NULL input");
   if (!colors) return fail(EOGS_ERR_NO_COLORS, "For non-RGB, provide precomputed Gaussian colors!");
   const bool have_sr = scales && rotations, have_cov = cov3D_precomp != nullptr;
@@ -174,59 +182,55 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
   const GeomWS g = geom_layout(base, P);
   if ((size_t)(base - (char*)geom) + g.bytes - 256 > geom_bytes)
     return fail(EOGS_ERR_WORKSPACE, "forward_prepare: geom workspace too small");
+  // The entry sort runs here, before the host knows how many entries there are, when the caller hands over a scratch
+  // buffer of the size eogs_rast_scratch_bytes() names; otherwise (or when the entries exceed its capacity) it runs in
+  // forward_render inside the binning workspace.
+  SortWS sw = sort_layout(nullptr, 0);
+  bool have_scratch = false;
+  if (scratch) {
+    char* sb = ws_base(scratch);
+    sw = sort_layout(sb, ent_cap(P));
+    have_scratch = (size_t)(sb - (char*)scratch) + sw.bytes - 256 <= scratch_bytes;
+    if (!have_scratch) return fail(EOGS_ERR_WORKSPACE, "forward_prepare: scratch smaller than eogs_rast_scratch_bytes()");
+  }
   hipStream_t s = (hipStream_t)stream;
   const bool debug = flags & EOGS_FLAG_DEBUG;
   if (!g_pinned) HIP_TRY(hipHostMalloc((void**)&g_pinned, MISC_WORDS * sizeof(uint32_t), hipHostMallocDefault));
 
-  // (g.misc needs no clearing: the pair-count scan writes every word the host reads, the error flag included)
+  // (g.misc needs no clearing: the scan writes every word the host reads, the error flag included)
   FwdPrepArgs a{P, H, W, means3D, scales, rotations, cov3D_precomp, opacities, colors, viewmatrix, scale_modifier,
                 (flags & EOGS_FLAG_ANTIALIASING) != 0, radii, raw, alt_affine};
   { ProfScope ps(PS_PREPROCESS, s); launch_preprocess_fwd(a, g, s); }
   LAUNCH_TRY(s, debug, "preprocess_fwd");
-  // pass 0's histogram of the depth sort, with the scan of the pair counts riding along as one extra workgroup
-  { ProfScope ps(PS_DEPTH_SORT, s); launch_depth_sort_head(g, P, s); }
-  LAUNCH_TRY(s, debug, "depth_sort_head");
-  // The pair count is read back on a side stream that waits only for the two kernels above, so the host wakes up
-  // while the caller's stream is still busy with the depth sort (which does not depend on num_rendered) and has the
-  // rest of the forward queued before the GPU runs dry.
+  { ProfScope ps(PS_BINNING, s); launch_pblock_scan(g, P, s); }
+  LAUNCH_TRY(s, debug, "pblock_scan");
+  // The counts are read back on a side stream that waits only for the two kernels above, so the host wakes up while the
+  // caller's stream is busy with the entry sort (which reads the entry count on the device) and has the rest of the
+  // forward queued before the GPU runs dry.
   Side* sd = side_for_current_device();
   if (!sd) return fail(EOGS_ERR_DEVICE, "forward_prepare: cannot create the readback stream");
   HIP_TRY(hipEventRecord(sd->ev, s));
   HIP_TRY(hipStreamWaitEvent(sd->stream, sd->ev, 0));
   HIP_TRY(hipMemcpyAsync(g_pinned, g.misc, MISC_READBACK * sizeof(uint32_t), hipMemcpyDeviceToHost, sd->stream));
-  { ProfScope ps(PS_DEPTH_SORT, s); launch_depth_sort(g, P, 0, 3, s, true); }
-  LAUNCH_TRY(s, debug, "depth_sort");
-  HIP_TRY(hipStreamSynchronize(sd->stream));
-  const uint32_t* sorted_ids = g.svalA;  // after an even number of depth-sort passes
-  {
-    // Fourth pass (bits 24..31) only if the listed Gaussians' keys differ there. EOGS altitudes span far less than
-    // a factor of two around 200 - altitude, so they normally share sign, exponent-high bits: one digit, no pass.
-    const uint32_t kmax = g_pinned[MISC_KEY_MAX], kmin = ~g_pinned[MISC_KEY_NMIN];
-    if (kmax != 0 && ((kmax ^ kmin) >> 24) == 0) {
-      // three passes left the order in buffer B (binning reads it from there); unlisted Gaussians (key 0xFFFFFFFF) may sit
-      // anywhere: they emit nothing
-      sorted_ids = g.svalB;
-    } else {
-      ProfScope ps(PS_DEPTH_SORT, s);
-      launch_depth_sort(g, P, 3, 4, s);
-    }
+  if (have_scratch) {
+    ProfScope ps(PS_BINNING, s);
+    launch_entry_sort(g, sw, P, H, W, s);
   }
-  LAUNCH_TRY(s, debug, "depth_sort_tail");
+  LAUNCH_TRY(s, debug, "entry_sort");
+  HIP_TRY(hipStreamSynchronize(sd->stream));
   const uint64_t total = (uint64_t)g_pinned[MISC_TOTAL_LO] | ((uint64_t)g_pinned[MISC_TOTAL_HI] << 32);
-  const uint64_t entries_big = (uint64_t)g_pinned[MISC_MACRO_LO] | ((uint64_t)g_pinned[MISC_MACRO_HI] << 32);
-  // List granularity of this forward (common.h "blocks"). Per-tile lists while footprints are small: every entry a
-  // wave reads is one it uses. Lists per 32 x 32-pixel block once a Gaussian is listed in many tiles: the sort then
-  // moves 4-7x fewer entries, which outweighs the block-list scan in the render waves (measured crossover at about nine
-  // listed tiles per Gaussian: 1024^2 trained -8 %, 2048^2 trained -28 %, 1024^2 at opacity 0.01 +13 % if forced).
-  // Block ids must fit the low half of the sort key.
-  const bool big_fits = (uint64_t)macro_grid_x(W, BLOCK_BIG) * macro_grid_y(H, BLOCK_BIG) <= (1u << MACRO_KEY_BITS);
+  const uint64_t entries = (uint64_t)g_pinned[MISC_MACRO_LO] | ((uint64_t)g_pinned[MISC_MACRO_HI] << 32);
+  // List granularity the render kernels read (common.h "blocks"). Per-tile lists while footprints are small: every entry a
+  // wave reads is one it uses. Lists per 32 x 32-pixel block once a Gaussian is listed in many tiles: the lists are then
+  // 4-7x shorter to write and re-read, which outweighs the block-list scan in the render waves (measured crossover at
+  // about nine listed tiles per Gaussian: 1024^2 trained -8 %, 2048^2 trained -28 %, 1024^2 at opacity 0.01 +13 % if forced).
   static const double block_switch = [] {  // tuning aid: EOGS_BLOCK_SWITCH=<tiles per Gaussian> overrides the default
     const char* e = getenv("EOGS_BLOCK_SWITCH");
     return e ? atof(e) : (double)EOGS_BLOCK_SWITCH;
   }();
   // Second criterion: termination. With opaque Gaussians a pixel stops after ~ln(1e4) / (mean alpha) list entries, so a
-  // tile's list (length L = pairs / tiles) is only rendered to a depth ~1 / opacity while binning still sorts all of it:
-  // per-tile binning then costs more than block-mode rendering loses. Measured over P = 1-4 M, opacities 0.01 ... trained
+  // tile's list (length L = pairs / tiles) is only rendered to a depth ~1 / opacity while binning still writes all of it:
+  // per-tile lists then cost more than block-mode rendering loses. Measured over P = 1-4 M, opacities 0.01 ... trained
   // (sigmoid(N(0,2))): block lists win when L * (mean pair opacity) exceeds ~115 (2 M Gaussians at trained opacities and
   // 7.9 listed tiles per Gaussian: 1.41 -> 1.18 ms per fwd+bwd; opacity 0.1 at 6.5: per-tile lists stay 8 % ahead).
   static const double depth_switch = [] {  // EOGS_DEPTH_SWITCH=<L * mean opacity> overrides; 0 disables the criterion
@@ -237,25 +241,18 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
   const double ntiles8 = (double)macro_grid_x(W, 1) * (double)macro_grid_y(H, 1);
   const double list_depth = (double)opw / 64.0 / ntiles8;  // = L * mean pair opacity
   const bool by_footprint = (double)total > block_switch * (double)P;
-  const bool by_depth = depth_switch > 0.0 && list_depth > depth_switch && total >= 2 * entries_big;  // blocks must merge entries
-  const int block = (big_fits && (by_footprint || by_depth)) ? BLOCK_BIG : 1;
-  const uint64_t entries = block > 1 ? entries_big : total;
-  // keep the GPU busy while the caller sizes and allocates the binning workspace: the depth-order gather and the
-  // chunk scan only touch the geometry workspace
-  if (total) {
-    ProfScope ps(PS_BINNING, s);
-    launch_binning_head(g, P, block, sorted_ids, s);
-  }
-  LAUNCH_TRY(s, debug, "binning_head");
+  const bool by_depth = depth_switch > 0.0 && list_depth > depth_switch && total >= 2 * entries;  // blocks must merge entries
+  const int block = (by_footprint || by_depth) ? BLOCK_BIG : 1;
   if (g_pinned[MISC_ERR] & 1u) return fail(EOGS_ERR_ALTITUDE, "Point is too high: altitude > 200");
-  if (total >= ((uint64_t)1 << 31) || entries >= ((uint64_t)1 << 30)) return fail(EOGS_ERR_OVERFLOW, "num_rendered overflows 31 bits");
-  *num_rendered = nr_pack((uint32_t)total, (uint32_t)entries, block);
+  if (total >= ((uint64_t)1 << 31) || entries >= ((uint64_t)1 << 29)) return fail(EOGS_ERR_OVERFLOW, "num_rendered overflows 31 bits");
+  *num_rendered = nr_pack((uint32_t)total, (uint32_t)entries, block, have_scratch && entries <= (uint64_t)sw.cap);
   return EOGS_OK;
 }
 
 int eogs_rast_forward_render(int P, int H, int W, int64_t R, const float* bg, unsigned flags,
                              void* geom, size_t geom_bytes, void* binning, size_t binning_bytes, void* image,
-                             size_t image_bytes, float* out_color, float* out_invdepth, void* stream) {
+                             size_t image_bytes, void* scratch, size_t scratch_bytes, float* out_color, float* out_invdepth,
+                             void* stream) {
   g_err[0] = 0;
   if (P < 0 || H <= 0 || W <= 0 || R < 0 || !out_color || !bg || !image)
     return fail(EOGS_ERR_INVALID_ARG, "forward_render: bad argument");
@@ -280,8 +277,20 @@ int eogs_rast_forward_render(int P, int H, int W, int64_t R, const float* bg, un
     if ((size_t)(bb - (char*)binning) + b.bytes - 256 > binning_bytes)
       return fail(EOGS_ERR_WORKSPACE, "forward_render: binning workspace too small");
   }
-  { ProfScope ps(PS_BINNING, s); launch_binning(g, b, im, P, H, W, R, s); }
-  LAUNCH_TRY(s, debug, "binning");
+  SortWS sw = b.sort;
+  if (R > 0 && nr_sorted(R)) {  // forward_prepare sorted the entries in the caller's scratch: the same buffer, untouched since
+    if (!scratch) return fail(EOGS_ERR_INVALID_ARG, "forward_render: the scratch buffer handed to forward_prepare is required");
+    char* sb = ws_base(scratch);
+    sw = sort_layout(sb, ent_cap(P));
+    if ((size_t)(sb - (char*)scratch) + sw.bytes - 256 > scratch_bytes)
+      return fail(EOGS_ERR_WORKSPACE, "forward_render: scratch smaller than eogs_rast_scratch_bytes()");
+  } else if (R > 0 && nr_entries(R)) {
+    ProfScope ps(PS_BINNING, s);
+    launch_entry_sort(g, sw, P, H, W, s);
+  }
+  LAUNCH_TRY(s, debug, "entry_sort");
+  { ProfScope ps(PS_DEPTH_SORT, s); launch_block_lists(g, sw, b, im, P, H, W, R, s); }
+  LAUNCH_TRY(s, debug, "block_lists");
   { ProfScope ps(PS_RENDER_FWD, s); launch_render_fwd(g, b, im, P, H, W, R, bg, out_color, out_invdepth, s); }
   LAUNCH_TRY(s, debug, "render_fwd");
   return EOGS_OK;

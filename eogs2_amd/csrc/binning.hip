@@ -2,26 +2,32 @@
 //
 // Replaces InclusiveSum + duplicateWithKeys + cub::DeviceRadixSort::SortPairs(64-bit keys, 32+log2(T) bits) +
 // identifyTileRanges (DGR/cuda_rasterizer/rasterizer_impl.cu:70-138,280-320) with a pipeline that produces
-// the SAME list order — by tile, then depth bits ascending, then Gaussian index — while moving far fewer bytes:
+// the SAME list order — by tile, then depth bits ascending, then Gaussian index — without any global sort on depth:
 //
-//   1. depth sort of the P Gaussians: stable LSD radix on the 32 depth bits, payload = Gaussian id (8 B/item,
-//      4 passes over P items instead of 6 passes over R pairs of 12 B);
-//   2. expand in depth order: list position = exclusive scan of the per-Gaussian tile counts over the depth-sorted
-//      Gaussians (their 32-byte binning records are gathered once into depth order); a workgroup stages its pairs
-//      in LDS and writes (tile id, {Gaussian id, record slot}) with contiguous lanes.
-//      Lists are built per INTERNAL tile (SUBX x SUBY pixels = one wave64) and only for the internal tiles of the
-//      reference's 16-px tile rect in which the Gaussian can reach alpha >= 1/255 (exact hit mask computed
-//      in preprocess): a subset of the reference's candidates that contains every (pixel, Gaussian) pair
-//      the reference blends, so rendering results are unchanged;
-//   3. stable LSD radix on the tile id only (ceil(log2 T) bits, 1-2 passes, 12 B/pair): stability keeps the
-//      depth order inside every tile;
-//   4. tile ranges from the sorted tile ids.
-// A (tile, Gaussian) pair is unique, so (tile, depth bits, index) is a total order and the result is
-// bit-identical to the reference's stable 64-bit-key sort.
+//   1. expand in Gaussian-ID order: one 16-byte ENTRY per (32 x 32-pixel block, Gaussian) = {block id | 16-bit sub-mask
+//      of the block's 4 x 4 internal tiles that list the Gaussian, depth key, Gaussian id, first record slot}. The
+//      per-Gaussian binning records are read in id order (coalesced: no gather), positions come from the scan of the
+//      per-workgroup entry counts preprocess wrote;
+//   2. ONE stable LSD radix sort of the entries on the block id only (ceil(log2 #blocks) bits: 10 at 1024^2): inside a
+//      block the entries stay in Gaussian-id order;
+//   3. block ranges + pairs per block from the sorted keys;
+//   4. one workgroup per block orders ITS entries by depth key (stable LSD radix, 8-bit digits, only the digits in which the
+//      listed Gaussians' keys differ: 3 for EOGS scenes) — a block holds a few thousand entries, so this is local work on
+//      L2-resident data — and splits them into the block's 16 per-tile lists (ballot + prefix count per tile): the
+//      render kernels get one {Gaussian id, record slot} list per internal 8 x 8 tile, exactly as before.
+// Lists are built per INTERNAL tile (SUBX x SUBY pixels = one wave64) and only for the internal tiles of the reference's
+// 16-px tile rect in which the Gaussian can reach alpha >= 1/255 (exact hit mask computed in preprocess): a subset of the
+// reference's candidates that contains every (pixel, Gaussian) pair the reference blends, so results are unchanged.
+// A (tile, Gaussian) pair is unique, so (tile, depth bits, index) is a total order: stable block sort of id-ordered
+// entries + stable depth sort inside the block = the reference's stable 64-bit-key sort, bit for bit.
+// (Rounds 1-2 sorted the P Gaussians by depth globally, gathered their records into depth order and sorted the R pairs by
+// tile in two passes: 20 launches and 0.226 ms at 1 M Gaussians / 1024^2; tools/sort_yardstick.hip has rocPRIM's numbers
+// for the same jobs.)
+// With block lists (BLOCK_BIG, large footprints) step 4 only orders the entries; the render waves filter by sub-mask.
 //
-// The depth sort runs only as many 8-bit passes as the key range needs (EOGS depths share their top byte).
-// All kernels: 256-thread workgroups (4 wave64); radix ranking is wave-private (ballot match on the digit bits, no
-// workgroup barrier), keys are re-ordered through LDS so each digit run is written contiguously. HBM-bound integer work.
+// Also here: the generic u32-key / u32-payload radix sort (knn.hip's Morton order).
+// All radix passes: 256-thread workgroups (4 wave64); ranking is wave-private (ballot match on the digit bits, no
+// workgroup barrier), items are re-ordered through LDS so each digit run is written contiguously. HBM-bound integer work.
 #include "common.h"
 
 namespace {
@@ -34,13 +40,6 @@ __device__ inline uint32_t wave_incl_scan_u32(uint32_t v) {
     if (lane >= o) v += n;
   }
   return v;
-}
-
-// LDS produced and consumed by the same wave (in-order LDS pipeline): only the compiler must not reorder.
-__device__ inline void wave_lds_sync_b() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // Exclusive scan across the 256 threads of a workgroup; `total` = sum over the workgroup. s_w: 4 words of LDS.
@@ -56,110 +55,133 @@ __device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, uint32_t& 
   return pre + inc - v;
 }
 
+// the entry count of this forward as the device knows it (written by pblock_scan_kernel); 0 when it does not fit `cap`
+__device__ inline uint32_t entries_on_device(const uint32_t* __restrict__ misc, uint32_t cap) {
+  const uint32_t lo = misc[MISC_MACRO_LO], hi = misc[MISC_MACRO_HI];
+  return (hi == 0u && lo <= cap) ? lo : 0u;
+}
+
 }  // namespace
 
-// Single workgroup: exclusive scan of the per-workgroup pair counts (-> record slots in Gaussian-id order), their
-// 64-bit total (= num_rendered) and the key range, written to misc[] for the host readback.
+// ---- exclusive scans of the per-workgroup pair and entry counts (-> record slots in Gaussian-id order, entry
+//      positions in id order), their 64-bit totals, the key range and the number of depth digits: misc[] ----
+// Single workgroup; 16 workgroups' counts per thread per round.
+namespace {
+__device__ inline unsigned long long wg_excl_scan_u64(unsigned long long v, unsigned long long* s_w, unsigned long long& total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned long long inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long nb = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += nb;
+  }
+  if (lane == 63) s_w[w] = inc;
+  __syncthreads();
+  unsigned long long pre = 0ull;
+  total = 0ull;
+#pragma unroll
+  for (int k = 0; k < BLK / 64; k++) {
+    if (k < w) pre += s_w[k];
+    total += s_w[k];
+  }
+  __syncthreads();
+  return pre + inc - v;
+}
+}  // namespace
 
-__device__ inline void pblock_scan_body(uint32_t* __restrict__ pblock, const uint32_t* __restrict__ pbkey, uint32_t nblk,
-                                        uint32_t* __restrict__ misc) {
-  __shared__ uint32_t s_w[4];
+__global__ __launch_bounds__(BLK) void pblock_scan_kernel(uint32_t* __restrict__ pblock, uint32_t* __restrict__ pblockE,
+                                                          const uint32_t* __restrict__ pbkey, uint32_t nblk,
+                                                          uint32_t* __restrict__ misc) {
+  __shared__ unsigned long long s_w[BLK / 64];
   __shared__ uint32_t s_k[2][BLK / 64];
-  unsigned long long carry = 0ull, entries = 0ull, opw = 0ull;
+  unsigned long long carry_t = 0ull, carry_e = 0ull, opw = 0ull;
   uint32_t kmax = 0, knmin = 0, err = 0;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (uint32_t b0 = 0; b0 < nblk; b0 += BLK * 16) {
     const uint32_t i0 = b0 + threadIdx.x * 16;
-    uint32_t v[16], sum = 0;
+    uint32_t v[16], e[16];
+    unsigned long long sum_t = 0ull, sum_e = 0ull;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-      v[k] = 0;
+      v[k] = 0; e[k] = 0;
       if (i0 + k < nblk) {
         v[k] = pblock[i0 + k];
-        const uint32_t a = pbkey[4 * (i0 + k)], b = pbkey[4 * (i0 + k) + 1];
-        kmax = a > kmax ? a : kmax;
-        knmin = b > knmin ? b : knmin;
-        entries += pbkey[4 * (i0 + k) + 2];
-        const uint32_t ow = pbkey[4 * (i0 + k) + 3];  // bit 31: error flag of the workgroup
-        opw += ow & 0x7FFFFFFFu;
-        err |= ow >> 31;
+        const uint4 q = reinterpret_cast<const uint4*>(pbkey)[i0 + k];
+        kmax = q.x > kmax ? q.x : kmax;
+        knmin = q.y > knmin ? q.y : knmin;
+        e[k] = q.z;
+        opw += q.w & 0x7FFFFFFFu;  // bit 31: error flag of the workgroup
+        err |= q.w >> 31;
       }
-      sum += v[k];
+      sum_t += v[k];
+      sum_e += e[k];
     }
-    uint32_t inc = sum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t nb = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += nb;
-    }
-    if (lane == 63) s_w[w] = inc;
-    __syncthreads();
-    const uint32_t w0 = s_w[0], w1 = s_w[1], w2 = s_w[2], w3 = s_w[3];
-    const uint32_t pre = (w > 0 ? w0 : 0u) + (w > 1 ? w1 : 0u) + (w > 2 ? w2 : 0u);
-    __syncthreads();
-    uint32_t run = (uint32_t)carry + pre + inc - sum;  // slots are u32: the host rejects totals >= 2^31
+    unsigned long long tot_t, tot_e;
+    const unsigned long long ex_t = wg_excl_scan_u64(sum_t, s_w, tot_t);
+    const unsigned long long ex_e = wg_excl_scan_u64(sum_e, s_w, tot_e);
+    // (slots and entry positions are u32: the host rejects totals that do not fit)
+    uint32_t run_t = (uint32_t)(carry_t + ex_t), run_e = (uint32_t)(carry_e + ex_e);
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-      if (i0 + k < nblk) pblock[i0 + k] = run;
-      run += v[k];
+      if (i0 + k < nblk) { pblock[i0 + k] = run_t; pblockE[i0 + k] = run_e; }
+      run_t += v[k];
+      run_e += e[k];
     }
-    carry += (unsigned long long)w0 + w1 + w2 + w3;
+    carry_t += tot_t;
+    carry_e += tot_e;
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
     const uint32_t a = __shfl_xor(kmax, o, 64), b = __shfl_xor(knmin, o, 64);
     kmax = a > kmax ? a : kmax;
     knmin = b > knmin ? b : knmin;
-  }
-  // total list entries: every thread holds a partial sum
-  __shared__ unsigned long long s_e[BLK / 64], s_o[BLK / 64];
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    entries += __shfl_xor(entries, o, 64);
     opw += __shfl_xor(opw, o, 64);
     err |= __shfl_xor(err, o, 64);
   }
+  __shared__ unsigned long long s_o[BLK / 64];
   __shared__ uint32_t s_err[BLK / 64];
-  if (lane == 0) { s_k[0][w] = kmax; s_k[1][w] = knmin; s_e[w] = entries; s_o[w] = opw; s_err[w] = err; }
+  if (lane == 0) { s_k[0][w] = kmax; s_k[1][w] = knmin; s_o[w] = opw; s_err[w] = err; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t a = s_k[0][0], b = s_k[1][0];
-    unsigned long long e = s_e[0], ow = s_o[0];
-    uint32_t er = s_err[0];
+    uint32_t a = s_k[0][0], b = s_k[1][0], er = s_err[0];
+    unsigned long long ow = s_o[0];
     for (int i = 1; i < BLK / 64; i++) {
       a = s_k[0][i] > a ? s_k[0][i] : a;
       b = s_k[1][i] > b ? s_k[1][i] : b;
-      e += s_e[i];
       ow += s_o[i];
       er |= s_err[i];
     }
-    misc[MISC_ERR] = er;  // every readback word is written here: the workspace needs no clearing
+    misc[MISC_ERR] = er;  // every word the host or a later kernel reads is written here: the workspace needs no clearing
     misc[MISC_OPW_LO] = (uint32_t)ow;
     misc[MISC_OPW_HI] = (uint32_t)(ow >> 32);
-    misc[MISC_MACRO_LO] = (uint32_t)e;
-    misc[MISC_MACRO_HI] = (uint32_t)(e >> 32);
-    pblock[nblk] = (uint32_t)carry;
-    misc[MISC_TOTAL_LO] = (uint32_t)carry;
-    misc[MISC_TOTAL_HI] = (uint32_t)(carry >> 32);
+    misc[MISC_MACRO_LO] = (uint32_t)carry_e;
+    misc[MISC_MACRO_HI] = (uint32_t)(carry_e >> 32);
+    pblock[nblk] = (uint32_t)carry_t;
+    pblockE[nblk] = (uint32_t)carry_e;
+    misc[MISC_TOTAL_LO] = (uint32_t)carry_t;
+    misc[MISC_TOTAL_HI] = (uint32_t)(carry_t >> 32);
     misc[MISC_KEY_MAX] = a;
     misc[MISC_KEY_NMIN] = b;
+    // depth digits in which the listed Gaussians' keys can differ (EOGS altitudes span far less than a factor of two
+    // around 200 - altitude: the keys share sign, exponent and the top mantissa bits -> 3 digits, not 4)
+    const uint32_t diff = a ^ ~b;  // max ^ min
+    misc[MISC_DEPTH_PASSES] = a == 0u ? 0u : (diff == 0u ? 0u : (uint32_t)((32 - __builtin_clz(diff) + 7) / 8));
   }
 }
 
+void launch_pblock_scan(const GeomWS& g, int P, hipStream_t s) {
+  hipLaunchKernelGGL(pblock_scan_kernel, dim3(1), dim3(BLK), 0, s, g.pblock, g.pblockE, g.pbkey, ceil_div_u32((uint64_t)P, BLK),
+                     g.misc);
+}
+
+// =====================================================================================================================
+// Generic radix passes: u32 keys + u32 payload (knn.hip)
+// =====================================================================================================================
 
 // ---- radix pass, kernel 1: per-workgroup digit histogram, written digit-major hist[d][blk] ----
-// The first pass of the depth sort runs one extra workgroup (blockIdx.x == nblk, `pblock` non-NULL) that does the
-// single-workgroup scan of the preprocess pair counts beside the histogram workgroups: one launch less on the forward's
-// critical path (a dependent single-workgroup kernel costs ~7 us however little it does).
 template <int ITEMS>
 __global__ __launch_bounds__(BLK) void radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift,
-                                                         uint32_t mask, uint32_t* __restrict__ hist, uint32_t nblk,
-                                                         uint32_t* __restrict__ pblock, const uint32_t* __restrict__ pbkey,
-                                                         uint32_t npb, uint32_t* __restrict__ misc) {
-  if (blockIdx.x == nblk) {  // (only launched when pblock != NULL)
-    pblock_scan_body(pblock, pbkey, npb, misc);
-    return;
-  }
+                                                         uint32_t mask, uint32_t* __restrict__ hist, uint32_t nblk) {
   __shared__ uint32_t h[256];
   const int t = threadIdx.x;
   h[t] = 0;
@@ -192,26 +214,30 @@ __global__ __launch_bounds__(BLK) void radix_rowscan_kernel(uint32_t* __restrict
 }
 
 // ---- radix pass, kernel 3: stable scatter ----
-// Wave w of the workgroup owns the contiguous segment [base + w*64*ITEMS, base + (w+1)*64*ITEMS) and takes it 64 keys
-// at a time (lane order == key order), so ranking needs NO workgroup barrier: per chunk a wave-level match by ballot
+// Wave w of the workgroup owns the contiguous segment [base + w*64*ITEMS, base + (w+1)*64*ITEMS) and takes it 64 items
+// at a time (lane order == item order), so ranking needs NO workgroup barrier: per chunk a wave-level match by ballot
 // on the digit bits gives the rank among equal digits inside the chunk, a wave-private LDS counter row gives the
 // count of that digit in the wave's earlier chunks. One barrier later the workgroup knows, per digit, its start in the
-// workgroup's sorted order and each wave's offset inside the digit; keys and payloads are then placed in LDS in
+// workgroup's sorted order and each wave's offset inside the digit; items are then placed in LDS in
 // sorted order and streamed out so that consecutive lanes write consecutive addresses inside each digit run.
 // Stable: (wave segment, chunk, lane) order is index order.
-template <int ITEMS, typename VT>
-__global__ __launch_bounds__(BLK) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
-                                                            const VT* __restrict__ vals_in,
-                                                            uint32_t* __restrict__ keys_out,
-                                                            VT* __restrict__ vals_out, uint32_t n, int shift,
-                                                            int nbits, const uint32_t* __restrict__ hist,
-                                                            uint32_t nblk, const uint32_t* __restrict__ dtotal) {
+// ET: the item type moved; KEY(e) its sort key. n is either the argument or, with n_misc != NULL, this forward's entry
+// count as the device knows it (the launch then covers the capacity and most workgroups leave at once).
+struct KeyOfU32Pair {
+  __device__ static inline uint32_t key(const uint2& e) { return e.x; }
+};
+struct KeyOfEntry {
+  __device__ static inline uint32_t key(const uint4& e) { return e.x; }
+};
+template <int ITEMS, typename ET, typename KEY>
+__device__ inline void radix_scatter_body(const ET* __restrict__ in, ET* __restrict__ out, uint32_t n, int shift, int nbits,
+                                          const uint32_t* __restrict__ hist, uint32_t nblk,
+                                          const uint32_t* __restrict__ dtotal) {
   constexpr int NW = BLK / 64, SEG = 64 * ITEMS, TILE_KEYS = BLK * ITEMS;
-  __shared__ uint32_t s_gbase[256];     // global output position of this workgroup's first key of each digit
+  __shared__ uint32_t s_gbase[256];     // global output position of this workgroup's first item of each digit
   __shared__ uint32_t s_dstart[256];    // start of each digit in the workgroup's sorted order
   __shared__ uint32_t s_wcnt[NW][256];  // per-wave digit counts -> per-wave offset inside the digit
-  __shared__ uint32_t s_key[TILE_KEYS];
-  __shared__ VT s_val[TILE_KEYS];
+  __shared__ ET s_item[TILE_KEYS];
   __shared__ uint32_t s_w[4];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const uint32_t mask = (1u << nbits) - 1u;
@@ -221,18 +247,17 @@ __global__ __launch_bounds__(BLK) void radix_scatter_kernel(const uint32_t* __re
 
   const uint32_t base = blockIdx.x * (uint32_t)TILE_KEYS + (uint32_t)w * SEG;
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  uint32_t key[ITEMS], lrank[ITEMS];
-  VT val[ITEMS];
+  ET item[ITEMS];
+  uint32_t lrank[ITEMS];
 #pragma unroll
   for (int i = 0; i < ITEMS; i++) {
     const uint32_t k = base + i * 64 + lane;
-    key[i] = k < n ? keys_in[k] : 0xFFFFFFFFu;
-    if (k < n) val[i] = vals_in[k];
+    if (k < n) item[i] = in[k];
   }
 #pragma unroll
   for (int i = 0; i < ITEMS; i++) {
     const bool live = base + i * 64 + lane < n;
-    const uint32_t d = (key[i] >> shift) & mask;
+    const uint32_t d = live ? (KEY::key(item[i]) >> shift) & mask : mask;
     unsigned long long peers = __ballot(live);
     for (int b = 0; b < nbits; b++) {
       const unsigned long long m = __ballot((d >> b) & 1u);
@@ -266,6 +291,86 @@ __global__ __launch_bounds__(BLK) void radix_scatter_kernel(const uint32_t* __re
 #pragma unroll
   for (int i = 0; i < ITEMS; i++) {
     if (base + i * 64 + lane < n) {
+      const uint32_t d = (KEY::key(item[i]) >> shift) & mask;
+      s_item[s_dstart[d] + s_wcnt[w][d] + lrank[i]] = item[i];
+    }
+  }
+  __syncthreads();
+  const uint32_t tile0 = blockIdx.x * (uint32_t)TILE_KEYS;
+  const uint32_t nvalid = n - tile0 < (uint32_t)TILE_KEYS ? n - tile0 : (uint32_t)TILE_KEYS;
+  for (uint32_t idx = t; idx < nvalid; idx += BLK) {
+    const ET e = s_item[idx];
+    const uint32_t d = (KEY::key(e) >> shift) & mask;
+    out[s_gbase[d] + (idx - s_dstart[d])] = e;
+  }
+}
+
+// (the u32 + u32 sort keeps keys and payloads in separate arrays: it packs them for the LDS re-order only)
+template <int ITEMS>
+__global__ __launch_bounds__(BLK) void radix_scatter_u32_kernel(const uint32_t* __restrict__ keys_in,
+                                                                const uint32_t* __restrict__ vals_in,
+                                                                uint32_t* __restrict__ keys_out,
+                                                                uint32_t* __restrict__ vals_out, uint32_t n, int shift,
+                                                                int nbits, const uint32_t* __restrict__ hist, uint32_t nblk,
+                                                                const uint32_t* __restrict__ dtotal) {
+  constexpr int NW = BLK / 64, SEG = 64 * ITEMS, TILE_KEYS = BLK * ITEMS;
+  __shared__ uint32_t s_gbase[256];
+  __shared__ uint32_t s_dstart[256];
+  __shared__ uint32_t s_wcnt[NW][256];
+  __shared__ uint32_t s_key[TILE_KEYS];
+  __shared__ uint32_t s_val[TILE_KEYS];
+  __shared__ uint32_t s_w[4];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const uint32_t mask = (1u << nbits) - 1u;
+#pragma unroll
+  for (int k = 0; k < NW; k++) s_wcnt[k][t] = 0;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * (uint32_t)TILE_KEYS + (uint32_t)w * SEG;
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  uint32_t key[ITEMS], val[ITEMS], lrank[ITEMS];
+#pragma unroll
+  for (int i = 0; i < ITEMS; i++) {
+    const uint32_t k = base + i * 64 + lane;
+    key[i] = k < n ? keys_in[k] : 0xFFFFFFFFu;
+    val[i] = k < n ? vals_in[k] : 0u;
+  }
+#pragma unroll
+  for (int i = 0; i < ITEMS; i++) {
+    const bool live = base + i * 64 + lane < n;
+    const uint32_t d = (key[i] >> shift) & mask;
+    unsigned long long peers = __ballot(live);
+    for (int b = 0; b < nbits; b++) {
+      const unsigned long long m = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? m : ~m;
+    }
+    const uint32_t r = (uint32_t)__popcll(peers & lt_mask);
+    uint32_t before = 0;
+    if (live) before = s_wcnt[w][d];
+    __builtin_amdgcn_wave_barrier();
+    if (live && r == 0) s_wcnt[w][d] = before + (uint32_t)__popcll(peers);
+    __builtin_amdgcn_wave_barrier();
+    lrank[i] = before + r;
+  }
+  __syncthreads();
+  {
+    uint32_t c[NW], tot = 0;
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+      c[k] = s_wcnt[k][t];
+      s_wcnt[k][t] = tot;
+      tot += c[k];
+    }
+    uint32_t all;
+    const uint32_t ex = block_excl_scan(tot, s_w, all);
+    s_dstart[t] = ex;
+    const uint32_t gtot = (uint32_t)t <= mask ? dtotal[t] : 0u;
+    const uint32_t gex = block_excl_scan(gtot, s_w, all);
+    s_gbase[t] = (uint32_t)t <= mask ? gex + hist[(size_t)t * nblk + blockIdx.x] : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < ITEMS; i++) {
+    if (base + i * 64 + lane < n) {
       const uint32_t d = (key[i] >> shift) & mask;
       const uint32_t pos = s_dstart[d] + s_wcnt[w][d] + lrank[i];
       s_key[pos] = key[i];
@@ -284,313 +389,75 @@ __global__ __launch_bounds__(BLK) void radix_scatter_kernel(const uint32_t* __re
   }
 }
 
-template <int ITEMS>
-static void radix_hist(const uint32_t* kin, uint32_t n, int shift, int nbits, uint32_t* hist, uint32_t nblk, hipStream_t s) {
-  hipLaunchKernelGGL((radix_hist_kernel<ITEMS>), dim3(nblk), dim3(BLK), 0, s, kin, n, shift, (1u << nbits) - 1u, hist, nblk,
-                     (uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, (uint32_t*)nullptr);
-}
-
-template <int ITEMS, typename VT>
-static void radix_pass(const uint32_t* kin, const VT* vin, uint32_t* kout, VT* vout, uint32_t n, int shift,
-                       int nbits, uint32_t* hist, uint32_t nblk, uint32_t* dtotal, hipStream_t s, bool hist_done = false) {
-  const uint32_t mask = (1u << nbits) - 1u;
-  if (!hist_done) radix_hist<ITEMS>(kin, n, shift, nbits, hist, nblk, s);
-  hipLaunchKernelGGL(radix_rowscan_kernel, dim3(mask + 1), dim3(BLK), 0, s, hist, nblk, dtotal);
-  hipLaunchKernelGGL((radix_scatter_kernel<ITEMS, VT>), dim3(nblk), dim3(BLK), 0, s, kin, vin, kout, vout, n, shift, nbits,
-                     hist, nblk, dtotal);
-}
-
-// Depth sort: stable 8-bit passes over the depth bits, ping-ponging A -> B -> A ...; after an even number of passes
-// the ids in depth order are in svalA.
-void launch_depth_sort(const GeomWS& g, int P, int first, int last, hipStream_t s, bool first_hist_done) {
-  for (int pass = first; pass < last; pass++) {
-    const bool a2b = (pass & 1) == 0;
-    radix_pass<SORTP_ITEMS, uint32_t>(a2b ? g.skeyA : g.skeyB, a2b ? g.svalA : g.svalB, a2b ? g.skeyB : g.skeyA,
-                                      a2b ? g.svalB : g.svalA, (uint32_t)P, 8 * pass, 8, g.hist, g.nblkP, g.dtotal, s,
-                                      first_hist_done && pass == first);
-  }
-}
-
-// Histogram of the depth sort's pass 0 + (one extra workgroup) the scan of the preprocess pair counts, whose totals the
-// host reads back: forward_prepare records its readback event right after this launch.
-void launch_depth_sort_head(const GeomWS& g, int P, hipStream_t s) {
-  hipLaunchKernelGGL((radix_hist_kernel<SORTP_ITEMS>), dim3(g.nblkP + 1), dim3(BLK), 0, s, g.skeyA, (uint32_t)P, 0, 255u, g.hist,
-                     g.nblkP, g.pblock, g.pbkey, ceil_div_u32((uint64_t)P, BLK), g.misc);
-}
-
 void launch_sort_u32(uint32_t* keyA, uint32_t* valA, uint32_t* keyB, uint32_t* valB, uint32_t n, int passes, uint32_t* hist,
                      uint32_t nblk, uint32_t* dtotal, hipStream_t s) {
   for (int pass = 0; pass < passes; pass++) {
     const bool a2b = (pass & 1) == 0;
-    radix_pass<SORTP_ITEMS, uint32_t>(a2b ? keyA : keyB, a2b ? valA : valB, a2b ? keyB : keyA, a2b ? valB : valA, n,
-                                      8 * pass, 8, hist, nblk, dtotal, s);
+    const uint32_t* kin = a2b ? keyA : keyB;
+    const uint32_t* vin = a2b ? valA : valB;
+    uint32_t* kout = a2b ? keyB : keyA;
+    uint32_t* vout = a2b ? valB : valA;
+    hipLaunchKernelGGL((radix_hist_kernel<SORTP_ITEMS>), dim3(nblk), dim3(BLK), 0, s, kin, n, 8 * pass, 255u, hist, nblk);
+    hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(BLK), 0, s, hist, nblk, dtotal);
+    hipLaunchKernelGGL((radix_scatter_u32_kernel<SORTP_ITEMS>), dim3(nblk), dim3(BLK), 0, s, kin, vin, kout, vout, n, 8 * pass,
+                       8, hist, nblk, dtotal);
   }
 }
 
-// ---- exclusive scan of a small array in place (single workgroup, 16 elements per thread per round);
-//      data[n] receives the total ----
-__global__ __launch_bounds__(BLK) void small_scan_kernel(uint32_t* __restrict__ data, uint32_t n) {
-  __shared__ uint32_t s_w[4];
-  uint32_t carry = 0;
-  for (uint32_t b0 = 0; b0 < n; b0 += BLK * 16) {
-    const uint32_t i0 = b0 + threadIdx.x * 16;
-    uint32_t v[16], sum = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      v[k] = i0 + k < n ? data[i0 + k] : 0u;
-      sum += v[k];
-    }
-    uint32_t tot;
-    uint32_t run = carry + block_excl_scan(sum, s_w, tot);
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      if (i0 + k < n) data[i0 + k] = run;
-      run += v[k];
-    }
-    carry += tot;
-  }
-  if (threadIdx.x == 0) data[n] = carry;
-}
-void launch_small_scan(uint32_t* data, uint32_t n, hipStream_t s) {
-  hipLaunchKernelGGL(small_scan_kernel, dim3(1), dim3(BLK), 0, s, data, n);
-}
-
-// ---- expand step A: pair count of each chunk of 256 depth-sorted Gaussians ----
-__global__ __launch_bounds__(BLK) void expand_count_kernel(const uint32_t* __restrict__ sorted_ids,
-                                                           const uint4* __restrict__ binfo, uint32_t P, int big,
-                                                           uint4* __restrict__ sinfo, uint32_t* __restrict__ blocksum) {
-  __shared__ uint32_t s_w[4];
-  const uint32_t k = blockIdx.x * BLK + threadIdx.x;
-  uint32_t v = 0;
-  if (k < P) {
-    // the only per-Gaussian gather of the binning stage: one 32-byte record, re-written in depth order
-    const uint32_t id = sorted_ids[k];
-    const uint4 a = binfo[2 * (size_t)id], b = binfo[2 * (size_t)id + 1];
-    sinfo[2 * (size_t)k] = a;
-    sinfo[2 * (size_t)k + 1] = b;
-    v = b.x ? (big ? (b.w >> 2) : b.x) : 0u;  // list entries of this Gaussian at the chosen block size
-  }
-  uint32_t tot;
-  (void)block_excl_scan(v, s_w, tot);
-  if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
-}
+// =====================================================================================================================
+// List entries: expand (id order), block sort, block ranges
+// =====================================================================================================================
 
 #define EXPAND_LANE_MAX 256u  // a single lane walks at most this many list entries
-// ---- expand step C, block size 1: emission of (internal tile id, record slot) in depth order ----
-// One lane per depth-sorted Gaussian. Its listed tiles are, by kind (GeomWS::binfo): the set bits of the hit mask, the
-// per-row column spans (row_span, re-evaluated on the bits preprocess counted with), or the whole rect.
-// Output position = depth-order offset (exclusive scan of the counts); payload = {Gaussian id, record slot in
-// Gaussian-id order}, carried through the tile sort so the render kernels read both with one coalesced load.
-// Gaussians with at most EXPAND_LANE_MAX tiles are walked by their own lane into an LDS window (tile id + owner lane),
-// FINE_STAGE pairs per round, and streamed out with consecutive lanes writing consecutive addresses; larger ones
-// are emitted by the whole wave, one after the other, straight to their (reserved) global positions.
-#ifndef FINE_STAGE
-#define FINE_STAGE 3072     // pairs per LDS window (12 KB of tile ids + 6 KB of owner lanes: 7 workgroups per CU; 6144 held the
-#endif                      // kernel at 3 per CU: binning -4 us at 4 and at 8.7 listed tiles per Gaussian; 1024 costs rounds at 8.7)
-struct FineItem {
-  uint32_t id, c, pos0, rbase, sx0, sy0, sw, sh;
-  unsigned long long m;
-};
-__device__ inline uint32_t fine_tile_of(const FineItem& it, uint32_t bit_or_q, uint32_t gsx) {
-  const uint32_t row = bit_or_q / it.sw, col = bit_or_q - row * it.sw;
-  return (it.sy0 + row) * gsx + it.sx0 + col;
-}
-__global__ __launch_bounds__(BLK) void expand_fine_kernel(const uint4* __restrict__ sinfo, const float4* __restrict__ bext,
-                                                     const uint32_t* __restrict__ pblock,
-                                                     const uint32_t* __restrict__ blocksum, uint32_t P, uint32_t gsx,
-                                                     uint32_t gsy, uint32_t* __restrict__ tkey,
-                                                     uint2* __restrict__ tval, uint2* __restrict__ ranges) {
-  __shared__ uint32_t s_w[4];
-  // the tile ranges are rewritten after the sort (tile_ranges_kernel): clear them here
-  for (uint32_t i = blockIdx.x * BLK + threadIdx.x; i < gsx * gsy; i += gridDim.x * BLK) ranges[i] = make_uint2(0u, 0u);
-  __shared__ uint32_t s_tk[FINE_STAGE];   // staged tile ids
-  __shared__ uint16_t s_own[FINE_STAGE];  // ... and the lane that owns each staged pair
-  __shared__ uint32_t s_id[BLK], s_l0[BLK], s_gp[BLK], s_rb[BLK];
-  const int lane = threadIdx.x & 63;
-  const uint32_t k = blockIdx.x * BLK + threadIdx.x;
-  FineItem it;
-  it.id = 0; it.c = 0; it.m = 0ull; it.sx0 = it.sy0 = 0; it.sw = 1; it.sh = 0; it.rbase = 0;
-  float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0;  // SpanParams of a BK_SPANS Gaussian
-  uint32_t kind = BK_RECT;
-  uint4 ia = make_uint4(0u, 0u, 0u, 0u), ib = ia;
-  if (k < P) {
-    ia = sinfo[2 * (size_t)k];
-    ib = sinfo[2 * (size_t)k + 1];
-    it.c = ib.x;
-    it.id = ib.z;
-  }
-  uint32_t tot;
-  it.pos0 = blocksum[blockIdx.x] + block_excl_scan(it.c, s_w, tot);
-  if (it.c) {
-    it.m = ((unsigned long long)ia.w << 32) | ia.z;
-    it.sx0 = ia.x & 0xFFFFu; it.sy0 = ia.y & 0xFFFFu;
-    it.sw = (ia.x >> 16) - it.sx0;  // internal-tile rect, already clipped (preprocess_fwd_kernel)
-    it.sh = (ia.y >> 16) - it.sy0;
-    it.rbase = pblock[it.id / BLK] + ib.y;  // pblock is 4 bytes per 256 Gaussians: cache resident
-    kind = ib.w & 3u;  // (the upper bits hold the entry count at block size BLOCK_BIG)
-    if (kind == BK_SPANS) {
-      e0 = bext[2 * (size_t)it.id];
-      e1 = bext[2 * (size_t)it.id + 1];
-    }
-  }
-  SpanParams sp;
-  sp.gx = e0.x; sp.gy = e0.y; sp.ex = e0.z; sp.ey = e0.w; sp.boa = e1.x; sp.boc = e1.y; sp.ta = e1.z; sp.da = e1.w;
-
-  // ---- lane-walked Gaussians: compact local positions among themselves, staged in rounds of FINE_STAGE ----
-  const bool mine = it.c != 0u && it.c <= EXPAND_LANE_MAX;
-  uint32_t ltot;
-  const uint32_t l0 = block_excl_scan(mine ? it.c : 0u, s_w, ltot);
-  s_id[threadIdx.x] = it.id; s_l0[threadIdx.x] = l0; s_gp[threadIdx.x] = it.pos0; s_rb[threadIdx.x] = it.rbase;
-  // per-lane cursor, carried across rounds so that every pair is generated exactly once
-  uint32_t l = l0;                     // local position of the lane's next pair
-  const uint32_t l_end = mine ? l0 + it.c : l0;
-  unsigned long long m_rem = it.m;     // BK_MASK: bits still to emit
-  uint32_t row = 0, q_cur = 0;         // BK_SPANS: current row / BK_RECT: next index
-  int c_cur = 0, c_end = 0;            // BK_SPANS: remaining columns of the current row
-  for (uint32_t base = 0; base < ltot; base += FINE_STAGE) {
-    __syncthreads();  // s_id.. visible (first round) / previous window drained
-    const uint32_t wend = base + FINE_STAGE < l_end ? base + FINE_STAGE : l_end;  // this lane stops here this round
-    if (l < wend) {  // (l >= base always: windows are consecutive and the lane stopped at the previous window's end)
-      if (kind == BK_MASK) {
-        for (; l < wend; l++, m_rem &= m_rem - 1ull) {
-          s_tk[l - base] = fine_tile_of(it, (uint32_t)__builtin_ctzll(m_rem), gsx);
-          s_own[l - base] = (uint16_t)threadIdx.x;
-        }
-      } else if (kind == BK_SPANS) {
-        while (l < wend) {
-          if (c_cur >= c_end) {  // next non-empty row
-            row_span(sp, (int)(it.sy0 + row), (int)it.sx0, (int)(it.sx0 + it.sw), c_cur, c_end);
-            row++;
-            if (row > it.sh) break;  // never: the spans add up to it.c
-            continue;
-          }
-          s_tk[l - base] = (it.sy0 + row - 1) * gsx + (uint32_t)c_cur;
-          s_own[l - base] = (uint16_t)threadIdx.x;
-          c_cur++;
-          l++;
-        }
-      } else {
-        for (; l < wend; l++, q_cur++) {
-          s_tk[l - base] = fine_tile_of(it, q_cur, gsx);
-          s_own[l - base] = (uint16_t)threadIdx.x;
-        }
-      }
-    }
-    __syncthreads();
-    const uint32_t nwin = ltot - base < (uint32_t)FINE_STAGE ? ltot - base : (uint32_t)FINE_STAGE;
-    for (uint32_t i = threadIdx.x; i < nwin; i += BLK) {
-      const uint32_t o = s_own[i], q = base + i - s_l0[o];  // q-th listed tile of its Gaussian
-      tkey[s_gp[o] + q] = s_tk[i];
-      tval[s_gp[o] + q] = make_uint2(s_id[o], s_rb[o] + q);
-    }
-  }
-
-  // ---- large Gaussians: the wave emits them cooperatively, one after the other ----
-  __syncthreads();  // the last window is drained: s_tk becomes four wave-private staging areas
-  uint32_t* wstage = s_tk + (threadIdx.x >> 6) * (FINE_STAGE / 4);
-  unsigned long long big = __ballot(it.c > EXPAND_LANE_MAX);
-  while (big) {
-    const int src = __builtin_ctzll(big);
-    big &= big - 1ull;
-    FineItem g;
-    g.id = __shfl(it.id, src, 64); g.c = __shfl(it.c, src, 64); g.pos0 = __shfl(it.pos0, src, 64);
-    g.rbase = __shfl(it.rbase, src, 64); g.sx0 = __shfl(it.sx0, src, 64); g.sy0 = __shfl(it.sy0, src, 64);
-    g.sw = __shfl(it.sw, src, 64); g.sh = __shfl(it.sh, src, 64);
-    if (__shfl(kind, src, 64) != BK_SPANS) {  // whole rect (a mask never has more than 64 tiles)
-      for (uint32_t q = lane; q < g.c; q += 64) {
-        tkey[g.pos0 + q] = fine_tile_of(g, q, gsx);
-        tval[g.pos0 + q] = make_uint2(g.id, g.rbase + q);
-      }
-      continue;
-    }
-    // BK_SPANS: lane = row of the rect (64 rows per step); a wave scan of the span lengths gives every row its place
-    SpanParams gs;
-    gs.gx = __shfl(sp.gx, src, 64); gs.gy = __shfl(sp.gy, src, 64); gs.ex = __shfl(sp.ex, src, 64);
-    gs.ey = __shfl(sp.ey, src, 64); gs.boa = __shfl(sp.boa, src, 64); gs.boc = __shfl(sp.boc, src, 64);
-    gs.ta = __shfl(sp.ta, src, 64); gs.da = __shfl(sp.da, src, 64);
-    uint32_t done = 0;  // pairs of this Gaussian emitted so far
-    for (uint32_t r0 = 0; r0 < g.sh; r0 += 64) {
-      const uint32_t row = r0 + (uint32_t)lane;
-      int c0 = 0, c1 = 0;
-      if (row < g.sh) row_span(gs, (int)(g.sy0 + row), (int)g.sx0, (int)(g.sx0 + g.sw), c0, c1);
-      const uint32_t len = (uint32_t)(c1 - c0);
-      const uint32_t inc = wave_incl_scan_u32(len);
-      const uint32_t chunk = __shfl(inc, 63, 64), off = inc - len;
-      const uint32_t t0 = (g.sy0 + row) * gsx + (uint32_t)c0;
-      if (chunk <= (uint32_t)(FINE_STAGE / 4)) {
-        // through wave-private LDS so that consecutive lanes write consecutive addresses
-        for (uint32_t j = 0; j < len; j++) wstage[off + j] = t0 + j;
-        wave_lds_sync_b();
-        for (uint32_t i = lane; i < chunk && done + i < g.c; i += 64) {
-          tkey[g.pos0 + done + i] = wstage[i];
-          tval[g.pos0 + done + i] = make_uint2(g.id, g.rbase + done + i);
-        }
-        wave_lds_sync_b();
-      } else {
-        for (uint32_t j = 0; j < len && done + off + j < g.c; j++) {
-          tkey[g.pos0 + done + off + j] = t0 + j;
-          tval[g.pos0 + done + off + j] = make_uint2(g.id, g.rbase + done + off + j);
-        }
-      }
-      done += chunk;
-    }
-    // never taken (the spans are a pure function of the stored bits); keeps every slot a valid tile id regardless
-    for (uint32_t i = done + lane; i < g.c; i += 64) {
-      tkey[g.pos0 + i] = g.sy0 * gsx + g.sx0;
-      tval[g.pos0 + i] = make_uint2(g.id, g.rbase + i);
-    }
-  }
-}
-
-// ---- expand step C: emission of the list entries in depth order ----
-// One lane per depth-sorted Gaussian. An entry = (macro block, Gaussian): key = block id | sub-mask << 16 (which internal
-// tiles of the block list the Gaussian), payload = {Gaussian id, record slot of the entry's first listed internal tile}
-// (the q-th set bit of the sub-mask owns slot + q; slots run through a Gaussian's entries in emission order and are
-// Gaussian-id ordered across Gaussians, see GeomWS::pblock). The blocks come from walk_macro_row (common.h), the same
-// code preprocess counted with. Output position = depth-order offset (exclusive scan of the entry counts).
-// Gaussians with at most EXPAND_LANE_MAX entries are walked by their own lane into an LDS window and streamed out with
-// consecutive lanes writing consecutive addresses; larger ones are emitted by the whole wave, one macro row per lane.
 #define EXPAND_STAGE 4096     // entries per LDS window (16 KB keys + 16 KB slots + 8 KB owner lanes; 2048 / 1024 measured: no better)
 struct ExpandItem {
-  uint32_t id, c, pos0, rbase, sx0, sy0, sx1, sy1, kind;
+  uint32_t id, c, pos0, rbase, sx0, sy0, sx1, sy1, kind, depth;
   unsigned long long m;
 };
+// One lane per Gaussian, in id order: workgroup b = preprocess workgroup b, so the per-workgroup prefixes pblock / pblockE
+// apply as they are and every input is read coalesced. An entry = (macro block, Gaussian): key = block id | sub-mask << 16
+// (which internal tiles of the block list the Gaussian), then the Gaussian's depth key, its id and the record slot of the
+// entry's first listed internal tile (the q-th set bit of the sub-mask owns slot + q; slots run through a Gaussian's
+// entries in emission order and are Gaussian-id ordered across Gaussians, see GeomWS::pblock). The blocks come from
+// walk_macro_row (common.h), the same code preprocess counted with.
+// Gaussians with at most EXPAND_LANE_MAX entries are walked by their own lane into an LDS window and streamed out with
+// consecutive lanes writing consecutive addresses; larger ones are emitted by the whole wave, one macro row per lane.
 template <int MACRO>
-__global__ __launch_bounds__(BLK) void expand_kernel(const uint4* __restrict__ sinfo, const float4* __restrict__ bext,
-                                                     const uint32_t* __restrict__ pblock,
-                                                     const uint32_t* __restrict__ blocksum, uint32_t P, uint32_t gmx,
-                                                     uint32_t nblocks, uint32_t* __restrict__ tkey,
-                                                     uint2* __restrict__ tval, uint2* __restrict__ ranges) {
+__global__ __launch_bounds__(BLK) void expand_entries_kernel(const uint4* __restrict__ binfo, const float4* __restrict__ bext,
+                                                             const uint32_t* __restrict__ pblock,
+                                                             const uint32_t* __restrict__ pblockE,
+                                                             const uint32_t* __restrict__ misc, uint32_t cap, uint32_t P,
+                                                             uint32_t gmx, uint32_t nblocks, uint4* __restrict__ ent) {
+  (void)nblocks;
+  if (entries_on_device(misc, cap) == 0u) return;  // nothing listed, or more entries than this buffer holds
   __shared__ uint32_t s_w[4];
-  // the block ranges are rewritten after the sort (tile_ranges_kernel): clear them here
-  for (uint32_t i = blockIdx.x * BLK + threadIdx.x; i < nblocks; i += gridDim.x * BLK) ranges[i] = make_uint2(0u, 0u);
   __shared__ uint32_t s_tk[EXPAND_STAGE];   // staged keys
   __shared__ uint32_t s_sl[EXPAND_STAGE];   // ... record slots
   __shared__ uint16_t s_own[EXPAND_STAGE];  // ... and the lane that owns each staged entry
-  __shared__ uint32_t s_id[BLK], s_l0[BLK], s_gp[BLK];
+  __shared__ uint32_t s_dk[BLK], s_l0[BLK], s_gp[BLK];
   const int lane = threadIdx.x & 63;
   const uint32_t k = blockIdx.x * BLK + threadIdx.x;
   ExpandItem it;
-  it.id = 0; it.c = 0; it.m = 0ull; it.sx0 = it.sy0 = it.sx1 = it.sy1 = 0; it.rbase = 0; it.kind = BK_RECT;
+  it.id = k; it.c = 0; it.m = 0ull; it.sx0 = it.sy0 = it.sx1 = it.sy1 = 0; it.rbase = 0; it.kind = BK_RECT; it.depth = 0;
   float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0;  // SpanParams of a BK_SPANS Gaussian
   uint4 ia = make_uint4(0u, 0u, 0u, 0u), ib = ia;
   if (k < P) {
-    ia = sinfo[2 * (size_t)k];
-    ib = sinfo[2 * (size_t)k + 1];
-    it.c = ib.x ? (MACRO > 1 ? (ib.w >> 2) : ib.x) : 0u;
-    it.id = ib.z;
+    ia = binfo[2 * (size_t)k];
+    ib = binfo[2 * (size_t)k + 1];
+    it.c = ib.x ? (ib.w >> 2) : 0u;
   }
   uint32_t tot;
-  it.pos0 = blocksum[blockIdx.x] + block_excl_scan(it.c, s_w, tot);
+  it.pos0 = pblockE[blockIdx.x] + block_excl_scan(it.c, s_w, tot);
   if (it.c) {
     it.m = ((unsigned long long)ia.w << 32) | ia.z;
     it.sx0 = ia.x & 0xFFFFu; it.sy0 = ia.y & 0xFFFFu;  // internal-tile rect, already clipped (preprocess_fwd_kernel)
     it.sx1 = ia.x >> 16; it.sy1 = ia.y >> 16;
-    it.rbase = pblock[it.id / BLK] + ib.y;  // pblock is 4 bytes per 256 Gaussians: cache resident
+    it.rbase = pblock[blockIdx.x] + ib.y;
+    it.depth = ib.z;
     it.kind = ib.w & 3u;
     if (it.kind == BK_SPANS) {
-      e0 = bext[2 * (size_t)it.id];
-      e1 = bext[2 * (size_t)it.id + 1];
+      e0 = bext[2 * (size_t)k];
+      e1 = bext[2 * (size_t)k + 1];
     }
   }
   SpanParams sp;
@@ -600,16 +467,16 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint4* __restrict__ s
   const bool mine = it.c != 0u && it.c <= EXPAND_LANE_MAX;
   uint32_t ltot;
   const uint32_t l0 = block_excl_scan(mine ? it.c : 0u, s_w, ltot);
-  s_id[threadIdx.x] = it.id; s_l0[threadIdx.x] = l0; s_gp[threadIdx.x] = it.pos0;
+  s_dk[threadIdx.x] = it.depth; s_l0[threadIdx.x] = l0; s_gp[threadIdx.x] = it.pos0;
   for (uint32_t base = 0; base < ltot; base += EXPAND_STAGE) {
-    __syncthreads();  // s_id.. visible (first round) / previous window drained
+    __syncthreads();  // s_dk.. visible (first round) / previous window drained
     if (mine && l0 < base + EXPAND_STAGE && l0 + it.c > base) {
       uint32_t l = l0, slot = it.rbase;
       for (int MY = (int)it.sy0 / MACRO; MY <= ((int)it.sy1 - 1) / MACRO; MY++)  // MACRO: template parameter
         walk_macro_row<MACRO>(it.kind, it.m, sp, (int)it.sx0, (int)it.sy0, (int)it.sx1, (int)it.sy1, MY, [&](int MX, uint32_t sub) {
           const uint32_t w = l - base;  // wraps below the window: fails the unsigned test
           if (w < (uint32_t)EXPAND_STAGE) {
-            s_tk[w] = ((uint32_t)MY * gmx + (uint32_t)MX) | (MACRO > 1 ? sub << MACRO_KEY_BITS : 0u);
+            s_tk[w] = ((uint32_t)MY * gmx + (uint32_t)MX) | (sub << MACRO_KEY_BITS);
             s_sl[w] = slot;
             s_own[w] = (uint16_t)threadIdx.x;
           }
@@ -621,8 +488,7 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint4* __restrict__ s
     const uint32_t nwin = ltot - base < (uint32_t)EXPAND_STAGE ? ltot - base : (uint32_t)EXPAND_STAGE;
     for (uint32_t i = threadIdx.x; i < nwin; i += BLK) {
       const uint32_t o = s_own[i], q = base + i - s_l0[o];  // q-th entry of its Gaussian
-      tkey[s_gp[o] + q] = s_tk[i];
-      tval[s_gp[o] + q] = make_uint2(s_id[o], s_sl[i]);
+      ent[s_gp[o] + q] = make_uint4(s_tk[i], s_dk[o], blockIdx.x * BLK + o, s_sl[i]);
     }
   }
 
@@ -635,6 +501,7 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint4* __restrict__ s
     g.id = __shfl(it.id, src, 64); g.c = __shfl(it.c, src, 64); g.pos0 = __shfl(it.pos0, src, 64);
     g.rbase = __shfl(it.rbase, src, 64); g.sx0 = __shfl(it.sx0, src, 64); g.sy0 = __shfl(it.sy0, src, 64);
     g.sx1 = __shfl(it.sx1, src, 64); g.sy1 = __shfl(it.sy1, src, 64); g.kind = __shfl(it.kind, src, 64);
+    g.depth = __shfl(it.depth, src, 64);
     const uint32_t mlo = __shfl((uint32_t)it.m, src, 64), mhi = __shfl((uint32_t)(it.m >> 32), src, 64);
     g.m = ((unsigned long long)mhi << 32) | mlo;
     SpanParams gs;
@@ -655,10 +522,8 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint4* __restrict__ s
       uint32_t l = done + ie - ne, slot = slot0 + jf - nf;
       if (MY <= MY1)
         walk_macro_row<MACRO>(g.kind, g.m, gs, (int)g.sx0, (int)g.sy0, (int)g.sx1, (int)g.sy1, MY, [&](int MX, uint32_t sub) {
-          if (l < g.c) {  // always (same walk as the count)
-            tkey[g.pos0 + l] = ((uint32_t)MY * gmx + (uint32_t)MX) | (MACRO > 1 ? sub << MACRO_KEY_BITS : 0u);
-            tval[g.pos0 + l] = make_uint2(g.id, slot);
-          }
+          if (l < g.c)  // always (same walk as the count)
+            ent[g.pos0 + l] = make_uint4(((uint32_t)MY * gmx + (uint32_t)MX) | (sub << MACRO_KEY_BITS), g.depth, g.id, slot);
           l++;
           slot += (uint32_t)__popc(sub);
         });
@@ -668,80 +533,632 @@ __global__ __launch_bounds__(BLK) void expand_kernel(const uint4* __restrict__ s
   }
 }
 
-// ---- block ranges from the sorted keys (identifyTileRanges, rasterizer_impl.cu:116-138) ----
-// With per-tile lists (one record slot per entry) it also clears the backward's per-record live flags.
-// Four consecutive keys per thread (one 16-byte load, one 4-byte store of cleared flags).
-__global__ __launch_bounds__(BLK) void tile_ranges_kernel(const uint32_t* __restrict__ skeys, uint32_t R, uint32_t kmask,
-                                                          uint2* __restrict__ ranges, uint8_t* __restrict__ live) {
-  const uint32_t i0 = (blockIdx.x * BLK + threadIdx.x) * 4u;
-  if (i0 >= R) return;
-  uint32_t k[4];
-  if (i0 + 4u <= R) {
-    const uint4 v = *reinterpret_cast<const uint4*>(skeys + i0);
-    k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w;
-    if (live) *reinterpret_cast<uint32_t*>(live + i0) = 0u;
+// ---- block sort: ONE stable counting pass on the whole block id when it has at most ES_MAXBITS bits (2048 blocks:
+//      every image up to 1024 x 2048 pixels), otherwise two passes of half the bits each. 8192 entries per workgroup
+//      (1024 threads x 8): the histogram tables stay small although the launch covers the buffer's capacity, and a
+//      workgroup's entries of one block form runs of several 16-byte entries in the output. ----
+#define ES_T 1024
+#define ES_ITEMS 8
+#define ES_TILE (ES_T * ES_ITEMS)
+#define ES_NW (ES_T / 64)
+#define ES_MAXBITS 11
+static_assert(ES_TILE == SORTE_TILE, "sort_layout sizes the histogram tables for this tile");
+
+// kernel 1: per-workgroup histogram of the digit, one ROW per workgroup (hist[blk][digit]: written and later read back as
+// one contiguous piece); with `histp` also the listed (internal tile, Gaussian) pairs per digit (single-pass sort: digit =
+// block, so the column sums are the blocks' entry and pair counts and nobody has to find the block boundaries in the
+// sorted array afterwards). Workgroups past the live entries leave at once; nobody reads their rows.
+__global__ __launch_bounds__(ES_T) void entry_hist_kernel(const uint4* __restrict__ ent, const uint32_t* __restrict__ misc,
+                                                          uint32_t cap, int shift, uint32_t mask, uint32_t* __restrict__ hist,
+                                                          uint32_t* __restrict__ histp) {
+  const uint32_t n = entries_on_device(misc, cap);
+  const int t = threadIdx.x;
+  const uint32_t base = blockIdx.x * (uint32_t)ES_TILE, nb = mask + 1u;
+  if (base >= n) return;  // (a launch covers the buffer's capacity)
+  __shared__ uint32_t h[1 << ES_MAXBITS], hp[1 << ES_MAXBITS];
+  for (uint32_t d = t; d < nb; d += ES_T) { h[d] = 0; hp[d] = 0; }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < ES_ITEMS; i++) {
+    const uint32_t k = base + i * ES_T + t;
+    if (k < n) {
+      const uint32_t key = ent[k].x, d = (key >> shift) & mask;
+      atomicAdd(&h[d], 1u);
+      if (histp) atomicAdd(&hp[d], (uint32_t)__popc(key >> MACRO_KEY_BITS));
+    }
+  }
+  __syncthreads();
+  for (uint32_t d = t; d < nb; d += ES_T) {
+    hist[(size_t)blockIdx.x * nb + d] = h[d];
+    if (histp) histp[(size_t)blockIdx.x * nb + d] = hp[d];
+  }
+}
+
+// kernel 2: per digit, exclusive scan of its column over the live workgroups + the column totals. One workgroup takes 64
+// digits (lane = digit: every access is a coalesced 256-byte piece of a row); its 16 waves each take a slab of rows.
+__global__ __launch_bounds__(ES_T) void entry_colscan_kernel(uint32_t* __restrict__ hist, const uint32_t* __restrict__ histp,
+                                                             const uint32_t* __restrict__ misc, uint32_t cap, uint32_t nb,
+                                                             uint32_t* __restrict__ dtotal, uint32_t* __restrict__ ptotal) {
+  const uint32_t n = entries_on_device(misc, cap);
+  const uint32_t nlive = (n + ES_TILE - 1u) / ES_TILE;  // rows that were written
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t d = blockIdx.x * 64u + (uint32_t)lane;
+  __shared__ uint32_t s_part[ES_NW][64], s_pp[ES_NW][64];
+  const uint32_t slab = (nlive + ES_NW - 1u) / ES_NW;
+  const uint32_t r0 = (uint32_t)w * slab, r1 = r0 + slab < nlive ? r0 + slab : nlive;
+  uint32_t sum = 0, psum = 0;
+  if (d < nb)
+    for (uint32_t r = r0; r < r1; r++) {
+      sum += hist[(size_t)r * nb + d];
+      if (histp) psum += histp[(size_t)r * nb + d];
+    }
+  s_part[w][lane] = sum;
+  s_pp[w][lane] = psum;
+  __syncthreads();
+  uint32_t run = 0, tot = 0, ptot = 0;
+#pragma unroll
+  for (int k = 0; k < ES_NW; k++) {
+    const uint32_t c = s_part[k][lane];
+    if (k < w) run += c;
+    tot += c;
+    ptot += s_pp[k][lane];
+  }
+  if (d < nb) {
+    for (uint32_t r = r0; r < r1; r++) {
+      const uint32_t c = hist[(size_t)r * nb + d];
+      hist[(size_t)r * nb + d] = run;
+      run += c;
+    }
+    if (w == 0) {
+      dtotal[d] = tot;
+      if (histp) ptotal[d] = ptot;
+    }
+  }
+}
+
+// kernel 3: stable scatter. Ranking as in radix_scatter_body (wave-private ballot match, nbits ballots per 64 entries);
+// the entries go from registers straight to their places (no LDS re-order: with a thousand digits a workgroup's runs are
+// a few entries long either way). 16-bit wave counters: a wave holds 512 entries.
+__global__ __launch_bounds__(ES_T) void entry_scatter_kernel(const uint4* __restrict__ in, uint4* __restrict__ out,
+                                                             const uint32_t* __restrict__ misc, uint32_t cap, int shift,
+                                                             int nbits, const uint32_t* __restrict__ hist,
+                                                             const uint32_t* __restrict__ dtotal) {
+  const uint32_t n = entries_on_device(misc, cap);
+  const uint32_t tile0 = blockIdx.x * (uint32_t)ES_TILE;
+  if (tile0 >= n) return;
+  __shared__ uint16_t s_wcnt[ES_NW][1 << ES_MAXBITS];  // per-wave digit counts -> per-wave offset inside the digit
+  __shared__ uint32_t s_gbase[1 << ES_MAXBITS];        // global output position of this workgroup's first entry of each digit
+  __shared__ uint32_t s_w[ES_NW];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const uint32_t mask = (1u << nbits) - 1u, nb = mask + 1u;
+  for (uint32_t d = 2u * t; d < nb; d += 2u * ES_T)
+#pragma unroll
+    for (int k = 0; k < ES_NW; k++) *reinterpret_cast<uint32_t*>(&s_wcnt[k][d]) = 0u;
+  __syncthreads();
+  const uint32_t base = tile0 + (uint32_t)w * (64 * ES_ITEMS);
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  uint4 item[ES_ITEMS];
+  uint32_t lrank[ES_ITEMS];
+#pragma unroll
+  for (int i = 0; i < ES_ITEMS; i++) {
+    const uint32_t k = base + i * 64 + lane;
+    item[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (k < n) item[i] = in[k];
+  }
+#pragma unroll
+  for (int i = 0; i < ES_ITEMS; i++) {
+    lrank[i] = 0;
+    if (base + i * 64 >= n) continue;  // (wave-uniform)
+    const bool live = base + i * 64 + lane < n;
+    const uint32_t d = (item[i].x >> shift) & mask;
+    unsigned long long peers = __ballot(live);
+    for (int b = 0; b < nbits; b++) {
+      const unsigned long long m = __ballot((d >> b) & 1u);
+      peers &= ((d >> b) & 1u) ? m : ~m;
+    }
+    const uint32_t r = (uint32_t)__popcll(peers & lt_mask);
+    uint32_t before = 0;
+    if (live) before = s_wcnt[w][d];  // this wave's earlier groups (LDS ops of one wave execute in order)
+    __builtin_amdgcn_wave_barrier();
+    if (live && r == 0) s_wcnt[w][d] = (uint16_t)(before + (uint32_t)__popcll(peers));  // one leader per digit
+    __builtin_amdgcn_wave_barrier();
+    lrank[i] = before + r;
+  }
+  __syncthreads();
+  // per digit: offsets of the waves inside the workgroup's run; exclusive scan of the digit totals over the digits
+  // (digits are dealt to threads as d = t, then t + 1024: nb <= 2048)
+  uint32_t carry = 0;
+  for (uint32_t d0 = 0; d0 < nb; d0 += ES_T) {
+    const uint32_t d = d0 + t;
+    const uint32_t v = d < nb ? dtotal[d] : 0u;
+    const uint32_t inc = wave_incl_scan_u32(v);
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    uint32_t pre = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < ES_NW; k++) {
+      if (k < w) pre += s_w[k];
+      tot += s_w[k];
+    }
+    if (d < nb) {
+      uint32_t run = 0;
+#pragma unroll
+      for (int k = 0; k < ES_NW; k++) {
+        const uint32_t c = s_wcnt[k][d];
+        s_wcnt[k][d] = (uint16_t)run;
+        run += c;
+      }
+      s_gbase[d] = carry + pre + inc - v + hist[(size_t)blockIdx.x * nb + d];
+    }
+    carry += tot;
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < ES_ITEMS; i++) {
+    if (base + i * 64 + lane < n) {
+      const uint32_t d = (item[i].x >> shift) & mask;
+      out[s_gbase[d] + s_wcnt[w][d] + lrank[i]] = item[i];
+    }
+  }
+}
+
+// ---- two-pass sort only: block ranges (identifyTileRanges, rasterizer_impl.cu:116-138, at block granularity) and the
+//      number of listed (internal tile, Gaussian) pairs per block, from the block-sorted entries. One wave takes 64
+//      consecutive entries: equal block ids are adjacent, so a wave adds its pair count with one atomic per block it meets
+//      (integer adds: order-independent). (A second word per 256 blocks, added to by every wave, was tried first: all waves
+//      of the launch then queue on four addresses, 314 us.) Written as per-block COUNTS, like the single-pass sort's totals. ----
+__global__ __launch_bounds__(BLK) void block_counts_kernel(const uint4* __restrict__ ent, const uint32_t* __restrict__ misc,
+                                                           uint32_t cap, uint32_t* __restrict__ dtotal,
+                                                           uint32_t* __restrict__ ptotal) {
+  const uint32_t n = entries_on_device(misc, cap);
+  const uint32_t i = blockIdx.x * BLK + threadIdx.x;
+  if ((blockIdx.x * BLK) >= n) return;
+  const bool livel = i < n;
+  const uint32_t key = livel ? ent[i].x : 0u;
+  const uint32_t blk = key & ((1u << MACRO_KEY_BITS) - 1u);
+  const uint32_t pc = livel ? (uint32_t)__popc(key >> MACRO_KEY_BITS) : 0u;  // 1..16 listed internal tiles
+  unsigned long long rem = __ballot(livel);
+  while (rem) {
+    const int first = __builtin_ctzll(rem);
+    const uint32_t b0 = __shfl(blk, first, 64);
+    const unsigned long long m = __ballot(livel && blk == b0) & rem;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int bit = 0; bit < 5; bit++) sum += (uint32_t)__popcll(__ballot((pc >> bit) & 1u) & m) << bit;
+    if ((threadIdx.x & 63) == first) {
+      atomicAdd(&dtotal[b0], (uint32_t)__popcll(m));
+      atomicAdd(&ptotal[b0], sum);
+    }
+    rem &= ~m;
+  }
+}
+__global__ __launch_bounds__(BLK) void clear_counts_kernel(uint32_t* __restrict__ a, uint32_t* __restrict__ b, uint32_t n) {
+  const uint32_t i = blockIdx.x * BLK + threadIdx.x;
+  if (i < n) { a[i] = 0u; b[i] = 0u; }
+}
+
+void launch_entry_sort(const GeomWS& g, const SortWS& w, int P, int H, int W, hipStream_t s) {
+  const uint32_t gmx = macro_grid_x(W, BLOCK_BIG), nblocks = gmx * macro_grid_y(H, BLOCK_BIG);
+  hipLaunchKernelGGL(expand_entries_kernel<BLOCK_BIG>, dim3(g.nblkE), dim3(BLK), 0, s, g.binfo, g.bext, g.pblock, g.pblockE,
+                     g.misc, w.cap, (uint32_t)P, gmx, nblocks, w.entA);
+  int passes, bits;
+  block_sort_geometry(H, W, passes, bits);
+  const uint4* in = w.entA;
+  uint4* out = w.entB;
+  for (int pass = 0; pass < passes; pass++) {
+    const int shift = pass * bits;
+    const uint32_t mask = (1u << bits) - 1u;
+    uint32_t* histp = passes == 1 ? w.histp : nullptr;
+    hipLaunchKernelGGL(entry_hist_kernel, dim3(w.nblk), dim3(ES_T), 0, s, in, g.misc, w.cap, shift, mask, w.hist, histp);
+    hipLaunchKernelGGL(entry_colscan_kernel, dim3((mask + 64u) / 64u), dim3(ES_T), 0, s, w.hist, histp, g.misc, w.cap, mask + 1u,
+                       passes == 1 ? g.bcount : w.dtotal, g.bpairs);
+    hipLaunchKernelGGL(entry_scatter_kernel, dim3(w.nblk), dim3(ES_T), 0, s, in, out, g.misc, w.cap, shift, bits, w.hist,
+                       passes == 1 ? g.bcount : w.dtotal);
+    const uint4* t = in; in = out; out = const_cast<uint4*>(t);
+  }
+  if (passes > 1) {
+    hipLaunchKernelGGL(clear_counts_kernel, dim3(ceil_div_u32(nblocks, BLK)), dim3(BLK), 0, s, g.bcount, g.bpairs, nblocks);
+    hipLaunchKernelGGL(block_counts_kernel, dim3(ceil_div_u32(w.cap, BLK)), dim3(BLK), 0, s, in, g.misc, w.cap, g.bcount, g.bpairs);
+  }
+}
+
+// =====================================================================================================================
+// Per block: depth order + split into the internal tiles' lists
+// =====================================================================================================================
+#define BL_T 1024                  // threads per workgroup (16 wave64)
+#define BL_ITEMS 4
+#define BL_CH (BL_T * BL_ITEMS)    // entries per chunk of a pass = longest list the LDS path takes
+#define BL_NW (BL_T / 64)
+
+namespace {
+__device__ inline uint32_t bl_sum(uint32_t v, uint32_t* s_red) {  // sum over the workgroup (all threads call)
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  uint32_t tot = 0;
+#pragma unroll
+  for (int k = 0; k < BL_NW; k++) tot += s_red[k];
+  return tot;
+}
+// rank of a lane's digit among the equal digits of its 64-entry group (lane order) and the group's count of that digit
+__device__ inline uint32_t bl_match8(uint32_t d, bool livel, unsigned long long lt_mask, uint32_t& count) {
+  unsigned long long peers = __ballot(livel);
+#pragma unroll
+  for (int bit = 0; bit < 8; bit++) {
+    const unsigned long long m = __ballot((d >> bit) & 1u);
+    peers &= ((d >> bit) & 1u) ? m : ~m;
+  }
+  count = (uint32_t)__popcll(peers);
+  return (uint32_t)__popcll(peers & lt_mask);
+}
+}  // namespace
+
+// One workgroup per 32 x 32-pixel block. Its n entries sit in ent[s0, s0+n) in Gaussian-id order (s0, n and the pairs
+// listed before the block: sums of the per-block counts the sort produced). The kernel orders them by depth key with
+// `npass` stable LSD radix passes of 8 bits (wave-private ballot ranking as in radix_scatter_body) over {depth key, index}
+// pairs, then
+//   MODE 1: walks the ordered entries and appends, per internal tile of the block, {Gaussian id, record slot} for every
+//       entry whose sub-mask lists the tile (per tile: ballot + prefix count, running offsets across waves and chunks in
+//       LDS) at that tile's place in point_list — tile lists of a block are adjacent, blocks follow each other in block
+//       order — and writes the 16 tile ranges and clears the block's share of the backward's live flags;
+//   MODE BLOCK_BIG: writes the ordered entries' {key, {Gaussian id, first slot}} for the block-list render kernels.
+// Up to BL_CH entries (the usual case: a block holds a few thousand) the pairs live in registers and move through LDS
+// between passes, the sub-mask travelling in the index word's upper half. Longer lists stream chunk by chunk through the
+// scratch ping-pong buffer ki (the entry buffer the block sort left free: 16 bytes per entry = two 8-byte pairs) with
+// running digit bases in LDS, the next digit's histogram taken while scattering; a block's data stays in its CU's L2.
+// Any n is handled (a block with a million entries only takes long).
+// Compiled for two workgroups per CU (64 VGPRs): the launch is one workgroup per block, all resident at once at 1024^2.
+template <int MODE>
+__global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __restrict__ ent, uint2* ki,
+                                                              const uint32_t* __restrict__ bcount,
+                                                              const uint32_t* __restrict__ bpairs,
+                                                              const uint32_t* __restrict__ misc, uint32_t gmx, uint32_t gsx,
+                                                              uint32_t gsy, uint2* __restrict__ point_list,
+                                                              uint32_t* __restrict__ sorted_keys, uint2* __restrict__ ranges,
+                                                              uint8_t* __restrict__ live) {
+  __shared__ uint16_t s_wcnt[BL_NW][256];
+  __shared__ uint32_t s_base[256], s_cb[256], s_h[256], s_hn[256];
+  __shared__ uint32_t s_red[BL_NW];
+  __shared__ uint32_t s_tc[16], s_tb[16], s_cw[BL_NW][16];
+  __shared__ uint2 s_stage[BL_CH];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const uint32_t b = blockIdx.x;
+  const int npass = (int)misc[MISC_DEPTH_PASSES];
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+  // where this block's entries and pairs start: sums of the counts of the blocks before it (a few loads per thread at the
+  // usual 1024 ... 4096 blocks)
+  uint32_t s0, pairs_before = 0;
+  const uint32_t n = bcount[b];
+  {
+    uint32_t ve = 0, vp = 0;
+    for (uint32_t i = t; i < b; i += BL_T) {
+      ve += bcount[i];
+      if (MODE == 1) vp += bpairs[i];
+    }
+    s0 = bl_sum(ve, s_red);
+    if (MODE == 1) pairs_before = bl_sum(vp, s_red);
+  }
+  if (MODE != 1 && t == 0) ranges[b] = make_uint2(s0, s0 + n);
+  if (t < 256) s_h[t] = 0;
+  if (t < 16) s_tc[t] = 0;
+  __syncthreads();
+
+  const bool fast = n <= (uint32_t)BL_CH;
+  uint2* src = ki + 2 * (size_t)s0;
+  uint2* dst = src + n;
+  // A chunk's 64-entry groups are dealt to the waves as equal contiguous runs (`per` groups each: a short list keeps every
+  // wave busy instead of filling the first waves' groups).
+  const uint32_t per0 = (((n < (uint32_t)BL_CH ? n : (uint32_t)BL_CH) + 63u) / 64u + BL_NW - 1u) / BL_NW;
+  const uint32_t wb0 = (uint32_t)w * per0 * 64u;
+
+  if (fast) {
+    // ---- LDS path: {depth key, sub-mask << 16 | index} in registers ----
+    uint32_t dk[BL_ITEMS], px[BL_ITEMS];
+    {
+      uint32_t cnt[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) cnt[j] = 0;
+#pragma unroll
+      for (int i = 0; i < BL_ITEMS; i++) {
+        dk[i] = 0xFFFFFFFFu; px[i] = 0;
+        if ((uint32_t)i >= per0 || wb0 + i * 64 >= n) continue;  // (wave-uniform)
+        const uint32_t k = wb0 + i * 64 + lane;
+        uint32_t sub = 0;
+        if (k < n) {
+          const uint2 kd = *reinterpret_cast<const uint2*>(ent + s0 + k);  // {key, depth key}
+          sub = kd.x >> MACRO_KEY_BITS;
+          dk[i] = kd.y; px[i] = (sub << 16) | k;
+        }
+        if (MODE == 1) {
+#pragma unroll
+          for (int j = 0; j < 16; j++) cnt[j] += (uint32_t)__popcll(__ballot((sub >> j) & 1u));
+        }
+      }
+      if (MODE == 1) {
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+          if (lane == j && cnt[j]) atomicAdd(&s_tc[j], cnt[j]);
+      }
+    }
+    for (int p = 0; p < npass; p++) {
+      const int sh = 8 * p;
+      for (int k = t; k < BL_NW * 128; k += BL_T) reinterpret_cast<uint32_t*>(&s_wcnt[0][0])[k] = 0u;
+      __syncthreads();  // (the previous pass has read its pairs back from s_stage)
+      uint32_t lr[BL_ITEMS];
+#pragma unroll
+      for (int i = 0; i < BL_ITEMS; i++) {
+        lr[i] = 0;
+        if ((uint32_t)i >= per0 || wb0 + i * 64 >= n) continue;  // (wave-uniform)
+        const bool livel = wb0 + i * 64 + lane < n;
+        const uint32_t d = (dk[i] >> sh) & 255u;
+        uint32_t count;
+        const uint32_t r = bl_match8(d, livel, lt_mask, count);
+        uint32_t before = 0;
+        if (livel) before = s_wcnt[w][d];
+        __builtin_amdgcn_wave_barrier();
+        if (livel && r == 0) s_wcnt[w][d] = (uint16_t)(before + count);
+        __builtin_amdgcn_wave_barrier();
+        lr[i] = before + r;
+      }
+      __syncthreads();
+      {  // digit t (threads 256.. carry zeros): offsets of the waves inside the digit, exclusive scan of the digit totals
+        uint32_t tot = 0;
+        if (t < 256) {
+#pragma unroll
+          for (int k = 0; k < BL_NW; k++) {
+            const uint32_t c = s_wcnt[k][t];
+            s_wcnt[k][t] = (uint16_t)tot;
+            tot += c;
+          }
+        }
+        const uint32_t inc = wave_incl_scan_u32(tot);
+        if (lane == 63) s_red[w] = inc;
+        __syncthreads();
+        uint32_t pre = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (k < w) pre += s_red[k];
+        if (t < 256) s_cb[t] = pre + inc - tot;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < BL_ITEMS; i++) {
+        if ((uint32_t)i < per0 && wb0 + i * 64 + lane < n) {
+          const uint32_t d = (dk[i] >> sh) & 255u;
+          s_stage[s_cb[d] + s_wcnt[w][d] + lr[i]] = make_uint2(dk[i], px[i]);
+        }
+      }
+      __syncthreads();
+      if (p + 1 < npass) {
+#pragma unroll
+        for (int i = 0; i < BL_ITEMS; i++) {
+          if ((uint32_t)i < per0 && wb0 + i * 64 + lane < n) {
+            const uint2 e = s_stage[wb0 + i * 64 + lane];
+            dk[i] = e.x; px[i] = e.y;
+          }
+        }
+      }
+    }
+    if (npass == 0) {  // all keys equal: id order
+#pragma unroll
+      for (int i = 0; i < BL_ITEMS; i++)
+        if ((uint32_t)i < per0 && wb0 + i * 64 + lane < n) s_stage[wb0 + i * 64 + lane] = make_uint2(dk[i], px[i]);
+    }
   } else {
+    // ---- streaming path: {depth key, index} pairs in the global ping-pong buffer ----
+    {
+      uint32_t cnt[16];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      k[j] = i0 + j < R ? skeys[i0 + j] : 0u;
-      if (live && i0 + j < R) live[i0 + j] = 0;
+      for (int j = 0; j < 16; j++) cnt[j] = 0;
+      for (uint32_t i0 = 0; i0 < n; i0 += BL_T) {
+        const uint32_t i = i0 + t;
+        uint32_t sub = 0;
+        if (i < n) {
+          const uint2 kd = *reinterpret_cast<const uint2*>(ent + s0 + i);
+          src[i] = make_uint2(kd.y, i);
+          if (npass > 0) atomicAdd(&s_h[kd.y & 255u], 1u);
+          sub = kd.x >> MACRO_KEY_BITS;
+        }
+        if (MODE == 1) {
+#pragma unroll
+          for (int j = 0; j < 16; j++) cnt[j] += (uint32_t)__popcll(__ballot((sub >> j) & 1u));
+        }
+      }
+      if (MODE == 1) {
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+          if (lane == j && cnt[j]) atomicAdd(&s_tc[j], cnt[j]);
+      }
+    }
+    for (int p = 0; p < npass; p++) {
+      const int sh = 8 * p;
+      __syncthreads();  // s_h complete; the pairs written so far are visible to the whole workgroup
+      {
+        // exclusive scan of the 256 digit counts (threads 256.. carry zeros)
+        const uint32_t v = t < 256 ? s_h[t] : 0u;
+        const uint32_t inc = wave_incl_scan_u32(v);
+        if (lane == 63) s_red[w] = inc;
+        __syncthreads();
+        uint32_t pre = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (k < w) pre += s_red[k];
+        if (t < 256) { s_base[t] = pre + inc - v; s_hn[t] = 0; }
+      }
+      for (uint32_t c0 = 0; c0 < n; c0 += BL_CH) {
+        for (int k = t; k < BL_NW * 128; k += BL_T) reinterpret_cast<uint32_t*>(&s_wcnt[0][0])[k] = 0u;
+        __syncthreads();  // (also orders s_base / s_hn of the scan above and the previous chunk's last reads)
+        uint32_t sdk[BL_ITEMS], six[BL_ITEMS], lr[BL_ITEMS];
+        const uint32_t cend = n - c0 < (uint32_t)BL_CH ? n : c0 + (uint32_t)BL_CH;
+        const uint32_t per = ((cend - c0 + 63u) / 64u + BL_NW - 1u) / BL_NW;  // 1..BL_ITEMS
+        const uint32_t wb = c0 + (uint32_t)w * per * 64u;
+#pragma unroll
+        for (int i = 0; i < BL_ITEMS; i++) {
+          const uint32_t k = wb + i * 64 + lane;
+          uint2 e = make_uint2(0xFFFFFFFFu, 0u);
+          if ((uint32_t)i < per && k < cend) e = src[k];
+          sdk[i] = e.x; six[i] = e.y;
+        }
+#pragma unroll
+        for (int i = 0; i < BL_ITEMS; i++) {
+          lr[i] = 0;
+          if ((uint32_t)i >= per || wb + i * 64 >= cend) continue;  // (wave-uniform)
+          const bool livel = wb + i * 64 + lane < cend;
+          const uint32_t d = (sdk[i] >> sh) & 255u;
+          uint32_t count;
+          const uint32_t r = bl_match8(d, livel, lt_mask, count);
+          uint32_t before = 0;
+          if (livel) before = s_wcnt[w][d];
+          __builtin_amdgcn_wave_barrier();
+          if (livel && r == 0) s_wcnt[w][d] = (uint16_t)(before + count);
+          __builtin_amdgcn_wave_barrier();
+          lr[i] = before + r;
+        }
+        __syncthreads();
+        if (t < 256) {  // digit t: offsets of the waves inside the digit, the chunk's place in the digit's run
+          uint32_t tot = 0;
+#pragma unroll
+          for (int k = 0; k < BL_NW; k++) {
+            const uint32_t c = s_wcnt[k][t];
+            s_wcnt[k][t] = (uint16_t)tot;
+            tot += c;
+          }
+          const uint32_t cb = s_base[t];
+          s_cb[t] = cb;
+          s_base[t] = cb + tot;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < BL_ITEMS; i++) {
+          if ((uint32_t)i < per && wb + i * 64 + lane < cend) {
+            const uint32_t d = (sdk[i] >> sh) & 255u;
+            dst[s_cb[d] + s_wcnt[w][d] + lr[i]] = make_uint2(sdk[i], six[i]);
+            if (p + 1 < npass) atomicAdd(&s_hn[(sdk[i] >> (sh + 8)) & 255u], 1u);
+          }
+        }
+        __syncthreads();
+      }
+      if (t < 256) s_h[t] = s_hn[t];
+      uint2* tmp = src; src = dst; dst = tmp;
     }
   }
-  uint32_t prev = i0 ? skeys[i0 - 1] & kmask : 0u;
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const uint32_t i = i0 + j;
-    if (i >= R) break;
-    const uint32_t cur = k[j] & kmask;
-    if (i == 0) ranges[cur].x = 0;
-    else if (cur != prev) {
-      ranges[prev].y = i;
-      ranges[cur].x = i;
+  __syncthreads();  // the ordered pairs (s_stage / src) and s_tc are visible
+
+  if (MODE != 1) {
+    for (uint32_t i = t; i < n; i += BL_T) {
+      const uint32_t idx = fast ? (s_stage[i].y & 0xFFFFu) : src[i].y;
+      const uint4 e = ent[s0 + idx];
+      sorted_keys[s0 + i] = e.x;
+      point_list[s0 + i] = make_uint2(e.z, e.w);
     }
-    if (i == R - 1) ranges[cur].y = R;
-    prev = cur;
-  }
-}
-
-void launch_binning_head(const GeomWS& g, int P, int block, const uint32_t* sorted_ids, hipStream_t s) {
-  hipLaunchKernelGGL(expand_count_kernel, dim3(g.nblkE), dim3(BLK), 0, s, sorted_ids, g.binfo, (uint32_t)P, (int)(block > 1),
-                     g.sinfo, g.blocksum);
-  // (Folding this scan into the emission kernels was measured twice: through per-group atomic sums the 4096 atomicAdds on 64
-  // addresses cost expand_count 14 us; with every emission workgroup summing the counts before it by itself — no atomics,
-  // <= 16 coalesced loads per thread — binning did not change at 4 listed tiles per Gaussian and lost 4 us in block mode.)
-  launch_small_scan(g.blocksum, g.nblkE, s);
-}
-
-void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, hipStream_t s) {
-  const int M = b.block;
-  const uint32_t gmx = macro_grid_x(W, M), nblocks = gmx * macro_grid_y(H, M);
-  const uint32_t Re = nr_entries(R), Rs = nr_slots(R);
-  if (Re == 0) {
-    (void)hipMemsetAsync(im.ranges, 0, (size_t)nblocks * sizeof(uint2), s);
     return;
   }
-  // The backward's per-record live flags: which records get written depends only on forward state (lists and
-  // n_contrib), so one clear per forward serves every backward over this workspace.
-  if (M > 1) (void)hipMemsetAsync(b.live, 0, (size_t)Rs, s);  // (per-tile lists: cleared by tile_ranges_kernel)
-  if (M > 1)
-    hipLaunchKernelGGL(expand_kernel<BLOCK_BIG>, dim3(g.nblkE), dim3(BLK), 0, s, g.sinfo, g.bext, g.pblock, g.blocksum,
-                       (uint32_t)P, gmx, nblocks, b.tkeyA, b.tvalA, im.ranges);
-  else  // per-tile lists: the specialised walker (set bits / spans directly, cursors carried across LDS windows)
-    hipLaunchKernelGGL(expand_fine_kernel, dim3(g.nblkE), dim3(BLK), 0, s, g.sinfo, g.bext, g.pblock, g.blocksum,
-                       (uint32_t)P, gmx, macro_grid_y(H, 1), b.tkeyA, b.tvalA, im.ranges);
-  uint32_t *ka = b.tkeyA, *kb = b.tkeyB;
-  uint2 *va = b.tvalA, *vb = b.tvalB;
-  int shift = 0;
-  for (int pass = 0; pass < b.passes; pass++) {
-    const int nbits = (b.tile_bits - shift) < b.bits_per_pass ? (b.tile_bits - shift) : b.bits_per_pass;
-    if (b.sort_items == SORTR_ITEMS_BIG)
-      radix_pass<SORTR_ITEMS_BIG, uint2>(ka, va, kb, vb, Re, shift, nbits, b.hist, b.nblkR, b.dtotal, s);
-    else
-      radix_pass<SORTR_ITEMS, uint2>(ka, va, kb, vb, Re, shift, nbits, b.hist, b.nblkR, b.dtotal, s);
-    shift += nbits;
-    uint32_t* tk = ka; ka = kb; kb = tk;
-    uint2* tv = va; va = vb; vb = tv;
+
+  // ---- the internal tiles' lists ----
+  if (t < 16) {
+    uint32_t pre = pairs_before;
+    for (int j = 0; j < t; j++) pre += s_tc[j];
+    s_tb[t] = pre;
+    const uint32_t tx = (b % gmx) * BLOCK_BIG + (uint32_t)(t % BLOCK_BIG), ty = (b / gmx) * BLOCK_BIG + (uint32_t)(t / BLOCK_BIG);
+    if (tx < gsx && ty < gsy) ranges[ty * gsx + tx] = make_uint2(pre, pre + s_tc[t]);
   }
-  hipLaunchKernelGGL(tile_ranges_kernel, dim3(ceil_div_u32((uint64_t)Re, BLK * 4)), dim3(BLK), 0, s, b.sorted_keys, Re,
-                     M > 1 ? (1u << MACRO_KEY_BITS) - 1u : 0xFFFFFFFFu, im.ranges, M > 1 ? (uint8_t*)nullptr : b.live);
+  {
+    // live flags of this block's pairs: which records get written depends only on forward state (lists and n_contrib),
+    // so one clear per forward serves every backward over this workspace
+    uint32_t total = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) total += s_tc[j];
+    const uint32_t a = pairs_before, e = pairs_before + total;
+    const uint32_t a4 = (a + 3u) & ~3u, e4 = e & ~3u;
+    if (a4 <= e4) {
+      for (uint32_t i = a + t; i < a4; i += BL_T) live[i] = 0;
+      for (uint32_t i = a4 + 4u * t; i < e4; i += 4u * BL_T) *reinterpret_cast<uint32_t*>(live + i) = 0u;
+      for (uint32_t i = e4 + t; i < e; i += BL_T) live[i] = 0;
+    } else {
+      for (uint32_t i = a + t; i < e; i += BL_T) live[i] = 0;
+    }
+  }
+  __syncthreads();
+  for (uint32_t c0 = 0; c0 < n; c0 += BL_CH) {
+    const uint32_t cend = n - c0 < (uint32_t)BL_CH ? n : c0 + (uint32_t)BL_CH;
+    const uint32_t per = ((cend - c0 + 63u) / 64u + BL_NW - 1u) / BL_NW;
+    const uint32_t wb = c0 + (uint32_t)w * per * 64u;
+    // this wave's entries per tile, in list order
+    uint32_t cnt[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) cnt[j] = 0;
+#pragma unroll 1
+    for (uint32_t i = 0; i < per; i++) {
+      if (wb + i * 64 >= cend) break;  // (wave-uniform)
+      const uint32_t k = wb + i * 64 + lane;
+      uint32_t sub = 0;
+      if (k < cend) sub = fast ? (s_stage[k].y >> 16) : (ent[s0 + src[k].y].x >> MACRO_KEY_BITS);
+#pragma unroll
+      for (int j = 0; j < 16; j++) cnt[j] += (uint32_t)__popcll(__ballot((sub >> j) & 1u));
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+      if (lane == j) s_cw[w][j] = cnt[j];
+    __syncthreads();
+    if (t < 16) {  // tile t: where each wave's entries of this chunk go, then advance the tile's running position
+      uint32_t run = s_tb[t];
+#pragma unroll
+      for (int k = 0; k < BL_NW; k++) {
+        const uint32_t c = s_cw[k][t];
+        s_cw[k][t] = run;
+        run += c;
+      }
+      s_tb[t] = run;
+    }
+    __syncthreads();
+    uint32_t off[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) off[j] = s_cw[w][j];
+#pragma unroll 1
+    for (uint32_t i = 0; i < per; i++) {
+      if (wb + i * 64 >= cend) break;  // (wave-uniform)
+      const uint32_t k = wb + i * 64 + lane;
+      uint32_t sub = 0, id = 0, sl = 0;
+      if (k < cend) {
+        const uint4 e = ent[s0 + (fast ? (s_stage[k].y & 0xFFFFu) : src[k].y)];
+        sub = e.x >> MACRO_KEY_BITS; id = e.z; sl = e.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        const bool has = (sub >> j) & 1u;
+        const unsigned long long m = __ballot(has);
+        if (has)
+          point_list[off[j] + (uint32_t)__popcll(m & lt_mask)] =
+              make_uint2(id, sl + (uint32_t)__popc(sub & ((1u << j) - 1u)));
+        off[j] += (uint32_t)__popcll(m);
+      }
+    }
+    __syncthreads();  // s_cw is rewritten by the next chunk
+  }
+}
+
+void launch_block_lists(const GeomWS& g, const SortWS& w, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R,
+                        hipStream_t s) {
+  (void)P;
+  const int M = b.block;
+  const uint32_t gmx = macro_grid_x(W, BLOCK_BIG), nblocks = gmx * macro_grid_y(H, BLOCK_BIG);
+  const uint32_t gsx = macro_grid_x(W, 1), gsy = macro_grid_y(H, 1);
+  if (nr_entries(R) == 0) {
+    (void)hipMemsetAsync(im.ranges, 0, (size_t)(M > 1 ? nblocks : gsx * gsy) * sizeof(uint2), s);
+    return;
+  }
+  const bool inA = entry_sort_result_in_A(H, W);
+  const uint4* ent = inA ? w.entA : w.entB;
+  uint2* ki = reinterpret_cast<uint2*>(inA ? w.entB : w.entA);
+  if (M > 1) {
+    (void)hipMemsetAsync(b.live, 0, (size_t)nr_slots(R), s);
+    hipLaunchKernelGGL(block_lists_kernel<BLOCK_BIG>, dim3(nblocks), dim3(BL_T), 0, s, ent, ki, g.bcount, g.bpairs, g.misc, gmx,
+                       gsx, gsy, b.point_list, b.sorted_keys, im.ranges, b.live);
+  } else {
+    hipLaunchKernelGGL(block_lists_kernel<1>, dim3(nblocks), dim3(BL_T), 0, s, ent, ki, g.bcount, g.bpairs, g.misc, gmx, gsx,
+                       gsy, b.point_list, b.sorted_keys, im.ranges, b.live);
+  }
 }

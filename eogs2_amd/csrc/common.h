@@ -41,14 +41,15 @@ static_assert(REC == 12, "record quarters");
 #define MISC_OPW_LO 8    // sum over listed (tile, Gaussian) pairs of round(64 opacity) (u64, lo/hi): mean pair opacity
 #define MISC_OPW_HI 9
 #define MISC_READBACK 10 // words copied to the host by forward_prepare
+#define MISC_DEPTH_PASSES 10  // 8-bit digits that cover the varying bits of the listed Gaussians' depth keys (0..4)
 #define MISC_WORDS 64
 
 // ---- radix sort geometry ----
-#define SORTP_ITEMS 8    // depth sort of P Gaussians: 2048 keys per workgroup
-#define SORTR_ITEMS 8    // tile sort of R pairs: 2048 keys per workgroup (12-byte items: key + {id, slot}) ...
-#define SORTR_ITEMS_BIG 16      // ... 4096 above SORTR_BIG_PAIRS pairs: longer digit runs per workgroup, measured
-#define SORTR_BIG_PAIRS (16u << 20)  // -14 % binning time at 32 M pairs, +12 % at 4 M
-#define EXPAND_ITEMS 1   // expand: 256 depth-sorted Gaussians per workgroup
+#define SORTP_ITEMS 8    // generic u32 key + u32 payload sort (knn.hip's Morton order): 2048 keys per workgroup
+#define SORTE_TILE 8192  // block sort of the list entries (16-byte items): entries per workgroup (binning.hip ES_TILE)
+#define SORTE_MAXBINS 2048  // ... and the widest digit of one pass (ES_MAXBITS)
+#define EXPAND_ITEMS 1   // expand: 256 Gaussians (one preprocess workgroup) per workgroup
+#define MAX_BLOCKS (1u << 16)  // 32 x 32-pixel blocks per image (their id is the low half of an entry's sort key)
 
 // ---- which internal tiles a Gaussian is listed in (GeomWS::binfo) ----
 #define BK_RECT 0u
@@ -192,76 +193,96 @@ static inline size_t ws_carve(char* base, size_t off, T*& p, size_t count) {
 
 static inline uint32_t ceil_div_u32(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
-// Geometry workspace: everything that is O(P). SoA, every array 256-B aligned.
+// Geometry workspace: everything that is O(P) and read again by backward (plus the per-block bookkeeping of one
+// forward, a fixed 0.8 MB). SoA, every array 256-B aligned.
 struct GeomWS {
   float4* packed;       // 4 x float4 = one 64-byte line per Gaussian, everything the render kernels gather:
                         //   {gx, gy, A, B} {C, opacity, f0, f1} {f2, f3, f4, 1/depth} {pad}
                         //   with the conic pre-scaled by log2 e: A = -a log2e/2, B = b log2e, C = -c log2e/2
   uint4* binfo;         // 2 x uint4 = 32 bytes per Gaussian, everything binning needs, written once by preprocess:
                         //   [0] = {sx0 | sx1<<16, sy0 | sy1<<16 (internal-tile rect, clipped), mask lo, mask hi}
-                        //   [1] = {tiles (internal tiles listed, 0 = none), lpre, Gaussian id, kind}
+                        //   [1] = {tiles (internal tiles listed, 0 = none), lpre, depth key, kind | block entries << 2}
                         //   kind BK_MASK : mask bit (sy-sy0)*(sx1-sx0) + (sx-sx0) set <=> internal tile (sx,sy) can reach
                         //                  alpha >= 1/255 (rects of <= 64 internal tiles)
                         //   kind BK_SPANS: larger rects; the listed tiles of row sy are row_span(bext[id], sy) (below)
                         //   kind BK_RECT : every internal tile of the rect (NaN opacity only)
                         //   lpre = exclusive prefix of `tiles` inside the Gaussian's preprocess workgroup (256 Gaussians)
+                        //   depth key = bits of (float)(200 - altitude), the reference's sort key (forward.cu:267)
   float4* bext;         // 2 x float4 = 32 bytes per Gaussian, written for BK_SPANS only: SpanParams
-  uint4* sinfo;         // the same records in DEPTH order (gathered once by expand_count_kernel)
   uint32_t* pbkey;      // per preprocess workgroup: {max depth key, max ~key, list entries, sum of tiles * round(64 opacity)}
-  uint32_t* pblock;     // per preprocess workgroup: total, then (scan_pblock_kernel) exclusive prefix over workgroups.
+  uint32_t* pblock;     // per preprocess workgroup: listed tiles, then (pblock_scan_kernel) exclusive prefix over workgroups.
                         // record slot of (Gaussian i, its q-th tile) = pblock[i/256] + lpre[i] + q: records are laid out
                         // in Gaussian-id order, so gaussian_bwd streams them
-  uint32_t* skeyA;      // depth-sort ping-pong (keys = depth bits, vals = Gaussian id)
-  uint32_t* skeyB;
-  uint32_t* svalA;
-  uint32_t* svalB;
-  uint32_t* hist;       // radix histograms [256][nblkP]
-  uint32_t* dtotal;     // per-digit totals [256]
-  uint32_t* blocksum;   // expand: per-workgroup pair counts / offsets [nblkE + 1]
+  uint32_t* pblockE;    // the same prefix for the list entries (one per listed 32 x 32-px block): where a preprocess
+                        // workgroup's entries start in the id-ordered entry array
+  uint32_t* bcount;     // [MAX_BLOCKS] per 32 x 32-px block: list entries (their sum over the blocks before b = where
+                        // block b's entries start in the block-sorted entry array)
+  uint32_t* bpairs;     // [MAX_BLOCKS] per block: listed (internal tile, Gaussian) pairs
   uint32_t* misc;       // MISC_WORDS
   float* vmpart;        // backward: per-workgroup partials of the 18 camera-gradient sums [ceil(P/256)][18]
-  uint32_t nblkP, nblkE;
+  uint32_t nblkE;
   size_t bytes;
 };
 
 static inline GeomWS geom_layout(char* base, int P) {
   GeomWS g;
   size_t n = (size_t)P, o = 0;
-  g.nblkP = ceil_div_u32(n, BLK * SORTP_ITEMS);
   g.nblkE = ceil_div_u32(n, BLK * EXPAND_ITEMS);
   o = ws_carve(base, o, g.packed, n * 4);
   o = ws_carve(base, o, g.binfo, n * 2);
-  o = ws_carve(base, o, g.sinfo, n * 2);
   o = ws_carve(base, o, g.bext, n * 2);
-  o = ws_carve(base, o, g.pblock, (size_t)ceil_div_u32(n, BLK) + 1);
-  o = ws_carve(base, o, g.pbkey, (size_t)ceil_div_u32(n, BLK) * 4);
-  o = ws_carve(base, o, g.skeyA, n);
-  o = ws_carve(base, o, g.skeyB, n);
-  o = ws_carve(base, o, g.svalA, n);
-  o = ws_carve(base, o, g.svalB, n);
-  o = ws_carve(base, o, g.hist, (size_t)256 * g.nblkP);
-  o = ws_carve(base, o, g.dtotal, 256);
-  o = ws_carve(base, o, g.blocksum, (size_t)g.nblkE + 1);
+  o = ws_carve(base, o, g.pblock, (size_t)g.nblkE + 1);
+  o = ws_carve(base, o, g.pblockE, (size_t)g.nblkE + 1);
+  o = ws_carve(base, o, g.pbkey, (size_t)g.nblkE * 4);
+  o = ws_carve(base, o, g.bcount, (size_t)MAX_BLOCKS);
+  o = ws_carve(base, o, g.bpairs, (size_t)MAX_BLOCKS);
   o = ws_carve(base, o, g.misc, MISC_WORDS);
-  o = ws_carve(base, o, g.vmpart, (size_t)ceil_div_u32(n, BLK) * 18);
+  o = ws_carve(base, o, g.vmpart, (size_t)g.nblkE * 18);
   g.bytes = ws_align(o) + 256;  // slack so a base that is only 1-aligned still fits after rounding
   return g;
 }
 
-// Binning workspace: everything that is O(R) (R = number of (tile,Gaussian) pairs).
+// Entry-sort workspace: the list entries (one per (32 x 32-px block, Gaussian)) of ONE forward, ping-pong, plus the radix
+// histograms. An entry is 16 bytes {key = block id | sub-mask << 16, depth key, Gaussian id, first record slot}.
+// Transient: dead once the forward has built its lists, so it lives in the caller's scratch buffer (shared by every
+// forward on a stream) and not in a workspace autograd keeps. Its capacity is fixed before the entry count is known
+// (ent_cap: six entries per Gaussian); a forward with more entries sorts inside its binning workspace instead.
+struct SortWS {
+  uint4* entA;
+  uint4* entB;
+  uint32_t* hist;    // [bins][nblk] entries per digit and workgroup -> exclusive prefix over the workgroups
+  uint32_t* histp;   // [bins][nblk] listed pairs per digit and workgroup (single-pass sort)
+  uint32_t* dtotal;  // [bins] (two-pass sort; a single pass writes its totals to GeomWS::bcount)
+  uint32_t cap, nblk;
+  size_t bytes;
+};
+static inline uint32_t ent_cap(int P) {
+  const uint64_t c = 6ull * (uint64_t)(P < 0 ? 0 : P);
+  return c < 4096ull ? 4096u : (c > (1ull << 29) ? (1u << 29) : (uint32_t)c);
+}
+static inline SortWS sort_layout(char* base, uint32_t cap) {
+  SortWS w;
+  size_t o = 0;
+  w.cap = cap;
+  w.nblk = ceil_div_u32(cap, (uint64_t)SORTE_TILE);
+  o = ws_carve(base, o, w.entA, (size_t)cap);
+  o = ws_carve(base, o, w.entB, (size_t)cap);
+  o = ws_carve(base, o, w.hist, (size_t)SORTE_MAXBINS * (w.nblk ? w.nblk : 1));
+  o = ws_carve(base, o, w.histp, (size_t)SORTE_MAXBINS * (w.nblk ? w.nblk : 1));
+  o = ws_carve(base, o, w.dtotal, SORTE_MAXBINS);
+  w.bytes = ws_align(o) + 256;
+  return w;
+}
+
+// Binning workspace: everything that is O(R) (R = number of (tile,Gaussian) pairs) and read again by backward.
 struct BinWS {
-  uint32_t* tkeyA;  // sort keys {macro block id | sub-mask << 16}, ping-pong
-  uint32_t* tkeyB;
-  uint2* tvalA;     // payload {Gaussian id, record slot of the entry's first listed internal tile}, ping-pong
-  uint2* tvalB;
-  uint32_t* hist;   // [nbins][nblkR]
-  uint32_t* dtotal; // [256]
+  uint2* point_list;     // the sorted lists. block 1: per (internal tile, Gaussian) pair {Gaussian id, record slot};
+                         // BLOCK_BIG: per (block, Gaussian) entry {Gaussian id, record slot of its first listed tile}
+  uint32_t* sorted_keys; // BLOCK_BIG only: per entry {block id | sub-mask << 16}
   float* records;   // backward scratch: REC floats per record slot (Gaussian-id order, see GeomWS::pblock)
   uint8_t* live;    // backward scratch: 1 = the pair's record was written (dead pairs are never touched)
-  uint32_t nblkR;
-  int tile_bits, passes, bits_per_pass, sort_items, block;
-  uint2* point_list;     // = tval buffer holding the sorted result: per list entry {Gaussian id, record slot}
-  uint32_t* sorted_keys; // = tkey buffer holding the sorted result
+  SortWS sort;      // entry sort of a forward whose entries did not fit the caller's scratch (nr_sorted(R) == 0)
+  int block;
   size_t bytes;
 };
 
@@ -272,37 +293,42 @@ static inline int ceil_log2_u32(uint32_t n) {  // smallest b with (1<<b) >= n
 }
 
 // num_rendered as handed across the C-ABI packs what a forward decided: the record slots (one per listed internal tile,
-// backward scratch) in bits 0..30, the sorted list entries (one per listed block) in bits 32..61, the block size in
-// bit 62 (set: BLOCK_BIG, clear: 1; then entries == slots).
+// backward scratch) in bits 0..30, the list entries (one per listed 32 x 32-px block) in bits 32..60, bit 61 = the
+// entries were sorted in the caller's scratch by forward_prepare, bit 62 = the render kernels read block lists
+// (BLOCK_BIG) instead of per-tile lists.
 static inline uint32_t nr_slots(int64_t R) { return (uint32_t)((uint64_t)R & 0x7FFFFFFFull); }
-static inline uint32_t nr_entries(int64_t R) { return (uint32_t)(((uint64_t)R >> 32) & 0x3FFFFFFFull); }
+static inline uint32_t nr_entries(int64_t R) { return (uint32_t)(((uint64_t)R >> 32) & 0x1FFFFFFFull); }
+static inline int nr_sorted(int64_t R) { return (int)(((uint64_t)R >> 61) & 1ull); }
 static inline int nr_block(int64_t R) { return (((uint64_t)R >> 62) & 1ull) ? BLOCK_BIG : 1; }
-static inline int64_t nr_pack(uint32_t slots, uint32_t entries, int block) {
-  return (int64_t)(((uint64_t)(block > 1) << 62) | ((uint64_t)entries << 32) | slots);
+static inline int64_t nr_pack(uint32_t slots, uint32_t entries, int block, int sorted) {
+  return (int64_t)(((uint64_t)(block > 1) << 62) | ((uint64_t)(sorted != 0) << 61) | ((uint64_t)entries << 32) | slots);
 }
 static inline uint32_t macro_grid_x(int W, int M) { return (uint32_t)(((W + SUBX - 1) / SUBX + M - 1) / M); }
 static inline uint32_t macro_grid_y(int H, int M) { return (uint32_t)(((H + SUBY - 1) / SUBY + M - 1) / M); }
+// the entry sort orders by block id: `passes` stable radix passes of `bits` bits each
+static inline void block_sort_geometry(int H, int W, int& passes, int& bits) {
+  const uint32_t nb = macro_grid_x(W, BLOCK_BIG) * macro_grid_y(H, BLOCK_BIG);
+  const int tb = ceil_log2_u32(nb) < 1 ? 1 : ceil_log2_u32(nb);
+  passes = tb <= 11 ? 1 : 2;  // one counting pass up to 2048 blocks (SORTE_MAXBINS)
+  bits = (tb + passes - 1) / passes;
+}
 
 static inline BinWS bin_layout(char* base, int H, int W, int64_t R) {
+  (void)H; (void)W;
   BinWS b;
-  size_t n = (size_t)nr_entries(R), nslots = (size_t)nr_slots(R), o = 0;
+  const size_t ne = (size_t)nr_entries(R), nslots = (size_t)nr_slots(R);
+  size_t o = 0;
   b.block = nr_block(R);
-  uint32_t T = macro_grid_x(W, b.block) * macro_grid_y(H, b.block);
-  b.tile_bits = ceil_log2_u32(T) < 1 ? 1 : ceil_log2_u32(T);
-  b.passes = (b.tile_bits + 7) / 8;
-  b.bits_per_pass = (b.tile_bits + b.passes - 1) / b.passes;
-  b.sort_items = n > SORTR_BIG_PAIRS ? SORTR_ITEMS_BIG : SORTR_ITEMS;
-  b.nblkR = ceil_div_u32(n, (uint64_t)BLK * b.sort_items);
-  o = ws_carve(base, o, b.tkeyA, n);
-  o = ws_carve(base, o, b.tkeyB, n);
-  o = ws_carve(base, o, b.tvalA, n);
-  o = ws_carve(base, o, b.tvalB, n);
-  o = ws_carve(base, o, b.hist, (size_t)256 * (b.nblkR ? b.nblkR : 1));
-  o = ws_carve(base, o, b.dtotal, 256);
+  o = ws_carve(base, o, b.point_list, b.block > 1 ? ne : nslots);
+  o = ws_carve(base, o, b.sorted_keys, b.block > 1 ? ne : (size_t)0);
   o = ws_carve(base, o, b.records, nslots * REC);
   o = ws_carve(base, o, b.live, nslots);
-  b.point_list = (b.passes & 1) ? b.tvalB : b.tvalA;
-  b.sorted_keys = (b.passes & 1) ? b.tkeyB : b.tkeyA;
+  b.sort = sort_layout(nullptr, 0);
+  if (!nr_sorted(R) && ne) {
+    o = ws_align(o);
+    b.sort = sort_layout(base ? base + o : nullptr, (uint32_t)ne);
+    o += b.sort.bytes;
+  }
   b.bytes = ws_align(o) + 256;
   return b;
 }
@@ -341,15 +367,23 @@ struct FwdPrepArgs {
   const float* alt_affine;
 };
 void launch_preprocess_fwd(const FwdPrepArgs& a, const GeomWS& g, hipStream_t s);
-// passes [first, last) of the 4-pass depth sort (8 bits each); pass p reads buffer A if p is even, B if odd
-void launch_depth_sort(const GeomWS& g, int P, int first, int last, hipStream_t s, bool first_hist_done = false);
-// pass 0's histogram + the scan of the preprocess pair counts (totals for the host readback) in one launch
-void launch_depth_sort_head(const GeomWS& g, int P, hipStream_t s);
-void launch_small_scan(uint32_t* data, uint32_t n, hipStream_t s);
-// part of binning that needs only the geometry workspace (queued by forward_prepare right after its sync);
-// sorted_ids: the depth-ordered Gaussian ids (svalA or svalB, whichever the last depth-sort pass wrote)
-void launch_binning_head(const GeomWS& g, int P, int block, const uint32_t* sorted_ids, hipStream_t s);
-void launch_binning(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, hipStream_t s);
+// exclusive scans of the per-workgroup pair / entry counts + the totals and depth-key range the host reads back (misc)
+void launch_pblock_scan(const GeomWS& g, int P, hipStream_t s);
+// expand the list entries in Gaussian-id order, sort them by block id (stable), find every block's range and pair count.
+// Reads the entry count from g.misc on the device: does nothing when it exceeds w.cap (so it can be queued before the host
+// knows the count).
+void launch_entry_sort(const GeomWS& g, const SortWS& w, int P, int H, int W, hipStream_t s);
+// which of w.entA / w.entB holds the block-sorted entries after launch_entry_sort
+static inline bool entry_sort_result_in_A(int H, int W) {
+  int passes, bits;
+  block_sort_geometry(H, W, passes, bits);
+  return (passes & 1) == 0;
+}
+// per block: depth order (stable radix on the depth keys, misc[MISC_DEPTH_PASSES] 8-bit digits) and, with per-tile lists,
+// the split of the block's entries into its internal tiles' lists; writes b.point_list (+ b.sorted_keys), im.ranges, clears
+// b.live
+void launch_block_lists(const GeomWS& g, const SortWS& w, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R,
+                        hipStream_t s);
 void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R,
                        const float* bg, float* out_color, float* out_invdepth, hipStream_t s);
 void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, const float* colors,

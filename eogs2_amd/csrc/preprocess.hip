@@ -118,7 +118,7 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
     const float* __restrict__ vm, const float* __restrict__ alt, float scale_modifier, int antialiasing,
     int* __restrict__ radii, float4* __restrict__ packed, uint4* __restrict__ binfo, float4* __restrict__ bext,
     uint32_t* __restrict__ pblock,
-    uint32_t* __restrict__ pbkey, uint32_t* __restrict__ skey, uint32_t* __restrict__ sval, uint32_t* __restrict__ misc) {
+    uint32_t* __restrict__ pbkey) {
   __shared__ float s_m[3 * BLK];
   __shared__ float s_s[3 * BLK];
   __shared__ float s_c[RAW ? 3 * BLK : 1];
@@ -299,14 +299,11 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
           // internal-tile rect [sx0,sx1) x [sy0,sy1) (16 bits each) + hit mask relative to it (0 = every tile)
           bi0 = make_uint4((uint32_t)sx0 | ((uint32_t)sx1 << 16), (uint32_t)sy0 | ((uint32_t)sy1 << 16), (uint32_t)m,
                            (uint32_t)(m >> 32));
-          key_bits = __float_as_uint(d);
-          skey[idx] = key_bits;
+          key_bits = __float_as_uint(d);  // the reference's depth sort key (rasterizer_impl.cu:103-106)
         }
       }
     }
-    if (my_tiles == 0) skey[idx] = 0xFFFFFFFFu;  // Gaussians that reach no pixel sort last and emit nothing
     radii[idx] = radius;
-    sval[idx] = (uint32_t)idx;
   }
   // exclusive prefix of the tile counts inside the workgroup (record slots in Gaussian-id order) and the
   // workgroup total
@@ -324,7 +321,7 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
   const uint32_t pre = (w > 0 ? w0 : 0u) + (w > 1 ? w1 : 0u) + (w > 2 ? w2 : 0u);
   if (t < rows) {
     binfo[2 * idx] = bi0;
-    binfo[2 * idx + 1] = make_uint4(my_tiles, pre + inc - my_tiles, (uint32_t)idx, bkind | (my_entries << 2));
+    binfo[2 * idx + 1] = make_uint4(my_tiles, pre + inc - my_tiles, key_bits, bkind | (my_entries << 2));
   }
   // range of the depth keys of listed Gaussians (lets the host drop sort passes whose digit is constant) and the
   // workgroup's pair count: plain stores, reduced by pblock_scan_kernel (same-address atomics from 16k waves cost
@@ -366,7 +363,7 @@ void launch_preprocess_fwd(const FwdPrepArgs& a, const GeomWS& g, hipStream_t s)
   auto* kern = a.raw ? preprocess_fwd_kernel<true> : preprocess_fwd_kernel<false>;
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(BLK), 0, s, a.P, a.H, a.W, gx, gy, a.means3D, a.scales, a.rotations,
                      a.cov3D_precomp, a.opacities, a.colors, a.viewmatrix, a.alt_affine, a.scale_modifier,
-                     (int)a.antialiasing, a.radii, g.packed, g.binfo, g.bext, g.pblock, g.pbkey, g.skeyA, g.svalA, g.misc);
+                     (int)a.antialiasing, a.radii, g.packed, g.binfo, g.bext, g.pblock, g.pbkey);
 }
 
 

@@ -94,6 +94,25 @@ class _Ctx:
             self.guard.__exit__(*a)
 
 
+_scratch_lock = threading.Lock()
+_scratch = {}  # (device, stream) -> uint8 tensor
+
+
+def _scratch_for(abi, dev, stream_id, P, H, W):
+    """The transient entry-sort buffer of a forward (include/eogs_rast.h `scratch`): one per device and stream, grown on
+    demand, never saved for backward (work on a stream is ordered, so the next forward may overwrite it)."""
+    n = ctypes.c_size_t()
+    abi.check(abi.scratch_bytes(P, H, W, ctypes.byref(n)))
+    if n.value == 0:
+        return None
+    key = (dev, stream_id)
+    with _scratch_lock:
+        t = _scratch.get(key)
+        if t is None or t.numel() < n.value:
+            t = _scratch[key] = torch.empty((n.value + n.value // 4,), dtype=torch.uint8, device=dev)
+    return t
+
+
 def rasterize_gaussians(
     means3D,
     means2D,
@@ -175,12 +194,14 @@ def _run_forward(rs, viewmat, means3D, colors, opacities, scales, rotations, cov
             abi.check(abi.image_bytes(H, W, ctypes.byref(nbytes)))
             img = torch.empty((nbytes.value,), dtype=torch.uint8, device=dev)
 
+            scratch = _scratch_for(abi, dev, cx.stream.value if cx.stream is not None else 0, P, H, W)
+            n_scratch = 0 if scratch is None else scratch.numel()
             R = ctypes.c_int64()
             abi.check(
                 abi.forward_prepare(
                     P, H, W, _ptr(m3), _ptr(sc), _ptr(rot), _ptr(cov), _ptr(opa), _ptr(col),
                     float(rs.scale_modifier), _ptr(vm), _ptr(pm), _ptr(alt), flags,
-                    _ptr(radii), _ptr(geom), geom.numel(), ctypes.byref(R), cx.stream,
+                    _ptr(radii), _ptr(geom), geom.numel(), _ptr(scratch), n_scratch, ctypes.byref(R), cx.stream,
                 )
             )
             num_rendered = R.value
@@ -190,7 +211,7 @@ def _run_forward(rs, viewmat, means3D, colors, opacities, scales, rotations, cov
                 abi.forward_render(
                     P, H, W, num_rendered, _ptr(bg), flags,
                     _ptr(geom), geom.numel(), _ptr(binning), binning.numel(), _ptr(img), img.numel(),
-                    _ptr(color), _ptr(invdepths), cx.stream,
+                    _ptr(scratch), n_scratch, _ptr(color), _ptr(invdepths), cx.stream,
                 )
             )
     return num_rendered, color, radii, invdepths, geom, binning, img

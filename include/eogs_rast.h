@@ -22,6 +22,10 @@
  * the caller, sized by the *_bytes queries, written by forward and re-read by
  * backward (the reference's geomBuffer / binningBuffer / imgBuffer,
  * DGR/rasterize_points.cu:78-85).  The library never allocates device memory.
+ * A fourth buffer, `scratch`, is transient: it holds one forward's list entries while they are sorted
+ * (the role of the reference's list_sorting_space, DGR/cuda_rasterizer/rasterizer_impl.cu:186-192) and is
+ * dead when eogs_rast_forward_render returns, so one buffer serves every forward on a stream and autograd
+ * never keeps it.
  */
 #ifndef EOGS_RAST_H_INCLUDED
 #define EOGS_RAST_H_INCLUDED
@@ -33,7 +37,7 @@
 extern "C" {
 #endif
 
-#define EOGS_RAST_ABI_VERSION 4
+#define EOGS_RAST_ABI_VERSION 5
 #define EOGS_RAST_CHANNELS 5 /* DGR/cuda_rasterizer/config.h:15 NUM_CHANNELS */
 #define EOGS_RAST_TILE 16    /* DGR/cuda_rasterizer/config.h:16-17 BLOCK_X/BLOCK_Y */
 
@@ -76,6 +80,8 @@ const char* eogs_rast_backend(void);
 int eogs_rast_geom_bytes(int P, size_t* bytes);
 int eogs_rast_image_bytes(int H, int W, size_t* bytes);
 int eogs_rast_binning_bytes(int P, int H, int W, int64_t num_rendered, size_t* bytes);
+/* Size of the transient scratch buffer of forward_prepare / forward_render (about 192 bytes per Gaussian). */
+int eogs_rast_scratch_bytes(int P, int H, int W, size_t* bytes);
 
 /* Forward, phase 1: per-Gaussian preprocess + overlap count.
  * Replaces the first half of CudaRasterizer::Rasterizer::forward
@@ -86,14 +92,19 @@ int eogs_rast_binning_bytes(int P, int H, int W, int64_t num_rendered, size_t* b
  * required when P > 0 (EOGS_ERR_NO_COLORS otherwise, DGR/cuda_rasterizer/rasterizer_impl.cu:244-247): the
  * per-Gaussian render record is written once, whole, by the preprocess kernel.
  * alt_affine: f32[4], required with EOGS_FLAG_RAW_PARAMS, otherwise ignored (pass NULL).
+ * scratch: eogs_rast_scratch_bytes() bytes, or NULL. With it the list entries are expanded and sorted by this call,
+ *   behind the count readback, so the device stays busy while the host sizes the binning workspace; the SAME buffer,
+ *   untouched, must then be handed to forward_render. Without it (or when a forward has more entries than the buffer
+ *   holds: six per Gaussian) forward_render does that work inside a correspondingly larger binning workspace.
  * Writes radii[P] and *num_rendered (host). num_rendered is an opaque token for the three calls below (it packs this
- * library's pair counts and list granularity, see csrc/common.h nr_pack); 0 means nothing is listed. */
+ * library's pair counts, list granularity and where the entries were sorted, see csrc/common.h nr_pack); 0 means
+ * nothing is listed. */
 int eogs_rast_forward_prepare(
     int P, int H, int W,
     const float* means3D, const float* scales, const float* rotations,
     const float* cov3D_precomp, const float* opacities, const float* colors, float scale_modifier,
     const float* viewmatrix, const float* projmatrix, const float* alt_affine, unsigned flags,
-    int* radii, void* geom, size_t geom_bytes,
+    int* radii, void* geom, size_t geom_bytes, void* scratch, size_t scratch_bytes,
     int64_t* num_rendered, void* stream);
 
 /* Forward, phase 2: duplicate-with-keys, (tile,depth) sort, tile ranges, alpha blend.
@@ -104,7 +115,7 @@ int eogs_rast_forward_render(
     int P, int H, int W, int64_t num_rendered,
     const float* bg, unsigned flags,
     void* geom, size_t geom_bytes, void* binning, size_t binning_bytes,
-    void* image, size_t image_bytes,
+    void* image, size_t image_bytes, void* scratch, size_t scratch_bytes,
     float* out_color, float* out_invdepth, void* stream);
 
 /* Backward.

@@ -155,6 +155,13 @@ int eogs_rast_binning_bytes(int P, int H, int W, int64_t R, size_t* bytes) {
   *bytes = binning_layout(NULL, R, NULL);
   return EOGS_OK;
 }
+/* the oracle sorts inside its binning workspace like the reference: the transient scratch of the ABI is unused */
+int eogs_rast_scratch_bytes(int P, int H, int W, size_t* bytes) {
+  (void)H; (void)W;
+  if (P < 0 || !bytes) return fail(EOGS_ERR_INVALID_ARG, "scratch_bytes: bad argument");
+  *bytes = 0;
+  return EOGS_OK;
+}
 
 /* ---- small helpers ---- */
 
@@ -356,9 +363,9 @@ int eogs_rast_forward_render(
     int P, int H, int W, int64_t R,
     const float* bg, unsigned flags,
     void* geom, size_t geom_bytes, void* binning, size_t binning_bytes,
-    void* image, size_t image_bytes,
+    void* image, size_t image_bytes, void* scratch, size_t scratch_bytes,
     float* out_color, float* out_invdepth, void* stream) {
-  (void)flags; (void)stream;
+  (void)flags; (void)stream; (void)scratch; (void)scratch_bytes;
   g_err[0] = 0;
   if (P < 0 || H <= 0 || W <= 0 || R < 0 || !out_color || !bg || !image)
     return fail(EOGS_ERR_INVALID_ARG, "forward_render: bad argument");
@@ -774,8 +781,9 @@ int eogs_rast_forward_prepare(
     const float* means3D, const float* scales, const float* rotations,
     const float* cov3D_precomp, const float* opacities, const float* colors, float scale_modifier,
     const float* viewmatrix, const float* projmatrix, const float* alt_affine, unsigned flags,
-    int* radii, void* geom, size_t geom_bytes,
+    int* radii, void* geom, size_t geom_bytes, void* scratch, size_t scratch_bytes,
     int64_t* num_rendered, void* stream) {
+  (void)scratch; (void)scratch_bytes;
   if (!(flags & EOGS_FLAG_RAW_PARAMS) || P <= 0)
     return forward_prepare_activated(P, H, W, means3D, scales, rotations, cov3D_precomp, opacities, colors,
                                      scale_modifier, viewmatrix, projmatrix, flags, radii, geom, geom_bytes,

@@ -61,10 +61,10 @@ def stub_forward(bg, means3D, colors, opacity, scales, rotations, scale_modifier
         m, sc, ro, cv, op, vm, pm = map(_c, (means3D, scales, rotations, cov3D_precomp, opacity, viewmatrix, projmatrix))
         col, b = _c(colors), _c(bg)
         abi.check(abi.forward_prepare(P, H, W, _p(m), _p(sc), _p(ro), _p(cv), _p(op), _p(col), float(scale_modifier), _p(vm), _p(pm), None,
-                                      flags, _p(radii), _p(geom), geom.numel(), ctypes.byref(R), None))
+                                      flags, _p(radii), _p(geom), geom.numel(), None, 0, ctypes.byref(R), None))
         abi.check(abi.binning_bytes(P, H, W, R.value, ctypes.byref(n))); binning = u8(n.value)
         abi.check(abi.forward_render(P, H, W, R.value, _p(b), flags, _p(geom), geom.numel(), _p(binning), binning.numel(),
-                                     _p(img), img.numel(), _p(color), _p(invd), None))
+                                     _p(img), img.numel(), None, 0, _p(color), _p(invd), None))
     return R.value, color, radii, geom, binning, img, invd
 
 

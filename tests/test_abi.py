@@ -37,7 +37,7 @@ def hip_lib():
 
 def test_hip_library_exports_everything(hip_lib):
     assert hip_lib.backend == "hip-gfx950"
-    assert hip_lib.cdll.eogs_rast_abi_version() == 4
+    assert hip_lib.cdll.eogs_rast_abi_version() == 5
     for name in header_symbols():
         assert hasattr(hip_lib.cdll, name), name
 
@@ -55,11 +55,13 @@ def test_hip_size_queries_and_arg_checks(hip_lib):
     R = ctypes.c_int64(7)
     # NULL inputs are rejected before anything touches a device
     assert hip_lib.forward_prepare(10, 32, 32, None, None, None, None, None, None, 1.0, None, None, None, 0, None, None, 0,
-                                   ctypes.byref(R), None) == -1
+                                   None, 0, ctypes.byref(R), None) == -1
     assert R.value == 0
     # P == 0 is a no-op
     assert hip_lib.forward_prepare(0, 32, 32, None, None, None, None, None, None, 1.0, None, None, None, 0, None, None, 0,
-                                   ctypes.byref(R), None) == 0
+                                   None, 0, ctypes.byref(R), None) == 0
+    hip_lib.check(hip_lib.scratch_bytes(1 << 20, 1024, 1024, ctypes.byref(n)))
+    assert 100e6 < n.value < 300e6  # transient, shared by every forward on a stream
 
 
 def test_oracle_library_exports_everything():
