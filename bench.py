@@ -797,14 +797,20 @@ def main():
     color = step()
     torch.cuda.synchronize()
     nr = int(color.grad_fn.num_rendered) if hasattr(color.grad_fn, "num_rendered") else -1
-    # the API's num_rendered packs both counts: (tile, Gaussian) record slots below, sorted list entries above
-    R, R_entries = (nr & 0x7FFFFFFF, (nr >> 32) & 0x3FFFFFFF) if nr >= 0 else (-1, -1)
+    # the API's num_rendered packs both counts: (tile, Gaussian) record slots below, (32-px block, Gaussian) list entries
+    # above (csrc/common.h nr_pack)
+    R, R_entries = (nr & 0x7FFFFFFF, (nr >> 32) & 0x1FFFFFFF) if nr >= 0 else (-1, -1)
 
     if rank == 0:
         ms_step = dt / a.steps * 1e3
         kern = {k: ms / a.steps for k, (ms, n) in prof.items() if n}  # device ms per step of each kernel group
         dom = max(kern, key=kern.get) if kern else None
         npx = H * W
+        # algorithmic bytes per launch group. Since round 3 the groups "binning" (count scan, entry expand,
+        # block sort) and "depth_sort" (per-block depth order + split into tile lists) together do the job the survey
+        # prices at 12 R + 2 x 24 R + 8 R (keys written, a two-pass sort of 12-byte pairs, ranges) and 64 P (the depth
+        # order): the figures stay the survey's, the split between the two groups follows what each kernel moves
+        # (16-byte entries: write + one sort pass; then 8-byte list items written once).
         alg = {
             "render_bwd": 52 * R + 32 * npx,
             "render_fwd": 52 * R + 32 * npx,

@@ -222,17 +222,18 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
   const uint64_t entries = (uint64_t)g_pinned[MISC_MACRO_LO] | ((uint64_t)g_pinned[MISC_MACRO_HI] << 32);
   // List granularity the render kernels read (common.h "blocks"). Per-tile lists while footprints are small: every entry a
   // wave reads is one it uses. Lists per 32 x 32-pixel block once a Gaussian is listed in many tiles: the lists are then
-  // 4-7x shorter to write and re-read, which outweighs the block-list scan in the render waves (measured crossover at
-  // about nine listed tiles per Gaussian: 1024^2 trained -8 %, 2048^2 trained -28 %, 1024^2 at opacity 0.01 +13 % if forced).
+  // 4-7x shorter to write and re-read, which outweighs the block-list scan in the render waves. Measured crossover since the
+  // lists are built per block (round 3): about 10.5 listed tiles per Gaussian, and the gain is small (1024^2 trained -2 %,
+  // 2048^2 trained -6 %; 1024^2 at opacity 0.01 +27 % if forced) — profiles/r03_regime_scan.txt.
   static const double block_switch = [] {  // tuning aid: EOGS_BLOCK_SWITCH=<tiles per Gaussian> overrides the default
     const char* e = getenv("EOGS_BLOCK_SWITCH");
     return e ? atof(e) : (double)EOGS_BLOCK_SWITCH;
   }();
   // Second criterion: termination. With opaque Gaussians a pixel stops after ~ln(1e4) / (mean alpha) list entries, so a
-  // tile's list (length L = pairs / tiles) is only rendered to a depth ~1 / opacity while binning still writes all of it:
-  // per-tile lists then cost more than block-mode rendering loses. Measured over P = 1-4 M, opacities 0.01 ... trained
-  // (sigmoid(N(0,2))): block lists win when L * (mean pair opacity) exceeds ~115 (2 M Gaussians at trained opacities and
-  // 7.9 listed tiles per Gaussian: 1.41 -> 1.18 ms per fwd+bwd; opacity 0.1 at 6.5: per-tile lists stay 8 % ahead).
+  // tile's list (length L = pairs / tiles) is only rendered to a depth ~1 / opacity while binning still writes all of it.
+  // While per-tile binning SORTED every pair (rounds 1-2) block lists won when L * (mean pair opacity) exceeded ~115; now a
+  // pair costs one 8-byte list item and the criterion loses or ties everywhere it used to fire (2 M Gaussians at opacity
+  // 0.3: 1.24 ms per-tile against 1.29; 2 M / 4 M trained: equal), so it is off by default.
   static const double depth_switch = [] {  // EOGS_DEPTH_SWITCH=<L * mean opacity> overrides; 0 disables the criterion
     const char* e = getenv("EOGS_DEPTH_SWITCH");
     return e ? atof(e) : (double)EOGS_DEPTH_SWITCH;

@@ -408,8 +408,8 @@ void launch_sort_u32(uint32_t* keyA, uint32_t* valA, uint32_t* keyB, uint32_t* v
 // List entries: expand (id order), block sort, block ranges
 // =====================================================================================================================
 
-#define EXPAND_LANE_MAX 256u  // a single lane walks at most this many list entries
-#define EXPAND_STAGE 4096     // entries per LDS window (16 KB keys + 16 KB slots + 8 KB owner lanes; 2048 / 1024 measured: no better)
+#define EXPAND_LANE_MAX 64u  // a single lane walks at most this many list entries
+#define EXPAND_STAGE 1024     // entries per LDS window (16 KB + 2 KB of owner lanes)
 struct ExpandItem {
   uint32_t id, c, pos0, rbase, sx0, sy0, sx1, sy1, kind, depth;
   unsigned long long m;
@@ -423,18 +423,13 @@ struct ExpandItem {
 // Gaussians with at most EXPAND_LANE_MAX entries are walked by their own lane into an LDS window and streamed out with
 // consecutive lanes writing consecutive addresses; larger ones are emitted by the whole wave, one macro row per lane.
 template <int MACRO>
-__global__ __launch_bounds__(BLK) void expand_entries_kernel(const uint4* __restrict__ binfo, const float4* __restrict__ bext,
-                                                             const uint32_t* __restrict__ pblock,
-                                                             const uint32_t* __restrict__ pblockE,
-                                                             const uint32_t* __restrict__ misc, uint32_t cap, uint32_t P,
-                                                             uint32_t gmx, uint32_t nblocks, uint4* __restrict__ ent) {
-  (void)nblocks;
+__global__ __launch_bounds__(BLK, 4) void expand_entries_kernel(const uint4* __restrict__ binfo, const float4* __restrict__ bext,
+                                                                const uint32_t* __restrict__ pblock,
+                                                                const uint32_t* __restrict__ pblockE,
+                                                                const uint32_t* __restrict__ misc, uint32_t cap, uint32_t P,
+                                                                uint32_t gmx, uint4* __restrict__ ent) {
   if (entries_on_device(misc, cap) == 0u) return;  // nothing listed, or more entries than this buffer holds
   __shared__ uint32_t s_w[4];
-  __shared__ uint32_t s_tk[EXPAND_STAGE];   // staged keys
-  __shared__ uint32_t s_sl[EXPAND_STAGE];   // ... record slots
-  __shared__ uint16_t s_own[EXPAND_STAGE];  // ... and the lane that owns each staged entry
-  __shared__ uint32_t s_dk[BLK], s_l0[BLK], s_gp[BLK];
   const int lane = threadIdx.x & 63;
   const uint32_t k = blockIdx.x * BLK + threadIdx.x;
   ExpandItem it;
@@ -463,21 +458,28 @@ __global__ __launch_bounds__(BLK) void expand_entries_kernel(const uint4* __rest
   SpanParams sp;
   sp.gx = e0.x; sp.gy = e0.y; sp.ex = e0.z; sp.ey = e0.w; sp.boa = e1.x; sp.boc = e1.y; sp.ta = e1.z; sp.da = e1.w;
 
-  // ---- lane-walked Gaussians: compact local positions among themselves, staged in rounds of EXPAND_STAGE ----
+  // ---- lane-walked Gaussians: their entries are staged in LDS in output order (EXPAND_STAGE per round, one round at the
+  //      usual 1.7 entries per Gaussian) and written out as whole 16-byte entries with consecutive lanes on consecutive
+  //      addresses (lanes storing their own entries straight to memory measured slower: 2.3x the bytes reach HBM as
+  //      partial lines) ----
+  __shared__ uint4 s_ent[EXPAND_STAGE];
   const bool mine = it.c != 0u && it.c <= EXPAND_LANE_MAX;
   uint32_t ltot;
-  const uint32_t l0 = block_excl_scan(mine ? it.c : 0u, s_w, ltot);
-  s_dk[threadIdx.x] = it.depth; s_l0[threadIdx.x] = l0; s_gp[threadIdx.x] = it.pos0;
+  const uint32_t l0 = block_excl_scan(mine ? it.c : 0u, s_w, ltot);  // local position among the lane-walked entries
+  // the lane-walked entries of this workgroup are NOT contiguous in the output when a large Gaussian sits between them:
+  // every staged entry carries its own output position in the owner's `pos0 - l0` (s_gp)
+  __shared__ uint32_t s_gp[BLK];
+  __shared__ uint16_t s_own[EXPAND_STAGE];
+  s_gp[threadIdx.x] = it.pos0 - l0;
   for (uint32_t base = 0; base < ltot; base += EXPAND_STAGE) {
-    __syncthreads();  // s_dk.. visible (first round) / previous window drained
+    __syncthreads();  // s_gp visible (first round) / previous window drained
     if (mine && l0 < base + EXPAND_STAGE && l0 + it.c > base) {
       uint32_t l = l0, slot = it.rbase;
       for (int MY = (int)it.sy0 / MACRO; MY <= ((int)it.sy1 - 1) / MACRO; MY++)  // MACRO: template parameter
         walk_macro_row<MACRO>(it.kind, it.m, sp, (int)it.sx0, (int)it.sy0, (int)it.sx1, (int)it.sy1, MY, [&](int MX, uint32_t sub) {
           const uint32_t w = l - base;  // wraps below the window: fails the unsigned test
           if (w < (uint32_t)EXPAND_STAGE) {
-            s_tk[w] = ((uint32_t)MY * gmx + (uint32_t)MX) | (sub << MACRO_KEY_BITS);
-            s_sl[w] = slot;
+            s_ent[w] = make_uint4(((uint32_t)MY * gmx + (uint32_t)MX) | (sub << MACRO_KEY_BITS), it.depth, it.id, slot);
             s_own[w] = (uint16_t)threadIdx.x;
           }
           l++;
@@ -486,10 +488,7 @@ __global__ __launch_bounds__(BLK) void expand_entries_kernel(const uint4* __rest
     }
     __syncthreads();
     const uint32_t nwin = ltot - base < (uint32_t)EXPAND_STAGE ? ltot - base : (uint32_t)EXPAND_STAGE;
-    for (uint32_t i = threadIdx.x; i < nwin; i += BLK) {
-      const uint32_t o = s_own[i], q = base + i - s_l0[o];  // q-th entry of its Gaussian
-      ent[s_gp[o] + q] = make_uint4(s_tk[i], s_dk[o], blockIdx.x * BLK + o, s_sl[i]);
-    }
+    for (uint32_t i = threadIdx.x; i < nwin; i += BLK) ent[s_gp[s_own[i]] + base + i] = s_ent[i];
   }
 
   // ---- large Gaussians: the wave emits them cooperatively, one after the other, one macro row per lane ----
@@ -616,24 +615,29 @@ __global__ __launch_bounds__(ES_T) void entry_colscan_kernel(uint32_t* __restric
   }
 }
 
-// kernel 3: stable scatter. Ranking as in radix_scatter_body (wave-private ballot match, nbits ballots per 64 entries);
-// the entries go from registers straight to their places (no LDS re-order: with a thousand digits a workgroup's runs are
-// a few entries long either way). 16-bit wave counters: a wave holds 512 entries.
+// kernel 3: stable scatter. Ranking as in radix_scatter_body (wave-private ballot match, NBITS ballots per 64 entries,
+// 16-bit wave counters: a wave holds 512 entries). The workgroup's entries are then brought into sorted order through an
+// LDS window, ES_WIN entries per round, and written so that consecutive lanes write consecutive addresses inside each
+// digit's run (entries stored straight from their ranking lanes reached HBM as partial lines: 2x the bytes written,
+// 26 us against the 6 us the histogram takes to read the same data).
+#define ES_WIN 2048
+template <int NBITS>
 __global__ __launch_bounds__(ES_T) void entry_scatter_kernel(const uint4* __restrict__ in, uint4* __restrict__ out,
                                                              const uint32_t* __restrict__ misc, uint32_t cap, int shift,
-                                                             int nbits, const uint32_t* __restrict__ hist,
+                                                             const uint32_t* __restrict__ hist,
                                                              const uint32_t* __restrict__ dtotal) {
+  constexpr int nbits = NBITS;
+  constexpr uint32_t nb = 1u << NBITS, mask = nb - 1u;
   const uint32_t n = entries_on_device(misc, cap);
   const uint32_t tile0 = blockIdx.x * (uint32_t)ES_TILE;
   if (tile0 >= n) return;
-  __shared__ uint16_t s_wcnt[ES_NW][1 << ES_MAXBITS];  // per-wave digit counts -> per-wave offset inside the digit
-  __shared__ uint32_t s_gbase[1 << ES_MAXBITS];        // global output position of this workgroup's first entry of each digit
-  __shared__ uint32_t s_w[ES_NW];
+  __shared__ uint16_t s_wcnt[ES_NW][nb < 2u ? 2u : nb];  // per-wave digit counts -> per-wave offset inside the digit
+  __shared__ uint32_t s_gbase[nb];   // global output position of this workgroup's first entry of each digit
+  __shared__ uint32_t s_dstart[nb];  // start of each digit in the workgroup's sorted order
+  __shared__ uint32_t s_w[ES_NW], s_w2[ES_NW];
+  __shared__ uint4 s_win[ES_WIN];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const uint32_t mask = (1u << nbits) - 1u, nb = mask + 1u;
-  for (uint32_t d = 2u * t; d < nb; d += 2u * ES_T)
-#pragma unroll
-    for (int k = 0; k < ES_NW; k++) *reinterpret_cast<uint32_t*>(&s_wcnt[k][d]) = 0u;
+  for (uint32_t k = t; k < (uint32_t)ES_NW * (nb < 2u ? 2u : nb) / 2u; k += ES_T) reinterpret_cast<uint32_t*>(&s_wcnt[0][0])[k] = 0u;
   __syncthreads();
   const uint32_t base = tile0 + (uint32_t)w * (64 * ES_ITEMS);
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -652,6 +656,7 @@ __global__ __launch_bounds__(ES_T) void entry_scatter_kernel(const uint4* __rest
     const bool live = base + i * 64 + lane < n;
     const uint32_t d = (item[i].x >> shift) & mask;
     unsigned long long peers = __ballot(live);
+#pragma unroll
     for (int b = 0; b < nbits; b++) {
       const unsigned long long m = __ballot((d >> b) & 1u);
       peers &= ((d >> b) & 1u) ? m : ~m;
@@ -665,40 +670,59 @@ __global__ __launch_bounds__(ES_T) void entry_scatter_kernel(const uint4* __rest
     lrank[i] = before + r;
   }
   __syncthreads();
-  // per digit: offsets of the waves inside the workgroup's run; exclusive scan of the digit totals over the digits
-  // (digits are dealt to threads as d = t, then t + 1024: nb <= 2048)
-  uint32_t carry = 0;
+  // per digit: offsets of the waves inside the workgroup's run; exclusive scans over the digits of the global totals
+  // (-> global base) and of the workgroup's totals (-> place in the workgroup's sorted order).
+  // Digits are dealt to threads as d = t, then t + 1024 (nb <= 2048).
+  uint32_t carry = 0, carry2 = 0;
   for (uint32_t d0 = 0; d0 < nb; d0 += ES_T) {
     const uint32_t d = d0 + t;
     const uint32_t v = d < nb ? dtotal[d] : 0u;
-    const uint32_t inc = wave_incl_scan_u32(v);
-    if (lane == 63) s_w[w] = inc;
-    __syncthreads();
-    uint32_t pre = 0, tot = 0;
-#pragma unroll
-    for (int k = 0; k < ES_NW; k++) {
-      if (k < w) pre += s_w[k];
-      tot += s_w[k];
-    }
+    uint32_t run = 0;
     if (d < nb) {
-      uint32_t run = 0;
 #pragma unroll
       for (int k = 0; k < ES_NW; k++) {
         const uint32_t c = s_wcnt[k][d];
         s_wcnt[k][d] = (uint16_t)run;
         run += c;
       }
+    }
+    const uint32_t inc = wave_incl_scan_u32(v), inc2 = wave_incl_scan_u32(run);
+    if (lane == 63) { s_w[w] = inc; s_w2[w] = inc2; }
+    __syncthreads();
+    uint32_t pre = 0, tot = 0, pre2 = 0, tot2 = 0;
+#pragma unroll
+    for (int k = 0; k < ES_NW; k++) {
+      if (k < w) { pre += s_w[k]; pre2 += s_w2[k]; }
+      tot += s_w[k];
+      tot2 += s_w2[k];
+    }
+    if (d < nb) {
       s_gbase[d] = carry + pre + inc - v + hist[(size_t)blockIdx.x * nb + d];
+      s_dstart[d] = carry2 + pre2 + inc2 - run;
     }
     carry += tot;
+    carry2 += tot2;
     __syncthreads();
   }
+  uint32_t lpos[ES_ITEMS];  // place in the workgroup's sorted order
 #pragma unroll
   for (int i = 0; i < ES_ITEMS; i++) {
-    if (base + i * 64 + lane < n) {
-      const uint32_t d = (item[i].x >> shift) & mask;
-      out[s_gbase[d] + s_wcnt[w][d] + lrank[i]] = item[i];
+    const uint32_t d = (item[i].x >> shift) & mask;
+    lpos[i] = base + i * 64 + lane < n ? s_dstart[d] + s_wcnt[w][d] + lrank[i] : 0xFFFFFFFFu;
+  }
+  const uint32_t nvalid = n - tile0 < (uint32_t)ES_TILE ? n - tile0 : (uint32_t)ES_TILE;
+  for (uint32_t w0 = 0; w0 < nvalid; w0 += ES_WIN) {
+#pragma unroll
+    for (int i = 0; i < ES_ITEMS; i++)
+      if (lpos[i] - w0 < (uint32_t)ES_WIN) s_win[lpos[i] - w0] = item[i];  // (wraps below the window: fails the test)
+    __syncthreads();
+    const uint32_t nwin = nvalid - w0 < (uint32_t)ES_WIN ? nvalid - w0 : (uint32_t)ES_WIN;
+    for (uint32_t idx = t; idx < nwin; idx += ES_T) {
+      const uint4 e = s_win[idx];
+      const uint32_t d = (e.x >> shift) & mask;
+      out[s_gbase[d] + (w0 + idx - s_dstart[d])] = e;
     }
+    __syncthreads();
   }
 }
 
@@ -737,10 +761,26 @@ __global__ __launch_bounds__(BLK) void clear_counts_kernel(uint32_t* __restrict_
   if (i < n) { a[i] = 0u; b[i] = 0u; }
 }
 
+template <int NBITS>
+static void launch_entry_scatter_n(uint32_t nblk, hipStream_t s, const uint4* in, uint4* out, const uint32_t* misc, uint32_t cap,
+                                   int shift, const uint32_t* hist, const uint32_t* dtotal) {
+  hipLaunchKernelGGL(entry_scatter_kernel<NBITS>, dim3(nblk), dim3(ES_T), 0, s, in, out, misc, cap, shift, hist, dtotal);
+}
+static void launch_entry_scatter(int bits, uint32_t nblk, hipStream_t s, const uint4* in, uint4* out, const uint32_t* misc,
+                                 uint32_t cap, int shift, const uint32_t* hist, const uint32_t* dtotal) {
+  switch (bits) {  // the ballot loop of the ranking is unrolled for the digit width
+#define ES_CASE(N) case N: launch_entry_scatter_n<N>(nblk, s, in, out, misc, cap, shift, hist, dtotal); break;
+    ES_CASE(1) ES_CASE(2) ES_CASE(3) ES_CASE(4) ES_CASE(5) ES_CASE(6) ES_CASE(7) ES_CASE(8) ES_CASE(9) ES_CASE(10)
+    default: launch_entry_scatter_n<11>(nblk, s, in, out, misc, cap, shift, hist, dtotal); break;
+#undef ES_CASE
+  }
+}
+
 void launch_entry_sort(const GeomWS& g, const SortWS& w, int P, int H, int W, hipStream_t s) {
   const uint32_t gmx = macro_grid_x(W, BLOCK_BIG), nblocks = gmx * macro_grid_y(H, BLOCK_BIG);
+  (void)nblocks;
   hipLaunchKernelGGL(expand_entries_kernel<BLOCK_BIG>, dim3(g.nblkE), dim3(BLK), 0, s, g.binfo, g.bext, g.pblock, g.pblockE,
-                     g.misc, w.cap, (uint32_t)P, gmx, nblocks, w.entA);
+                     g.misc, w.cap, (uint32_t)P, gmx, w.entA);
   int passes, bits;
   block_sort_geometry(H, W, passes, bits);
   const uint4* in = w.entA;
@@ -752,8 +792,7 @@ void launch_entry_sort(const GeomWS& g, const SortWS& w, int P, int H, int W, hi
     hipLaunchKernelGGL(entry_hist_kernel, dim3(w.nblk), dim3(ES_T), 0, s, in, g.misc, w.cap, shift, mask, w.hist, histp);
     hipLaunchKernelGGL(entry_colscan_kernel, dim3((mask + 64u) / 64u), dim3(ES_T), 0, s, w.hist, histp, g.misc, w.cap, mask + 1u,
                        passes == 1 ? g.bcount : w.dtotal, g.bpairs);
-    hipLaunchKernelGGL(entry_scatter_kernel, dim3(w.nblk), dim3(ES_T), 0, s, in, out, g.misc, w.cap, shift, bits, w.hist,
-                       passes == 1 ? g.bcount : w.dtotal);
+    launch_entry_scatter(bits, w.nblk, s, in, out, g.misc, w.cap, shift, w.hist, passes == 1 ? g.bcount : w.dtotal);
     const uint4* t = in; in = out; out = const_cast<uint4*>(t);
   }
   if (passes > 1) {
