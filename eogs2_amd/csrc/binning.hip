@@ -408,8 +408,8 @@ void launch_sort_u32(uint32_t* keyA, uint32_t* valA, uint32_t* keyB, uint32_t* v
 // List entries: expand (id order), block sort, block ranges
 // =====================================================================================================================
 
-#define EXPAND_LANE_MAX 64u  // a single lane walks at most this many list entries
-#define EXPAND_STAGE 1024     // entries per LDS window (16 KB + 2 KB of owner lanes)
+#define EXPAND_LANE_MAX 256u  // a single lane walks at most this many list entries
+#define EXPAND_STAGE 2048     // entries per LDS window (32 KB + 4 KB of owner lanes)
 struct ExpandItem {
   uint32_t id, c, pos0, rbase, sx0, sy0, sx1, sy1, kind, depth;
   unsigned long long m;
@@ -532,15 +532,15 @@ __global__ __launch_bounds__(BLK, 4) void expand_entries_kernel(const uint4* __r
   }
 }
 
-// ---- block sort: ONE stable counting pass on the whole block id when it has at most ES_MAXBITS bits (2048 blocks:
-//      every image up to 1024 x 2048 pixels), otherwise two passes of half the bits each. 8192 entries per workgroup
+// ---- block sort: ONE stable counting pass on the whole block id when it has at most ES_MAXBITS bits (4096 blocks:
+//      every image up to 2048 x 2048 pixels), otherwise two passes of half the bits each. 8192 entries per workgroup
 //      (1024 threads x 8): the histogram tables stay small although the launch covers the buffer's capacity, and a
 //      workgroup's entries of one block form runs of several 16-byte entries in the output. ----
 #define ES_T 1024
 #define ES_ITEMS 8
 #define ES_TILE (ES_T * ES_ITEMS)
 #define ES_NW (ES_T / 64)
-#define ES_MAXBITS 11
+#define ES_MAXBITS 12
 static_assert(ES_TILE == SORTE_TILE, "sort_layout sizes the histogram tables for this tile");
 
 // kernel 1: per-workgroup histogram of the digit, one ROW per workgroup (hist[blk][digit]: written and later read back as
@@ -621,36 +621,38 @@ __global__ __launch_bounds__(ES_T) void entry_colscan_kernel(uint32_t* __restric
 // digit's run (entries stored straight from their ranking lanes reached HBM as partial lines: 2x the bytes written,
 // 26 us against the 6 us the histogram takes to read the same data).
 #define ES_WIN 2048
-template <int NBITS>
-__global__ __launch_bounds__(ES_T) void entry_scatter_kernel(const uint4* __restrict__ in, uint4* __restrict__ out,
+// T_ threads per workgroup (ES_TILE / T_ entries per thread): 1024 up to 2048 digits, 512 for 4096 (the wave counters are
+// NW x digits x 2 bytes of LDS).
+template <int NBITS, int T_>
+__global__ __launch_bounds__(T_) void entry_scatter_kernel(const uint4* __restrict__ in, uint4* __restrict__ out,
                                                              const uint32_t* __restrict__ misc, uint32_t cap, int shift,
                                                              const uint32_t* __restrict__ hist,
                                                              const uint32_t* __restrict__ dtotal) {
-  constexpr int nbits = NBITS;
+  constexpr int nbits = NBITS, ES_ITEMS_ = ES_TILE / T_, ES_NW_ = T_ / 64;
   constexpr uint32_t nb = 1u << NBITS, mask = nb - 1u;
   const uint32_t n = entries_on_device(misc, cap);
   const uint32_t tile0 = blockIdx.x * (uint32_t)ES_TILE;
   if (tile0 >= n) return;
-  __shared__ uint16_t s_wcnt[ES_NW][nb < 2u ? 2u : nb];  // per-wave digit counts -> per-wave offset inside the digit
+  __shared__ uint16_t s_wcnt[ES_NW_][nb < 2u ? 2u : nb];  // per-wave digit counts -> per-wave offset inside the digit
   __shared__ uint32_t s_gbase[nb];   // global output position of this workgroup's first entry of each digit
   __shared__ uint32_t s_dstart[nb];  // start of each digit in the workgroup's sorted order
-  __shared__ uint32_t s_w[ES_NW], s_w2[ES_NW];
+  __shared__ uint32_t s_w[ES_NW_], s_w2[ES_NW_];
   __shared__ uint4 s_win[ES_WIN];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  for (uint32_t k = t; k < (uint32_t)ES_NW * (nb < 2u ? 2u : nb) / 2u; k += ES_T) reinterpret_cast<uint32_t*>(&s_wcnt[0][0])[k] = 0u;
+  for (uint32_t k = t; k < (uint32_t)ES_NW_ * (nb < 2u ? 2u : nb) / 2u; k += T_) reinterpret_cast<uint32_t*>(&s_wcnt[0][0])[k] = 0u;
   __syncthreads();
-  const uint32_t base = tile0 + (uint32_t)w * (64 * ES_ITEMS);
+  const uint32_t base = tile0 + (uint32_t)w * (64 * ES_ITEMS_);
   const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  uint4 item[ES_ITEMS];
-  uint32_t lrank[ES_ITEMS];
+  uint4 item[ES_ITEMS_];
+  uint32_t lrank[ES_ITEMS_];
 #pragma unroll
-  for (int i = 0; i < ES_ITEMS; i++) {
+  for (int i = 0; i < ES_ITEMS_; i++) {
     const uint32_t k = base + i * 64 + lane;
     item[i] = make_uint4(0u, 0u, 0u, 0u);
     if (k < n) item[i] = in[k];
   }
 #pragma unroll
-  for (int i = 0; i < ES_ITEMS; i++) {
+  for (int i = 0; i < ES_ITEMS_; i++) {
     lrank[i] = 0;
     if (base + i * 64 >= n) continue;  // (wave-uniform)
     const bool live = base + i * 64 + lane < n;
@@ -672,15 +674,15 @@ __global__ __launch_bounds__(ES_T) void entry_scatter_kernel(const uint4* __rest
   __syncthreads();
   // per digit: offsets of the waves inside the workgroup's run; exclusive scans over the digits of the global totals
   // (-> global base) and of the workgroup's totals (-> place in the workgroup's sorted order).
-  // Digits are dealt to threads as d = t, then t + 1024 (nb <= 2048).
+  // Digits are dealt to threads as d = t, t + T_, ...
   uint32_t carry = 0, carry2 = 0;
-  for (uint32_t d0 = 0; d0 < nb; d0 += ES_T) {
+  for (uint32_t d0 = 0; d0 < nb; d0 += T_) {
     const uint32_t d = d0 + t;
     const uint32_t v = d < nb ? dtotal[d] : 0u;
     uint32_t run = 0;
     if (d < nb) {
 #pragma unroll
-      for (int k = 0; k < ES_NW; k++) {
+      for (int k = 0; k < ES_NW_; k++) {
         const uint32_t c = s_wcnt[k][d];
         s_wcnt[k][d] = (uint16_t)run;
         run += c;
@@ -691,7 +693,7 @@ __global__ __launch_bounds__(ES_T) void entry_scatter_kernel(const uint4* __rest
     __syncthreads();
     uint32_t pre = 0, tot = 0, pre2 = 0, tot2 = 0;
 #pragma unroll
-    for (int k = 0; k < ES_NW; k++) {
+    for (int k = 0; k < ES_NW_; k++) {
       if (k < w) { pre += s_w[k]; pre2 += s_w2[k]; }
       tot += s_w[k];
       tot2 += s_w2[k];
@@ -704,20 +706,20 @@ __global__ __launch_bounds__(ES_T) void entry_scatter_kernel(const uint4* __rest
     carry2 += tot2;
     __syncthreads();
   }
-  uint32_t lpos[ES_ITEMS];  // place in the workgroup's sorted order
+  uint32_t lpos[ES_ITEMS_];  // place in the workgroup's sorted order
 #pragma unroll
-  for (int i = 0; i < ES_ITEMS; i++) {
+  for (int i = 0; i < ES_ITEMS_; i++) {
     const uint32_t d = (item[i].x >> shift) & mask;
     lpos[i] = base + i * 64 + lane < n ? s_dstart[d] + s_wcnt[w][d] + lrank[i] : 0xFFFFFFFFu;
   }
   const uint32_t nvalid = n - tile0 < (uint32_t)ES_TILE ? n - tile0 : (uint32_t)ES_TILE;
   for (uint32_t w0 = 0; w0 < nvalid; w0 += ES_WIN) {
 #pragma unroll
-    for (int i = 0; i < ES_ITEMS; i++)
+    for (int i = 0; i < ES_ITEMS_; i++)
       if (lpos[i] - w0 < (uint32_t)ES_WIN) s_win[lpos[i] - w0] = item[i];  // (wraps below the window: fails the test)
     __syncthreads();
     const uint32_t nwin = nvalid - w0 < (uint32_t)ES_WIN ? nvalid - w0 : (uint32_t)ES_WIN;
-    for (uint32_t idx = t; idx < nwin; idx += ES_T) {
+    for (uint32_t idx = t; idx < nwin; idx += T_) {
       const uint4 e = s_win[idx];
       const uint32_t d = (e.x >> shift) & mask;
       out[s_gbase[d] + (w0 + idx - s_dstart[d])] = e;
@@ -764,14 +766,15 @@ __global__ __launch_bounds__(BLK) void clear_counts_kernel(uint32_t* __restrict_
 template <int NBITS>
 static void launch_entry_scatter_n(uint32_t nblk, hipStream_t s, const uint4* in, uint4* out, const uint32_t* misc, uint32_t cap,
                                    int shift, const uint32_t* hist, const uint32_t* dtotal) {
-  hipLaunchKernelGGL(entry_scatter_kernel<NBITS>, dim3(nblk), dim3(ES_T), 0, s, in, out, misc, cap, shift, hist, dtotal);
+  constexpr int T_ = NBITS <= 11 ? 1024 : 512;
+  hipLaunchKernelGGL((entry_scatter_kernel<NBITS, T_>), dim3(nblk), dim3(T_), 0, s, in, out, misc, cap, shift, hist, dtotal);
 }
 static void launch_entry_scatter(int bits, uint32_t nblk, hipStream_t s, const uint4* in, uint4* out, const uint32_t* misc,
                                  uint32_t cap, int shift, const uint32_t* hist, const uint32_t* dtotal) {
   switch (bits) {  // the ballot loop of the ranking is unrolled for the digit width
 #define ES_CASE(N) case N: launch_entry_scatter_n<N>(nblk, s, in, out, misc, cap, shift, hist, dtotal); break;
-    ES_CASE(1) ES_CASE(2) ES_CASE(3) ES_CASE(4) ES_CASE(5) ES_CASE(6) ES_CASE(7) ES_CASE(8) ES_CASE(9) ES_CASE(10)
-    default: launch_entry_scatter_n<11>(nblk, s, in, out, misc, cap, shift, hist, dtotal); break;
+    ES_CASE(1) ES_CASE(2) ES_CASE(3) ES_CASE(4) ES_CASE(5) ES_CASE(6) ES_CASE(7) ES_CASE(8) ES_CASE(9) ES_CASE(10) ES_CASE(11)
+    default: launch_entry_scatter_n<12>(nblk, s, in, out, misc, cap, shift, hist, dtotal); break;
 #undef ES_CASE
   }
 }

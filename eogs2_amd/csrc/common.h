@@ -47,7 +47,7 @@ static_assert(REC == 12, "record quarters");
 // ---- radix sort geometry ----
 #define SORTP_ITEMS 8    // generic u32 key + u32 payload sort (knn.hip's Morton order): 2048 keys per workgroup
 #define SORTE_TILE 8192  // block sort of the list entries (16-byte items): entries per workgroup (binning.hip ES_TILE)
-#define SORTE_MAXBINS 2048  // ... and the widest digit of one pass (ES_MAXBITS)
+#define SORTE_MAXBINS 4096  // ... and the widest digit of one pass (ES_MAXBITS)
 #define EXPAND_ITEMS 1   // expand: 256 Gaussians (one preprocess workgroup) per workgroup
 #define MAX_BLOCKS (1u << 16)  // 32 x 32-pixel blocks per image (their id is the low half of an entry's sort key)
 
@@ -310,7 +310,7 @@ static inline uint32_t macro_grid_y(int H, int M) { return (uint32_t)(((H + SUBY
 static inline void block_sort_geometry(int H, int W, int& passes, int& bits) {
   const uint32_t nb = macro_grid_x(W, BLOCK_BIG) * macro_grid_y(H, BLOCK_BIG);
   const int tb = ceil_log2_u32(nb) < 1 ? 1 : ceil_log2_u32(nb);
-  passes = tb <= 11 ? 1 : 2;  // one counting pass up to 2048 blocks (SORTE_MAXBINS)
+  passes = tb <= 12 ? 1 : 2;  // one counting pass up to 4096 blocks (SORTE_MAXBINS)
   bits = (tb + passes - 1) / passes;
 }
 
