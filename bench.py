@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--ar-chunks", type=int, default=0,
                     help="Gaussian ranges of the overlapped gradient exchange (eogs_rast_backward_range); 0 = pick the "
                          "faster of 1 and 4 during warmup")
+    ap.add_argument("--ar-algo", default="auto", choices=("auto", "all_reduce", "rs_ag"),
+                    help="gradient exchange: one all-reduce, or reduce-scatter + all-gather of the same buffer; auto = "
+                         "measure both (with --ar-chunks candidates) during warmup and time the fastest")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="collective backend; gloo + --share-gpu rehearses the N-rank path on a one-GPU box (not a measurement)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
@@ -221,7 +224,7 @@ def _ssim_window(dev, C=3):
     return w1.mm(w1.t()).float().expand(C, 1, 11, 11).contiguous().to(dev)
 
 
-def train_iteration(sc, P, H, W, dev, fused, iters=5):
+def train_iteration(sc, P, H, W, dev, fused, iters=5, dist=None, view_seed=0, algo="all_reduce"):
     """Extra, reported beside the headline: one synthetic EOGS++ training iteration as the reference schedules it after
     iteration 1000 (GS/train_pan.py:278,305-316,375-391): three renders of the same Gaussians — the view (H x W), the
     sun camera (2H x 2W, affine_cameras.py:366-367) and a random virtual camera (H x W) — each forward + backward,
@@ -230,7 +233,12 @@ def train_iteration(sc, P, H, W, dev, fused, iters=5):
     one Adam step on the five raw parameter tensors (torch.optim.Adam as the reference configures it, or FusedAdam).
     fused=False: the reference's PyTorch ops around the drop-in GaussianRasterizer (activations, feature assembly,
     SSIM as five depthwise conv2d) — what a user of the reference gets after the drop-in alone.
-    fused=True: `eogs2_amd.fused.rasterize_raw` (§8 f1) + `eogs2_amd.losses.photometric_loss` (§8 f2)."""
+    fused=True: `eogs2_amd.fused.rasterize_raw` (§8 f1) + `eogs2_amd.losses.photometric_loss` (§8 f2).
+    dist: the initialised torch.distributed module of an N-rank run. Every rank then renders ITS three views (`view_seed`)
+    of the same Gaussians and the iteration ends with ONE synchronous exchange of the 56 B/Gaussian raw-parameter gradients
+    (`GradBucket.all_reduce()`: the three backward passes accumulate first, so the exchange cannot start earlier) before the
+    optimizer step — the reference's iteration (train_pan.py:278,308,469,664-690) under view-sharded data parallelism.
+    Reported: ms per iteration (max over ranks), the same without the exchange, and the exchange alone."""
     from eogs2_amd import GaussianRasterizer
     from eogs2_amd.fused import rasterize_raw
     from eogs2_amd.losses import photometric_loss
@@ -248,15 +256,20 @@ def train_iteration(sc, P, H, W, dev, fused, iters=5):
     else:  # the reference's optimizer (gaussian_model.py:262)
         opt = torch.optim.Adam([{"params": [v], "lr": 1e-4, "name": k} for k, v in params.items()], lr=0.0, eps=1e-15)
     win = _ssim_window(dev)
+    bucket = None
+    if dist is not None:
+        from eogs2_amd.parallel import GradBucket
+
+        bucket = GradBucket(list(params.values()), algo=algo)
     views = []
     for seed, (h, w) in ((11, (H, W)), (12, (2 * H, 2 * W)), (13, (H, W))):
-        vm = make_camera(h, w, seed=seed, device=dev)
+        vm = make_camera(h, w, seed=seed + 100 * view_seed, device=dev)
         g = torch.Generator().manual_seed(seed)
         dL = (torch.randn(5, h, w, generator=g) / (h * w)).to(dev)
         views.append((settings_for(dict(sc, viewmatrix=vm), h, w), vm[:, 2].contiguous(), torch.zeros(P, 3, device=dev), dL))
     gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(5)).to(dev)
 
-    def it():
+    def it(exchange=True):
         opt.zero_grad(set_to_none=True)
         for vi, (rs, alt, m2, dL) in enumerate(views):
             if fused:
@@ -274,16 +287,40 @@ def train_iteration(sc, P, H, W, dev, fused, iters=5):
                 (loss + (color[3:] * dL[3:]).sum()).backward()
             else:
                 torch.autograd.backward([color], [dL])
+        if bucket is not None and exchange:
+            bucket.all_reduce()
         opt.step()
 
-    it()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        it()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / iters
-    return {"iters_per_s": 1.0 / dt, "ms_per_iter": dt * 1e3, "renders_per_iter": 3,
+    def timed(fn, n):
+        fn()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        if dist is not None:  # the slowest rank's clock
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    dt = timed(it, iters)
+    extra = {}
+    if bucket is not None:
+        world = dist.get_world_size()
+        extra = {"n_gpus": world, "iters_per_s_all_ranks": world / dt, "views_per_s_all_ranks": 3 * world / dt,
+                 "compute_only_ms": timed(lambda: it(exchange=False), iters) * 1e3,
+                 "exchange_alone_ms": timed(lambda: bucket._exchange_whole(async_op=False), 10) * 1e3,
+                 "exchange": {"algo": bucket.algo, "bytes": int(bucket.flat.numel() * 4),
+                              "bytes_per_gaussian": bucket.bytes_per_gaussian,
+                              "how": "GradBucket.all_reduce() after the iteration's three backward passes, before the optimizer step"}}
+        bucket.close()
+    return {"iters_per_s": 1.0 / dt, "ms_per_iter": dt * 1e3, "renders_per_iter": 3, **extra,
             "what": f"3 renders ({H}x{W}, {2 * H}x{2 * W} sun camera, {H}x{W}) fwd+bwd + L1/DSSIM loss on the view + Adam "
                     f"on raw parameters; activations, loss and optimizer " + ("inside HIP kernels (EOGS_FLAG_RAW_PARAMS, "
                     "eogs_loss_*, eogs_adam_step)" if fused else "as the reference's PyTorch ops")}
@@ -695,8 +732,9 @@ def main():
     means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
     dL = sc["dL_dcolor"]
     names = ("means3D", "colors", "opacities", "scales", "rotations")
-    bucket = GradBucket([params[k] for k in names], cols=[slice(0, 3), slice(0, 3), slice(0, 1), slice(0, 3), slice(0, 4)],
-                        names=names, chunks=max(1, a.ar_chunks))
+    bucket_cols = [slice(0, 3), slice(0, 3), slice(0, 1), slice(0, 3), slice(0, 4)]
+    bucket = GradBucket([params[k] for k in names], cols=bucket_cols, names=names, chunks=max(1, a.ar_chunks),
+                        algo="all_reduce" if a.ar_algo == "auto" else a.ar_algo)
     rast = GaussianRasterizer(rs)
 
     def step(exchange=True):
@@ -744,10 +782,19 @@ def main():
         tt = torch.tensor([(time.perf_counter() - t0) / 10], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         exchange["allreduce_ms"] = float(tt.item()) * 1e3
-        # ranges of the overlapped exchange: measured, not guessed (same choice on every rank: max over ranks)
-        cand = [a.ar_chunks] if a.ar_chunks > 0 else [1, 4]
+        # How the exchange is issued is measured, not guessed: {all-reduce, reduce-scatter + all-gather} x Gaussian ranges
+        # {1, 4} of the overlapped backward (ranges only with the all-reduce). Every rank times every candidate, the
+        # clocks are combined with MAX over the ranks, so every rank picks the same one.
+        algos = ["all_reduce", "rs_ag"] if (a.ar_algo == "auto" and world > 1 and a.backend == "nccl") else [bucket.algo]
+        cand = [(al, k) for al in algos for k in ([a.ar_chunks] if a.ar_chunks > 0 else [1, 4]) if al == "all_reduce" or k == 1]
+        if not cand:
+            cand = [(algos[0], 1)]
+        buckets = {bucket.algo: bucket}
         tried = {}
-        for k in cand:
+        for al, k in cand:
+            if al not in buckets:
+                buckets[al] = GradBucket([params[n] for n in names], cols=bucket_cols, names=names, algo=al)
+            bucket = buckets[al]
             bucket.chunks = k
             for _ in range(3):
                 step()
@@ -758,9 +805,14 @@ def main():
             fence()
             tt = torch.tensor([(time.perf_counter() - t0) / 10], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            tried[str(k)] = float(tt.item()) * 1e3
-        bucket.chunks = int(min(tried, key=tried.get))
-        exchange.update(chunks=bucket.chunks, chunks_tried_ms_per_step=tried)
+            tried[f"{al}/{k}"] = float(tt.item()) * 1e3
+        best = min(tried, key=tried.get)
+        bucket = buckets[best.split("/")[0]]
+        bucket.chunks = int(best.split("/")[1])
+        for al, b in buckets.items():
+            if b is not bucket:
+                b.close()
+        exchange.update(algo=bucket.algo, chunks=bucket.chunks, candidates_tried_ms_per_step=tried)
     for _ in range(a.warmup):
         step()
     fence()
@@ -801,6 +853,10 @@ def main():
     # above (csrc/common.h nr_pack)
     R, R_entries = (nr & 0x7FFFFFFF, (nr >> 32) & 0x1FFFFFFF) if nr >= 0 else (-1, -1)
 
+    ti_dist = None
+    if use_dist and not a.no_train_iter:
+        # the iteration that can actually scale: three renders, ONE exchange, the optimizer step
+        ti_dist = train_iteration(sc, P, H, W, dev, fused=True, dist=dist, view_seed=rank, algo=bucket.algo)
     if rank == 0:
         ms_step = dt / a.steps * 1e3
         kern = {k: ms / a.steps for k, (ms, n) in prof.items() if n}  # device ms per step of each kernel group
@@ -869,6 +925,8 @@ def main():
             line["exchange"] = exchange
             line["rccl_ranks"] = exchange["rccl_ranks"]
             line["allreduce_ms"] = exchange["allreduce_ms"]
+        if use_dist and not a.no_train_iter:
+            line["train_iter_fused"] = ti_dist
         if world == 1 and not use_dist and not a.no_train_iter:
             line["train_iter"] = train_iteration(sc, P, H, W, dev, fused=False)
             line["train_iter_fused"] = train_iteration(sc, P, H, W, dev, fused=True)

@@ -57,6 +57,7 @@ SIGNATURES = {
         + [_p] * 4  # out_color, out_invdepth, dL_dout_color, dL_dout_invdepth
         + [_p, _z, _p, _z, _p, _z]  # geom, binning, image workspaces
         + [_p] * 9  # 7 gradients + dL_dT_sum + dL_dvm_mean
+        + [_p, _i]  # dL_dcolors_lead, lead_cols
         + [_p],  # stream
     ),
     "eogs_rast_backward_range": (
@@ -67,6 +68,7 @@ SIGNATURES = {
         + [_p] * 4
         + [_p, _z, _p, _z, _p, _z]
         + [_p] * 9
+        + [_p, _i]  # dL_dcolors_lead, lead_cols
         + [_i, _i]  # p_begin, p_end
         + [_p],
     ),

@@ -305,8 +305,8 @@ int eogs_rast_backward_range(int P, int H, int W, int64_t R, const float* bg, co
                              const float* dL_dout_color, const float* dL_dout_invdepth, const void* geom, size_t geom_bytes,
                              const void* binning, size_t binning_bytes, const void* image, size_t image_bytes,
                              float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D,
-                             float* dL_dscales, float* dL_drotations, float* dL_dT_sum, float* dL_dvm_mean, int p_begin,
-                             int p_end, void* stream) {
+                             float* dL_dscales, float* dL_drotations, float* dL_dT_sum, float* dL_dvm_mean,
+                             float* dL_dcolors_lead, int lead_cols, int p_begin, int p_end, void* stream) {
   (void)bg;
   g_err[0] = 0;
   if (P < 0 || H <= 0 || W <= 0 || R < 0) return fail(EOGS_ERR_INVALID_ARG, "backward: bad sizes");
@@ -331,6 +331,7 @@ int eogs_rast_backward_range(int P, int H, int W, int64_t R, const float* bg, co
   if (raw && (!have_sr || !alt_affine))
     return fail(EOGS_ERR_INVALID_ARG, "backward: EOGS_FLAG_RAW_PARAMS needs scales, rotations and alt_affine");
   if (R > 0 && !binning) return fail(EOGS_ERR_INVALID_ARG, "backward: NULL binning workspace");
+  if (dL_dcolors_lead && (lead_cols <= 0 || lead_cols > (raw ? 3 : NCH))) return fail(EOGS_ERR_INVALID_ARG, "backward: bad lead_cols");
 
   char* gb = ws_base(geom);
   const GeomWS g = geom_layout(gb, P);
@@ -353,7 +354,8 @@ int eogs_rast_backward_range(int P, int H, int W, int64_t R, const float* bg, co
   GaussBwdArgs a{P, H, W, means3D, have_sr ? scales : nullptr, have_sr ? rotations : nullptr, cov3D_precomp, opacities,
                  viewmatrix, projmatrix, radii, scale_modifier, (flags & EOGS_FLAG_ANTIALIASING) != 0,
                  dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, have_sr ? dL_dscales : nullptr,
-                 have_sr ? dL_drotations : nullptr, dL_dT_sum, dL_dvm_mean, raw, alt_affine};
+                 have_sr ? dL_drotations : nullptr, dL_dT_sum, dL_dvm_mean, raw, alt_affine, dL_dcolors_lead,
+                 dL_dcolors_lead ? lead_cols : 0};
   { ProfScope ps(PS_GAUSS_BWD, s); launch_gaussian_bwd(a, g, b, p_begin, p_end, s); }
   LAUNCH_TRY(s, debug, "gaussian_bwd");
   return EOGS_OK;
@@ -367,12 +369,13 @@ int eogs_rast_backward(int P, int H, int W, int64_t R, const float* bg, const fl
                        const float* dL_dout_color, const float* dL_dout_invdepth, const void* geom, size_t geom_bytes,
                        const void* binning, size_t binning_bytes, const void* image, size_t image_bytes,
                        float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D,
-                       float* dL_dscales, float* dL_drotations, float* dL_dT_sum, float* dL_dvm_mean, void* stream) {
+                       float* dL_dscales, float* dL_drotations, float* dL_dT_sum, float* dL_dvm_mean,
+                       float* dL_dcolors_lead, int lead_cols, void* stream) {
   return eogs_rast_backward_range(P, H, W, R, bg, means3D, radii, colors, opacities, scales, rotations, scale_modifier,
                                   cov3D_precomp, viewmatrix, projmatrix, alt_affine, flags, out_color, out_invdepth,
                                   dL_dout_color, dL_dout_invdepth, geom, geom_bytes, binning, binning_bytes, image,
                                   image_bytes, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dscales,
-                                  dL_drotations, dL_dT_sum, dL_dvm_mean, 0, P < 0 ? 0 : P, stream);
+                                  dL_drotations, dL_dT_sum, dL_dvm_mean, dL_dcolors_lead, lead_cols, 0, P < 0 ? 0 : P, stream);
 }
 
 int eogs_rast_path_info(int P, int64_t R, int* list_block_px, int* fwd_kernel, int* bwd_kernel) {

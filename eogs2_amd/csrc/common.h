@@ -403,6 +403,8 @@ struct GaussBwdArgs {
   float *dL_dT_sum, *dL_dvm_mean;
   bool raw;  // EOGS_FLAG_RAW_PARAMS
   const float* alt_affine;
+  float* dL_dcolors_lead;  // second destination of the colour gradient's first lead_cols columns (or NULL)
+  int lead_cols;
 };
 // per-Gaussian backward over rows [p_begin, p_end) (p_begin a multiple of BLK); the camera sums are finished by the call
 // whose p_end == P

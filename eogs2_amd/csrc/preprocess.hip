@@ -328,7 +328,10 @@ __global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
   // 0.36 ms here)
   __shared__ uint32_t s_k[5][BLK / 64];
   uint32_t kmax = my_tiles ? key_bits : 0u, knmin = my_tiles ? ~key_bits : 0u, esum = my_tiles ? my_entries : 0u;
-  uint32_t osum = my_tiles * op64;  // <= 65536 tiles * 64 per Gaussian, 256 Gaussians per workgroup: below 2^31
+  // a lane's share saturates at 2^23 - 1 so that the workgroup's sum (256 lanes) stays below 2^31 whatever the image size:
+  // bit 31 of the stored word is the error flag (the sum only feeds the list-granularity heuristic)
+  const unsigned long long o64 = (unsigned long long)my_tiles * op64;
+  uint32_t osum = o64 > 0x7FFFFFull ? 0x7FFFFFu : (uint32_t)o64;
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
     const uint32_t a = __shfl_xor(kmax, o, 64), b = __shfl_xor(knmin, o, 64);
@@ -380,7 +383,8 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
     const uint8_t* __restrict__ live,
     float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscales,
-    float* __restrict__ dL_drotations, bool want_T, bool want_vm, float* __restrict__ vmpart, uint32_t blk0) {
+    float* __restrict__ dL_drotations, bool want_T, bool want_vm, float* __restrict__ vmpart, uint32_t blk0,
+    float* __restrict__ dL_dcolors_lead, int lead_cols) {
   __shared__ float s_m[3 * BLK];
   __shared__ float s_s[3 * BLK];
   __shared__ float s_red[BLK / 64][18];
@@ -588,6 +592,11 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
 #pragma unroll
       for (int ch = 0; ch < NCH; ch++) dL_dcolors[NCH * idx + ch] = acc[6 + ch];
     }
+    if (dL_dcolors_lead) {  // (uniform) the leading columns once more, contiguous: a data-parallel caller's exchange buffer
+#pragma unroll
+      for (int ch = 0; ch < NCH; ch++)
+        if (ch < lead_cols) dL_dcolors_lead[(size_t)lead_cols * idx + ch] = (RAW ? SH_C0 : 1.f) * acc[6 + ch];
+    }
     dL_dopacity[idx] = dop;
 #pragma unroll
     for (int k = 0; k < 3; k++) dL_dmeans3D[3 * idx + k] = dmean3[k];
@@ -667,7 +676,8 @@ void launch_gaussian_bwd(const GaussBwdArgs& a, const GeomWS& g, const BinWS& b,
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(BLK), 0, s, a.P, a.H, a.W, a.means3D, a.scales, a.rotations,
                        a.cov3D_precomp, a.opacities, a.viewmatrix, a.projmatrix, a.alt_affine, a.radii, a.scale_modifier,
                        (int)a.antialiasing, g.binfo, g.pblock, b.records, b.live, a.dL_dmeans2D, a.dL_dcolors, a.dL_dopacity,
-                       a.dL_dmeans3D, a.dL_dcov3D, a.dL_dscales, a.dL_drotations, want_T, want_vm, g.vmpart, blk0);
+                       a.dL_dmeans3D, a.dL_dcov3D, a.dL_dscales, a.dL_drotations, want_T, want_vm, g.vmpart, blk0,
+                       a.dL_dcolors_lead, a.lead_cols);
   if ((want_T || want_vm) && p_end == a.P)
     hipLaunchKernelGGL(camera_sum_kernel, dim3(1), dim3(BLK), 0, s, g.vmpart, nblk_all, a.dL_dT_sum, a.dL_dvm_mean);
 }

@@ -221,7 +221,8 @@ class BackwardPlan:
     """How the next backward hands over its per-Gaussian gradients (used by eogs2_amd.parallel.GradBucket).
 
     `alloc(name, shape, device)` may return the tensor a gradient is written into (name in "means3D", "colors",
-    "opacities", "scales", "rotations"; None -> torch.empty). With `chunks` > 1 the per-Gaussian pass runs over that
+    "opacities", "scales", "rotations"; None -> torch.empty); for "colors_lead" (activated inputs only) it may return a
+    contiguous [P, k] tensor, k <= 5, that receives the first k columns of the colour gradient a second time. With `chunks` > 1 the per-Gaussian pass runs over that
     many ascending Gaussian ranges (eogs_rast_backward_range) and `on_chunk(i, p0, p1, grads)` is called right after
     range i has been queued on the stream — the caller starts its collective on those rows while the next range
     computes. A plan is consumed by ONE backward."""
@@ -300,6 +301,12 @@ def _run_backward(rs, num_rendered, grad_out_color, grad_out_depth, means3D, col
 
         d_means2D = torch.empty((P, 3), **f32)
         d_colors = out("colors", (P, 3 if raw else NUM_CHANNELS))
+        # a plan that exchanges only the leading (f_dc) columns of colors_precomp gets them written a second time,
+        # contiguous, into its buffer (include/eogs_rast.h dL_dcolors_lead)
+        lead = plan.alloc("colors_lead", (P, 3), dev) if (plan is not None and not raw) else None
+        if lead is not None and (lead.dtype != torch.float32 or lead.device != dev or not lead.is_contiguous()
+                                 or lead.ndim != 2 or lead.shape[0] != P or not 0 < lead.shape[1] <= NUM_CHANNELS):
+            raise RuntimeError("backward plan: bad buffer for colors_lead")
         d_opacity = out("opacities", (P, 1))
         d_means3D = out("means3D", (P, 3))
         d_cov3D = None if (raw or have_sr) else torch.empty((P, 6), **f32)  # only returned for cov3D_precomp inputs
@@ -318,7 +325,7 @@ def _run_backward(rs, num_rendered, grad_out_color, grad_out_depth, means3D, col
             _ptr(color), _ptr(invdepths), _ptr(g_color), _ptr(g_depth),
             _ptr(geom), geom.numel(), _ptr(binning), binning.numel(), _ptr(img), img.numel(),
             _ptr(d_means2D), _ptr(d_colors), _ptr(d_opacity), _ptr(d_means3D), _ptr(d_cov3D),
-            _ptr(d_scales), _ptr(d_rot), _ptr(dT_sum), _ptr(dvm_mean),
+            _ptr(d_scales), _ptr(d_rot), _ptr(dT_sum), _ptr(dvm_mean), _ptr(lead), 0 if lead is None else int(lead.shape[1]),
         )
         if plan is None or plan.chunks <= 1:
             abi.check(abi.backward(*args, cx.stream))

@@ -136,6 +136,10 @@ int eogs_rast_forward_render(
  *     (the reference kernel writes dL_dT[idx+k], DGR/cuda_rasterizer/backward.cu:320-325).
  *   dL_dvm_mean f32[12] or NULL: [0:9] = means3D^T @ dL_dmeans2D (3x3 row-major), [9:12] = sum_P dL_dmeans2D
  *     (DGR/diff_gaussian_rasterization/__init__.py:193-201).
+ *   dL_dcolors_lead f32[P, lead_cols] or NULL: a second destination for the first lead_cols columns of every dL_dcolors
+ *     row, contiguous. A data-parallel caller points it at the f_dc block of its gradient exchange buffer (the three
+ *     colour columns of colors_precomp are model parameters, the altitude / constant columns are not), so that no
+ *     copy kernel runs between the backward and the collective. dL_dcolors is written in full either way.
  */
 int eogs_rast_backward(
     int P, int H, int W, int64_t num_rendered,
@@ -149,7 +153,7 @@ int eogs_rast_backward(
     const void* image, size_t image_bytes,
     float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity,
     float* dL_dmeans3D, float* dL_dcov3D, float* dL_dscales, float* dL_drotations,
-    float* dL_dT_sum, float* dL_dvm_mean, void* stream);
+    float* dL_dT_sum, float* dL_dvm_mean, float* dL_dcolors_lead, int lead_cols, void* stream);
 
 /* Backward over a range of Gaussians: the same computation as eogs_rast_backward, split so that a data-parallel
  * caller can hand finished gradient rows to the collective while later rows are still being computed
@@ -172,7 +176,7 @@ int eogs_rast_backward_range(
     const void* image, size_t image_bytes,
     float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity,
     float* dL_dmeans3D, float* dL_dcov3D, float* dL_dscales, float* dL_drotations,
-    float* dL_dT_sum, float* dL_dvm_mean, int p_begin, int p_end, void* stream);
+    float* dL_dT_sum, float* dL_dvm_mean, float* dL_dcolors_lead, int lead_cols, int p_begin, int p_end, void* stream);
 
 /* Replaces CudaRasterizer::Rasterizer::markVisible (DGR/cuda_rasterizer/rasterizer_impl.cu:141-153).
  * The reference predicate has its culling commented out (DGR/cuda_rasterizer/auxiliary.h:151-176),

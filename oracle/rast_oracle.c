@@ -802,7 +802,7 @@ int eogs_rast_forward_prepare(
   return rc;
 }
 
-int eogs_rast_backward(
+static int backward_full(
     int P, int H, int W, int64_t R,
     const float* bg, const float* means3D, const int* radii, const float* colors,
     const float* opacities, const float* scales, const float* rotations,
@@ -876,7 +876,7 @@ int eogs_rast_backward(
 
 /* Range form of the backward (include/eogs_rast.h): the checker evaluates the whole backward into temporaries and copies
  * rows [p_begin, p_end) out — K times the work for K ranges, which only ever run at test sizes. */
-int eogs_rast_backward_range(
+static int backward_range_impl(
     int P, int H, int W, int64_t R,
     const float* bg, const float* means3D, const int* radii, const float* colors,
     const float* opacities, const float* scales, const float* rotations,
@@ -892,7 +892,7 @@ int eogs_rast_backward_range(
   if (P < 0 || p_begin < 0 || p_end < p_begin || p_end > P || (p_begin % 256) != 0 || (p_end != P && (p_end % 256) != 0))
     return fail(EOGS_ERR_INVALID_ARG, "backward: the Gaussian range must lie in [0, P] with multiples of 256 as inner bounds");
   if (p_begin == 0 && p_end == P)
-    return eogs_rast_backward(P, H, W, R, bg, means3D, radii, colors, opacities, scales, rotations, scale_modifier,
+    return backward_full(P, H, W, R, bg, means3D, radii, colors, opacities, scales, rotations, scale_modifier,
                               cov3D_precomp, viewmatrix, projmatrix, alt_affine, flags, out_color, out_invdepth,
                               dL_dout_color, dL_dout_invdepth, geom, geom_bytes, binning, binning_bytes, image,
                               image_bytes, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dscales,
@@ -906,7 +906,7 @@ int eogs_rast_backward_range(
     if (dst[k] && !(tmp[k] = (float*)malloc(n * w[k] * 4 + 4))) rc = fail(EOGS_ERR_DEVICE, "backward: out of host memory");
   float tsum[6], vsum[12];
   if (rc == EOGS_OK)
-    rc = eogs_rast_backward(P, H, W, R, bg, means3D, radii, colors, opacities, scales, rotations, scale_modifier,
+    rc = backward_full(P, H, W, R, bg, means3D, radii, colors, opacities, scales, rotations, scale_modifier,
                             cov3D_precomp, viewmatrix, projmatrix, alt_affine, flags, out_color, out_invdepth,
                             dL_dout_color, dL_dout_invdepth, geom, geom_bytes, binning, binning_bytes, image, image_bytes,
                             tmp[0], tmp[1], tmp[2], tmp[3], tmp[4], tmp[5], tmp[6], dL_dT_sum ? tsum : NULL,
@@ -955,4 +955,63 @@ int eogs_rast_selftest(void* scratch, unsigned* failed, void* stream) {
   (void)scratch; (void)stream;
   if (failed) *failed = 0;
   return EOGS_OK;
+}
+
+/* Exported backward entry points: the computation above plus the optional second destination of the colour gradient's
+ * leading columns (include/eogs_rast.h dL_dcolors_lead: a data-parallel caller's exchange buffer). */
+static void copy_lead(int P, unsigned flags, const float* dL_dcolors, float* lead, int lead_cols, int p0, int p1) {
+  const int ncol = (flags & EOGS_FLAG_RAW_PARAMS) ? 3 : C_;
+  if (!lead || P <= 0) return;
+  for (int i = p0; i < p1; i++)
+    for (int k = 0; k < lead_cols; k++) lead[(size_t)i * lead_cols + k] = dL_dcolors[(size_t)i * ncol + k];
+}
+static int lead_ok(unsigned flags, const float* lead, int lead_cols) {
+  const int ncol = (flags & EOGS_FLAG_RAW_PARAMS) ? 3 : C_;
+  return !lead || (lead_cols > 0 && lead_cols <= ncol);
+}
+
+int eogs_rast_backward(
+    int P, int H, int W, int64_t R,
+    const float* bg, const float* means3D, const int* radii, const float* colors,
+    const float* opacities, const float* scales, const float* rotations,
+    float scale_modifier, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* alt_affine, unsigned flags,
+    const float* out_color, const float* out_invdepth,
+    const float* dL_dout_color, const float* dL_dout_invdepth,
+    const void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes,
+    const void* image, size_t image_bytes,
+    float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity,
+    float* dL_dmeans3D, float* dL_dcov3D, float* dL_dscales, float* dL_drotations,
+    float* dL_dT_sum, float* dL_dvm_mean, float* dL_dcolors_lead, int lead_cols, void* stream) {
+  if (!lead_ok(flags, dL_dcolors_lead, lead_cols)) return fail(EOGS_ERR_INVALID_ARG, "backward: bad lead_cols");
+  const int rc = backward_full(P, H, W, R, bg, means3D, radii, colors, opacities, scales, rotations, scale_modifier,
+                               cov3D_precomp, viewmatrix, projmatrix, alt_affine, flags, out_color, out_invdepth,
+                               dL_dout_color, dL_dout_invdepth, geom, geom_bytes, binning, binning_bytes, image, image_bytes,
+                               dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dscales, dL_drotations,
+                               dL_dT_sum, dL_dvm_mean, stream);
+  if (rc == EOGS_OK) copy_lead(P, flags, dL_dcolors, dL_dcolors_lead, lead_cols, 0, P);
+  return rc;
+}
+
+int eogs_rast_backward_range(
+    int P, int H, int W, int64_t R,
+    const float* bg, const float* means3D, const int* radii, const float* colors,
+    const float* opacities, const float* scales, const float* rotations,
+    float scale_modifier, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* alt_affine, unsigned flags,
+    const float* out_color, const float* out_invdepth,
+    const float* dL_dout_color, const float* dL_dout_invdepth,
+    const void* geom, size_t geom_bytes, const void* binning, size_t binning_bytes,
+    const void* image, size_t image_bytes,
+    float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity,
+    float* dL_dmeans3D, float* dL_dcov3D, float* dL_dscales, float* dL_drotations,
+    float* dL_dT_sum, float* dL_dvm_mean, float* dL_dcolors_lead, int lead_cols, int p_begin, int p_end, void* stream) {
+  if (!lead_ok(flags, dL_dcolors_lead, lead_cols)) return fail(EOGS_ERR_INVALID_ARG, "backward: bad lead_cols");
+  const int rc = backward_range_impl(P, H, W, R, bg, means3D, radii, colors, opacities, scales, rotations, scale_modifier,
+                                     cov3D_precomp, viewmatrix, projmatrix, alt_affine, flags, out_color, out_invdepth,
+                                     dL_dout_color, dL_dout_invdepth, geom, geom_bytes, binning, binning_bytes, image,
+                                     image_bytes, dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dscales,
+                                     dL_drotations, dL_dT_sum, dL_dvm_mean, p_begin, p_end, stream);
+  if (rc == EOGS_OK) copy_lead(P, flags, dL_dcolors, dL_dcolors_lead, lead_cols, p_begin, p_end);
+  return rc;
 }

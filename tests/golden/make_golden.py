@@ -88,7 +88,7 @@ def stub_backward(bg, means3D, radii, colors, opacities, scales, rotations, scal
             float(scale_modifier), _p(cv), _p(vm), _p(pm), None, flags, None, None, _p(gcol), _p(gdep),
             _p(geom), geom.numel(), _p(binning), binning.numel(), _p(img), img.numel(),
             _p(d_m2), _p(d_col), _p(d_op), _p(d_m3), _p(d_cov), _p(d_sc) if have_sr else None, _p(d_rot) if have_sr else None,
-            _p(dTs), _p(dvm), None))
+            _p(dTs), _p(dvm), None, 0, None))
         d_T[0] = dTs
     return d_m2, d_col, d_op, d_m3, d_cov, d_sh, d_sc, d_rot, d_T
 

@@ -79,6 +79,7 @@ def _worker(rank, world, port, out_dir):
     for chunks in (1, 2):
         p2, b2 = _overlapped_step(rank, chunks)
         assert b2.exchanges == chunks
+        assert all(b2._placed), "every exchanged column is written by the backward itself (dL_dcolors_lead for colors)"
         for i, k in enumerate(NAMES):
             assert b2._is_block(p2[k].grad, i) == (k != "colors"), k
         ov[chunks] = {k: p2[k].grad.clone() for k in NAMES}
@@ -119,6 +120,60 @@ def test_two_rank_grad_allreduce(tmp_path):
         assert torch.equal(outs[r]["den"], torch.full((P, 1), 2.0))
         assert torch.equal(outs[r]["mr"], torch.maximum(singles[0][1], singles[1][1]).float())
     assert torch.equal(outs[0]["grads"]["means3D"], outs[1]["grads"]["means3D"])
+
+
+def test_overlapped_path_refuses_other_gradient_sources():
+    """The begin()/finish() path is only right when the bucketed gradients come from the one rasterizer backward: a second
+    backward while armed raises at once, a loss term that autograd sums into a parameter's gradient raises in finish(),
+    and the synchronous all_reduce() takes both cases."""
+    import oracle
+    from eogs2_amd import GaussianRasterizer, _lib
+    from eogs2_amd.parallel import GradBucket
+    from eogs2_amd.synthetic import make_camera, make_scene, settings_for
+
+    product_get = _lib.get
+    _lib.get = oracle.abi  # test-only checker backend (CPU tensors)
+    try:
+        sc = make_scene(P, H, W, seed=0, opacity="trained", scale_mult=3.0)
+        sc["viewmatrix"] = make_camera(H, W, seed=0)
+        params = {k: sc[k].clone().requires_grad_(True) for k in NAMES}
+        rast = GaussianRasterizer(settings_for(sc, H, W))
+
+        def render():
+            return rast(params["means3D"], torch.zeros(P, 3), params["opacities"], colors_precomp=params["colors"],
+                        scales=params["scales"], rotations=params["rotations"])[0]
+
+        bucket = GradBucket([params[k] for k in NAMES], cols=COLS, names=NAMES)
+        # (1) the plain single-backward step passes, twice (first step verified by value, second by identity)
+        for _ in range(2):
+            bucket.begin()
+            (render() * sc["dL_dcolor"]).sum().backward()
+            bucket.finish()
+        ref = {k: params[k].grad.clone() for k in NAMES}
+        # (2) a regulariser on the opacities in the same backward: autograd sums it into the gradient
+        bucket.begin()
+        ((render() * sc["dL_dcolor"]).sum() + params["opacities"].sum()).backward()
+        with pytest.raises(RuntimeError, match="another loss term"):
+            bucket.finish()
+        # (3) a second render + backward while armed
+        bucket.begin()
+        (render() * sc["dL_dcolor"]).sum().backward()
+        with pytest.raises(RuntimeError, match="second gradient"):
+            (render() * sc["dL_dcolor"]).sum().backward()
+        bucket._armed = False
+        from eogs2_amd.rasterizer import set_backward_plan
+        set_backward_plan(None)
+        # (4) the synchronous path takes any number of sources
+        for p in params.values():
+            p.grad = None
+        for _ in range(2):
+            ((render() * sc["dL_dcolor"]).sum() + params["opacities"].sum()).backward()
+        bucket.all_reduce()
+        assert torch.allclose(params["means3D"].grad, 2 * ref["means3D"], rtol=1e-6, atol=1e-12)
+        assert torch.allclose(params["opacities"].grad, 2 * ref["opacities"] + 2, rtol=1e-6, atol=1e-9)
+        bucket.close()
+    finally:
+        _lib.get = product_get
 
 
 @pytest.mark.parametrize("n", [2, 4])
@@ -182,6 +237,21 @@ def test_view_sharded_schedule():
             s8["position_lr_max_steps"]) == (1250, 62, 12, 375, 3750)
     assert s8["densify_until_iter"] == -1 and s8["lambda_dssim"] == 0.2 and s8["only_prune"] is True and s8["grad_average"]
     assert math.isclose(s8["position_lr_init"], 1.6e-4 * math.sqrt(8)) and math.isclose(s8["feature_lr"], 0.0025 * math.sqrt(8))
+    assert s8["iterend_opacity_reset_interval"] == 999999999  # the reference's "never" stays never
     # views seen before each event differ from the reference's by less than one step's worth of views
     for k in ("iterations", "densify_from_iter", "densification_interval", "opacity_reset_interval"):
         assert abs(s8[k] * 8 - opt[k]) < 8, k
+    # the reference's own layout (gs_config/train.yaml:87-130): densification knobs one level down, per-loss thresholds
+    nested = {"iterations": 10000, "position_lr_init": 1.6e-4, "opacity_reset_interval": 3000,
+              "densification_strategy": {"densify_from_iter": 500, "densification_interval": 100, "densify_grad_threshold": 2e-6},
+              "iterstart_shadowmapping": 1000, "iterstart_L_new_resample": 1000, "iterstart_L_opacity": -1,
+              "iterstart_L_erank": 9999999999, "iterend_L_opacity": 99999999}
+    n8 = view_sharded_schedule(nested, 8, strict=True)
+    assert n8["densification_strategy"] == {"densify_from_iter": 62, "densification_interval": 12, "densify_grad_threshold": 2e-6}
+    assert (n8["iterstart_shadowmapping"], n8["iterstart_L_new_resample"], n8["iterstart_L_opacity"]) == (125, 125, -1)
+    assert n8["iterstart_L_erank"] == 9999999999 and n8["iterend_L_opacity"] == 99999999
+    assert nested["densification_strategy"]["densify_from_iter"] == 500  # the input is not modified
+    with pytest.raises(RuntimeError, match="lack"):
+        view_sharded_schedule({"feature_lr": 0.0025}, 8, strict=True)
+    with pytest.warns(UserWarning, match="lack"):
+        view_sharded_schedule({"feature_lr": 0.0025}, 8)

@@ -26,8 +26,13 @@ def test_two_rank_bench_rehearsal():
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["parallelism"] == "view-dp2"
     ex = line["exchange"]
     assert ex["rccl_ranks"] == 2 and ex["bytes_per_gaussian"] == 56 and ex["chunks"] in (1, 4)
-    assert set(ex["chunks_tried_ms_per_step"]) == {"1", "4"}
+    # (reduce-scatter + all-gather is an RCCL candidate only: over gloo the all-reduce with 1 and 4 ranges is measured)
+    assert set(ex["candidates_tried_ms_per_step"]) == {"all_reduce/1", "all_reduce/4"} and ex["algo"] == "all_reduce"
     assert line["value"] > 0 and line["ms_per_step"] > 0
+    # the iteration that scales: three renders, ONE synchronous exchange of the raw-parameter gradients, the optimizer step
+    ti = line["train_iter_fused"]
+    assert ti["n_gpus"] == 2 and ti["renders_per_iter"] == 3 and ti["exchange"]["bytes_per_gaussian"] == 56
+    assert ti["ms_per_iter"] >= ti["compute_only_ms"] * 0.8 and ti["exchange_alone_ms"] > 0
 
 
 def test_two_rank_bench_under_torchrun():
