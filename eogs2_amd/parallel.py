@@ -82,7 +82,7 @@ class GradBucket(BackwardPlan):
       armed steps, by identity afterwards.
     """
 
-    def __init__(self, params, cols=None, names=None, chunks=1, group=None, algo="all_reduce", verify_steps=1):
+    def __init__(self, params, cols=None, names=None, chunks=1, group=None, algo="all_reduce", verify_steps=1, async_whole=True):
         self.params = list(params)
         P = self.params[0].shape[0]
         assert all(p.ndim >= 2 and p.shape[0] == P for p in self.params)
@@ -112,6 +112,7 @@ class GradBucket(BackwardPlan):
         self.algo = algo if (backend == "nccl" and self.world > 1) else "all_reduce"
         # one grouped launch for the pieces of a Gaussian range: RCCL only (decided once, never per call)
         self._coalesce = backend == "nccl" and hasattr(dist, "_coalescing_manager")
+        self._async_whole = bool(async_whole)  # whole-buffer exchange of the armed path: asynchronous handle, or issued in line
         self._shard = torch.empty(o // self.world, dtype=torch.float32, device=self.flat.device) if self.algo == "rs_ag" else None
         self._works = []
         self._armed = False      # begin() called, backward not yet seen
@@ -266,7 +267,7 @@ class GradBucket(BackwardPlan):
         if not _dist_on():
             return
         if whole:
-            self._works += self._exchange_whole(async_op=True)
+            self._works += self._exchange_whole(async_op=self._async_whole)
         elif self._coalesce:  # one grouped launch for the pieces of this range
             with dist._coalescing_manager(group=self.group, async_ops=True) as cm:
                 for v in views:

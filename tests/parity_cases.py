@@ -1,14 +1,18 @@
-"""Shared pieces of the GPU parity tests: the seeded case tables, the comparison with its tolerances, and the
-ATTRIBUTION of every out-of-tolerance element to a blend / skip decision that sits on a threshold.
+"""Shared pieces of the GPU parity tests: the seeded case tables, the comparison with its tolerances, and the CAUSAL
+attribution of every out-of-tolerance element to a blend / skip decision that sits on a threshold.
 
-North_star's tolerance is 1e-4 relative. The reference algorithm has three discontinuities per (pixel, Gaussian) pair
+North_star's tolerance is 1e-4 relative. The reference algorithm has data-dependent decisions per (pixel, Gaussian) pair
 (DGR/cuda_rasterizer/forward.cu:366-382): skip if power > 0, skip if alpha < 1/255, stop the pixel BEFORE the Gaussian that
 would make T < 1e-4. Two fp32 implementations (libm expf on the host, v_exp_f32 on the GPU, different but equally valid
 association of the exponent) can land on different sides of a threshold for a pair that sits within a few ulp of it; the
-pixel then differs by up to alpha T |c| and so does every gradient fed by that pixel. Such elements are allowed ONLY when
-attributed: `threshold_map` recomputes, on the CPU from the case's inputs, which pixels hold a pair within a stated number
-of ulp of a threshold, and an out-of-tolerance element must belong to such a pixel (images) or to a Gaussian whose tile
-rect contains such a pixel (per-Gaussian gradients). Everything else must meet the tolerance outright.
+pixel then differs by up to alpha T |c| and so does every gradient fed by that pixel. Such elements are accepted ONLY when
+the oracle itself reproduces them with the decision moved: the oracle is re-run with both thresholds shifted by
+-k / +k ulp (k = (16 + 8 |power|) for the alpha test, (16 + 4 n) for the stop test: `eogs_oracle_threshold_nudge`), a
+per-pixel sign is chosen from the three images so that the oracle's image matches the HIP image, the oracle runs once more
+with that per-pixel map, and every output and gradient must then agree with THAT run to the plain tolerance (or, where one
+pixel holds several near pairs that flipped differently, lie inside the interval the four oracle runs span). What is still
+outside must be explained by the oracle's own ill-conditioning (sensitivity map) or the test fails. The number of accepted
+elements per tensor is capped: a regression cannot hide behind the mechanism.
 """
 import numpy as np
 import torch
@@ -64,127 +68,8 @@ def sweep_case(seed):
     case.update(H=H, W=W, antialiasing=aa)
     if dgrad:
         case["dL_dinvdepth"] = (torch.randn(1, H, W, generator=g) / (H * W) * 100).numpy()
-    stress = scale_mult >= 6.0 or aniso >= 0.7  # cancellation-heavy gradient sums: tests/util.py GRAD_RTOL
+    stress = scale_mult >= 6.0 and aniso >= 0.7  # cancellation-heavy gradient sums: tests/util.py GRAD_RTOL
     return case, ("seed15" if stress else f"sweep{seed}")
-
-
-class ThresholdMap:
-    """Which pixels hold a (pixel, Gaussian) pair within a stated number of ulp of a blend / skip / stop threshold,
-    evaluated per 16 x 16 tile ON DEMAND (at 1 M Gaussians / 1024^2 a full map costs minutes; the tiles behind a handful
-    of out-of-tolerance elements cost seconds).
-
-    near pixel: some candidate Gaussian of the pixel (its 16-px tile lies in the Gaussian's tile rect, power <= 0, the
-    pixel not yet terminated) has |alpha 255 - 1| <= (k_alpha[0] + k_alpha[1] |power|) ulp — the exponent carries a
-    relative rounding error of a few ulp, which the exponential turns into |power| times that — or a transmittance test
-    with |T' / 1e-4 - 1| <= (k_T[0] + k_T[1] n) ulp, n = Gaussians blended so far at the pixel (T' is a product of n
-    rounded factors). Evaluated in fp32 with the reference's own formulas (oracle/torch_dense.py restates them).
-    touched Gaussian: its tile rect contains a near pixel (a flipped pixel changes the gradients of the flipped
-    Gaussian and of everything blended behind it there)."""
-
-    def __init__(self, case, k_alpha=(16.0, 8.0), k_T=(16.0, 4.0)):
-        from oracle.torch_dense import TILE, cov3d_full, cov6_to_full, project
-
-        self.k_alpha, self.k_T, self.TILE = k_alpha, k_T, TILE
-        t = lambda k: torch.from_numpy(np.asarray(case[k]))
-        self.H, self.W = int(case["H"]), int(case["W"])
-        H, W = self.H, self.W
-        means3D, opac0, vm = t("means3D"), t("opacities").reshape(-1), t("viewmatrix")
-        self.P = means3D.shape[0]
-        self.tiles = {}  # (ty, tx) -> bool [th, tw]
-        self.gx, self.gy = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
-        if self.P == 0:
-            return
-        self.pix, depth = project(means3D, vm, H, W)
-        Sigma = cov6_to_full(t("cov3D_precomp")) if "cov3D_precomp" in case else cov3d_full(t("scales"), t("rotations"), 1.0)
-        s = torch.tensor([W / 2.0, H / 2.0])
-        T = vm[:3, :2].t() * s[:, None]
-        cov2 = T @ Sigma @ T.t()
-        a0, b0, c0 = cov2[:, 0, 0], cov2[:, 0, 1], cov2[:, 1, 1]
-        det0 = a0 * c0 - b0 * b0
-        a, c, b = a0 + 0.3, c0 + 0.3, b0
-        det = a * c - b * b
-        self.opac = opac0 * torch.sqrt(torch.clamp(det0 / det, min=0.000025)) if bool(case["antialiasing"]) else opac0
-        self.ca, self.cb, self.cc = c / det, -b / det, a / det
-        mid = 0.5 * (a + c)
-        root = torch.sqrt(torch.clamp(mid * mid - det, min=0.1))
-        radius = torch.ceil(3.0 * torch.sqrt(torch.maximum(mid + root, mid - root)))
-        ri = radius.to(torch.int32).float()
-        tdiv = lambda v: torch.trunc(v / TILE).to(torch.int64)
-        self.x0, self.y0 = tdiv(self.pix[:, 0] - ri).clamp(0, self.gx), tdiv(self.pix[:, 1] - ri).clamp(0, self.gy)
-        self.x1 = tdiv(self.pix[:, 0] + ri + (TILE - 1)).clamp(0, self.gx)
-        self.y1 = tdiv(self.pix[:, 1] + ri + (TILE - 1)).clamp(0, self.gy)
-        self.visible = (det != 0) & ((self.x1 - self.x0) * (self.y1 - self.y0) > 0)
-        order = torch.sort(depth, stable=True).indices
-        self.order = order[self.visible[order]]
-        # depth-ordered copies of the rects: one boolean pass per tile
-        self.ox0, self.ox1, self.oy0, self.oy1 = (v[self.order] for v in (self.x0, self.x1, self.y0, self.y1))
-
-    def tile(self, ty, tx):
-        """near mask of the 16 x 16 tile (ty, tx) (clipped at the image border)."""
-        key = (int(ty), int(tx))
-        if key in self.tiles:
-            return self.tiles[key]
-        TILE, H, W = self.TILE, self.H, self.W
-        ys, xs = torch.arange(ty * TILE, min((ty + 1) * TILE, H)), torch.arange(tx * TILE, min((tx + 1) * TILE, W))
-        out = torch.zeros(ys.numel(), xs.numel(), dtype=torch.bool)
-        ids = self.order[(self.ox0 <= tx) & (self.ox1 > tx) & (self.oy0 <= ty) & (self.oy1 > ty)] if self.P else None
-        if ids is not None and ids.numel():
-            PY, PX = torch.meshgrid(ys, xs, indexing="ij")
-            pxf, pyf = PX.reshape(-1).float(), PY.reshape(-1).float()
-            dx = self.pix[ids, 0][:, None] - pxf[None, :]
-            dy = self.pix[ids, 1][:, None] - pyf[None, :]
-            power = -0.5 * (self.ca[ids][:, None] * dx * dx + self.cc[ids][:, None] * dy * dy) - self.cb[ids][:, None] * dx * dy
-            alpha = torch.clamp(self.opac[ids][:, None] * torch.exp(power), max=0.99)
-            cand = power <= 0  # (every listed Gaussian's rect contains the whole tile)
-            valid = cand & (alpha >= 1.0 / 255.0)
-            av = torch.where(valid, alpha, torch.zeros_like(alpha))
-            T_after = torch.cumprod(1 - av, dim=0)
-            nblend = torch.cumsum(valid.to(torch.int32), dim=0).float()
-            # a pixel keeps evaluating candidates until it stops; widen "not yet stopped" by the T margin itself
-            tolT = (self.k_T[0] + self.k_T[1] * nblend) * ULP
-            alive = torch.cumsum((valid & (T_after < 0.0001 * (1 - tolT))).to(torch.int32), dim=0) == 0
-            tolA = (self.k_alpha[0] + self.k_alpha[1] * power.abs()) * ULP
-            near_a = cand & alive & ((alpha * 255.0 - 1.0).abs() <= tolA)
-            near_t = valid & alive & ((T_after / 0.0001 - 1.0).abs() <= tolT)
-            out = (near_a | near_t).any(dim=0).view(ys.numel(), xs.numel())
-        self.tiles[key] = out
-        return out
-
-    def pixels_near(self, ys, xs):
-        """bool per (y, x) pair: is that pixel a near-threshold pixel?"""
-        res = torch.zeros(len(ys), dtype=torch.bool)
-        for i, (y, x) in enumerate(zip(ys.tolist(), xs.tolist())):
-            res[i] = self.tile(y // self.TILE, x // self.TILE)[y % self.TILE, x % self.TILE]
-        return res
-
-    def gaussians_touched(self, idx):
-        """bool per Gaussian index: does its tile rect contain a near-threshold pixel?"""
-        res = torch.zeros(len(idx), dtype=torch.bool)
-        for i, g in enumerate(idx.tolist()):
-            if not bool(self.visible[g]):
-                continue
-            hit = False
-            for ty in range(int(self.y0[g]), int(self.y1[g])):
-                for tx in range(int(self.x0[g]), int(self.x1[g])):
-                    if bool(self.tile(ty, tx).any()):
-                        hit = True
-                        break
-                if hit:
-                    break
-            res[i] = hit
-        return res
-
-
-def threshold_map(case):
-    """(near[H,W] bool, touched[P] bool), everything evaluated (small cases / diagnostics)."""
-    tm = ThresholdMap(case)
-    near = torch.zeros(tm.H, tm.W, dtype=torch.bool)
-    for ty in range(tm.gy):
-        for tx in range(tm.gx):
-            m = tm.tile(ty, tx)
-            near[ty * tm.TILE:ty * tm.TILE + m.shape[0], tx * tm.TILE:tx * tm.TILE + m.shape[1]] = m
-    touched = tm.gaussians_touched(torch.arange(tm.P)) if tm.P else torch.zeros(0, dtype=torch.bool)
-    return near, touched
 
 
 def oracle_run(case, backend=None):
@@ -204,6 +89,44 @@ def oracle_run(case, backend=None):
 
 
 SENS_ULPS, SENS_DRAWS, SENS_FACTOR = 4.0, 4, 4.0
+
+
+def nudged_run(case, uniform=0, sign_map=None):
+    """The case through the oracle with its blend / stop thresholds moved (oracle/rast_oracle.c
+    eogs_oracle_threshold_nudge): uniformly by `uniform` in {-1, +1} margins, or per pixel by `sign_map` (int8 [H, W])."""
+    import ctypes
+
+    import oracle
+
+    lib = oracle.abi().cdll
+    lib.eogs_oracle_threshold_nudge.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    if sign_map is not None:
+        m = np.ascontiguousarray(sign_map, dtype=np.int8)
+        lib.eogs_oracle_threshold_nudge(0, m.ctypes.data_as(ctypes.c_void_p), m.size, None)
+    else:
+        lib.eogs_oracle_threshold_nudge(int(uniform), None, 0, None)
+    try:
+        return oracle_run(case)
+    finally:
+        lib.eogs_oracle_threshold_nudge(0, None, 0, None)
+
+
+def formulation_delta(case, base):
+    """|oracle evaluated with the HIP path's formulation of dL/dalpha - oracle|: front to back, the sum behind a Gaussian
+    taken as (rendered total - running prefix) instead of the reference's back-to-front recursion (render.hip; algebraically
+    identical). Where a Gaussian's contribution is orders below the pixel's total (image-sized opaque Gaussians stacked
+    hundreds deep) the subtraction carries an absolute error of an ulp of the TOTAL. This is a property of the implementation
+    under test, so it is NOT part of the sensitivity map: elements only it explains are reported and accepted under a
+    separate, much tighter allowance (check_close). tools/suffix_probe.py."""
+    import oracle
+
+    lib = oracle.abi().cdll
+    lib.eogs_oracle_suffix_by_subtraction(1)
+    try:
+        res = oracle_run(case)
+    finally:
+        lib.eogs_oracle_suffix_by_subtraction(0)
+    return {k: np.abs(np.asarray(res[k], dtype=np.float64) - np.asarray(base[k], dtype=np.float64)) for k in base if k != "out_radii"}
 
 
 def sensitivity_map(case, base=None):
@@ -226,17 +149,6 @@ def sensitivity_map(case, base=None):
         res = oracle_run(case)
     finally:
         lib.eogs_oracle_accum_float(0)
-    for k in out:
-        out[k] = np.maximum(out[k], np.abs(np.asarray(res[k], dtype=np.float64) - np.asarray(base[k], dtype=np.float64)))
-    # the HIP path's own formulation of dL/dalpha — front to back, the sum behind a Gaussian taken as (rendered total -
-    # running prefix) instead of the reference's back-to-front recursion (render.hip; algebraically identical) — evaluated
-    # by the ORACLE in fp32: where a Gaussian's contribution is orders below the pixel's total (image-sized opaque Gaussians
-    # stacked hundreds deep) the subtraction carries an absolute error of an ulp of the TOTAL. tools/suffix_probe.py.
-    lib.eogs_oracle_suffix_by_subtraction(1)
-    try:
-        res = oracle_run(case)
-    finally:
-        lib.eogs_oracle_suffix_by_subtraction(0)
     for k in out:
         out[k] = np.maximum(out[k], np.abs(np.asarray(res[k], dtype=np.float64) - np.asarray(base[k], dtype=np.float64)))
     # rounding alone: the same restatement built with fused multiply-adds (oracle/Makefile). Expressions of the reference
@@ -263,23 +175,65 @@ def sensitivity_map(case, base=None):
     return out
 
 
+IMAGE_KEYS = ("out_color", "out_invdepth")
+# accepted out-of-tolerance elements per tensor: at most this fraction of its elements (and never fewer than MIN allowed)
+ATTR_FRAC, ATTR_MIN = 1e-3, 16
+# elements explained only by the implementation's own dL/dalpha formulation (formulation_delta): count and size
+FORM_MAX, FORM_RTOL = 2, 1e-3
+
+
 class Attribution:
-    """Lazily evaluated threshold tiles and sensitivity map of one case (only computed when some element is out of
-    tolerance, the threshold tiles only where such elements sit, and the sensitivity map only when the thresholds do not
-    explain them). `cache`: a file prefix for the sensitivity map, which depends on the case alone, so processes that
-    replay the same case (tests/path_child.py) share it."""
+    """Lazily evaluated explanations of one case's out-of-tolerance elements: the nudged oracle runs (only computed when
+    some element is out of tolerance), the sensitivity map (only when the nudges do not explain them) and the formulation
+    delta (only when neither does). `cache`: a file prefix for the sensitivity map, which depends on the case alone, so
+    processes that replay the same case (tests/path_child.py) share it."""
 
-    def __init__(self, case, ref=None, cache=None):
+    def __init__(self, case, out, ref, cache=None):
         self.case = case
-        self.ref = ref
+        self.out = out    # HIP outputs (torch tensors)
+        self.ref = ref    # oracle outputs (numpy)
         self.cache = cache
-        self._tm = None
+        self._matched = None
+        self._hull = None
         self._sens = None
+        self._form = None
+        self.flipped_pixels = 0
 
-    def thresholds(self):
-        if self._tm is None:
-            self._tm = ThresholdMap(self.case)
-        return self._tm
+    def matched(self):
+        """(oracle outputs with per-pixel threshold nudges chosen to reproduce the HIP image, {key: (lo, hi)} over the four
+        oracle runs)."""
+        import time
+
+        if self._matched is None:
+            t0 = time.perf_counter()
+            runs = {-1: nudged_run(self.case, uniform=-1), 0: self.ref, 1: nudged_run(self.case, uniform=1)}
+            H, W = int(self.case["H"]), int(self.case["W"])
+            err = {}
+            for sgn, r in runs.items():
+                e = np.zeros((H, W))
+                for k in IMAGE_KEYS:
+                    if k in self.out and k in r:
+                        a = self.out[k].detach().cpu().double().numpy().reshape(-1, H, W)
+                        b = np.asarray(r[k], dtype=np.float64).reshape(-1, H, W)
+                        scale = max(float(np.abs(np.asarray(self.ref[k])).max()), 1e-30)
+                        e = np.maximum(e, np.abs(a - b).max(0) / scale)
+                err[sgn] = e
+            sign = np.zeros((H, W), dtype=np.int8)
+            better_m, better_p = err[-1] < err[0], err[1] < err[0]
+            off = err[0] > RTOL  # only where the un-nudged oracle disagrees with the HIP image
+            sign[off & better_p & (err[1] <= err[-1])] = 1
+            sign[off & better_m & (err[-1] < err[1])] = -1
+            self.flipped_pixels = int((sign != 0).sum())
+            m = nudged_run(self.case, sign_map=sign) if self.flipped_pixels else self.ref
+            hull = {}
+            for k in self.ref:
+                if k == "out_radii":
+                    continue
+                stack = np.stack([np.asarray(r[k], dtype=np.float64) for r in (runs[-1], runs[0], runs[1], m)])
+                hull[k] = (stack.min(0), stack.max(0))
+            self._matched, self._hull = m, hull
+            print(f"threshold nudges: {self.flipped_pixels} pixels re-decided, {time.perf_counter() - t0:.1f} s of oracle")
+        return self._matched, self._hull
 
     def sensitivity(self, key):
         import os
@@ -299,13 +253,21 @@ class Attribution:
                     np.savez(f, **self._sens)
         return torch.from_numpy(self._sens[key])
 
+    def formulation(self, key):
+        if self._form is None:
+            self._form = formulation_delta(self.case, self.ref)
+        return torch.from_numpy(self._form[key])
 
-def check_close(got, ref, what, rtol, attribution=None, kind=None, flip_rtol=5e-2, key=None, sens_rtol=1e-1, flip_abs=0.0):
-    """|got - ref| <= rtol * max|ref| elementwise; elements beyond it must be attributed — to a threshold pixel (kind
-    "image": the pixel is a near-threshold pixel; kind "gaussian": the row's Gaussian is touched by one; bounded by
-    flip_rtol), or, failing that, to the oracle's own sensitivity: the element moves by at least err / SENS_FACTOR when
-    the inputs are perturbed by SENS_ULPS ulp (bounded by sens_rtol).
-    Returns (max error, number of attributed outliers)."""
+
+def check_close(got, ref, what, rtol, attribution=None, key=None, sens_rtol=1e-1):
+    """|got - ref| <= rtol * max|ref| elementwise. Elements beyond it must be explained, in this order:
+      1. by a moved blend / stop decision: the element agrees to rtol with the oracle re-run whose per-pixel threshold
+         nudges reproduce the HIP image, or lies (to rtol) inside the interval spanned by the oracle runs with the thresholds
+         at -k, 0, +k ulp and that matched run;
+      2. by the oracle's own ill-conditioning: it moves by at least err / SENS_FACTOR when the oracle's inputs are perturbed
+         by SENS_ULPS ulp / its sums are accumulated in fp32 / it is built with FMA contraction (bounded by sens_rtol);
+      3. at most FORM_MAX elements per tensor, each below FORM_RTOL, by the HIP path's own dL/dalpha formulation.
+    Accepted elements are capped at max(ATTR_MIN, ATTR_FRAC x elements) per tensor. Returns (max error, accepted elements)."""
     a = torch.as_tensor(got, dtype=torch.float64).cpu()
     b = torch.as_tensor(np.asarray(ref), dtype=torch.float64)
     assert tuple(a.shape) == tuple(b.shape), f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
@@ -317,23 +279,19 @@ def check_close(got, ref, what, rtol, attribution=None, kind=None, flip_rtol=5e-
     nbad = int(bad.sum())
     if nbad == 0:
         return float(err.max()), 0
-    assert attribution is not None and kind is not None, f"{what}: max err {float(err.max()):.3e} (x scale {scale:.3e}), {nbad} elements beyond {rtol:g}"
-    tm = attribution.thresholds()
-    ok = torch.zeros_like(bad)
-    where = torch.nonzero(bad)
-    if kind == "image":  # [..., H, W]: the element's pixel must be a near-threshold pixel
-        ys, xs = where[:, -2], where[:, -1]
-        pix = torch.unique(torch.stack([ys, xs], 1), dim=0)
-        hit = tm.pixels_near(pix[:, 0], pix[:, 1])
-        lut = {(int(y), int(x)): bool(h) for (y, x), h in zip(pix.tolist(), hit.tolist())}
-        ok[tuple(where.t())] = torch.tensor([lut[(int(y), int(x))] for y, x in zip(ys.tolist(), xs.tolist())])
-    else:                # [P, ...]: the row's Gaussian must be touched by a near-threshold pixel
-        rows = torch.unique(where[:, 0])
-        hit = tm.gaussians_touched(rows)
-        lut = dict(zip(rows.tolist(), hit.tolist()))
-        ok[tuple(where.t())] = torch.tensor([lut[int(r)] for r in where[:, 0].tolist()])
+    assert attribution is not None and key is not None, f"{what}: max err {float(err.max()):.3e} (x scale {scale:.3e}), {nbad} elements beyond {rtol:g}"
+    cap = max(ATTR_MIN, int(ATTR_FRAC * b.numel()))
+    assert nbad <= cap, f"{what}: {nbad} of {b.numel()} elements beyond {rtol:g} (max {float(err.max()):.3e}): more than attribution may accept ({cap})"
+    m, hull = attribution.matched()
+    mm = torch.as_tensor(np.asarray(m[key]), dtype=torch.float64).reshape(a.shape)
+    lo = torch.as_tensor(hull[key][0]).reshape(a.shape) - rtol * scale
+    hi = torch.as_tensor(hull[key][1]).reshape(a.shape) + rtol * scale
+    ok = ((a - mm).abs() / scale <= rtol) | ((a >= lo) & (a <= hi))
     unexplained = bad & ~ok
-    if bool(unexplained.any()) and key is not None:
+    if bool((bad & ok).any()):
+        print(f"{what}: {int((bad & ok).sum())} elements explained by moved blend / stop decisions "
+              f"(max err vs the un-nudged oracle {float(err[bad & ok].max()):.3e})")
+    if bool(unexplained.any()):
         delta = attribution.sensitivity(key).reshape(err.shape) / scale
         sens_ok = err <= SENS_FACTOR * delta + rtol
         n_sens = int((unexplained & sens_ok).sum())
@@ -343,55 +301,60 @@ def check_close(got, ref, what, rtol, attribution=None, kind=None, flip_rtol=5e-
             print(f"{what}: {n_sens} elements attributed to ill-conditioning (oracle moves by >= err/{SENS_FACTOR:g} under "
                   f"{SENS_ULPS:g}-ulp input perturbation), max err {float(err[unexplained & sens_ok].max()):.3e}")
         unexplained = unexplained & ~sens_ok
+    if bool(unexplained.any()) and key.startswith("g_"):
+        fd = attribution.formulation(key).reshape(err.shape) / scale
+        form_ok = unexplained & (err <= SENS_FACTOR * fd + rtol) & (err <= FORM_RTOL)
+        if bool(form_ok.any()) and int(form_ok.sum()) <= FORM_MAX:
+            print(f"{what}: {int(form_ok.sum())} element(s) at the precision limit of the front-to-back dL/dalpha formulation "
+                  f"(DESIGN.md 5), max err {float(err[form_ok].max()):.3e} — accepted under the separate allowance")
+            unexplained = unexplained & ~form_ok
     assert not bool(unexplained.any()), (
-        f"{what}: {int(unexplained.sum())} of {nbad} out-of-tolerance elements are neither at a threshold pixel nor "
-        f"ill-conditioned (max unexplained err {float(err[unexplained].max()):.3e}, rtol {rtol:g}, scale {scale:.3e})")
-    flipped = bad & ok
-    if bool(flipped.any()):
-        # a flipped blend decision moves a pixel by one contribution alpha T |c| <= |c|_max / 255 (flip_abs, absolute): in a
-        # faint image (few low-opacity Gaussians) that can be several per cent of the image's own scale
-        lim = max(flip_rtol, flip_abs / scale)
-        assert float(err[flipped].max()) <= lim, f"{what}: attributed flip of {float(err[flipped].max()):.3e} exceeds {lim:.3g}"
+        f"{what}: {int(unexplained.sum())} of {nbad} out-of-tolerance elements are explained neither by a moved blend / stop "
+        f"decision nor by ill-conditioning (max unexplained err {float(err[unexplained].max()):.3e}, rtol {rtol:g}, scale {scale:.3e})")
     return float(err.max()), nbad
-
-
-IMAGE_KEYS = ("out_color", "out_invdepth")
 
 
 def compare(out, ref, name, case, stats=None, cache=None):
     """HIP outputs + gradients of one case against the oracle's. radii bit-exact; images and per-Gaussian gradients to
-    RTOL (GRAD_RTOL for the stress fixtures), out-of-tolerance elements only where attributed to a threshold pixel."""
+    RTOL (GRAD_RTOL for the stress fixtures); out-of-tolerance elements only where explained (check_close)."""
     assert np.array_equal(out["out_radii"].cpu().numpy(), np.asarray(ref["out_radii"])), f"{name}: radii differ"
-    att = Attribution(case, ref={k: v for k, v in ref.items() if k.startswith(("out_", "g_"))}, cache=cache)
+    refs = {k: v for k, v in ref.items() if k.startswith(("out_", "g_"))}
+    att = Attribution(case, out, refs, cache=cache)
     flips = 0
-    for k, v in out.items():
-        if k == "out_radii" or k.startswith("_"):
-            continue
+    # images first: gradients are only ever explained through decisions the images show
+    keys = [k for k in out if k != "out_radii" and not k.startswith("_") and k != "g_viewmatrix"]
+    keys.sort(key=lambda k: (k not in IMAGE_KEYS, k))
+    for k in keys:
         r = np.asarray(ref[k])
-        if k == "g_viewmatrix":
-            # a cancelling sum over all Gaussians of terms that are each within tolerance: the meaningful scale is the
-            # sum of magnitudes |means3D|^T @ |dL_dmeans2D| (and sum |dL_dmeans2D| for the last row), not |sum|
-            g2 = torch.as_tensor(np.asarray(ref["g_means2D"])).abs().double()
-            m = torch.as_tensor(np.asarray(case["means3D"])).abs().double()
-            rt = torch.as_tensor(r).double()
-            scale = max(float((m.t() @ g2).max()), float(g2.sum(0).max()), float(rt.abs().max()), 1e-30)
-            err = float((v.cpu().double() - rt).abs().max()) / scale
-            # the [:3,:2] block comes from the covariance backward, the worst-conditioned part; a threshold flip
-            # anywhere in the image moves these 16 global sums: x4 when the case has flips
-            lim = GRAD_RTOL.get(name, RTOL) * (4 if (flips or name.startswith(("sweep", "seed15"))) else 1)
-            assert err <= lim, f"{name}:{k}: {err:.3e} of the magnitude sum (limit {lim:g})"
-            continue
         grad = k.startswith("g_")
-        flip_abs = 0.0
-        if k == "out_color":    # one blended / skipped Gaussian at alpha ~ 1/255: |c|_max / 255 (+ a few per cent)
-            flip_abs = 1.05 / 255.0 * float(np.abs(np.asarray(case["colors"])).max()) if np.asarray(case["colors"]).size else 0.0
-        elif k == "out_invdepth" and np.asarray(case["means3D"]).size:
-            vm = np.asarray(case["viewmatrix"], dtype=np.float64)
-            depth = 200.0 - (np.asarray(case["means3D"], dtype=np.float64) @ vm[:3, 2] + vm[3, 2])
-            flip_abs = 1.05 / 255.0 / float(depth[depth > 0].min()) if (depth > 0).any() else 0.0
-        _, n = check_close(v, r, f"{name}:{k}", GRAD_RTOL.get(name, RTOL) if grad else RTOL, att,
-                           "gaussian" if grad else "image", flip_rtol=1e-1 if grad else 2e-2, key=k, flip_abs=flip_abs)
+        _, n = check_close(out[k], r, f"{name}:{k}", GRAD_RTOL.get(name, RTOL) if grad else RTOL, att, key=k)
         flips += n
+    if "g_viewmatrix" in out:
+        # a cancelling sum over all Gaussians of terms that are each within tolerance: the meaningful scale is the
+        # sum of magnitudes |means3D|^T @ |dL_dmeans2D| (and sum |dL_dmeans2D| for the last row), not |sum|
+        v = out["g_viewmatrix"]
+        g2 = torch.as_tensor(np.asarray(ref["g_means2D"])).abs().double()
+        m3 = torch.as_tensor(np.asarray(case["means3D"])).abs().double()
+        rt = torch.as_tensor(np.asarray(ref["g_viewmatrix"])).double()
+        scale = max(float((m3.t() @ g2).max()), float(g2.sum(0).max()), float(rt.abs().max()), 1e-30)
+        lim = GRAD_RTOL.get(name, RTOL)
+        err = float((v.cpu().double() - rt).abs().max()) / scale
+        if err > lim and flips:
+            # decisions moved somewhere in the image move these 16 global sums: the matched oracle run is the reference then
+            mt = torch.as_tensor(np.asarray(att.matched()[0]["g_viewmatrix"])).double()
+            err = min(err, float((v.cpu().double() - mt).abs().max()) / scale)
+        if err > lim:
+            # the [:3,:2] block comes from the covariance backward, the worst-conditioned part: accepted only as far as the
+            # ORACLE's own sums move under a few-ulp perturbation of its inputs (elementwise, same rule as check_close)
+            d = (v.cpu().double() - rt).abs() / scale
+            delta = att.sensitivity("g_viewmatrix").reshape(d.shape) / scale
+            assert bool((d <= SENS_FACTOR * delta + lim).all()) and err <= 1e-2, (
+                f"{name}:g_viewmatrix: {err:.3e} of the magnitude sum (limit {lim:g}; the oracle itself moves by "
+                f"{float(delta.max()):.3e} under {SENS_ULPS:g}-ulp input perturbation)")
+            print(f"{name}:g_viewmatrix: {err:.3e} of the magnitude sum attributed to ill-conditioning "
+                  f"(oracle moves by {float(delta.max()):.3e})")
+            err = lim
+        assert err <= lim, f"{name}:g_viewmatrix: {err:.3e} of the magnitude sum (limit {lim:g})"
     if stats is not None:
         stats[name] = flips
     return flips

@@ -123,3 +123,38 @@ def test_config1_plumbing_1k_128(oracle_backend):
     assert float((color - c2).abs().max()) <= 1e-5
     assert float((invd - i2).abs().max()) <= 1e-5
     assert float((color[:3] - sc["bg"][:3, None, None]).abs().max()) > 1e-3  # something was blended
+
+
+def test_threshold_nudge_moves_exactly_the_near_threshold_decision(oracle_backend):
+    """eogs_oracle_threshold_nudge (the causal flip attribution of tests/parity_cases.py): a Gaussian centred on pixel
+    (8, 8) with alpha = (1/255)(1 + 4 ulp) there is blended by the reference's arithmetic and with the thresholds moved
+    down, skipped with them moved up by their (16 + 8|power|)-ulp margin; no other pixel changes, a per-pixel map moves
+    only its pixel, and sign 0 is the reference's arithmetic bit for bit."""
+    import sys
+    import os
+
+    import numpy as np
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from parity_cases import nudged_run, oracle_run
+
+    H = W = 16
+    op = np.float32(1.0 / 255.0) * np.float32(1.0 + 4 * 2.0 ** -23)
+    vm = np.eye(4, dtype=np.float32)
+    case = dict(means3D=np.array([[1 / 16, 1 / 16, 10.0]], np.float32), scales=np.full((1, 3), 0.05, np.float32),
+                rotations=np.array([[1, 0, 0, 0]], np.float32), opacities=np.array([[op]], np.float32),
+                colors=np.array([[0.9, 0.1, 0.5, 10.0, 1.0]], np.float32), bg=np.zeros(5, np.float32), viewmatrix=vm,
+                dL_dcolor=np.ones((5, H, W), np.float32), H=H, W=W, antialiasing=False)
+    base, down, up = oracle_run(case), nudged_run(case, uniform=-1), nudged_run(case, uniform=1)
+    assert base["out_color"][0, 8, 8] > 0 and float(base["g_opacities"].sum()) != 0  # blended at its centre pixel
+    for k in base:
+        assert np.array_equal(base[k], down[k]), k
+        assert np.array_equal(base[k], nudged_run(case, uniform=0)[k]), k
+    assert up["out_color"][0, 8, 8] == 0 and float(np.abs(up["g_opacities"]).sum()) == 0  # skipped: forward AND backward
+    diff = np.abs(up["out_color"] - base["out_color"]).max(0)
+    assert int((diff > 0).sum()) == 1 and diff[8, 8] > 0
+    m = np.zeros((H, W), np.int8)
+    m[3, 3] = 1  # a pixel without a near pair: nothing moves
+    assert all(np.array_equal(base[k], v) for k, v in nudged_run(case, sign_map=m).items())
+    m[8, 8] = 1
+    assert all(np.array_equal(up[k], v) for k, v in nudged_run(case, sign_map=m).items())

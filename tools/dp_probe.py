@@ -40,6 +40,10 @@ print("plain            ms", timeit(0))
 print("bucket, no dist  ms", timeit(1))
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29544")
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-print("bucket + rccl(1) ms", timeit(1))
+for label, kw in (("bucket + rccl(1), async handle", dict(async_whole=True)), ("bucket + rccl(1), issued in line", dict(async_whole=False))):
+    bucket.close()
+    bucket = GradBucket([params[k] for k in names], cols=[slice(0, 3), slice(0, 3), slice(0, 1), slice(0, 3), slice(0, 4)],
+                        names=names, chunks=chunks, **kw)
+    print(label, "ms", timeit(1))
 print("plain again      ms", timeit(0))
 dist.destroy_process_group()
