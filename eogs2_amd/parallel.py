@@ -58,7 +58,7 @@ def _copy_cols(block, g, cols, to_block):
 class GradBucket(BackwardPlan):
     """The exchange buffer of the Gaussian parameter gradients.
 
-    params: [P, k] leaf tensors.  cols: per parameter, the slice of its columns that are model parameters (default:
+    params: leaf tensors with P rows ([P], [P, k], [P, 1, 3], ...).  cols: per parameter, the slice of its columns that are model parameters (default:
     all; `colors_precomp` carries f_dc in columns 0:3, the altitude / constant channels stay rank-local).
     names: per parameter, the name of the rasterizer gradient it receives ("means3D", "colors", "opacities",
     "scales", "rotations") — needed only for the overlapped path (`begin()` ... backward ... `finish()`).
@@ -85,7 +85,7 @@ class GradBucket(BackwardPlan):
     def __init__(self, params, cols=None, names=None, chunks=1, group=None, algo="all_reduce", verify_steps=1, async_whole=True):
         self.params = list(params)
         P = self.params[0].shape[0]
-        assert all(p.ndim >= 2 and p.shape[0] == P for p in self.params)
+        assert all(p.ndim >= 1 and p.shape[0] == P for p in self.params)  # [P], [P, k], [P, 1, 3], ...
         self.P = P
         rowlen = [p.numel() // max(P, 1) if P else int(torch.tensor(p.shape[1:]).prod()) for p in self.params]
         self.cols = list(cols) if cols is not None else [slice(0, n) for n in rowlen]
