@@ -55,6 +55,24 @@ __device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, uint32_t& 
   return pre + inc - v;
 }
 
+// rank of a lane's digit among the equal digits of its 64-entry group (lane order) and the group's count of that digit.
+// Per bit: the lanes whose bit equals mine stay peers, peers &= ~(ballot ^ mine), mine = 0 / ~0 — one v_bfe_i32, one compare
+// and one v_bitop3_b32 per half (the select-and-mask form the compiler makes of `bit ? m : ~m` is nine instructions).
+template <int NBITS>
+__device__ inline uint32_t match_rank(uint32_t d, bool livel, uint32_t& count) {
+  const unsigned long long live = __ballot(livel);
+  uint32_t plo = (uint32_t)live, phi = (uint32_t)(live >> 32);
+#pragma unroll
+  for (int bit = 0; bit < NBITS; bit++) {
+    const int x = __builtin_amdgcn_sbfe((int)d, bit, 1);  // 0 or -1
+    const unsigned long long m = __ballot(x != 0);
+    plo = __builtin_amdgcn_bitop3_b32(plo, (uint32_t)m, (uint32_t)x, 0x90);  // a & ~(b ^ c)
+    phi = __builtin_amdgcn_bitop3_b32(phi, (uint32_t)(m >> 32), (uint32_t)x, 0x90);
+  }
+  count = (uint32_t)__popc(plo) + (uint32_t)__popc(phi);
+  return __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));  // peers in the lanes below mine
+}
+
 // the entry count of this forward as the device knows it (written by pblock_scan_kernel); 0 when it does not fit `cap`
 __device__ inline uint32_t entries_on_device(const uint32_t* __restrict__ misc, uint32_t cap) {
   const uint32_t lo = misc[MISC_MACRO_LO], hi = misc[MISC_MACRO_HI];
@@ -628,7 +646,7 @@ __global__ __launch_bounds__(T_) void entry_scatter_kernel(const uint4* __restri
                                                              const uint32_t* __restrict__ misc, uint32_t cap, int shift,
                                                              const uint32_t* __restrict__ hist,
                                                              const uint32_t* __restrict__ dtotal) {
-  constexpr int nbits = NBITS, ES_ITEMS_ = ES_TILE / T_, ES_NW_ = T_ / 64;
+  constexpr int ES_ITEMS_ = ES_TILE / T_, ES_NW_ = T_ / 64;
   constexpr uint32_t nb = 1u << NBITS, mask = nb - 1u;
   const uint32_t n = entries_on_device(misc, cap);
   const uint32_t tile0 = blockIdx.x * (uint32_t)ES_TILE;
@@ -642,7 +660,6 @@ __global__ __launch_bounds__(T_) void entry_scatter_kernel(const uint4* __restri
   for (uint32_t k = t; k < (uint32_t)ES_NW_ * (nb < 2u ? 2u : nb) / 2u; k += T_) reinterpret_cast<uint32_t*>(&s_wcnt[0][0])[k] = 0u;
   __syncthreads();
   const uint32_t base = tile0 + (uint32_t)w * (64 * ES_ITEMS_);
-  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   uint4 item[ES_ITEMS_];
   uint32_t lrank[ES_ITEMS_];
 #pragma unroll
@@ -657,17 +674,12 @@ __global__ __launch_bounds__(T_) void entry_scatter_kernel(const uint4* __restri
     if (base + i * 64 >= n) continue;  // (wave-uniform)
     const bool live = base + i * 64 + lane < n;
     const uint32_t d = (item[i].x >> shift) & mask;
-    unsigned long long peers = __ballot(live);
-#pragma unroll
-    for (int b = 0; b < nbits; b++) {
-      const unsigned long long m = __ballot((d >> b) & 1u);
-      peers &= ((d >> b) & 1u) ? m : ~m;
-    }
-    const uint32_t r = (uint32_t)__popcll(peers & lt_mask);
+    uint32_t count;
+    const uint32_t r = match_rank<NBITS>(d, live, count);
     uint32_t before = 0;
     if (live) before = s_wcnt[w][d];  // this wave's earlier groups (LDS ops of one wave execute in order)
     __builtin_amdgcn_wave_barrier();
-    if (live && r == 0) s_wcnt[w][d] = (uint16_t)(before + (uint32_t)__popcll(peers));  // one leader per digit
+    if (live && r == 0) s_wcnt[w][d] = (uint16_t)(before + count);  // one leader per digit
     __builtin_amdgcn_wave_barrier();
     lrank[i] = before + r;
   }
@@ -824,17 +836,6 @@ __device__ inline uint32_t bl_sum(uint32_t v, uint32_t* s_red) {  // sum over th
   for (int k = 0; k < BL_NW; k++) tot += s_red[k];
   return tot;
 }
-// rank of a lane's digit among the equal digits of its 64-entry group (lane order) and the group's count of that digit
-__device__ inline uint32_t bl_match8(uint32_t d, bool livel, unsigned long long lt_mask, uint32_t& count) {
-  unsigned long long peers = __ballot(livel);
-#pragma unroll
-  for (int bit = 0; bit < 8; bit++) {
-    const unsigned long long m = __ballot((d >> bit) & 1u);
-    peers &= ((d >> bit) & 1u) ? m : ~m;
-  }
-  count = (uint32_t)__popcll(peers);
-  return (uint32_t)__popcll(peers & lt_mask);
-}
 }  // namespace
 
 // One workgroup per 32 x 32-pixel block. Its n entries sit in ent[s0, s0+n) in Gaussian-id order (s0, n and the pairs
@@ -868,7 +869,6 @@ __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __res
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const uint32_t b = blockIdx.x;
   const int npass = (int)misc[MISC_DEPTH_PASSES];
-  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
   // where this block's entries and pairs start: sums of the counts of the blocks before it (a few loads per thread at the
   // usual 1024 ... 4096 blocks)
@@ -899,30 +899,13 @@ __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __res
   if (fast) {
     // ---- LDS path: {depth key, sub-mask << 16 | index} in registers ----
     uint32_t dk[BL_ITEMS], px[BL_ITEMS];
-    {
-      uint32_t cnt[16];
 #pragma unroll
-      for (int j = 0; j < 16; j++) cnt[j] = 0;
-#pragma unroll
-      for (int i = 0; i < BL_ITEMS; i++) {
-        dk[i] = 0xFFFFFFFFu; px[i] = 0;
-        if ((uint32_t)i >= per0 || wb0 + i * 64 >= n) continue;  // (wave-uniform)
-        const uint32_t k = wb0 + i * 64 + lane;
-        uint32_t sub = 0;
-        if (k < n) {
-          const uint2 kd = *reinterpret_cast<const uint2*>(ent + s0 + k);  // {key, depth key}
-          sub = kd.x >> MACRO_KEY_BITS;
-          dk[i] = kd.y; px[i] = (sub << 16) | k;
-        }
-        if (MODE == 1) {
-#pragma unroll
-          for (int j = 0; j < 16; j++) cnt[j] += (uint32_t)__popcll(__ballot((sub >> j) & 1u));
-        }
-      }
-      if (MODE == 1) {
-#pragma unroll
-        for (int j = 0; j < 16; j++)
-          if (lane == j && cnt[j]) atomicAdd(&s_tc[j], cnt[j]);
+    for (int i = 0; i < BL_ITEMS; i++) {
+      dk[i] = 0xFFFFFFFFu; px[i] = 0;
+      const uint32_t k = wb0 + i * 64 + lane;
+      if ((uint32_t)i < per0 && k < n) {
+        const uint2 kd = *reinterpret_cast<const uint2*>(ent + s0 + k);  // {key, depth key}
+        dk[i] = kd.y; px[i] = (kd.x & 0xFFFF0000u) | k;
       }
     }
     for (int p = 0; p < npass; p++) {
@@ -937,7 +920,7 @@ __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __res
         const bool livel = wb0 + i * 64 + lane < n;
         const uint32_t d = (dk[i] >> sh) & 255u;
         uint32_t count;
-        const uint32_t r = bl_match8(d, livel, lt_mask, count);
+        const uint32_t r = match_rank<8>(d, livel, count);
         uint32_t before = 0;
         if (livel) before = s_wcnt[w][d];
         __builtin_amdgcn_wave_barrier();
@@ -1051,7 +1034,7 @@ __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __res
           const bool livel = wb + i * 64 + lane < cend;
           const uint32_t d = (sdk[i] >> sh) & 255u;
           uint32_t count;
-          const uint32_t r = bl_match8(d, livel, lt_mask, count);
+          const uint32_t r = match_rank<8>(d, livel, count);
           uint32_t before = 0;
           if (livel) before = s_wcnt[w][d];
           __builtin_amdgcn_wave_barrier();
@@ -1100,6 +1083,38 @@ __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __res
   }
 
   // ---- the internal tiles' lists ----
+  // this wave's entries of a chunk per tile, in list order -> s_cw[w][tile]
+  auto count_chunk = [&](uint32_t c0) {
+    const uint32_t cend = n - c0 < (uint32_t)BL_CH ? n : c0 + (uint32_t)BL_CH;
+    const uint32_t per = ((cend - c0 + 63u) / 64u + BL_NW - 1u) / BL_NW;
+    const uint32_t wb = c0 + (uint32_t)w * per * 64u;
+    uint32_t cnt[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) cnt[j] = 0;
+#pragma unroll 1
+    for (uint32_t i = 0; i < per; i++) {
+      if (wb + i * 64 >= cend) break;  // (wave-uniform)
+      const uint32_t k = wb + i * 64 + lane;
+      uint32_t sub = 0;
+      if (k < cend) sub = fast ? (s_stage[k].y >> 16) : (ent[s0 + src[k].y].x >> MACRO_KEY_BITS);
+#pragma unroll
+      for (int j = 0; j < 16; j++) cnt[j] += (uint32_t)__popcll(__ballot((sub >> j) & 1u));
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+      if (lane == j) s_cw[w][j] = cnt[j];
+  };
+  if (fast) {  // one chunk: its per-wave counts also give the block's entries per tile (the streaming path counted them up front)
+    count_chunk(0);
+    __syncthreads();
+    if (t < 16) {
+      uint32_t tot = 0;
+#pragma unroll
+      for (int k = 0; k < BL_NW; k++) tot += s_cw[k][t];
+      s_tc[t] = tot;
+    }
+    __syncthreads();
+  }
   if (t < 16) {
     uint32_t pre = pairs_before;
     for (int j = 0; j < t; j++) pre += s_tc[j];
@@ -1128,23 +1143,10 @@ __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __res
     const uint32_t cend = n - c0 < (uint32_t)BL_CH ? n : c0 + (uint32_t)BL_CH;
     const uint32_t per = ((cend - c0 + 63u) / 64u + BL_NW - 1u) / BL_NW;
     const uint32_t wb = c0 + (uint32_t)w * per * 64u;
-    // this wave's entries per tile, in list order
-    uint32_t cnt[16];
-#pragma unroll
-    for (int j = 0; j < 16; j++) cnt[j] = 0;
-#pragma unroll 1
-    for (uint32_t i = 0; i < per; i++) {
-      if (wb + i * 64 >= cend) break;  // (wave-uniform)
-      const uint32_t k = wb + i * 64 + lane;
-      uint32_t sub = 0;
-      if (k < cend) sub = fast ? (s_stage[k].y >> 16) : (ent[s0 + src[k].y].x >> MACRO_KEY_BITS);
-#pragma unroll
-      for (int j = 0; j < 16; j++) cnt[j] += (uint32_t)__popcll(__ballot((sub >> j) & 1u));
+    if (!fast) {
+      count_chunk(c0);
+      __syncthreads();
     }
-#pragma unroll
-    for (int j = 0; j < 16; j++)
-      if (lane == j) s_cw[w][j] = cnt[j];
-    __syncthreads();
     if (t < 16) {  // tile t: where each wave's entries of this chunk go, then advance the tile's running position
       uint32_t run = s_tb[t];
 #pragma unroll
@@ -1173,7 +1175,7 @@ __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __res
         const bool has = (sub >> j) & 1u;
         const unsigned long long m = __ballot(has);
         if (has)
-          point_list[off[j] + (uint32_t)__popcll(m & lt_mask)] =
+          point_list[off[j] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
               make_uint2(id, sl + (uint32_t)__popc(sub & ((1u << j) - 1u)));
         off[j] += (uint32_t)__popcll(m);
       }
