@@ -222,9 +222,10 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
   const uint64_t entries = (uint64_t)g_pinned[MISC_MACRO_LO] | ((uint64_t)g_pinned[MISC_MACRO_HI] << 32);
   // List granularity the render kernels read (common.h "blocks"). Per-tile lists while footprints are small: every entry a
   // wave reads is one it uses. Lists per 32 x 32-pixel block once a Gaussian is listed in many tiles: the lists are then
-  // 4-7x shorter to write and re-read, which outweighs the block-list scan in the render waves. Measured crossover since the
-  // lists are built per block (round 3): about 10.5 listed tiles per Gaussian, and the gain is small (1024^2 trained -2 %,
-  // 2048^2 trained -6 %; 1024^2 at opacity 0.01 +27 % if forced) — profiles/r03_regime_scan.txt.
+  // 4-7x shorter to write and re-read, which can outweigh the block-list scan in the render waves. Since the lists are built
+  // per block and split locally (round 3) per-tile lists with the quad kernels win up to at least 13.8 listed tiles per
+  // Gaussian (1024^2 trained 0.694 against 0.704 ms, 300 k / 1600^2 0.679 against 0.722); block lists still win at 31
+  // (2048^2 trained: 1.536 against 1.596): the switch sits between — profiles/r03_regime_scan.txt.
   static const double block_switch = [] {  // tuning aid: EOGS_BLOCK_SWITCH=<tiles per Gaussian> overrides the default
     const char* e = getenv("EOGS_BLOCK_SWITCH");
     return e ? atof(e) : (double)EOGS_BLOCK_SWITCH;

@@ -126,7 +126,7 @@ __device__ inline bool block_hit(float gx, float gy, float a, float b, float c, 
 // fewer for footprints of tens of pixels, where binning otherwise costs as much as rendering. forward_prepare picks
 // the mode from the two pair counts it reads back (api.hip) and hands it on inside num_rendered.
 #define BLOCK_BIG 4
-#define EOGS_BLOCK_SWITCH 10.5  // listed internal tiles per Gaussian (average) above which a forward uses BLOCK_BIG
+#define EOGS_BLOCK_SWITCH 20  // listed internal tiles per Gaussian (average) above which a forward uses BLOCK_BIG
 #define EOGS_DEPTH_SWITCH 0  // (pairs per tile) x (mean pair opacity) above which a forward uses BLOCK_BIG; 0 = never
                              // (round 3: per-tile lists cost one 8-byte item per pair to build, the criterion no longer pays)
 #define MACRO_KEY_BITS 16  // M > 1: block id in the low half of the key, sub-mask in the high half

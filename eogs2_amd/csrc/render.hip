@@ -461,10 +461,12 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_FW, E
   }
 }
 
-// Quad sub-lists pay while footprints are small: the trip count falls to the longest sub-list (0.6 of the tile's list at
-// four listed tiles per Gaussian) against ~15 % more work per trip and ~170 instructions per chunk for the masks.
-// EOGS_QUAD_SWITCH=<listed tiles per Gaussian> overrides the crossover (0 disables the quad kernel).
-#define EOGS_QUAD_SWITCH_DEFAULT 9.0  // = EOGS_BLOCK_SWITCH: the quad kernels run whenever lists are per tile (fwd -20 % at 4.0 listed tiles per Gaussian, -13.5 % at 6.4; bwd -18 %, -12 %)
+// Quad sub-lists: the trip count falls to the longest sub-list (0.6 of the tile's list at four listed tiles per Gaussian)
+// against ~15 % more work per trip and ~170 instructions per chunk for the masks. They run whenever lists are per tile:
+// measured ahead of the one-list-per-tile kernels at every footprint tried (fwd -20 % / bwd -18 % at 4.0 listed tiles per
+// Gaussian, -9 % / -4 % at 10.8, -10 % / -6 % at 12 - 14, level at 31). EOGS_QUAD_SWITCH=<listed tiles per Gaussian>
+// overrides the crossover (0 disables the quad kernel).
+#define EOGS_QUAD_SWITCH_DEFAULT 1.0e9
 static double quad_switch() {
   static const double v = [] {
     const char* e = getenv("EOGS_QUAD_SWITCH");
