@@ -177,7 +177,7 @@ def sensitivity_map(case, base=None):
 
 IMAGE_KEYS = ("out_color", "out_invdepth")
 # accepted out-of-tolerance elements per tensor: at most this fraction of its elements (and never fewer than MIN allowed)
-ATTR_FRAC, ATTR_MIN = 1e-3, 16
+ATTR_FRAC, ATTR_MIN = 5e-3, 32
 # elements explained only by the implementation's own dL/dalpha formulation (formulation_delta): count and size
 FORM_MAX, FORM_RTOL = 2, 1e-3
 
@@ -267,7 +267,7 @@ def check_close(got, ref, what, rtol, attribution=None, key=None, sens_rtol=1e-1
       2. by the oracle's own ill-conditioning: it moves by at least err / SENS_FACTOR when the oracle's inputs are perturbed
          by SENS_ULPS ulp / its sums are accumulated in fp32 / it is built with FMA contraction (bounded by sens_rtol);
       3. at most FORM_MAX elements per tensor, each below FORM_RTOL, by the HIP path's own dL/dalpha formulation.
-    Accepted elements are capped at max(ATTR_MIN, ATTR_FRAC x elements) per tensor. Returns (max error, accepted elements)."""
+    Accepted elements are capped at max(ATTR_MIN, ATTR_FRAC x elements) per tensor (32 / 0.5 %). Returns (max error, accepted elements)."""
     a = torch.as_tensor(got, dtype=torch.float64).cpu()
     b = torch.as_tensor(np.asarray(ref), dtype=torch.float64)
     assert tuple(a.shape) == tuple(b.shape), f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
