@@ -899,7 +899,12 @@ def main():
                 # VALU wave-instruction counted as 64 lanes x 2 FLOP, i.e. an upper bound on useful work. The headline
                 # `frac` stays the HBM one, as the task prescribes.
                 tf = valu * 64 * 2 / (kern[dom] * 1e-3) / 1e12
-                roof["valu"] = {"bound": "valu", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3}
+                # ... and against what the kernel's own instruction mix can issue at best: its trips timed as bare instruction
+                # SEQUENCES (tools/ubench.hip, profiles/r02_ubench.txt: 105 cycles per wave for the backward trip's 32 VALU
+                # + 2 SALU at 8 waves per SIMD, LDS traffic overlapped) = 3.3 SIMD-cycles per VALU instruction
+                floor_cyc = 105.0 / 32.0
+                roof["valu"] = {"bound": "valu", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
+                                "issue_floor_simd_cycles_per_inst": floor_cyc, "frac_of_issue_floor": floor_cyc / cyc}
         # every kernel group against the HBM roofline (the render kernels are VALU-issue-bound: DESIGN.md §4)
         per_kernel = {}
         for k, ms in kern.items():
