@@ -820,8 +820,6 @@ void launch_entry_sort(const GeomWS& g, const SortWS& w, int P, int H, int W, hi
 // Per block: depth order + split into the internal tiles' lists
 // =====================================================================================================================
 #define BL_T 1024                  // threads per workgroup (16 wave64)
-#define BL_ITEMS 4
-#define BL_CH (BL_T * BL_ITEMS)    // entries per chunk of a pass = longest list the LDS path takes
 #define BL_NW (BL_T / 64)
 
 namespace {
@@ -847,13 +845,16 @@ __device__ inline uint32_t bl_sum(uint32_t v, uint32_t* s_red) {  // sum over th
 //       LDS) at that tile's place in point_list — tile lists of a block are adjacent, blocks follow each other in block
 //       order — and writes the 16 tile ranges and clears the block's share of the backward's live flags;
 //   MODE BLOCK_BIG: writes the ordered entries' {key, {Gaussian id, first slot}} for the block-list render kernels.
-// Up to BL_CH entries (the usual case: a block holds a few thousand) the pairs live in registers and move through LDS
+// Up to BL_CH = 1024 x BL_ITEMS entries (the usual case: a block holds a few thousand) the pairs live in registers and move through LDS
 // between passes, the sub-mask travelling in the index word's upper half. Longer lists stream chunk by chunk through the
 // scratch ping-pong buffer ki (the entry buffer the block sort left free: 16 bytes per entry = two 8-byte pairs) with
 // running digit bases in LDS, the next digit's histogram taken while scattering; a block's data stays in its CU's L2.
 // Any n is handled (a block with a million entries only takes long).
 // Compiled for two workgroups per CU (64 VGPRs): the launch is one workgroup per block, all resident at once at 1024^2.
-template <int MODE>
+// BL_ITEMS = 4 (LDS path up to 4096 entries, no spills) unless the average block holds 2800 ... 6000 entries: then 8
+// (8192 entries, a few spilled registers: 2 M Gaussians at trained opacities 218 -> 158 us; at 1700 entries per block the
+// 4-item build is faster, 59 against 77 us, and beyond 6000 the 8-item build loses to the 4-item streaming path).
+template <int MODE, int BL_ITEMS>
 __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __restrict__ ent, uint2* ki,
                                                               const uint32_t* __restrict__ bcount,
                                                               const uint32_t* __restrict__ bpairs,
@@ -861,6 +862,7 @@ __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __res
                                                               uint32_t gsy, uint2* __restrict__ point_list,
                                                               uint32_t* __restrict__ sorted_keys, uint2* __restrict__ ranges,
                                                               uint8_t* __restrict__ live) {
+  constexpr int BL_CH = BL_T * BL_ITEMS;  // entries per chunk of a pass = longest list the LDS path takes
   __shared__ uint16_t s_wcnt[BL_NW][256];
   __shared__ uint32_t s_base[256], s_cb[256], s_h[256], s_hn[256];
   __shared__ uint32_t s_red[BL_NW];
@@ -1197,12 +1199,16 @@ void launch_block_lists(const GeomWS& g, const SortWS& w, const BinWS& b, const 
   const bool inA = entry_sort_result_in_A(H, W);
   const uint4* ent = inA ? w.entA : w.entB;
   uint2* ki = reinterpret_cast<uint2*>(inA ? w.entB : w.entA);
+  const double avg = (double)nr_entries(R) / (double)nblocks;
+  const bool wide = avg > 2800.0 && avg <= 6000.0;
   if (M > 1) {
     (void)hipMemsetAsync(b.live, 0, (size_t)nr_slots(R), s);
-    hipLaunchKernelGGL(block_lists_kernel<BLOCK_BIG>, dim3(nblocks), dim3(BL_T), 0, s, ent, ki, g.bcount, g.bpairs, g.misc, gmx,
-                       gsx, gsy, b.point_list, b.sorted_keys, im.ranges, b.live);
+    auto* kern = wide ? block_lists_kernel<BLOCK_BIG, 8> : block_lists_kernel<BLOCK_BIG, 4>;
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(BL_T), 0, s, ent, ki, g.bcount, g.bpairs, g.misc, gmx, gsx, gsy, b.point_list,
+                       b.sorted_keys, im.ranges, b.live);
   } else {
-    hipLaunchKernelGGL(block_lists_kernel<1>, dim3(nblocks), dim3(BL_T), 0, s, ent, ki, g.bcount, g.bpairs, g.misc, gmx, gsx,
-                       gsy, b.point_list, b.sorted_keys, im.ranges, b.live);
+    auto* kern = wide ? block_lists_kernel<1, 8> : block_lists_kernel<1, 4>;
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(BL_T), 0, s, ent, ki, g.bcount, g.bpairs, g.misc, gmx, gsx, gsy, b.point_list,
+                       b.sorted_keys, im.ranges, b.live);
   }
 }

@@ -98,6 +98,34 @@ def test_depth_ties_and_overlap_order(dev):
     assert_close(invd, inv2, "tie-order invdepth")
 
 
+@pytest.mark.parametrize("P,label", [(50_000, "8-item LDS path"), (130_000, "streaming path"), (2_000, "4-item LDS path")])
+def test_long_block_lists_against_oracle(dev, P, label):
+    """The three ways block_lists_kernel orders a block (csrc/binning.hip): up to 4096 entries per 32 x 32-px block in
+    registers / LDS, the 8-item build for blocks of 2800 ... 6000 entries on average, and chunked streaming through the
+    scratch ping-pong buffer beyond the LDS path. A 128 x 128 image has 16 blocks; the Gaussian count sets the block length.
+    Every output and gradient against the oracle (the list order decides the blend order at every pixel)."""
+    import oracle
+    from eogs2_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib
+    from eogs2_amd.synthetic import make_scene
+
+    H = W = 128
+    sc = make_scene(P, H, W, seed=41, opacity=0.05, scale_mult=0.6)
+    case = {k: v.numpy() for k, v in sc.items()}
+    case.update(H=H, W=W, antialiasing=False)
+    got = run_case(case, dev, GaussianRasterizer, GaussianRasterizationSettings)
+    entries = (got["_num_rendered"] >> 32) & 0x1FFFFFFF
+    per_block = entries / 16.0
+    assert {"8-item LDS path": 2800 < per_block <= 6000, "streaming path": per_block > 6000,
+            "4-item LDS path": per_block <= 2800}[label], per_block
+    hip = _lib.get
+    _lib.get = oracle.abi
+    try:
+        ref = run_case(case, torch.device("cpu"), GaussianRasterizer, GaussianRasterizationSettings)
+    finally:
+        _lib.get = hip
+    _compare(got, {k: v.cpu().numpy() for k, v in ref.items() if not k.startswith('_')}, f"blocks-{P}", case)
+
+
 def test_wide_altitude_range_uses_all_sort_passes(dev, monkeypatch):
     """Depth keys spanning several binades (200 - altitude from ~25 to ~305): the top byte of the key differs, so the
     fourth depth-sort pass must run (with EOGS-like altitudes it is skipped). Compared with the oracle."""
