@@ -126,6 +126,29 @@ def test_long_block_lists_against_oracle(dev, P, label):
     _compare(got, {k: v.cpu().numpy() for k, v in ref.items() if not k.startswith('_')}, f"blocks-{P}", case)
 
 
+def test_entry_sort_in_scratch_and_in_the_binning_workspace_agree(dev, monkeypatch):
+    """The entry sort runs in the caller's scratch behind the count readback (ABI v5) or, without scratch / with more
+    entries than its capacity, in the binning workspace after the readback: same kernels, same lists — outputs and
+    gradients are bit-identical, and the token records where the sort ran."""
+    from eogs2_amd import GaussianRasterizationSettings, GaussianRasterizer, rasterizer
+    from eogs2_amd.synthetic import make_scene
+
+    for P, scale_mult, want_sorted in ((20000, 1.0, 1), (300, 14.0, 0)):  # (0: six entries per Gaussian are not enough)
+        sc = make_scene(P, 200, 168, seed=51, opacity="trained", scale_mult=scale_mult)
+        case = {k: v.numpy() for k, v in sc.items()}
+        case.update(H=200, W=168, antialiasing=False)
+        a = run_case(case, dev, GaussianRasterizer, GaussianRasterizationSettings)
+        assert (a["_num_rendered"] >> 61) & 1 == want_sorted
+        with monkeypatch.context() as m:
+            m.setattr(rasterizer, "_scratch_for", lambda *args: None)
+            b = run_case(case, dev, GaussianRasterizer, GaussianRasterizationSettings)
+        assert (b["_num_rendered"] >> 61) & 1 == 0
+        assert (a["_num_rendered"] & 0x7FFFFFFF) == (b["_num_rendered"] & 0x7FFFFFFF)
+        for k in a:
+            if not k.startswith("_"):
+                assert torch.equal(a[k], b[k]), k
+
+
 def test_wide_altitude_range_uses_all_sort_passes(dev, monkeypatch):
     """Depth keys spanning several binades (200 - altitude from ~25 to ~305): the top byte of the key differs, so the
     fourth depth-sort pass must run (with EOGS-like altitudes it is skipped). Compared with the oracle."""
