@@ -83,7 +83,11 @@ __device__ inline uint32_t entries_on_device(const uint32_t* __restrict__ misc, 
 
 // ---- exclusive scans of the per-workgroup pair and entry counts (-> record slots in Gaussian-id order, entry
 //      positions in id order), their 64-bit totals, the key range and the number of depth digits: misc[] ----
-// Single workgroup; 16 workgroups' counts per thread per round.
+// Single workgroup of 1024 threads, four workgroups' counts per thread per round (one round up to 1 M Gaussians): the
+// kernel sits between preprocess and the host's readback, so what counts is its latency — few loads per thread, close
+// together (with 256 threads x 16 counts the loads of a wave were 256 bytes apart: 10 us; now 7).
+#define PS_T 1024
+#define PS_PER 4
 namespace {
 __device__ inline unsigned long long wg_excl_scan_u64(unsigned long long v, unsigned long long* s_w, unsigned long long& total) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -98,7 +102,7 @@ __device__ inline unsigned long long wg_excl_scan_u64(unsigned long long v, unsi
   unsigned long long pre = 0ull;
   total = 0ull;
 #pragma unroll
-  for (int k = 0; k < BLK / 64; k++) {
+  for (int k = 0; k < PS_T / 64; k++) {
     if (k < w) pre += s_w[k];
     total += s_w[k];
   }
@@ -107,20 +111,20 @@ __device__ inline unsigned long long wg_excl_scan_u64(unsigned long long v, unsi
 }
 }  // namespace
 
-__global__ __launch_bounds__(BLK) void pblock_scan_kernel(uint32_t* __restrict__ pblock, uint32_t* __restrict__ pblockE,
-                                                          const uint32_t* __restrict__ pbkey, uint32_t nblk,
-                                                          uint32_t* __restrict__ misc) {
-  __shared__ unsigned long long s_w[BLK / 64];
-  __shared__ uint32_t s_k[2][BLK / 64];
+__global__ __launch_bounds__(PS_T) void pblock_scan_kernel(uint32_t* __restrict__ pblock, uint32_t* __restrict__ pblockE,
+                                                           const uint32_t* __restrict__ pbkey, uint32_t nblk,
+                                                           uint32_t* __restrict__ misc) {
+  __shared__ unsigned long long s_w[PS_T / 64];
+  __shared__ uint32_t s_k[2][PS_T / 64];
   unsigned long long carry_t = 0ull, carry_e = 0ull, opw = 0ull;
   uint32_t kmax = 0, knmin = 0, err = 0;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (uint32_t b0 = 0; b0 < nblk; b0 += BLK * 16) {
-    const uint32_t i0 = b0 + threadIdx.x * 16;
-    uint32_t v[16], e[16];
+  for (uint32_t b0 = 0; b0 < nblk; b0 += PS_T * PS_PER) {
+    const uint32_t i0 = b0 + threadIdx.x * PS_PER;
+    uint32_t v[PS_PER], e[PS_PER];
     unsigned long long sum_t = 0ull, sum_e = 0ull;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
+    for (int k = 0; k < PS_PER; k++) {
       v[k] = 0; e[k] = 0;
       if (i0 + k < nblk) {
         v[k] = pblock[i0 + k];
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(BLK) void pblock_scan_kernel(uint32_t* __restrict__
     // (slots and entry positions are u32: the host rejects totals that do not fit)
     uint32_t run_t = (uint32_t)(carry_t + ex_t), run_e = (uint32_t)(carry_e + ex_e);
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
+    for (int k = 0; k < PS_PER; k++) {
       if (i0 + k < nblk) { pblock[i0 + k] = run_t; pblockE[i0 + k] = run_e; }
       run_t += v[k];
       run_e += e[k];
@@ -156,14 +160,14 @@ __global__ __launch_bounds__(BLK) void pblock_scan_kernel(uint32_t* __restrict__
     opw += __shfl_xor(opw, o, 64);
     err |= __shfl_xor(err, o, 64);
   }
-  __shared__ unsigned long long s_o[BLK / 64];
-  __shared__ uint32_t s_err[BLK / 64];
+  __shared__ unsigned long long s_o[PS_T / 64];
+  __shared__ uint32_t s_err[PS_T / 64];
   if (lane == 0) { s_k[0][w] = kmax; s_k[1][w] = knmin; s_o[w] = opw; s_err[w] = err; }
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t a = s_k[0][0], b = s_k[1][0], er = s_err[0];
     unsigned long long ow = s_o[0];
-    for (int i = 1; i < BLK / 64; i++) {
+    for (int i = 1; i < PS_T / 64; i++) {
       a = s_k[0][i] > a ? s_k[0][i] : a;
       b = s_k[1][i] > b ? s_k[1][i] : b;
       ow += s_o[i];
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(BLK) void pblock_scan_kernel(uint32_t* __restrict__
 }
 
 void launch_pblock_scan(const GeomWS& g, int P, hipStream_t s) {
-  hipLaunchKernelGGL(pblock_scan_kernel, dim3(1), dim3(BLK), 0, s, g.pblock, g.pblockE, g.pbkey, ceil_div_u32((uint64_t)P, BLK),
+  hipLaunchKernelGGL(pblock_scan_kernel, dim3(1), dim3(PS_T), 0, s, g.pblock, g.pblockE, g.pbkey, ceil_div_u32((uint64_t)P, BLK),
                      g.misc);
 }
 
