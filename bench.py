@@ -153,9 +153,19 @@ def measured_traffic(kernel, a):
             pm = json.load(open(d))
         except Exception:
             continue
+        # a launch group of the library (kernels_ms key) -> the kernels it launches once per step
+        group = {"depth_sort": ("block_lists_kernel",),
+                 "binning": ("pblock_scan_kernel", "expand_entries_kernel", "entry_hist_kernel", "entry_colscan_kernel",
+                             "entry_scatter_kernel")}.get(kernel, (kernel + "_kernel", kernel + "_quad_kernel", kernel + "_mfma_kernel"))
+        total, hit = 0.0, False
         for name, c in pm.items():
-            if name.startswith((kernel + "_kernel", kernel + "_quad_kernel", kernel + "_mfma_kernel")) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                return int((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024), os.path.relpath(d, ROOT)
+            if name.startswith(group) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                total += (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
+                hit = True
+                if kernel not in ("depth_sort", "binning"):
+                    break
+        if hit:
+            return int(total), os.path.relpath(d, ROOT)
     return None, None
 
 
