@@ -126,6 +126,28 @@ def test_long_block_lists_against_oracle(dev, P, label):
     _compare(got, {k: v.cpu().numpy() for k, v in ref.items() if not k.startswith('_')}, f"blocks-{P}", case)
 
 
+def test_image_with_more_than_4096_blocks_takes_the_two_pass_sort(dev):
+    """2304 x 2176 pixels = 72 x 68 blocks of 32 x 32: 13 bits of block id, beyond the one-pass counting sort (4096 blocks):
+    two passes + the block-count kernel (csrc/binning.hip). Every output and gradient against the oracle."""
+    import oracle
+    from eogs2_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib
+    from eogs2_amd.synthetic import make_scene
+
+    H, W, P = 2176, 2304, 6000
+    assert ((H + 31) // 32) * ((W + 31) // 32) > 4096
+    sc = make_scene(P, H, W, seed=43, opacity="trained", scale_mult=2.0)
+    case = {k: v.numpy() for k, v in sc.items()}
+    case.update(H=H, W=W, antialiasing=False)
+    got = run_case(case, dev, GaussianRasterizer, GaussianRasterizationSettings)
+    hip = _lib.get
+    _lib.get = oracle.abi
+    try:
+        ref = run_case(case, torch.device("cpu"), GaussianRasterizer, GaussianRasterizationSettings)
+    finally:
+        _lib.get = hip
+    _compare(got, {k: v.cpu().numpy() for k, v in ref.items() if not k.startswith('_')}, "two-pass", case)
+
+
 def test_entry_sort_in_scratch_and_in_the_binning_workspace_agree(dev, monkeypatch):
     """The entry sort runs in the caller's scratch behind the count readback (ABI v5) or, without scratch / with more
     entries than its capacity, in the binning workspace after the readback: same kernels, same lists — outputs and
