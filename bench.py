@@ -862,7 +862,8 @@ def main():
     # num_rendered of this rank's view, straight from the API's own bookkeeping
     color = step()
     torch.cuda.synchronize()
-    nr = int(color.grad_fn.num_rendered) if hasattr(color.grad_fn, "num_rendered") else -1
+    # (num_rendered_exact: this forward's own counts; num_rendered may name a workspace sized from the previous forward)
+    nr = int(getattr(color.grad_fn, "num_rendered_exact", getattr(color.grad_fn, "num_rendered", -1)))
     # the API's num_rendered packs both counts: (tile, Gaussian) record slots below, (32-px block, Gaussian) list entries
     # above (csrc/common.h nr_pack)
     R, R_entries = (nr & 0x7FFFFFFF, (nr >> 32) & 0x1FFFFFFF) if nr >= 0 else (-1, -1)
@@ -939,6 +940,12 @@ def main():
             "roofline": roof, "pipeline": pipe, "kernels_ms": kern, "kernel_rooflines": per_kernel,
             "ramp_s": ramp_s,  # untimed clock ramp before the contract's warmup (a fresh box starts at idle clocks)
         }
+        # how much of the step the host adds on top of the kernels (launch gaps, the count readback), and how the forwards
+        # of the run obtained their counts (eogs2_amd/rasterizer.py: "hit" = queued whole on the previous forward's counts)
+        from eogs2_amd import rasterizer as _rz
+        ksum = float(sum(kern.values()))
+        line["host"] = {"kernel_sum_ms": ksum, "step_over_kernel_sum": ms_step / ksum if ksum > 0 else None,
+                        "count_readback": _rz.speculation_stats()}
         if exchange is not None:
             exchange["backend"] = a.backend + (" (rehearsal: ranks share one GPU)" if a.share_gpu else "")
             line["exchange"] = exchange

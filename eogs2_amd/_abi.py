@@ -6,7 +6,7 @@ exports the same symbols over host pointers.
 """
 import ctypes as C
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 EOGS_OK = 0
 ERR_NAMES = {
@@ -20,6 +20,9 @@ ERR_NAMES = {
 FLAG_ANTIALIASING = 1
 FLAG_DEBUG = 2
 FLAG_RAW_PARAMS = 4
+FLAG_DEFER_COUNTS = 8
+FLAG_NO_READBACK = 16
+MIRROR_BYTES = 64
 LOSS_L1 = 1
 LOSS_SSIM = 2
 MLOSS_SUN = 0
@@ -45,6 +48,12 @@ SIGNATURES = {
         _i,
         [_i, _i, _i, _p, _p, _p, _p, _p, _p, _f, _p, _p, _p, _u, _p, _p, _z, _p, _z, C.POINTER(_i64), _p],
     ),
+    "eogs_rast_forward_counts": (_i, [C.POINTER(_i64)]),
+    "eogs_rast_read_counts": (_i, [_i, _i, _i, _p, _z, _i, _p, C.POINTER(_i64)]),
+    "eogs_rast_mirror_arm": (_i, [_p]),
+    "eogs_rast_mirror_counts": (_i, [_i, _p, _z, _p, _p]),
+    "eogs_rast_mirror_token": (_i, [_i, _i, _i, _p, _i, C.POINTER(_i64), C.POINTER(_i)]),
+    "eogs_rast_capacity_token": (_i, [_i, _i64, C.c_double, _i, _i64, C.POINTER(_i64), C.POINTER(_i)]),
     "eogs_rast_forward_render": (
         _i,
         [_i, _i, _i, _i64, _p, _u, _p, _z, _p, _z, _p, _z, _p, _z, _p, _p, _p],

@@ -14,6 +14,9 @@ namespace {
 
 thread_local char g_err[512] = "";
 thread_local uint32_t* g_pinned = nullptr;  // MISC_WORDS u32, pinned host memory (one per calling thread)
+// the forward_prepare whose count readback is still pending on this thread (EOGS_FLAG_DEFER_COUNTS)
+struct PendingCounts { bool valid; int P, H, W; bool have_scratch; uint32_t sort_cap; hipStream_t side; };
+thread_local PendingCounts g_pending_counts = {false, 0, 0, 0, false, 0u, nullptr};
 
 // per calling thread and device: a non-blocking side stream + event for the num_rendered readback
 struct Side { int dev; hipStream_t stream; hipEvent_t ev; };
@@ -162,6 +165,7 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
                               size_t geom_bytes, void* scratch, size_t scratch_bytes, int64_t* num_rendered, void* stream) {
   (void)projmatrix;
   g_err[0] = 0;
+  g_pending_counts.valid = false;
   if (P < 0 || H <= 0 || W <= 0 || !num_rendered) return fail(EOGS_ERR_INVALID_ARG, "forward_prepare: bad sizes");
   *num_rendered = 0;
   if (P == 0) return EOGS_OK;
@@ -195,7 +199,11 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
   }
   hipStream_t s = (hipStream_t)stream;
   const bool debug = flags & EOGS_FLAG_DEBUG;
-  if (!g_pinned) HIP_TRY(hipHostMalloc((void**)&g_pinned, MISC_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+  const bool readback = !(flags & EOGS_FLAG_NO_READBACK);
+  if (!readback && !(flags & EOGS_FLAG_DEFER_COUNTS))
+    return fail(EOGS_ERR_INVALID_ARG, "forward_prepare: EOGS_FLAG_NO_READBACK needs EOGS_FLAG_DEFER_COUNTS");
+  if (!readback && debug) return fail(EOGS_ERR_INVALID_ARG, "forward_prepare: EOGS_FLAG_DEBUG waits for the stream: not with EOGS_FLAG_NO_READBACK");
+  if (readback && !g_pinned) HIP_TRY(hipHostMalloc((void**)&g_pinned, MISC_WORDS * sizeof(uint32_t), hipHostMallocDefault));
 
   // (g.misc needs no clearing: the scan writes every word the host reads, the error flag included)
   FwdPrepArgs a{P, H, W, means3D, scales, rotations, cov3D_precomp, opacities, colors, viewmatrix, scale_modifier,
@@ -207,19 +215,31 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
   // The counts are read back on a side stream that waits only for the two kernels above, so the host wakes up while the
   // caller's stream is busy with the entry sort (which reads the entry count on the device) and has the rest of the
   // forward queued before the GPU runs dry.
-  Side* sd = side_for_current_device();
-  if (!sd) return fail(EOGS_ERR_DEVICE, "forward_prepare: cannot create the readback stream");
-  HIP_TRY(hipEventRecord(sd->ev, s));
-  HIP_TRY(hipStreamWaitEvent(sd->stream, sd->ev, 0));
-  HIP_TRY(hipMemcpyAsync(g_pinned, g.misc, MISC_READBACK * sizeof(uint32_t), hipMemcpyDeviceToHost, sd->stream));
+  Side* sd = nullptr;
+  if (readback) {
+    sd = side_for_current_device();
+    if (!sd) return fail(EOGS_ERR_DEVICE, "forward_prepare: cannot create the readback stream");
+    HIP_TRY(hipEventRecord(sd->ev, s));
+    HIP_TRY(hipStreamWaitEvent(sd->stream, sd->ev, 0));
+    HIP_TRY(hipMemcpyAsync(g_pinned, g.misc, MISC_READBACK * sizeof(uint32_t), hipMemcpyDeviceToHost, sd->stream));
+  }
   if (have_scratch) {
     ProfScope ps(PS_BINNING, s);
     launch_entry_sort(g, sw, P, H, W, s);
   }
   LAUNCH_TRY(s, debug, "entry_sort");
-  HIP_TRY(hipStreamSynchronize(sd->stream));
-  const uint64_t total = (uint64_t)g_pinned[MISC_TOTAL_LO] | ((uint64_t)g_pinned[MISC_TOTAL_HI] << 32);
-  const uint64_t entries = (uint64_t)g_pinned[MISC_MACRO_LO] | ((uint64_t)g_pinned[MISC_MACRO_HI] << 32);
+  if (!readback) return EOGS_OK;  // (the caller reads the counts itself: eogs_rast_read_counts)
+  g_pending_counts = PendingCounts{true, P, H, W, have_scratch, sw.cap, sd->stream};
+  if (flags & EOGS_FLAG_DEFER_COUNTS) return EOGS_OK;  // the caller asks for the token later (eogs_rast_forward_counts)
+  return eogs_rast_forward_counts(num_rendered);
+}
+
+}  // extern "C"
+namespace {
+// exact token of a forward from its count words (host copy of GeomWS::misc)
+int token_from_counts(const uint32_t* m, int P, int H, int W, bool have_scratch, uint32_t sort_cap, int64_t* num_rendered) {
+  const uint64_t total = (uint64_t)m[MISC_TOTAL_LO] | ((uint64_t)m[MISC_TOTAL_HI] << 32);
+  const uint64_t entries = (uint64_t)m[MISC_MACRO_LO] | ((uint64_t)m[MISC_MACRO_HI] << 32);
   // List granularity the render kernels read (common.h "blocks"). Per-tile lists while footprints are small: every entry a
   // wave reads is one it uses. Lists per 32 x 32-pixel block once a Gaussian is listed in many tiles: the lists are then
   // 4-7x shorter to write and re-read, which can outweigh the block-list scan in the render waves. Since the lists are built
@@ -239,15 +259,98 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
     const char* e = getenv("EOGS_DEPTH_SWITCH");
     return e ? atof(e) : (double)EOGS_DEPTH_SWITCH;
   }();
-  const uint64_t opw = (uint64_t)g_pinned[MISC_OPW_LO] | ((uint64_t)g_pinned[MISC_OPW_HI] << 32);
+  const uint64_t opw = (uint64_t)m[MISC_OPW_LO] | ((uint64_t)m[MISC_OPW_HI] << 32);
   const double ntiles8 = (double)macro_grid_x(W, 1) * (double)macro_grid_y(H, 1);
   const double list_depth = (double)opw / 64.0 / ntiles8;  // = L * mean pair opacity
   const bool by_footprint = (double)total > block_switch * (double)P;
   const bool by_depth = depth_switch > 0.0 && list_depth > depth_switch && total >= 2 * entries;  // blocks must merge entries
   const int block = (by_footprint || by_depth) ? BLOCK_BIG : 1;
-  if (g_pinned[MISC_ERR] & 1u) return fail(EOGS_ERR_ALTITUDE, "Point is too high: altitude > 200");
+  if (m[MISC_ERR] & 1u) return fail(EOGS_ERR_ALTITUDE, "Point is too high: altitude > 200");
   if (total >= ((uint64_t)1 << 31) || entries >= ((uint64_t)1 << 29)) return fail(EOGS_ERR_OVERFLOW, "num_rendered overflows 31 bits");
-  *num_rendered = nr_pack((uint32_t)total, (uint32_t)entries, block, have_scratch && entries <= (uint64_t)sw.cap);
+  // block_lists_kernel's 8-item build pays when the average block holds 2800 ... 6000 entries (csrc/binning.hip)
+  const double per_block = (double)entries / ((double)macro_grid_x(W, BLOCK_BIG) * (double)macro_grid_y(H, BLOCK_BIG));
+  *num_rendered = nr_pack((uint32_t)total, (uint32_t)entries, block, have_scratch && entries <= (uint64_t)sort_cap,
+                          per_block > 2800.0 && per_block <= 6000.0);
+  return EOGS_OK;
+}
+
+
+}  // namespace
+extern "C" {
+
+int eogs_rast_forward_counts(int64_t* num_rendered) {
+  g_err[0] = 0;
+  if (!num_rendered) return fail(EOGS_ERR_INVALID_ARG, "forward_counts: NULL argument");
+  *num_rendered = 0;
+  if (!g_pending_counts.valid) return fail(EOGS_ERR_INVALID_ARG, "forward_counts: no forward_prepare pending on this thread");
+  const PendingCounts pc = g_pending_counts;
+  g_pending_counts.valid = false;
+  const int P = pc.P, H = pc.H, W = pc.W;
+  HIP_TRY(hipStreamSynchronize(pc.side));
+  return token_from_counts(g_pinned, P, H, W, pc.have_scratch, pc.sort_cap, num_rendered);
+}
+
+int eogs_rast_read_counts(int P, int H, int W, const void* geom, size_t geom_bytes, int have_scratch, void* stream,
+                          int64_t* num_rendered) {
+  g_err[0] = 0;
+  if (P <= 0 || H <= 0 || W <= 0 || !geom || !num_rendered) return fail(EOGS_ERR_INVALID_ARG, "read_counts: bad argument");
+  *num_rendered = 0;
+  char* base = ws_base(const_cast<void*>(geom));
+  const GeomWS g = geom_layout(base, P);
+  if ((size_t)(base - (const char*)geom) + g.bytes - 256 > geom_bytes) return fail(EOGS_ERR_WORKSPACE, "read_counts: geom workspace too small");
+  uint32_t m[MISC_WORDS];
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipMemcpyAsync(m, g.misc, MISC_READBACK * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return token_from_counts(m, P, H, W, have_scratch != 0, ent_cap(P), num_rendered);
+}
+
+static_assert(MISC_READBACK * sizeof(uint32_t) <= EOGS_MIRROR_BYTES, "mirror buffer");
+#define MIRROR_PENDING 0xFFFFFFFFu  // (never a legitimate high word of a 64-bit count below 2^31)
+
+int eogs_rast_mirror_arm(void* host) {
+  if (!host || ((uintptr_t)host & 63u)) return fail(EOGS_ERR_INVALID_ARG, "mirror_arm: NULL or unaligned host buffer");
+  volatile uint32_t* m = (volatile uint32_t*)host;
+  for (int i = 0; i < MISC_READBACK; i++) m[i] = MIRROR_PENDING;
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+  return EOGS_OK;
+}
+
+int eogs_rast_mirror_counts(int P, const void* geom, size_t geom_bytes, void* host, void* stream) {
+  g_err[0] = 0;
+  if (P <= 0 || !geom || !host || ((uintptr_t)host & 63u)) return fail(EOGS_ERR_INVALID_ARG, "mirror_counts: bad argument");
+  char* base = ws_base(const_cast<void*>(geom));
+  const GeomWS g = geom_layout(base, P);
+  if ((size_t)(base - (const char*)geom) + g.bytes - 256 > geom_bytes) return fail(EOGS_ERR_WORKSPACE, "mirror_counts: geom workspace too small");
+  HIP_TRY(hipMemcpyAsync(host, g.misc, MISC_READBACK * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return EOGS_OK;
+}
+
+int eogs_rast_mirror_token(int P, int H, int W, const void* host, int have_scratch, int64_t* num_rendered, int* arrived) {
+  g_err[0] = 0;
+  if (P <= 0 || H <= 0 || W <= 0 || !host || !num_rendered || !arrived) return fail(EOGS_ERR_INVALID_ARG, "mirror_token: bad argument");
+  *arrived = 0;
+  const volatile uint32_t* v = (const volatile uint32_t*)host;
+  // the first and the last 64-bit count both there (the copy is 40 bytes inside one 64-byte line)
+  if (v[MISC_TOTAL_HI] == MIRROR_PENDING || v[MISC_OPW_HI] == MIRROR_PENDING || v[MISC_MACRO_HI] == MIRROR_PENDING) return EOGS_OK;
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  uint32_t m[MISC_READBACK];
+  for (int i = 0; i < MISC_READBACK; i++) m[i] = v[i];
+  *arrived = 1;
+  return token_from_counts(m, P, H, W, have_scratch != 0, ent_cap(P), num_rendered);
+}
+
+int eogs_rast_capacity_token(int P, int64_t num_rendered, double slack, int have_scratch, int64_t exact, int64_t* capacity,
+                             int* fits) {
+  if (P < 0 || num_rendered < 0 || !(slack >= 0.0) || !capacity) return fail(EOGS_ERR_INVALID_ARG, "capacity_token: bad argument");
+  uint64_t slots = (uint64_t)((double)nr_slots(num_rendered) * (1.0 + slack)) + 4096u;
+  uint64_t ents = (uint64_t)((double)nr_entries(num_rendered) * (1.0 + slack)) + 1024u;
+  if (slots > 0x7FFFFFFFull) slots = 0x7FFFFFFFull;
+  if (ents > 0x1FFFFFFFull) ents = 0x1FFFFFFFull;
+  // "sorted in scratch" only if every forward that fits this capacity also fits the scratch (then forward_prepare did sort)
+  const int sorted = have_scratch && ents <= (uint64_t)ent_cap(P);
+  *capacity = nr_pack((uint32_t)slots, (uint32_t)ents, nr_block(num_rendered), sorted, nr_wide(num_rendered));
+  if (fits) *fits = exact > 0 && nr_slots(exact) <= slots && nr_entries(exact) <= ents;
   return EOGS_OK;
 }
 

@@ -865,7 +865,8 @@ __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __res
                                                               const uint32_t* __restrict__ misc, uint32_t gmx, uint32_t gsx,
                                                               uint32_t gsy, uint2* __restrict__ point_list,
                                                               uint32_t* __restrict__ sorted_keys, uint2* __restrict__ ranges,
-                                                              uint8_t* __restrict__ live) {
+                                                              uint8_t* __restrict__ live, uint32_t cap_slots,
+                                                              uint32_t cap_entries) {
   constexpr int BL_CH = BL_T * BL_ITEMS;  // entries per chunk of a pass = longest list the LDS path takes
   __shared__ uint16_t s_wcnt[BL_NW][256];
   __shared__ uint32_t s_base[256], s_cb[256], s_h[256], s_hn[256];
@@ -875,6 +876,23 @@ __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __res
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const uint32_t b = blockIdx.x;
   const int npass = (int)misc[MISC_DEPTH_PASSES];
+  {
+    // The workspaces may have been sized before the host knew this forward's counts (EOGS_FLAG_DEFER_COUNTS): a forward
+    // that does not fit them (or lists nothing: the entry sort then left the per-block counts alone) gets empty lists —
+    // every later kernel reads lists through `ranges` only — and the host, which learns the counts a moment later, repeats
+    // the call with workspaces that fit.
+    const uint32_t ne = misc[MISC_MACRO_LO];
+    const bool fits = misc[MISC_TOTAL_HI] == 0u && misc[MISC_MACRO_HI] == 0u && misc[MISC_TOTAL_LO] <= cap_slots && ne <= cap_entries;
+    if (!fits || ne == 0u) {  // (uniform over the grid)
+      if (MODE != 1) {
+        if (t == 0) ranges[b] = make_uint2(0u, 0u);
+      } else if (t < 16) {
+        const uint32_t tx = (b % gmx) * BLOCK_BIG + (uint32_t)(t % BLOCK_BIG), ty = (b / gmx) * BLOCK_BIG + (uint32_t)(t / BLOCK_BIG);
+        if (tx < gsx && ty < gsy) ranges[ty * gsx + tx] = make_uint2(0u, 0u);
+      }
+      return;
+    }
+  }
 
   // where this block's entries and pairs start: sums of the counts of the blocks before it (a few loads per thread at the
   // usual 1024 ... 4096 blocks)
@@ -1203,16 +1221,16 @@ void launch_block_lists(const GeomWS& g, const SortWS& w, const BinWS& b, const 
   const bool inA = entry_sort_result_in_A(H, W);
   const uint4* ent = inA ? w.entA : w.entB;
   uint2* ki = reinterpret_cast<uint2*>(inA ? w.entB : w.entA);
-  const double avg = (double)nr_entries(R) / (double)nblocks;
-  const bool wide = avg > 2800.0 && avg <= 6000.0;
+  const bool wide = nr_wide(R) != 0;  // 2800 ... 6000 entries per block on average (api.hip forward_counts)
+  const uint32_t cap_slots = nr_slots(R), cap_entries = nr_entries(R) < w.cap ? nr_entries(R) : w.cap;
   if (M > 1) {
     (void)hipMemsetAsync(b.live, 0, (size_t)nr_slots(R), s);
     auto* kern = wide ? block_lists_kernel<BLOCK_BIG, 8> : block_lists_kernel<BLOCK_BIG, 4>;
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(BL_T), 0, s, ent, ki, g.bcount, g.bpairs, g.misc, gmx, gsx, gsy, b.point_list,
-                       b.sorted_keys, im.ranges, b.live);
+                       b.sorted_keys, im.ranges, b.live, cap_slots, cap_entries);
   } else {
     auto* kern = wide ? block_lists_kernel<1, 8> : block_lists_kernel<1, 4>;
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(BL_T), 0, s, ent, ki, g.bcount, g.bpairs, g.misc, gmx, gsx, gsy, b.point_list,
-                       b.sorted_keys, im.ranges, b.live);
+                       b.sorted_keys, im.ranges, b.live, cap_slots, cap_entries);
   }
 }

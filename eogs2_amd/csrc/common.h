@@ -296,13 +296,16 @@ static inline int ceil_log2_u32(uint32_t n) {  // smallest b with (1<<b) >= n
 // num_rendered as handed across the C-ABI packs what a forward decided: the record slots (one per listed internal tile,
 // backward scratch) in bits 0..30, the list entries (one per listed 32 x 32-px block) in bits 32..60, bit 61 = the
 // entries were sorted in the caller's scratch by forward_prepare, bit 62 = the render kernels read block lists
-// (BLOCK_BIG) instead of per-tile lists.
+// (BLOCK_BIG) instead of per-tile lists, bit 31 = a block holds 2800 ... 6000 entries on average (block_lists_kernel's
+// 8-item build; a property of the forward the token was counted on, carried over into capacity tokens).
 static inline uint32_t nr_slots(int64_t R) { return (uint32_t)((uint64_t)R & 0x7FFFFFFFull); }
 static inline uint32_t nr_entries(int64_t R) { return (uint32_t)(((uint64_t)R >> 32) & 0x1FFFFFFFull); }
 static inline int nr_sorted(int64_t R) { return (int)(((uint64_t)R >> 61) & 1ull); }
 static inline int nr_block(int64_t R) { return (((uint64_t)R >> 62) & 1ull) ? BLOCK_BIG : 1; }
-static inline int64_t nr_pack(uint32_t slots, uint32_t entries, int block, int sorted) {
-  return (int64_t)(((uint64_t)(block > 1) << 62) | ((uint64_t)(sorted != 0) << 61) | ((uint64_t)entries << 32) | slots);
+static inline int nr_wide(int64_t R) { return (int)(((uint64_t)R >> 31) & 1ull); }
+static inline int64_t nr_pack(uint32_t slots, uint32_t entries, int block, int sorted, int wide) {
+  return (int64_t)(((uint64_t)(block > 1) << 62) | ((uint64_t)(sorted != 0) << 61) | ((uint64_t)entries << 32) |
+                   ((uint64_t)(wide != 0) << 31) | slots);
 }
 static inline uint32_t macro_grid_x(int W, int M) { return (uint32_t)(((W + SUBX - 1) / SUBX + M - 1) / M); }
 static inline uint32_t macro_grid_y(int H, int M) { return (uint32_t)(((H + SUBY - 1) / SUBY + M - 1) / M); }

@@ -13,7 +13,7 @@ Same no-fallback rule as `rasterizer.py`: arithmetic only in the HIP library.
 """
 import torch
 
-from .rasterizer import NUM_CHANNELS, _run_backward, _run_forward
+from .rasterizer import NUM_CHANNELS, _run_backward, _run_forward, last_exact_token
 
 
 class _RasterizeRaw(torch.autograd.Function):
@@ -28,7 +28,8 @@ class _RasterizeRaw(torch.autograd.Function):
             alt_affine=alt_affine, raw=True,
         )
         ctx.raster_settings = rs
-        ctx.num_rendered = num_rendered
+        ctx.num_rendered = num_rendered  # layout of the workspaces (may be a capacity: see _run_forward)
+        ctx.num_rendered_exact = last_exact_token(xyz.device) if num_rendered else 0
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(radii)
         ctx.save_for_backward(xyz, f_dc, opacity_logit, log_scaling, raw_rotation, alt_affine, radii,

@@ -1,0 +1,100 @@
+"""A training / rendering step recorded once into a HIP graph and replayed (torch.cuda.CUDAGraph over hipGraph).
+
+Small scenes are host-bound in an eager loop: at 100 k Gaussians / 512^2 the kernels of forward + backward need 0.17 ms, the
+Python + autograd + launch path 0.31 ms (profiles/r03_host_path.txt). The reference cannot be captured at all — its forward
+waits for `num_rendered` on the host to size the sort buffers (DGR/cuda_rasterizer/rasterizer_impl.cu:284,
+DGR/rasterize_points.cu:35-131 resizes torch tensors from inside the call). Here a forward inside a capture only queues
+kernels (EOGS_FLAG_DEFER_COUNTS | EOGS_FLAG_NO_READBACK, include/eogs_rast.h): its workspaces are sized from the counts the
+same step had when it ran eagerly, plus slack, the device builds no lists when a replay outgrows them
+(csrc/binning.hip block_lists_kernel), and `GraphedStep` reads the counts back after each replay and re-records the graph
+with larger workspaces when that happened.
+
+    step = GraphedStep(lambda: fwd_bwd(params, camera_buffers))   # eager warm-up runs, then one capture
+    for it in range(n):
+        camera_buffers.copy_(next_camera)                         # inputs live in fixed tensors, updated in place
+        color, loss, *grads = step()                              # replay (+ check)
+        optimizer.step()
+
+`fn` follows the rules of torch.cuda.graph: it reads its inputs from tensors that exist before the capture, allocates
+everything else itself, and never waits for the device. Gradients: set them to None at the start of `fn`
+(`p.grad = None`), so the backward inside the capture writes fresh tensors instead of accumulating; a replay rewrites
+exactly those tensors — p.grad keeps pointing at them as long as nothing else (an eager step, zero_grad(set_to_none=True))
+replaces it; returning them from `fn` keeps a handle either way.
+"""
+import torch
+
+from . import rasterizer
+
+
+class CapacityExceeded(RuntimeError):
+    """A replay needed larger list workspaces than any recorded graph of this step had, twice in a row."""
+
+
+class GraphedStep:
+    MAX_MIRRORED = 16  # forwards per step whose counts are mirrored (further ones are read back after the replay)
+
+    def __init__(self, fn, warmup=2, idempotent=True):
+        """fn() -> anything (tensors it returns are the graph's output buffers, rewritten by every replay).
+        warmup: eager runs before the capture (at least 1: their counts size the captured workspaces).
+        idempotent: fn may simply be run again when a replay did not fit (true for forward + backward; false as soon as fn
+        updates its own inputs, e.g. an optimizer step inside — then __call__ raises CapacityExceeded instead and the
+        caller decides)."""
+        if warmup < 1:
+            raise ValueError("GraphedStep needs at least one eager run before the capture")
+        self.fn, self.idempotent = fn, idempotent
+        self.replays = self.recaptures = 0
+        # pinned host slots the graph copies each forward's counts into (include/eogs_rast.h eogs_rast_mirror_counts):
+        # fits() polls them instead of waiting for the whole replay
+        self._mirror = torch.empty((64 * (self.MAX_MIRRORED + 1),), dtype=torch.uint8, pin_memory=True)
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):  # (torch.cuda.graph's own recipe: warm up on a side stream)
+            for _ in range(warmup):
+                fn()
+        cur.wait_stream(side)
+        self._capture()
+
+    def _capture(self):
+        torch.cuda.current_stream().synchronize()  # (a replay of the graph being replaced may still be running)
+        self.graph = None  # (frees the previous graph's pool before the new capture allocates)
+        self.outputs = None
+        graph = torch.cuda.CUDAGraph()
+        with rasterizer.record_captured(self._mirror) as forwards:
+            with torch.cuda.graph(graph):
+                out = self.fn()
+        self.graph, self.outputs, self.forwards = graph, out, list(forwards)
+
+    def replay(self):
+        """Queues one replay; returns without waiting. Call fits() before trusting the results."""
+        for f in self.forwards:
+            f.arm()
+        self.graph.replay()
+        self.replays += 1
+
+    def fits(self):
+        """True when every forward of the last replay had room for its lists. Waits only until the forwards' counts have
+        reached the host — each a few kernels into its forward — not for the replay to finish. (Also raises the forward's
+        own errors — EOGS_ERR_ALTITUDE — which a captured forward cannot report in line.)"""
+        ok = True
+        for f in self.forwards:
+            ok = f.fits() and ok  # (every forward is read: each updates the counts the next capture is sized from)
+        return ok
+
+    def __call__(self):
+        self.replay()
+        if self.fits():
+            return self.outputs
+        if not self.idempotent:
+            self._capture()
+            raise CapacityExceeded("the replayed step outgrew its list workspaces: its results are not valid; the graph "
+                                   "has been recorded again with larger ones")
+        self.recaptures += 1
+        self._capture()  # (the counts just read now size the workspaces; the capture itself does not run the step)
+        self.replay()
+        if not self.fits():
+            raise CapacityExceeded("the step outgrew its list workspaces twice in a row")
+        return self.outputs
+
+
+__all__ = ["GraphedStep", "CapacityExceeded"]

@@ -17,6 +17,8 @@ arithmetic step runs in the HIP library reached through `_lib.get()`. There is n
 CPU fallback; a missing library raises.
 """
 import ctypes
+import os
+import time
 import threading
 from typing import NamedTuple
 
@@ -24,7 +26,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._abi import FLAG_ANTIALIASING, FLAG_DEBUG, FLAG_RAW_PARAMS, RastError
+from ._abi import FLAG_ANTIALIASING, FLAG_DEBUG, FLAG_DEFER_COUNTS, FLAG_NO_READBACK, FLAG_RAW_PARAMS, MIRROR_BYTES, RastError
 
 NUM_CHANNELS = 5  # DGR/cuda_rasterizer/config.h:15
 
@@ -96,6 +98,122 @@ class _Ctx:
 
 _scratch_lock = threading.Lock()
 _scratch = {}  # (device, stream) -> uint8 tensor
+
+# Deferred count readback (include/eogs_rast.h EOGS_FLAG_DEFER_COUNTS): the exact token of the last forward per shape
+SPECULATION_SLACK = 0.25
+_speculate = os.environ.get("EOGS_SPECULATE", "0") == "1"
+_spec = {}  # (device, P, H, W, raw) -> exact num_rendered token of the previous forward of that shape
+_spec_stats = {"exact": 0, "hit": 0, "redo": 0}
+_last_exact = {}  # device -> exact token of the last forward (the token a forward returns may be a capacity)
+
+
+def set_speculation(on, forget=False):
+    """Turns the deferred count readback on or off (default off; EOGS_SPECULATE=1 in the environment turns it on); returns
+    the previous setting. Off: every forward waits for its counts before it queues binning and blending, as the
+    reference does. (In an eager loop the wait only moves from the middle of the forward to its end — no step got faster on
+    MI355X, profiles/r03_host_path.txt — so it is off by default.) `forget` drops the remembered counts, so the next forward of every shape waits for its own."""
+    global _speculate
+    old, _speculate = _speculate, bool(on)
+    if forget:
+        _spec.clear()
+    return old
+
+
+def speculation_stats(reset=False):
+    """{"exact": forwards that waited for their counts, "hit": forwards queued whole, "redo": forwards repeated because the
+    workspace guessed from the previous one was too small}"""
+    out = dict(_spec_stats)
+    if reset:
+        for k in _spec_stats:
+            _spec_stats[k] = 0
+    return out
+
+
+# Forwards recorded into a HIP graph (torch.cuda.graph): no readback at all inside the capture (EOGS_FLAG_NO_READBACK); the
+# workspaces hold GRAPH_SLACK more than the largest counts any eager forward of the shape has had, and whoever replays the
+# graph checks afterwards that this was enough (eogs2_amd/graph.py).
+GRAPH_SLACK = 0.25
+_peak = {}  # (device, P, H, W, raw) -> token with the largest slot and entry counts seen, flags of the latest forward
+_recording = None  # the record_captured scope of the capture in progress
+_SLOTS, _ENTRIES = 0x7FFFFFFF, 0x1FFFFFFF << 32  # csrc/common.h nr_slots / nr_entries
+
+
+def _merge_counts(peak, exact):
+    if peak is None:
+        return exact
+    return (exact & ~(_SLOTS | _ENTRIES)) | max(peak & _SLOTS, exact & _SLOTS) | max(peak & _ENTRIES, exact & _ENTRIES)
+
+
+class CapturedForward:
+    """One forward inside a captured graph: after a replay `fits()` obtains this forward's counts and tells whether the
+    capacity recorded with it held them; a forward that did not fit has rendered the background. With a `mirror` (a slot
+    of pinned host memory the graph copies the counts into, a few kernels into the forward) fits() polls that slot and
+    returns while the rest of the graph is still running; without, it waits for the stream (eogs_rast_read_counts)."""
+
+    POLL_SECONDS = 0.05  # then wait for the stream instead (after which the copy has landed by definition)
+
+    def __init__(self, abi, key, geom, capacity, have_scratch, mirror=None):
+        self.abi, self.key, self.geom, self.capacity, self.have_scratch = abi, key, geom, capacity, have_scratch
+        self.mirror = mirror  # ctypes.c_void_p or None
+
+    def arm(self):
+        if self.mirror is not None:
+            self.abi.check(self.abi.mirror_arm(self.mirror))
+
+    def fits(self):
+        dev, P, H, W, _ = self.key
+        R, arrived = ctypes.c_int64(), ctypes.c_int(0)
+        if self.mirror is not None:
+            deadline = time.perf_counter() + self.POLL_SECONDS
+            while True:
+                self.abi.check(self.abi.mirror_token(P, H, W, self.mirror, int(self.have_scratch), ctypes.byref(R), ctypes.byref(arrived)))
+                if arrived.value:
+                    break
+                if time.perf_counter() > deadline:
+                    torch.cuda.current_stream(dev).synchronize()
+                    self.abi.check(self.abi.mirror_token(P, H, W, self.mirror, int(self.have_scratch), ctypes.byref(R), ctypes.byref(arrived)))
+                    break
+        if not arrived.value:
+            with torch.cuda.device(dev):
+                stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                self.abi.check(self.abi.read_counts(P, H, W, _ptr(self.geom), self.geom.numel(), int(self.have_scratch), stream,
+                                                    ctypes.byref(R)))
+        exact = R.value
+        _peak[self.key] = _merge_counts(_peak.get(self.key), exact)
+        _spec[self.key] = _last_exact[dev] = exact
+        return (exact & _SLOTS) <= (self.capacity & _SLOTS) and (exact & _ENTRIES) <= (self.capacity & _ENTRIES)
+
+
+class record_captured:
+    """Context manager around a graph capture: collects the CapturedForward of every rasterizer forward recorded inside.
+    `mirror`: pinned uint8 tensor (allocated before the capture) whose 64-byte slots receive the forwards' counts."""
+
+    def __init__(self, mirror=None):
+        self.slots = []
+        if mirror is not None:
+            if not mirror.is_pinned() or mirror.dtype != torch.uint8:
+                raise ValueError("record_captured: mirror must be a pinned uint8 tensor")
+            p0 = (mirror.data_ptr() + 63) // 64 * 64
+            n = (mirror.data_ptr() + mirror.numel() - p0) // MIRROR_BYTES
+            self.slots = [ctypes.c_void_p(p0 + i * MIRROR_BYTES) for i in range(max(0, n))]
+        self.forwards = []
+
+    def take_slot(self):
+        return self.slots.pop(0) if self.slots else None
+
+    def __enter__(self):
+        global _recording
+        self.prev, _recording = _recording, self
+        return self.forwards
+
+    def __exit__(self, *a):
+        global _recording
+        _recording = self.prev
+
+
+def last_exact_token(device):
+    """The exact num_rendered token of the last forward on `device` (what bench.py reports as counts)."""
+    return _last_exact.get(torch.device(device) if not isinstance(device, torch.device) else device)
 
 
 def _scratch_for(abi, dev, stream_id, P, H, W):
@@ -194,26 +312,86 @@ def _run_forward(rs, viewmat, means3D, colors, opacities, scales, rotations, cov
             abi.check(abi.image_bytes(H, W, ctypes.byref(nbytes)))
             img = torch.empty((nbytes.value,), dtype=torch.uint8, device=dev)
 
-            scratch = _scratch_for(abi, dev, cx.stream.value if cx.stream is not None else 0, P, H, W)
+            capturing = dev.type == "cuda" and torch.cuda.is_current_stream_capturing()
+            if capturing:  # a buffer of the graph's own pool (the cached one belongs to eager work on another stream)
+                abi.check(abi.scratch_bytes(P, H, W, ctypes.byref(nbytes)))
+                scratch = torch.empty((nbytes.value,), dtype=torch.uint8, device=dev) if nbytes.value else None
+            else:
+                scratch = _scratch_for(abi, dev, cx.stream.value if cx.stream is not None else 0, P, H, W)
             n_scratch = 0 if scratch is None else scratch.numel()
             R = ctypes.c_int64()
-            abi.check(
-                abi.forward_prepare(
-                    P, H, W, _ptr(m3), _ptr(sc), _ptr(rot), _ptr(cov), _ptr(opa), _ptr(col),
-                    float(rs.scale_modifier), _ptr(vm), _ptr(pm), _ptr(alt), flags,
-                    _ptr(radii), _ptr(geom), geom.numel(), _ptr(scratch), n_scratch, ctypes.byref(R), cx.stream,
+
+            def prepare(extra_flags):
+                abi.check(
+                    abi.forward_prepare(
+                        P, H, W, _ptr(m3), _ptr(sc), _ptr(rot), _ptr(cov), _ptr(opa), _ptr(col),
+                        float(rs.scale_modifier), _ptr(vm), _ptr(pm), _ptr(alt), flags | extra_flags,
+                        _ptr(radii), _ptr(geom), geom.numel(), _ptr(scratch), n_scratch, ctypes.byref(R), cx.stream,
+                    )
                 )
-            )
-            num_rendered = R.value
-            abi.check(abi.binning_bytes(P, H, W, num_rendered, ctypes.byref(nbytes)))
-            binning = torch.empty((nbytes.value,), dtype=torch.uint8, device=dev)
-            abi.check(
-                abi.forward_render(
-                    P, H, W, num_rendered, _ptr(bg), flags,
-                    _ptr(geom), geom.numel(), _ptr(binning), binning.numel(), _ptr(img), img.numel(),
-                    _ptr(scratch), n_scratch, _ptr(color), _ptr(invdepths), cx.stream,
+
+            def render(token):
+                abi.check(abi.binning_bytes(P, H, W, token, ctypes.byref(nbytes)))
+                ws = torch.empty((nbytes.value,), dtype=torch.uint8, device=dev)
+                abi.check(
+                    abi.forward_render(
+                        P, H, W, token, _ptr(bg), flags,
+                        _ptr(geom), geom.numel(), _ptr(ws), ws.numel(), _ptr(img), img.numel(),
+                        _ptr(scratch), n_scratch, _ptr(color), _ptr(invdepths), cx.stream,
+                    )
                 )
-            )
+                return ws
+
+            # The reference blocks on the count readback in the middle of every forward (rasterizer_impl.cu:284), and so
+            # does the first forward of a shape here. Later forwards of the same shape size the binning workspace from the
+            # previous one's counts plus slack and queue the whole forward before asking for the counts
+            # (EOGS_FLAG_DEFER_COUNTS): the device builds no lists when the guess does not hold them, and the forward is then
+            # repeated with the exact counts. The results do not depend on which way a forward went.
+            key = (dev, P, H, W, bool(raw))
+            last = _spec.get(key) if (_speculate and abi.backend != "cpu-oracle") else None
+            if capturing:
+                # Recorded into a graph: nothing may wait. The workspaces hold GRAPH_SLACK more than any eager forward of
+                # this shape has needed; the replaying side checks each replay (CapturedForward.fits, eogs2_amd/graph.py).
+                peak = _peak.get(key)
+                if peak is None:
+                    raise RuntimeError("rasterizer forward inside a graph capture: run the same step once outside the "
+                                       "capture first (its counts size the captured workspaces)")
+                if flags & FLAG_DEBUG:
+                    raise RuntimeError("debug=True waits for the stream after every kernel: not inside a graph capture")
+                cap = ctypes.c_int64()
+                abi.check(abi.capacity_token(P, peak, GRAPH_SLACK, int(scratch is not None), 0, ctypes.byref(cap), None))
+                prepare(FLAG_DEFER_COUNTS | FLAG_NO_READBACK)
+                exact = num_rendered = cap.value
+                binning = render(num_rendered)
+                if _recording is not None:
+                    slot = _recording.take_slot()
+                    if slot is not None:  # the counts reach the host while the rest of the graph runs
+                        abi.check(abi.mirror_counts(P, _ptr(geom), geom.numel(), slot, cx.stream))
+                    _recording.forwards.append(CapturedForward(abi, key, geom, num_rendered, scratch is not None, slot))
+            elif last is None:
+                prepare(0)
+                exact = num_rendered = R.value
+                binning = render(num_rendered)
+                _spec_stats["exact"] += 1
+            else:
+                prepare(FLAG_DEFER_COUNTS)
+                cap, fits = ctypes.c_int64(), ctypes.c_int()
+                abi.check(abi.capacity_token(P, last, SPECULATION_SLACK, int(scratch is not None), 0, ctypes.byref(cap), None))
+                binning = render(cap.value)
+                abi.check(abi.forward_counts(ctypes.byref(R)))
+                exact = R.value
+                abi.check(abi.capacity_token(P, last, SPECULATION_SLACK, int(scratch is not None), exact, ctypes.byref(cap), ctypes.byref(fits)))
+                if fits.value:
+                    num_rendered = cap.value
+                    _spec_stats["hit"] += 1
+                else:
+                    num_rendered = exact
+                    binning = render(exact)
+                    _spec_stats["redo"] += 1
+            if not capturing:
+                _spec[key] = exact
+                _peak[key] = _merge_counts(_peak.get(key), exact)
+            _last_exact[dev] = exact
     return num_rendered, color, radii, invdepths, geom, binning, img
 
 
@@ -368,7 +546,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             rs, viewmat, means3D, colors_precomp, opacities, scales, rotations, cov3Ds_precomp
         )
         ctx.raster_settings = rs
-        ctx.num_rendered = num_rendered
+        ctx.num_rendered = num_rendered  # layout of the workspaces (may be a capacity: see _run_forward)
+        ctx.num_rendered_exact = last_exact_token(means3D.device) if num_rendered else 0
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(radii)
         ctx.save_for_backward(

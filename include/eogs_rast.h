@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define EOGS_RAST_ABI_VERSION 5
+#define EOGS_RAST_ABI_VERSION 6
 #define EOGS_RAST_CHANNELS 5 /* DGR/cuda_rasterizer/config.h:15 NUM_CHANNELS */
 #define EOGS_RAST_TILE 16    /* DGR/cuda_rasterizer/config.h:16-17 BLOCK_X/BLOCK_Y */
 
@@ -67,6 +67,17 @@ extern "C" {
  * dL_dscales = d/d log-scale, dL_drotations = d/d raw quat, dL_dopacity = d/d logit, dL_dcolors = f32[P,3] d/d f_dc,
  * dL_dmeans3D includes the altitude-feature path; dL_dcov3D may be NULL. */
 #define EOGS_FLAG_RAW_PARAMS 4u
+/* forward_prepare only: do not wait for the count readback. *num_rendered is left 0; the caller may go on queueing —
+ * eogs_rast_forward_render with a CAPACITY token (eogs_rast_capacity_token: workspaces sized from an earlier forward of the
+ * same shape) — and must then call eogs_rast_forward_counts, which waits for the readback (by then usually complete) and
+ * returns the exact token: if the forward's counts exceed the capacity the device has built NO lists (the image is the
+ * background) and the caller repeats forward_render with the exact token. The reference has no counterpart: it blocks
+ * on the 4-byte readback inside forward (DGR/cuda_rasterizer/rasterizer_impl.cu:284). */
+#define EOGS_FLAG_DEFER_COUNTS 8u
+/* forward_prepare only, with EOGS_FLAG_DEFER_COUNTS: no readback at all — the call only queues kernels on `stream`, so it
+ * may be recorded into a HIP graph (hipStreamBeginCapture). eogs_rast_forward_counts is not available for such a forward;
+ * after the stream's work (or a replay of the graph) has been queued, eogs_rast_read_counts returns its counts. */
+#define EOGS_FLAG_NO_READBACK 16u
 
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char* eogs_rast_last_error(void);
@@ -106,6 +117,32 @@ int eogs_rast_forward_prepare(
     const float* viewmatrix, const float* projmatrix, const float* alt_affine, unsigned flags,
     int* radii, void* geom, size_t geom_bytes, void* scratch, size_t scratch_bytes,
     int64_t* num_rendered, void* stream);
+
+/* Exact token of the last eogs_rast_forward_prepare(..., EOGS_FLAG_DEFER_COUNTS) on this thread: waits for its count
+ * readback. Errors as forward_prepare reports them (EOGS_ERR_ALTITUDE, EOGS_ERR_OVERFLOW). */
+int eogs_rast_forward_counts(int64_t* num_rendered);
+/* Exact token (and error state, as forward_prepare reports it) of the forward that last ran over `geom`: copies its count
+ * words back on `stream` and WAITS for the stream. For forwards queued with EOGS_FLAG_NO_READBACK — a replayed graph — whose
+ * caller checks afterwards that the capacity it recorded was enough (eogs_rast_capacity_token's `fits`). */
+int eogs_rast_read_counts(int P, int H, int W, const void* geom, size_t geom_bytes, int have_scratch, void* stream,
+                          int64_t* num_rendered);
+/* The same without waiting for the stream: the count words of a forward mirrored into host memory by a copy that is part
+ * of the stream's work (and so of a captured graph). `host`: EOGS_MIRROR_BYTES of pinned (hipHostMalloc, coherent) memory,
+ * 64-byte aligned, owned by the caller.
+ *   eogs_rast_mirror_arm    marks `host` "not arrived" (call before the work — the replay — is queued);
+ *   eogs_rast_mirror_counts queues the copy on `stream`; call it after forward_prepare(..., EOGS_FLAG_NO_READBACK) of the
+ *                           forward over `geom` (any time before the next forward_prepare over the same `geom`);
+ *   eogs_rast_mirror_token  *arrived = 0 while the copy has not landed (poll; the counts are final a few kernels into the
+ *                           forward, long before the stream is idle), else 1 and the exact token / error as read_counts. */
+#define EOGS_MIRROR_BYTES 64
+int eogs_rast_mirror_arm(void* host);
+int eogs_rast_mirror_counts(int P, const void* geom, size_t geom_bytes, void* host, void* stream);
+int eogs_rast_mirror_token(int P, int H, int W, const void* host, int have_scratch, int64_t* num_rendered, int* arrived);
+/* A token whose workspaces hold `slack` (e.g. 0.25) more record slots and list entries than `num_rendered` (an exact token
+ * of an earlier forward with the same P, H, W) describes, for a deferred-count forward; *fits (optional) receives whether an
+ * exact token `exact` (0: not asked) fits inside it. have_scratch: the caller passes a scratch buffer to both calls. */
+int eogs_rast_capacity_token(int P, int64_t num_rendered, double slack, int have_scratch, int64_t exact,
+                             int64_t* capacity, int* fits);
 
 /* Forward, phase 2: duplicate-with-keys, (tile,depth) sort, tile ranges, alpha blend.
  * Replaces DGR/cuda_rasterizer/rasterizer_impl.cu:290-340 (duplicateWithKeys,

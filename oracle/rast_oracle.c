@@ -811,6 +811,18 @@ static int activate_raw(int P, const float* means3D, const float* log_scales, co
   return 1;
 }
 
+/* EOGS_FLAG_DEFER_COUNTS (include/eogs_rast.h): the oracle knows its count synchronously; it keeps it for
+ * eogs_rast_forward_counts and hands back 0 as the ABI says. It never works from a capacity token: its
+ * eogs_rast_capacity_token returns the exact token unchanged. */
+static __thread int64_t g_deferred_token = -1;
+static __thread int64_t g_last_token = -1; /* eogs_rast_read_counts: the forward that last ran on this thread */
+static int forward_prepare_now(
+    int P, int H, int W,
+    const float* means3D, const float* scales, const float* rotations,
+    const float* cov3D_precomp, const float* opacities, const float* colors, float scale_modifier,
+    const float* viewmatrix, const float* projmatrix, const float* alt_affine, unsigned flags,
+    int* radii, void* geom, size_t geom_bytes, int64_t* num_rendered, void* stream);
+
 int eogs_rast_forward_prepare(
     int P, int H, int W,
     const float* means3D, const float* scales, const float* rotations,
@@ -819,6 +831,76 @@ int eogs_rast_forward_prepare(
     int* radii, void* geom, size_t geom_bytes, void* scratch, size_t scratch_bytes,
     int64_t* num_rendered, void* stream) {
   (void)scratch; (void)scratch_bytes;
+  g_deferred_token = -1;
+  const int rc = forward_prepare_now(P, H, W, means3D, scales, rotations, cov3D_precomp, opacities, colors, scale_modifier,
+                                     viewmatrix, projmatrix, alt_affine, flags, radii, geom, geom_bytes, num_rendered, stream);
+  g_last_token = rc == EOGS_OK ? *num_rendered : -1;
+  if (rc == EOGS_OK && (flags & EOGS_FLAG_DEFER_COUNTS) && P > 0) {
+    if (!(flags & EOGS_FLAG_NO_READBACK)) g_deferred_token = *num_rendered;
+    *num_rendered = 0;
+  }
+  return rc;
+}
+
+/* (the oracle is synchronous and keeps no counts in `geom`: the token of this thread's last forward_prepare) */
+int eogs_rast_read_counts(int P, int H, int W, const void* geom, size_t geom_bytes, int have_scratch, void* stream,
+                          int64_t* num_rendered) {
+  (void)H; (void)W; (void)geom_bytes; (void)have_scratch; (void)stream;
+  g_err[0] = 0;
+  if (P <= 0 || !geom || !num_rendered) return fail(EOGS_ERR_INVALID_ARG, "read_counts: bad argument");
+  *num_rendered = 0;
+  if (g_last_token < 0) return fail(EOGS_ERR_INVALID_ARG, "read_counts: no forward ran on this thread");
+  *num_rendered = g_last_token;
+  return EOGS_OK;
+}
+
+int eogs_rast_forward_counts(int64_t* num_rendered) {
+  g_err[0] = 0;
+  if (!num_rendered) return fail(EOGS_ERR_INVALID_ARG, "forward_counts: NULL argument");
+  *num_rendered = 0;
+  if (g_deferred_token < 0) return fail(EOGS_ERR_INVALID_ARG, "forward_counts: no forward_prepare pending on this thread");
+  *num_rendered = g_deferred_token;
+  g_deferred_token = -1;
+  return EOGS_OK;
+}
+
+/* count mirror (include/eogs_rast.h): the oracle is synchronous — "arrived" as soon as mirror_counts has been called */
+int eogs_rast_mirror_arm(void* host) {
+  if (!host) return fail(EOGS_ERR_INVALID_ARG, "mirror_arm: NULL host buffer");
+  ((int64_t*)host)[0] = -1;
+  return EOGS_OK;
+}
+int eogs_rast_mirror_counts(int P, const void* geom, size_t geom_bytes, void* host, void* stream) {
+  (void)geom_bytes; (void)stream;
+  g_err[0] = 0;
+  if (P <= 0 || !geom || !host) return fail(EOGS_ERR_INVALID_ARG, "mirror_counts: bad argument");
+  ((int64_t*)host)[0] = g_last_token;
+  return EOGS_OK;
+}
+int eogs_rast_mirror_token(int P, int H, int W, const void* host, int have_scratch, int64_t* num_rendered, int* arrived) {
+  (void)H; (void)W; (void)have_scratch;
+  g_err[0] = 0;
+  if (P <= 0 || !host || !num_rendered || !arrived) return fail(EOGS_ERR_INVALID_ARG, "mirror_token: bad argument");
+  *arrived = ((const int64_t*)host)[0] >= 0;
+  if (*arrived) *num_rendered = ((const int64_t*)host)[0];
+  return EOGS_OK;
+}
+
+int eogs_rast_capacity_token(int P, int64_t num_rendered, double slack, int have_scratch, int64_t exact, int64_t* capacity,
+                             int* fits) {
+  (void)have_scratch;
+  if (P < 0 || num_rendered < 0 || !(slack >= 0.0) || !capacity) return fail(EOGS_ERR_INVALID_ARG, "capacity_token: bad argument");
+  *capacity = num_rendered;
+  if (fits) *fits = exact > 0 && exact == num_rendered;
+  return EOGS_OK;
+}
+
+static int forward_prepare_now(
+    int P, int H, int W,
+    const float* means3D, const float* scales, const float* rotations,
+    const float* cov3D_precomp, const float* opacities, const float* colors, float scale_modifier,
+    const float* viewmatrix, const float* projmatrix, const float* alt_affine, unsigned flags,
+    int* radii, void* geom, size_t geom_bytes, int64_t* num_rendered, void* stream) {
   if (!(flags & EOGS_FLAG_RAW_PARAMS) || P <= 0)
     return forward_prepare_activated(P, H, W, means3D, scales, rotations, cov3D_precomp, opacities, colors,
                                      scale_modifier, viewmatrix, projmatrix, flags, radii, geom, geom_bytes,

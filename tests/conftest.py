@@ -26,3 +26,14 @@ def oracle_backend(monkeypatch):
     abi = oracle.abi()
     monkeypatch.setattr(_lib, "get", lambda: abi)
     return abi
+
+
+@pytest.fixture
+def exact_counts():
+    """Every forward waits for its own counts (no workspace guessed from the previous forward of the same shape): for
+    tests that read the token to see which kernels ran."""
+    from eogs2_amd import rasterizer
+
+    old = rasterizer.set_speculation(False)
+    yield
+    rasterizer.set_speculation(old)

@@ -37,7 +37,7 @@ def hip_lib():
 
 def test_hip_library_exports_everything(hip_lib):
     assert hip_lib.backend == "hip-gfx950"
-    assert hip_lib.cdll.eogs_rast_abi_version() == 5
+    assert hip_lib.cdll.eogs_rast_abi_version() == 6
     for name in header_symbols():
         assert hasattr(hip_lib.cdll, name), name
 
@@ -62,6 +62,66 @@ def test_hip_size_queries_and_arg_checks(hip_lib):
                                    None, 0, ctypes.byref(R), None) == 0
     hip_lib.check(hip_lib.scratch_bytes(1 << 20, 1024, 1024, ctypes.byref(n)))
     assert 100e6 < n.value < 300e6  # transient, shared by every forward on a stream
+
+
+def test_capacity_token_and_counts_without_a_pending_forward(hip_lib):
+    """Host-only pieces of the deferred count readback (EOGS_FLAG_DEFER_COUNTS): the capacity token keeps the list
+    granularity, holds `slack` more slots and entries, claims "sorted in scratch" only if everything that fits it fits
+    the scratch (6 entries per Gaussian), and `fits` compares both counts."""
+    def pack(slots, entries, block, sorted_):
+        return (block << 62) | (sorted_ << 61) | (entries << 32) | slots
+
+    cap, fits = ctypes.c_int64(), ctypes.c_int()
+    P = 100_000
+    last = pack(1_000_000, 200_000, 0, 1)
+    hip_lib.check(hip_lib.capacity_token(P, last, 0.25, 1, pack(1_200_000, 250_000, 0, 1), ctypes.byref(cap), ctypes.byref(fits)))
+    c = cap.value
+    assert (c & 0x7FFFFFFF) == 1_250_000 + 4096 and ((c >> 32) & 0x1FFFFFFF) == 250_000 + 1024
+    assert (c >> 61) & 1 == 1 and (c >> 62) & 1 == 0 and fits.value == 1
+    hip_lib.check(hip_lib.capacity_token(P, last, 0.25, 1, pack(1_254_097, 250_000, 0, 1), ctypes.byref(cap), ctypes.byref(fits)))
+    assert fits.value == 0
+    hip_lib.check(hip_lib.capacity_token(P, last, 0.25, 1, pack(1_000, 251_025, 0, 1), ctypes.byref(cap), ctypes.byref(fits)))
+    assert fits.value == 0
+    # 500 k entries x 1.25 exceed the scratch of 100 k Gaussians (600 k entries): the forward sorts in its binning workspace
+    hip_lib.check(hip_lib.capacity_token(P, pack(9_000_000, 500_000, 1, 1), 0.25, 1, 0, ctypes.byref(cap), None))
+    assert (cap.value >> 61) & 1 == 0 and (cap.value >> 62) & 1 == 1
+    hip_lib.check(hip_lib.capacity_token(P, last, 0.25, 0, 0, ctypes.byref(cap), None))
+    assert (cap.value >> 61) & 1 == 0  # no scratch, no sort in scratch
+    assert hip_lib.capacity_token(P, last, -1.0, 1, 0, ctypes.byref(cap), None) == -1
+    R = ctypes.c_int64(5)
+    assert hip_lib.forward_counts(ctypes.byref(R)) == -1 and R.value == 0
+    assert b"pending" in hip_lib.cdll.eogs_rast_last_error()
+
+
+def test_oracle_defers_nothing(oracle_backend):
+    """The checker library keeps the ABI's shape: with EOGS_FLAG_DEFER_COUNTS forward_prepare hands back 0 and
+    forward_counts the token, once; its capacity token is the exact token."""
+    import numpy as np
+    from eogs2_amd._abi import FLAG_DEFER_COUNTS
+    from eogs2_amd.synthetic import make_scene
+
+    a = oracle_backend
+    P, H, W = 200, 48, 48
+    sc = {k: np.ascontiguousarray(v.numpy()) for k, v in make_scene(P, H, W, seed=2).items()}
+    ptr = lambda x: ctypes.c_void_p(x.ctypes.data)  # noqa: E731
+    n = ctypes.c_size_t()
+    a.check(a.geom_bytes(P, ctypes.byref(n)))
+    geom, radii = np.zeros(n.value, np.uint8), np.zeros(P, np.int32)
+    tokens = []
+    for flags in (0, FLAG_DEFER_COUNTS):
+        R = ctypes.c_int64(-1)
+        a.check(a.forward_prepare(P, H, W, ptr(sc["means3D"]), ptr(sc["scales"]), ptr(sc["rotations"]), None, ptr(sc["opacities"]),
+                                  ptr(sc["colors"]), 1.0, ptr(sc["viewmatrix"]), ptr(sc["viewmatrix"]), None, flags, ptr(radii),
+                                  ptr(geom), geom.size, None, 0, ctypes.byref(R), None))
+        tokens.append(R.value)
+    assert tokens[0] > 0 and tokens[1] == 0
+    R = ctypes.c_int64(-1)
+    a.check(a.forward_counts(ctypes.byref(R)))
+    assert R.value == tokens[0]
+    assert a.forward_counts(ctypes.byref(R)) == -1  # consumed
+    cap, fits = ctypes.c_int64(), ctypes.c_int()
+    a.check(a.capacity_token(P, tokens[0], 0.25, 0, tokens[0], ctypes.byref(cap), ctypes.byref(fits)))
+    assert cap.value == tokens[0] and fits.value == 1
 
 
 def test_oracle_library_exports_everything():

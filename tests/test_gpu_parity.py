@@ -99,7 +99,7 @@ def test_depth_ties_and_overlap_order(dev):
 
 
 @pytest.mark.parametrize("P,label", [(50_000, "8-item LDS path"), (130_000, "streaming path"), (2_000, "4-item LDS path")])
-def test_long_block_lists_against_oracle(dev, P, label):
+def test_long_block_lists_against_oracle(dev, P, label, exact_counts):
     """The three ways block_lists_kernel orders a block (csrc/binning.hip): up to 4096 entries per 32 x 32-px block in
     registers / LDS, the 8-item build for blocks of 2800 ... 6000 entries on average, and chunked streaming through the
     scratch ping-pong buffer beyond the LDS path. A 128 x 128 image has 16 blocks; the Gaussian count sets the block length.
@@ -148,7 +148,7 @@ def test_image_with_more_than_4096_blocks_takes_the_two_pass_sort(dev):
     _compare(got, {k: v.cpu().numpy() for k, v in ref.items() if not k.startswith('_')}, "two-pass", case)
 
 
-def test_entry_sort_in_scratch_and_in_the_binning_workspace_agree(dev, monkeypatch):
+def test_entry_sort_in_scratch_and_in_the_binning_workspace_agree(dev, monkeypatch, exact_counts):
     """The entry sort runs in the caller's scratch behind the count readback (ABI v5) or, without scratch / with more
     entries than its capacity, in the binning workspace after the readback: same kernels, same lists — outputs and
     gradients are bit-identical, and the token records where the sort ran."""

@@ -84,6 +84,7 @@ def run_case(case, device, rasterizer_mod, settings_cls):
     nr = getattr(color.grad_fn, "num_rendered", None)
     if nr is not None:
         out["_num_rendered"] = int(nr)  # the library's opaque token: tells which kernels ran (eogs_rast_path_info)
+        out["_num_rendered_exact"] = int(getattr(color.grad_fn, "num_rendered_exact", nr))  # this forward's own counts
     if P:
         loss.backward()
         out.update(g_means3D=means3D.grad, g_means2D=means2D.grad, g_opacities=opac.grad, g_colors=colors.grad,
