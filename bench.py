@@ -53,9 +53,75 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="collective backend; gloo + --share-gpu rehearses the N-rank path on a one-GPU box (not a measurement)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--graph-extras", action="store_true", help="child mode: the graph-replay measurements only")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher self-test: ranks rendezvous over gloo, all-reduce one number and exit before any GPU call")
     return ap.parse_args()
+
+
+def graph_extras(a):
+    """Child mode (--graph-extras): fwd+bwd of the bench step, and the fused training iteration, as replayed HIP graphs."""
+    from eogs2_amd import GaussianRasterizer
+    from eogs2_amd.graph import GraphedStep
+    from eogs2_amd.synthetic import make_scene, settings_for
+
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    P, H, W = a.gaussians, a.size, a.size
+    op = a.opacity if a.opacity in ("init", "trained") else float(a.opacity)
+    sc = make_scene(P, H, W, seed=0, opacity=op, device=dev)
+    rast = GaussianRasterizer(settings_for(sc, H, W))
+    names = ("means3D", "colors", "opacities", "scales", "rotations")
+    params = {k: sc[k].clone().requires_grad_(True) for k in names}
+    means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
+
+    def step():
+        means2D.grad = None
+        for p in params.values():
+            p.grad = None
+        color, _, _ = rast(params["means3D"], means2D, params["opacities"], colors_precomp=params["colors"],
+                           scales=params["scales"], rotations=params["rotations"])
+        torch.autograd.backward([color], [sc["dL_dcolor"]])
+        return color.detach()  # (a result that kept the autograd graph alive would tie the next backward to this stream)
+
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < 1.5:
+        step()
+    gs = GraphedStep(step, warmup=2)
+    for _ in range(max(a.warmup, 10)):
+        gs()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        gs()
+    torch.cuda.synchronize()
+    g_ms = (time.perf_counter() - t0) / a.steps * 1e3
+    out = {"graphed_step": {"ms_per_step": g_ms, "views_per_s": 1e3 / g_ms, "recaptures": gs.recaptures,
+                            "what": "GraphedStep: fwd+bwd of the bench step as one hipGraph replay, list capacity checked "
+                                    "per replay while it runs"}}
+    del gs
+    if not a.no_train_iter:
+        out["train_iter_fused_graphed"] = train_iteration(sc, P, H, W, dev, fused=True, graphed=True, iters=20)
+    print(json.dumps(out), flush=True)
+
+
+def graph_extras_from_child(a, kernel_sum_ms):
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--graph-extras", "--gaussians", str(a.gaussians), "--size", str(a.size),
+           "--opacity", str(a.opacity), "--steps", str(a.steps), "--warmup", str(a.warmup)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        rows = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not rows:
+            return {"graphed_step": {"error": f"child exited {r.returncode}: {r.stderr[-300:]}"}}
+        out = json.loads(rows[-1])
+        if kernel_sum_ms and "ms_per_step" in out.get("graphed_step", {}):
+            out["graphed_step"]["step_over_kernel_sum"] = out["graphed_step"]["ms_per_step"] / kernel_sum_ms
+        return out
+    except Exception as e:  # noqa: BLE001 (an extra must never cost the bench line)
+        return {"graphed_step": {"error": repr(e)[:300]}}
 
 
 def _free_port():
@@ -234,7 +300,7 @@ def _ssim_window(dev, C=3):
     return w1.mm(w1.t()).float().expand(C, 1, 11, 11).contiguous().to(dev)
 
 
-def train_iteration(sc, P, H, W, dev, fused, iters=5, dist=None, view_seed=0, algo="all_reduce"):
+def train_iteration(sc, P, H, W, dev, fused, iters=5, dist=None, view_seed=0, algo="all_reduce", graphed=False):
     """Extra, reported beside the headline: one synthetic EOGS++ training iteration as the reference schedules it after
     iteration 1000 (GS/train_pan.py:278,305-316,375-391): three renders of the same Gaussians — the view (H x W), the
     sun camera (2H x 2W, affine_cameras.py:366-367) and a random virtual camera (H x W) — each forward + backward,
@@ -248,7 +314,9 @@ def train_iteration(sc, P, H, W, dev, fused, iters=5, dist=None, view_seed=0, al
     of the same Gaussians and the iteration ends with ONE synchronous exchange of the 56 B/Gaussian raw-parameter gradients
     (`GradBucket.all_reduce()`: the three backward passes accumulate first, so the exchange cannot start earlier) before the
     optimizer step — the reference's iteration (train_pan.py:278,308,469,664-690) under view-sharded data parallelism.
-    Reported: ms per iteration (max over ranks), the same without the exchange, and the exchange alone."""
+    Reported: ms per iteration (max over ranks), the same without the exchange, and the exchange alone.
+    graphed (one rank, fused): the three renders, the loss and their backward passes are recorded once into a HIP graph
+    (eogs2_amd.graph.GraphedStep) and replayed; the optimizer step stays outside (its bias correction is host arithmetic)."""
     from eogs2_amd import GaussianRasterizer
     from eogs2_amd.fused import rasterize_raw
     from eogs2_amd.losses import photometric_loss
@@ -279,7 +347,7 @@ def train_iteration(sc, P, H, W, dev, fused, iters=5, dist=None, view_seed=0, al
         views.append((settings_for(dict(sc, viewmatrix=vm), h, w), vm[:, 2].contiguous(), torch.zeros(P, 3, device=dev), dL))
     gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(5)).to(dev)
 
-    def it(exchange=True):
+    def it(exchange=True, step=True):
         opt.zero_grad(set_to_none=True)
         for vi, (rs, alt, m2, dL) in enumerate(views):
             if fused:
@@ -299,7 +367,20 @@ def train_iteration(sc, P, H, W, dev, fused, iters=5, dist=None, view_seed=0, al
                 torch.autograd.backward([color], [dL])
         if bucket is not None and exchange:
             bucket.all_reduce()
-        opt.step()
+        if step:
+            opt.step()
+
+    graph_info = {}
+    if graphed:
+        from eogs2_amd.graph import GraphedStep
+
+        assert fused and dist is None
+        gs = GraphedStep(lambda: it(step=False), warmup=2)
+        eager_it = it
+
+        def it(exchange=True):  # noqa: F811
+            gs()
+            opt.step()
 
     def timed(fn, n):
         fn()
@@ -330,7 +411,9 @@ def train_iteration(sc, P, H, W, dev, fused, iters=5, dist=None, view_seed=0, al
                               "bytes_per_gaussian": bucket.bytes_per_gaussian,
                               "how": "GradBucket.all_reduce() after the iteration's three backward passes, before the optimizer step"}}
         bucket.close()
-    return {"iters_per_s": 1.0 / dt, "ms_per_iter": dt * 1e3, "renders_per_iter": 3, **extra,
+    if graphed:
+        graph_info = {"graph": {"replays": gs.replays, "recaptures": gs.recaptures, "forwards_per_replay": len(gs.forwards)}}
+    return {"iters_per_s": 1.0 / dt, "ms_per_iter": dt * 1e3, "renders_per_iter": 3, **extra, **graph_info,
             "what": f"3 renders ({H}x{W}, {2 * H}x{2 * W} sun camera, {H}x{W}) fwd+bwd + L1/DSSIM loss on the view + Adam "
                     f"on raw parameters; activations, loss and optimizer " + ("inside HIP kernels (EOGS_FLAG_RAW_PARAMS, "
                     "eogs_loss_*, eogs_adam_step)" if fused else "as the reference's PyTorch ops")}
@@ -712,6 +795,8 @@ def main():
     if a.dry_run:
         return dry_run(a, rank, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+    if a.graph_extras:
+        return graph_extras(a)
     dev = torch.device("cuda", 0 if a.share_gpu else local_rank)
     torch.cuda.set_device(dev)
     dist = None
@@ -956,6 +1041,10 @@ def main():
         if world == 1 and not use_dist and not a.no_train_iter:
             line["train_iter"] = train_iteration(sc, P, H, W, dev, fused=False)
             line["train_iter_fused"] = train_iteration(sc, P, H, W, dev, fused=True)
+            # The same step and the same iteration recorded into HIP graphs and replayed (eogs2_amd/graph.py): beside the
+            # headline, never the headline — `value` stays the eager call through the reference's API. Measured in a child
+            # process started after everything above is done: a failed capture must not cost this line.
+            line.update(graph_extras_from_child(a, line["host"]["kernel_sum_ms"]))
             line["photometric_loss"] = photometric_loss_bench(abi, dev, H, W)
             line["optimizer"] = optimizer_bench(abi, dev, P)
             line["resample"] = resample_bench(abi, dev, H, W)
