@@ -559,7 +559,9 @@ __global__ __launch_bounds__(BLK, 4) void expand_entries_kernel(const uint4* __r
 //      (1024 threads x 8): the histogram tables stay small although the launch covers the buffer's capacity, and a
 //      workgroup's entries of one block form runs of several 16-byte entries in the output. ----
 #define ES_T 1024
+#ifndef ES_ITEMS
 #define ES_ITEMS 8
+#endif
 #define ES_TILE (ES_T * ES_ITEMS)
 #define ES_NW (ES_T / 64)
 #define ES_MAXBITS 12

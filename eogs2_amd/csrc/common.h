@@ -46,7 +46,10 @@ static_assert(REC == 12, "record quarters");
 
 // ---- radix sort geometry ----
 #define SORTP_ITEMS 8    // generic u32 key + u32 payload sort (knn.hip's Morton order): 2048 keys per workgroup
-#define SORTE_TILE 8192  // block sort of the list entries (16-byte items): entries per workgroup (binning.hip ES_TILE)
+#ifndef SORTE_TILE
+#define SORTE_TILE 8192
+#endif
+// SORTE_TILE: block sort of the list entries (16-byte items): entries per workgroup (binning.hip ES_TILE)
 #define SORTE_MAXBINS 4096  // ... and the widest digit of one pass (ES_MAXBITS)
 #define EXPAND_ITEMS 1   // expand: 256 Gaussians (one preprocess workgroup) per workgroup
 #define MAX_BLOCKS (1u << 16)  // 32 x 32-pixel blocks per image (their id is the low half of an entry's sort key)

@@ -110,8 +110,15 @@ __device__ inline float wave_sum(float v) {
 
 // RAW (EOGS_FLAG_RAW_PARAMS): scales/rotations/opacities/colors are the model's raw parameters; the activations and
 // the [rgb, altitude, 1] feature assembly of renderer.py:72-96 happen here instead of in ~10 PyTorch kernels.
+// Compiled for six waves per SIMD (80 VGPRs, 38 spilled to scratch on the rarely taken paths) instead of the four that its
+// 123 VGPRs allow: the kernel waits 62 % of its wave time on memory, 52 -> 48 us (trained 56 -> 50); five waves changed
+// nothing, eight spill in the main path (48 / 57). -DEOGS_PP_WAVES=n overrides.
+#ifndef EOGS_PP_WAVES
+#define EOGS_PP_WAVES 6
+#endif
+#define PP_ATTR __attribute__((amdgpu_waves_per_eu(EOGS_PP_WAVES, EOGS_PP_WAVES)))
 template <bool RAW>
-__global__ __launch_bounds__(BLK) void preprocess_fwd_kernel(
+__global__ __launch_bounds__(BLK) PP_ATTR void preprocess_fwd_kernel(
     int P, int H, int W, int gx, int gy,
     const float* __restrict__ means3D, const float* __restrict__ scales, const float* __restrict__ rotations,
     const float* __restrict__ cov3D_precomp, const float* __restrict__ opacities, const float* __restrict__ colors,
