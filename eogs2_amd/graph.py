@@ -15,6 +15,12 @@ with larger workspaces when that happened.
         color, loss, *grads = step()                              # replay (+ check)
         optimizer.step()
 
+What a recorded forward freezes besides its capacities is the list granularity (per-tile lists or 32-px block lists,
+DESIGN.md §2.3) of the last eager forward of that shape: an eager loop re-decides it per forward, so near the switch the two
+loops take different — equally valid, individually oracle-tested — kernel variants and their gradients differ at the
+level of threshold flips (examples/train_synthetic.py at 200 k / 512²: identical loss curves with the switch disabled,
+0.00815 against 0.00844 after 200 iterations with it).
+
 `fn` follows the rules of torch.cuda.graph: it reads its inputs from tensors that exist before the capture, allocates
 everything else itself, and never waits for the device. Gradients: set them to None at the start of `fn`
 (`p.grad = None`), so the backward inside the capture writes fresh tensors instead of accumulating; a replay rewrites

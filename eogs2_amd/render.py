@@ -67,7 +67,11 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_
     out = {"render": image, "viewspace_points": viewspace_points}
     if pipe.require_radii:
         out["radii"] = radii
-        out["visibility_filter"] = torch.nonzero(radii > 0)
+        # renderer.py:128-130 returns the INDICES (`nonzero`, which waits for the device to learn how many there are). While
+        # a HIP graph is being recorded nothing may wait: the boolean mask is returned instead — `t[visibility_filter]`
+        # reads and writes the same elements either way (train_pan.py:679-686).
+        capturing = radii.is_cuda and torch.cuda.is_current_stream_capturing()
+        out["visibility_filter"] = (radii > 0) if capturing else torch.nonzero(radii > 0)
     return out
 
 

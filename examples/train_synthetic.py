@@ -81,6 +81,9 @@ def main(argv=None):
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--quiet", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="record renders + losses + backward once into a HIP graph and replay it (eogs2_amd.graph.GraphedStep); "
+                         "the optimizers stay outside, the graph is recorded again after every prune")
     a = ap.parse_args(argv)
     dev = torch.device("cuda:0")
     P, H, W = a.gaussians, a.size, a.size
@@ -126,27 +129,41 @@ def main(argv=None):
     dist2 = torch.clamp_min(distCUDA2(sc["means3D"]), 1e-7)  # gaussian_model.py:179-182
     model = Gaussians(sc["means3D"] + 2e-4 * noise(P, 3), (sc["colors"][:, :3] + 0.2 * noise(P, 3)).clamp(0.02, 0.98),
                       torch.full((P,), 0.3, device=dev), torch.sqrt(dist2)[:, None].repeat(1, 3), sc["rotations"])
-    first = last = None
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for it in range(1, a.iters + 1):
+    def fwd_bwd():
+        """Everything between two optimizer steps; reads the model's and the camera's parameter tensors in place."""
+        model.optimizer.zero_grad(set_to_none=True)
+        camera_optimizer.zero_grad(set_to_none=True)
         out, img, sample, sun_uv, sun_altitude_diff, shaded = view(model, cc_cam)
         loss, _ = photometric_loss(shaded["final"], gt, 0.2)
         L_sun_alt, L_sun_rgb = suncamera_l(img, sample[:3], sun_altitude_diff, sun_uv)
         loss = loss + 1e-4 * L_sun_alt + 1e-3 * L_sun_rgb + 1e-3 * translucentshadows_l(shaded["shadowmap"])
         loss.backward()
+        return loss.detach(), out["radii"]
+
+    first = last = None
+    step = None  # the recorded graph of fwd_bwd for the current set of Gaussians
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(1, a.iters + 1):
+        if a.graph:
+            if step is None:
+                from eogs2_amd.graph import GraphedStep
+
+                step = GraphedStep(fwd_bwd, warmup=1)  # (the eager warm-up run changes nothing: no optimizer step inside)
+            loss, radii = step()
+        else:
+            loss, radii = fwd_bwd()
         model.optimizer.step()
         camera_optimizer.step()
-        model.optimizer.zero_grad(set_to_none=True)
-        camera_optimizer.zero_grad(set_to_none=True)
         with torch.no_grad():
-            model.max_radii2D = torch.maximum(model.max_radii2D, out["radii"].float())
+            model.max_radii2D = torch.maximum(model.max_radii2D, radii.float())
             if it % 50 == 0:  # train_pan.py:673-678
                 keep = model._opacity.squeeze() >= math.log(0.005 / 0.995)
                 if not bool(keep.all()):
                     model.prune(keep)
+                    step = None  # new parameter tensors, new shapes: record again
         if it == 1 or it % 25 == 0 or it == a.iters:
-            v = float(loss.detach())
+            v = float(loss)
             first = v if first is None else first
             last = v
             if not a.quiet:

@@ -18,3 +18,18 @@ def test_synthetic_training_loss_falls():
     first, last, n = train_synthetic.main(["--gaussians", "30000", "--size", "192", "--iters", "120", "--quiet"])
     assert last < 0.6 * first, (first, last)
     assert 0 < n <= 30000
+
+
+def test_synthetic_training_as_replayed_graph_matches_eager():
+    """The same run with renders + resample + render pipeline + losses + backward recorded into a HIP graph
+    (eogs2_amd.graph.GraphedStep; optimizers outside, re-recorded after each prune): same loss curve, same prune."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import train_synthetic
+
+    args = ["--gaussians", "30000", "--size", "192", "--iters", "120", "--quiet"]
+    eager = train_synthetic.main(args)
+    graph = train_synthetic.main(args + ["--graph"])
+    assert graph[2] == eager[2]  # the prune kept the same Gaussians
+    assert abs(graph[0] - eager[0]) <= 1e-6 * abs(eager[0]) and abs(graph[1] - eager[1]) <= 1e-4 * abs(eager[1]), (eager, graph)
