@@ -111,7 +111,8 @@ def set_speculation(on, forget=False):
     """Turns the deferred count readback on or off (default off; EOGS_SPECULATE=1 in the environment turns it on); returns
     the previous setting. Off: every forward waits for its counts before it queues binning and blending, as the
     reference does. (In an eager loop the wait only moves from the middle of the forward to its end — no step got faster on
-    MI355X, profiles/r03_host_path.txt — so it is off by default.) `forget` drops the remembered counts, so the next forward of every shape waits for its own."""
+    MI355X, profiles/r03_host_path.txt — so it is off by default.) `forget` drops the remembered counts, so the next
+    forward of every shape waits for its own."""
     global _speculate
     old, _speculate = _speculate, bool(on)
     if forget:

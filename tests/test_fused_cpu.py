@@ -107,3 +107,27 @@ def test_render_entry_point_delegates_what_it_does_not_fuse(oracle_backend):
     assert render(cam, pc, pipe, scene["bg"], 2.0, fallback=lambda *a: seen.append(a) or "theirs") == "theirs"
     assert seen[0][:5] == (cam, pc, pipe, scene["bg"], 2.0) and len(seen[0]) == 8
 
+
+
+def test_count_bookkeeping_of_deferred_and_captured_forwards():
+    """Host logic behind EOGS_FLAG_DEFER_COUNTS / GraphedStep (eogs2_amd/rasterizer.py): the capacity a capture is sized from
+    is the component-wise maximum of the counts seen, with the flags (list granularity, 8-item build) of the LATEST
+    forward; the switches report their previous state."""
+    from eogs2_amd import rasterizer as rz
+
+    def tok(slots, entries, block=0, wide=0, sorted_=0):
+        return (block << 62) | (sorted_ << 61) | (entries << 32) | (wide << 31) | slots
+
+    assert rz._merge_counts(None, tok(5, 3, block=1)) == tok(5, 3, block=1)
+    m = rz._merge_counts(tok(1000, 10, block=1, wide=1, sorted_=1), tok(400, 50))
+    assert m == tok(1000, 50)  # max of each count, flags of the later one
+    m = rz._merge_counts(tok(400, 50), tok(1000, 10, block=1, wide=1))
+    assert m == tok(1000, 50, block=1, wide=1)
+    assert (tok(0x7FFFFFFF, 0x1FFFFFFF) & rz._SLOTS) == 0x7FFFFFFF and (tok(0, 0x1FFFFFFF) & rz._ENTRIES) >> 32 == 0x1FFFFFFF
+    old = rz.set_speculation(True)
+    try:
+        assert rz.set_speculation(False) is True and rz.set_speculation(True, forget=True) is False and not rz._spec
+    finally:
+        rz.set_speculation(old)
+    rz.speculation_stats(reset=True)
+    assert rz.speculation_stats() == {"exact": 0, "hit": 0, "redo": 0}
