@@ -112,7 +112,7 @@ def graph_extras_from_child(a, kernel_sum_ms):
            "--opacity", str(a.opacity), "--steps", str(a.steps), "--warmup", str(a.warmup)]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
     try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=150)
         rows = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if r.returncode != 0 or not rows:
             return {"graphed_step": {"error": f"child exited {r.returncode}: {r.stderr[-300:]}"}}
