@@ -647,8 +647,14 @@ __global__ __launch_bounds__(ES_T) void entry_colscan_kernel(uint32_t* __restric
 #define ES_WIN 2048
 // T_ threads per workgroup (ES_TILE / T_ entries per thread): 1024 up to 2048 digits, 512 for 4096 (the wave counters are
 // NW x digits x 2 bytes of LDS).
+// Up to 1024 digits two workgroups fit a CU's LDS (2 x 74 KB): compiled for 64 VGPRs (4 spilled at 10 bits) so that they
+// also fit its registers — the launch has more workgroups than CUs from 2.1 M entries on (1 M Gaussians at trained
+// opacities: 325; scatter 34 -> 30 us, 2 M: -9 us), and is unchanged below (208 workgroups at opacity 0.01).
+#ifndef ES_WAVES
+#define ES_WAVES 8
+#endif
 template <int NBITS, int T_>
-__global__ __launch_bounds__(T_) void entry_scatter_kernel(const uint4* __restrict__ in, uint4* __restrict__ out,
+__global__ __launch_bounds__(T_, (NBITS <= 10 && T_ == 1024 ? ES_WAVES : 4)) void entry_scatter_kernel(const uint4* __restrict__ in, uint4* __restrict__ out,
                                                              const uint32_t* __restrict__ misc, uint32_t cap, int shift,
                                                              const uint32_t* __restrict__ hist,
                                                              const uint32_t* __restrict__ dtotal) {
