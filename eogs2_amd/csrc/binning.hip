@@ -654,7 +654,7 @@ __global__ __launch_bounds__(ES_T) void entry_colscan_kernel(uint32_t* __restric
 #define ES_WAVES 8
 #endif
 template <int NBITS, int T_>
-__global__ __launch_bounds__(T_, (NBITS <= 10 && T_ == 1024 ? ES_WAVES : 4)) void entry_scatter_kernel(const uint4* __restrict__ in, uint4* __restrict__ out,
+__global__ __launch_bounds__(T_, (NBITS <= 10 && T_ == 1024 ? ES_WAVES : 1)) void entry_scatter_kernel(const uint4* __restrict__ in, uint4* __restrict__ out,
                                                              const uint32_t* __restrict__ misc, uint32_t cap, int shift,
                                                              const uint32_t* __restrict__ hist,
                                                              const uint32_t* __restrict__ dtotal) {
