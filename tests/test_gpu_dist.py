@@ -52,3 +52,32 @@ def test_two_rank_bench_under_torchrun():
     assert len(lines) == 1, r.stdout[-2000:]  # one line, from rank 0
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["exchange"]["rccl_ranks"] == 2 and line["config"]["parallelism"] == "view-dp2"
+
+
+def test_one_gpu_bench_line_and_its_graph_extras():
+    """The driver's own command at a small size: ONE JSON line with the contract's keys, `roofline` and `host`, and — from
+    the child process bench.py starts after its own measurements — the graph-replay figures beside the eager ones."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+                        "--gaussians", "30000", "--size", "160", "--no-cpu-baseline"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["steps"] == 5 and line["dtype"] == "f32" and line["vs_baseline"] is None
+    assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
+    host = line["host"]
+    assert host["kernel_sum_ms"] > 0 and host["count_readback"]["hit"] == 0  # the eager headline waits for its counts
+    gs = line["graphed_step"]
+    assert "error" not in gs, gs
+    assert gs["ms_per_step"] > 0 and gs["recaptures"] == 0
+    tg = line["train_iter_fused_graphed"]
+    assert tg["graph"]["forwards_per_replay"] == 3 and tg["ms_per_iter"] > 0
+    # at this size the eager step is host-bound: the replayed graph must not be slower than it
+    assert gs["ms_per_step"] <= 1.1 * line["ms_per_step"], (gs["ms_per_step"], line["ms_per_step"])
