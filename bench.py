@@ -54,6 +54,8 @@ def parse():
                     help="collective backend; gloo + --share-gpu rehearses the N-rank path on a one-GPU box (not a measurement)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--graph-extras", action="store_true", help="child mode: the graph-replay measurements only")
+    ap.add_argument("--graph-train-iter", action="store_true",
+                    help="N ranks: also report the training iteration with its compute recorded into a HIP graph (opt-in)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher self-test: ranks rendezvous over gloo, all-reduce one number and exit before any GPU call")
     return ap.parse_args()
@@ -348,7 +350,10 @@ def train_iteration(sc, P, H, W, dev, fused, iters=5, dist=None, view_seed=0, al
     gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(5)).to(dev)
 
     def it(exchange=True, step=True):
-        opt.zero_grad(set_to_none=True)
+        if graphed and bucket is not None:
+            bucket.zero_()  # the gradients live in the exchange buffer: the same tensors in every replay
+        else:
+            opt.zero_grad(set_to_none=True)
         for vi, (rs, alt, m2, dL) in enumerate(views):
             if fused:
                 color, _, _ = rasterize_raw(params["xyz"], m2, params["f_dc"], params["opacity"], params["scaling"],
@@ -374,12 +379,14 @@ def train_iteration(sc, P, H, W, dev, fused, iters=5, dist=None, view_seed=0, al
     if graphed:
         from eogs2_amd.graph import GraphedStep
 
-        assert fused and dist is None
-        gs = GraphedStep(lambda: it(step=False), warmup=2)
+        assert fused
         eager_it = it
+        gs = GraphedStep(lambda: eager_it(exchange=False, step=False), warmup=2)
 
         def it(exchange=True):  # noqa: F811
             gs()
+            if bucket is not None and exchange:
+                bucket.all_reduce()  # (outside the graph; finds the gradients already in its buffer)
             opt.step()
 
     def timed(fn, n):
@@ -957,6 +964,11 @@ def main():
     if use_dist and not a.no_train_iter:
         # the iteration that can actually scale: three renders, ONE exchange, the optimizer step
         ti_dist = train_iteration(sc, P, H, W, dev, fused=True, dist=dist, view_seed=rank, algo=bucket.algo)
+    ti_dist_graphed = None
+    if use_dist and not a.no_train_iter and a.graph_train_iter:
+        # opt-in (never part of the driver's line): the same iteration with its three renders, loss and backward passes
+        # recorded into a HIP graph per rank; the exchange and the optimizer step stay outside
+        ti_dist_graphed = train_iteration(sc, P, H, W, dev, fused=True, dist=dist, view_seed=rank, algo=bucket.algo, graphed=True)
     if rank == 0:
         ms_step = dt / a.steps * 1e3
         kern = {k: ms / a.steps for k, (ms, n) in prof.items() if n}  # device ms per step of each kernel group
@@ -1038,6 +1050,8 @@ def main():
             line["allreduce_ms"] = exchange["allreduce_ms"]
         if use_dist and not a.no_train_iter:
             line["train_iter_fused"] = ti_dist
+            if ti_dist_graphed is not None:
+                line["train_iter_fused_graphed"] = ti_dist_graphed
         if world == 1 and not use_dist and not a.no_train_iter:
             line["train_iter"] = train_iteration(sc, P, H, W, dev, fused=False)
             line["train_iter_fused"] = train_iteration(sc, P, H, W, dev, fused=True)

@@ -205,6 +205,28 @@ class GradBucket(BackwardPlan):
                     p.grad = torch.zeros_like(p)
                 _copy_cols(self.block(i), p.grad, c, False)
 
+    def zero_(self):
+        """Gradients that start at zero INSIDE the buffer: clears it and makes every parameter's .grad the view of its block
+        (partially bucketed parameters: their own zeroed tensor). The backward passes of the step then accumulate in place and
+        all_reduce() finds nothing to copy. This is what a recorded step needs (eogs2_amd.graph.GraphedStep): the same gradient
+        tensors in every replay —
+
+            def fwd_bwd(): bucket.zero_(); ...renders, losses...; loss.backward()
+            step = GraphedStep(fwd_bwd)
+            step(); bucket.all_reduce(); optimizer.step()
+        """
+        if self._armed:
+            raise RuntimeError("GradBucket.zero_() while armed by begin(): call finish()")
+        self.flat.zero_()
+        for i, p in enumerate(self.params):
+            if self._full(i):
+                if not self._is_block(p.grad, i):
+                    p.grad = self.block(i).view(p.shape)
+            elif p.grad is None:
+                p.grad = torch.zeros_like(p)
+            else:
+                p.grad.zero_()
+
     def all_reduce(self, average=False):
         if self._armed:
             raise RuntimeError("GradBucket.all_reduce() while armed by begin(): call finish()")

@@ -131,3 +131,33 @@ def test_count_bookkeeping_of_deferred_and_captured_forwards():
         rz.set_speculation(old)
     rz.speculation_stats(reset=True)
     assert rz.speculation_stats() == {"exact": 0, "hit": 0, "redo": 0}
+
+
+def test_gradbucket_zero_keeps_the_gradients_inside_the_exchange_buffer():
+    """GradBucket.zero_(): .grad of every parameter is the (cleared) view of its block, backward passes accumulate in
+    place — any number of them — and all_reduce() exchanges without a copy: the same tensors every step, which is what a
+    step recorded into a graph needs."""
+    from eogs2_amd.parallel import GradBucket
+
+    torch.manual_seed(0)
+    P = 300
+    params = [torch.randn(P, 3, requires_grad=True), torch.randn(P, 1, 3, requires_grad=True), torch.randn(P, 1, requires_grad=True)]
+    bucket = GradBucket(params)
+
+    def loss(k):
+        return sum(((p * (k + 1.0)) ** 2).sum() for p in params)
+
+    bucket.zero_()
+    views = [p.grad for p in params]
+    assert all(bucket._is_block(p.grad, i) for i, p in enumerate(params)) and float(bucket.flat.abs().sum()) == 0.0
+    for k in range(3):
+        loss(k).backward()
+    assert all(p.grad is v for p, v in zip(params, views))  # accumulated in place
+    bucket.all_reduce()  # (no process group: nothing to exchange, nothing to copy)
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(params, views))
+    want = [2.0 * p.detach() * sum((k + 1.0) ** 2 for k in range(3)) for p in params]
+    for p, w in zip(params, want):
+        assert torch.allclose(p.grad, w, rtol=1e-6, atol=1e-6)
+    bucket.zero_()  # the next step: same tensors, cleared
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(params, views)) and float(bucket.flat.abs().sum()) == 0.0
+    bucket.close()

@@ -81,3 +81,20 @@ def test_one_gpu_bench_line_and_its_graph_extras():
     assert tg["graph"]["forwards_per_replay"] == 3 and tg["ms_per_iter"] > 0
     # at this size the eager step is host-bound: the replayed graph must not be slower than it
     assert gs["ms_per_step"] <= 1.1 * line["ms_per_step"], (gs["ms_per_step"], line["ms_per_step"])
+
+
+def test_two_rank_training_iteration_with_the_compute_as_a_graph():
+    """Opt-in (`--graph-train-iter`): on every rank the three renders, the loss and their backward passes are one replayed
+    HIP graph whose gradients accumulate inside the GradBucket buffer (GradBucket.zero_()); the exchange and FusedAdam stay
+    outside. Rehearsal over gloo with both ranks on one GPU: the line carries both iterations."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
+                        "--steps", "4", "--warmup", "1", "--gaussians", "30000", "--size", "160", "--graph-train-iter"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    eager, graphed = line["train_iter_fused"], line["train_iter_fused_graphed"]
+    assert graphed["n_gpus"] == 2 and graphed["graph"]["forwards_per_replay"] == 3 and graphed["graph"]["recaptures"] == 0
+    assert graphed["exchange"]["bytes_per_gaussian"] == 56 and graphed["ms_per_iter"] > 0 and eager["ms_per_iter"] > 0
