@@ -245,6 +245,53 @@ int main() {
   r = replay(&ex, &fits, &early);
   CHECK(fits == 1 && r == eager_first, "and the graph still replays the first scene bit for bit afterwards");
 
+  // ---- for the record: what a C++ host pays per step either way (not a pass criterion) ----
+  {
+    const int n = 200;
+    hipEvent_t e0, e1;
+    HIPCK(hipEventCreate(&e0));
+    HIPCK(hipEventCreate(&e1));
+    size_t nb_exact = 0;
+    RCK(eogs_rast_binning_bytes(P, H, W, exact_first, &nb_exact));
+    Dev<uint8_t> bin_exact(nb_exact);
+    auto eager_loop = [&](int iters) {
+      for (int i = 0; i < iters; i++) {
+        int64_t R = 0;
+        RCK(b.prepare(0u, &R, st));  // waits for the counts, like the reference's forward
+        RCK(b.render(R, bin_exact.p, nb_exact, st));
+        RCK(b.backward(R, bin_exact.p, nb_exact, st));
+      }
+    };
+    auto replay_loop = [&](int iters) {
+      for (int i = 0; i < iters; i++) {
+        RCK(eogs_rast_mirror_arm(mirror));
+        HIPCK(hipGraphLaunch(exec, st));
+        int arrived = 0;
+        int64_t t = 0;
+        while (!arrived) RCK(eogs_rast_mirror_token(P, H, W, mirror, 1, &t, &arrived));  // capacity check, every replay
+      }
+    };
+    float ms_eager = 0.f, ms_graph = 0.f;
+    eager_loop(20);
+    HIPCK(hipStreamSynchronize(st));
+    HIPCK(hipEventRecord(e0, st));
+    eager_loop(n);
+    HIPCK(hipEventRecord(e1, st));
+    HIPCK(hipEventSynchronize(e1));
+    HIPCK(hipEventElapsedTime(&ms_eager, e0, e1));
+    replay_loop(20);
+    HIPCK(hipStreamSynchronize(st));
+    HIPCK(hipEventRecord(e0, st));
+    replay_loop(n);
+    HIPCK(hipEventRecord(e1, st));
+    HIPCK(hipEventSynchronize(e1));
+    HIPCK(hipEventElapsedTime(&ms_graph, e0, e1));
+    printf("C++ host, %d Gaussians / %dx%d, fwd+bwd per step: eager (count wait) %.3f ms, graph replay + capacity check %.3f ms\n", P, H, W,
+           ms_eager / n, ms_graph / n);
+    HIPCK(hipEventDestroy(e0));
+    HIPCK(hipEventDestroy(e1));
+  }
+
   HIPCK(hipGraphExecDestroy(exec));
   HIPCK(hipGraphDestroy(graph));
   HIPCK(hipHostFree(mirror));
