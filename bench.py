@@ -30,6 +30,9 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+# what a plain streaming kernel reaches on the driver's box class (tools/hbm_stream.hip, profiles/r03_hbm_stream.txt): reported
+# beside the peak, never used as the denominator of `frac`
+HBM_ACHIEVABLE_GBS = {"read": 6500.0, "copy": 5700.0, "write": 4800.0, "source": "profiles/r03_hbm_stream.txt (tools/hbm_stream.hip)"}
 
 
 def parse():
@@ -1022,6 +1025,7 @@ def main():
                                  "frac": alg[k] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tr}
         pipe_bytes = 432 * P + 268 * R + 64 * npx
         pipe = {"algorithmic_bytes": pipe_bytes, "achieved": pipe_bytes / (ms_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                "achievable_stream_GBps": HBM_ACHIEVABLE_GBS,
                 "unit": "GB/s", "frac": pipe_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "ideal_sort_frac": (432 * P + 148 * R + 64 * npx) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
         line = {
