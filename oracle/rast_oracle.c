@@ -57,7 +57,10 @@ int eogs_oracle_accum_float(int on) { const int old = g_acc_float; g_acc_float =
  * in fp32 — instead of the reference's back-to-front recursion. Algebraically identical; used to measure how much of a
  * HIP-vs-oracle difference is this formulation. Needs forward's out_color (out_invdepth with an invdepth gradient). */
 static int g_suffix_by_subtraction = 0;
-int eogs_oracle_suffix_by_subtraction(int on) { const int old = g_suffix_by_subtraction; g_suffix_by_subtraction = on != 0; return old; }
+/* 0: the reference's back-to-front recursion. 1: front to back, sum behind a Gaussian = rendered total (from out_color) minus running
+ * prefix — the HIP path's formulation. 2: the same with the total taken from the running sum's own end value (a first walk over the list)
+ * instead of the rendered image: tells how much of (1)'s deviation is the mismatch between the two differently associated totals. */
+int eogs_oracle_suffix_by_subtraction(int on) { const int old = g_suffix_by_subtraction; g_suffix_by_subtraction = on; return old; }
 /* Diagnostic (tests/parity_cases.py, causal attribution of threshold flips): the reference's two data-dependent blend
  * decisions (forward.cu:374-382) evaluated with their thresholds moved by a stated number of ulp, per pixel:
  *   skip    if  alpha < (1/255) (1 + s (ka0 + ka1 |power|) ulp)     (the exponent's rounding error scales with |power|)
@@ -562,6 +565,24 @@ static int backward_activated(
         float Dfinal = 0.f, Dacc = 0.f, Tf = 1.0f;
         for (int ch = 0; ch < C_; ch++) Dfinal += dL_dpixel[ch] * out_color[ch * HW + pix_id];
         if (dL_dout_invdepth && out_invdepth) Dfinal += dL_invdepth * out_invdepth[pix_id];
+        if (g_suffix_by_subtraction == 2) { /* the running sum's own total: same operations, same order as the loop below */
+          float Dt = 0.f, Tt = 1.0f;
+          for (uint32_t k = r0; k < r1 && k - r0 < last_contributor; k++) {
+            const uint32_t id = b.values[k];
+            const float dx = g.means2D[2 * (size_t)id] - pixfx, dy = g.means2D[2 * (size_t)id + 1] - pixfy;
+            const float* co = g.conic_opacity + 4 * (size_t)id;
+            const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+            if (power > 0.0f) continue;
+            const float alpha = fminf(0.99f, co[3] * expf(power));
+            if (alpha < alpha_min(nudge_sign(pix_id), power)) continue;
+            float gc = 0.f;
+            for (int ch = 0; ch < C_; ch++) gc += dL_dpixel[ch] * colors[(size_t)id * C_ + ch];
+            if (dL_dout_invdepth) gc += dL_invdepth * (1.f / g.depths[id]);
+            Dt += gc * (alpha * Tt);
+            Tt *= (1.f - alpha);
+          }
+          Dfinal = Dt + T_final * bg_dot_dpixel;
+        }
         for (uint32_t k = r0; alt && k < r1 && k - r0 < last_contributor; k++) {
           const uint32_t id = b.values[k];
           const float dx = g.means2D[2 * (size_t)id] - pixfx, dy = g.means2D[2 * (size_t)id + 1] - pixfy;

@@ -18,13 +18,18 @@ lib = oracle.abi().cdll
 for seed in map(int, sys.argv[1:] or ["1258"]):
     case, label = sweep_case(seed)
     base = oracle_run(case)
-    lib.eogs_oracle_suffix_by_subtraction(1)
-    try:
-        alt = oracle_run(case)
-    finally:
-        lib.eogs_oracle_suffix_by_subtraction(0)
+    alts = {}
+    for mode in (1, 2):  # 1: total from the rendered image (the HIP path); 2: total = the running sum's own end value (two walks)
+        lib.eogs_oracle_suffix_by_subtraction(mode)
+        try:
+            alts[mode] = oracle_run(case)
+        finally:
+            lib.eogs_oracle_suffix_by_subtraction(0)
+    alt = alts[1]
     print(seed, label, case["means3D"].shape[0], "Gaussians", f'{case["H"]}x{case["W"]}')
-    for k in ("g_rotations", "g_scales", "g_means3D", "g_opacities", "g_colors"):
+    for k in ("g_rotations", "g_scales", "g_means3D", "g_opacities", "g_colors", "g_viewmatrix"):
         sc = np.abs(base[k]).max()
         d = np.abs(alt[k].astype(np.float64) - base[k]) / max(sc, 1e-30)
-        print(f"   {k:12s} max |front-to-back - back-to-front| = {d.max():.2e} of the tensor scale ({int((d > 1e-4).sum())} elements beyond 1e-4)")
+        d2 = np.abs(alts[2][k].astype(np.float64) - base[k]) / max(sc, 1e-30)
+        print(f"   {k:12s} max |front-to-back - back-to-front| = {d.max():.2e} of the tensor scale ({int((d > 1e-4).sum())} elements beyond 1e-4);"
+              f" with a self-consistent total {d2.max():.2e}")
