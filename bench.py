@@ -961,7 +961,7 @@ def main():
     nr = int(getattr(color.grad_fn, "num_rendered_exact", getattr(color.grad_fn, "num_rendered", -1)))
     # the API's num_rendered packs both counts: (tile, Gaussian) record slots below, (32-px block, Gaussian) list entries
     # above (csrc/common.h nr_pack)
-    R, R_entries = (nr & 0x7FFFFFFF, (nr >> 32) & 0x1FFFFFFF) if nr >= 0 else (-1, -1)
+    R, R_entries = (nr & 0x7FFFFFFF, (nr >> 32) & 0x0FFFFFFF) if nr >= 0 else (-1, -1)
 
     ti_dist = None
     if use_dist and not a.no_train_iter:

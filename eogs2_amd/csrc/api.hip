@@ -264,13 +264,23 @@ int token_from_counts(const uint32_t* m, int P, int H, int W, bool have_scratch,
   const double list_depth = (double)opw / 64.0 / ntiles8;  // = L * mean pair opacity
   const bool by_footprint = (double)total > block_switch * (double)P;
   const bool by_depth = depth_switch > 0.0 && list_depth > depth_switch && total >= 2 * entries;  // blocks must merge entries
-  const int block = (by_footprint || by_depth) ? BLOCK_BIG : 1;
+  // Gaussians that list a tenth of the image's tiles each (sigma of hundreds of pixels on a small image: outside the reference's
+  // operating range — the bench's regimes sit at 0.0002 ... 0.0014 — inside the parity sweeps'): lists hundreds deep under a
+  // few opaque front Gaussians. There the front-to-back form
+  // of dL/dalpha (render.hip) loses what the reference's back-to-front recursion keeps; such forwards take
+  // per-tile lists and the back-to-front backward, which is the reference's arithmetic (bit 60 of the token).
+  static const double btf_switch = [] {  // EOGS_BTF_SWITCH=<fraction of the image's tiles a Gaussian lists on average>; 0 = never
+    const char* e = getenv("EOGS_BTF_SWITCH");
+    return e ? atof(e) : 0.1;
+  }();
+  const bool btf = P > 0 && btf_switch > 0.0 && (double)total >= btf_switch * (double)P * ntiles8;
+  const int block = btf ? 1 : ((by_footprint || by_depth) ? BLOCK_BIG : 1);
   if (m[MISC_ERR] & 1u) return fail(EOGS_ERR_ALTITUDE, "Point is too high: altitude > 200");
-  if (total >= ((uint64_t)1 << 31) || entries >= ((uint64_t)1 << 29)) return fail(EOGS_ERR_OVERFLOW, "num_rendered overflows 31 bits");
+  if (total >= ((uint64_t)1 << 31) || entries >= ((uint64_t)1 << 28)) return fail(EOGS_ERR_OVERFLOW, "num_rendered overflows 31 bits");
   // block_lists_kernel's 8-item build pays when the average block holds 2800 ... 6000 entries (csrc/binning.hip)
   const double per_block = (double)entries / ((double)macro_grid_x(W, BLOCK_BIG) * (double)macro_grid_y(H, BLOCK_BIG));
   *num_rendered = nr_pack((uint32_t)total, (uint32_t)entries, block, have_scratch && entries <= (uint64_t)sort_cap,
-                          per_block > 2800.0 && per_block <= 6000.0);
+                          per_block > 2800.0 && per_block <= 6000.0, btf);
   return EOGS_OK;
 }
 
@@ -346,10 +356,10 @@ int eogs_rast_capacity_token(int P, int64_t num_rendered, double slack, int have
   uint64_t slots = (uint64_t)((double)nr_slots(num_rendered) * (1.0 + slack)) + 4096u;
   uint64_t ents = (uint64_t)((double)nr_entries(num_rendered) * (1.0 + slack)) + 1024u;
   if (slots > 0x7FFFFFFFull) slots = 0x7FFFFFFFull;
-  if (ents > 0x1FFFFFFFull) ents = 0x1FFFFFFFull;
+  if (ents > 0x0FFFFFFFull) ents = 0x0FFFFFFFull;
   // "sorted in scratch" only if every forward that fits this capacity also fits the scratch (then forward_prepare did sort)
   const int sorted = have_scratch && ents <= (uint64_t)ent_cap(P);
-  *capacity = nr_pack((uint32_t)slots, (uint32_t)ents, nr_block(num_rendered), sorted, nr_wide(num_rendered));
+  *capacity = nr_pack((uint32_t)slots, (uint32_t)ents, nr_block(num_rendered), sorted, nr_wide(num_rendered), nr_btf(num_rendered));
   if (fits) *fits = exact > 0 && nr_slots(exact) <= slots && nr_entries(exact) <= ents;
   return EOGS_OK;
 }
@@ -411,7 +421,6 @@ int eogs_rast_backward_range(int P, int H, int W, int64_t R, const float* bg, co
                              float* dL_dmeans2D, float* dL_dcolors, float* dL_dopacity, float* dL_dmeans3D, float* dL_dcov3D,
                              float* dL_dscales, float* dL_drotations, float* dL_dT_sum, float* dL_dvm_mean,
                              float* dL_dcolors_lead, int lead_cols, int p_begin, int p_end, void* stream) {
-  (void)bg;
   g_err[0] = 0;
   if (P < 0 || H <= 0 || W <= 0 || R < 0) return fail(EOGS_ERR_INVALID_ARG, "backward: bad sizes");
   if (p_begin < 0 || p_end < p_begin || p_end > P || (p_begin % BLK) != 0 || (p_end != P && (p_end % BLK) != 0))
@@ -435,6 +444,7 @@ int eogs_rast_backward_range(int P, int H, int W, int64_t R, const float* bg, co
   if (raw && (!have_sr || !alt_affine))
     return fail(EOGS_ERR_INVALID_ARG, "backward: EOGS_FLAG_RAW_PARAMS needs scales, rotations and alt_affine");
   if (R > 0 && !binning) return fail(EOGS_ERR_INVALID_ARG, "backward: NULL binning workspace");
+  if (R > 0 && nr_btf(R) && !bg) return fail(EOGS_ERR_INVALID_ARG, "backward: bg is required (back-to-front backward)");
   if (dL_dcolors_lead && (lead_cols <= 0 || lead_cols > (raw ? 3 : NCH))) return fail(EOGS_ERR_INVALID_ARG, "backward: bad lead_cols");
 
   char* gb = ws_base(geom);
@@ -452,7 +462,7 @@ int eogs_rast_backward_range(int P, int H, int W, int64_t R, const float* bg, co
     return fail(EOGS_ERR_WORKSPACE, "backward: workspace too small");
 
   if (R > 0 && p_begin == 0) {  // the per-pixel pass covers the whole image: once, with the first range
-    { ProfScope ps(PS_RENDER_BWD, s); launch_render_bwd(g, b, im, P, H, W, R, colors, out_color, out_invdepth, dL_dout_color, dL_dout_invdepth, s); }
+    { ProfScope ps(PS_RENDER_BWD, s); launch_render_bwd(g, b, im, P, H, W, R, colors, out_color, out_invdepth, dL_dout_color, dL_dout_invdepth, bg, s); }
     LAUNCH_TRY(s, debug, "render_bwd");
   }
   GaussBwdArgs a{P, H, W, means3D, have_sr ? scales : nullptr, have_sr ? rotations : nullptr, cov3D_precomp, opacities,

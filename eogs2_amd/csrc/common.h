@@ -262,7 +262,7 @@ struct SortWS {
 };
 static inline uint32_t ent_cap(int P) {
   const uint64_t c = 6ull * (uint64_t)(P < 0 ? 0 : P);
-  return c < 4096ull ? 4096u : (c > (1ull << 29) ? (1u << 29) : (uint32_t)c);
+  return c < 4096ull ? 4096u : (c > 0x0FFFFFFFull ? 0x0FFFFFFFu : (uint32_t)c);
 }
 static inline SortWS sort_layout(char* base, uint32_t cap) {
   SortWS w;
@@ -300,15 +300,18 @@ static inline int ceil_log2_u32(uint32_t n) {  // smallest b with (1<<b) >= n
 // backward scratch) in bits 0..30, the list entries (one per listed 32 x 32-px block) in bits 32..60, bit 61 = the
 // entries were sorted in the caller's scratch by forward_prepare, bit 62 = the render kernels read block lists
 // (BLOCK_BIG) instead of per-tile lists, bit 31 = a block holds 2800 ... 6000 entries on average (block_lists_kernel's
-// 8-item build; a property of the forward the token was counted on, carried over into capacity tokens).
+// 8-item build; a property of the forward the token was counted on, carried over into capacity tokens), bit 60 = the
+// Gaussians list a tenth of the image's tiles each on average: per-tile lists and the back-to-front backward
+// (render_bwd_btf_kernel).
 static inline uint32_t nr_slots(int64_t R) { return (uint32_t)((uint64_t)R & 0x7FFFFFFFull); }
-static inline uint32_t nr_entries(int64_t R) { return (uint32_t)(((uint64_t)R >> 32) & 0x1FFFFFFFull); }
+static inline uint32_t nr_entries(int64_t R) { return (uint32_t)(((uint64_t)R >> 32) & 0x0FFFFFFFull); }
+static inline int nr_btf(int64_t R) { return (int)(((uint64_t)R >> 60) & 1ull); }
 static inline int nr_sorted(int64_t R) { return (int)(((uint64_t)R >> 61) & 1ull); }
 static inline int nr_block(int64_t R) { return (((uint64_t)R >> 62) & 1ull) ? BLOCK_BIG : 1; }
 static inline int nr_wide(int64_t R) { return (int)(((uint64_t)R >> 31) & 1ull); }
-static inline int64_t nr_pack(uint32_t slots, uint32_t entries, int block, int sorted, int wide) {
-  return (int64_t)(((uint64_t)(block > 1) << 62) | ((uint64_t)(sorted != 0) << 61) | ((uint64_t)entries << 32) |
-                   ((uint64_t)(wide != 0) << 31) | slots);
+static inline int64_t nr_pack(uint32_t slots, uint32_t entries, int block, int sorted, int wide, int btf) {
+  return (int64_t)(((uint64_t)(block > 1) << 62) | ((uint64_t)(sorted != 0) << 61) | ((uint64_t)(btf != 0) << 60) |
+                   ((uint64_t)entries << 32) | ((uint64_t)(wide != 0) << 31) | slots);
 }
 static inline uint32_t macro_grid_x(int W, int M) { return (uint32_t)(((W + SUBX - 1) / SUBX + M - 1) / M); }
 static inline uint32_t macro_grid_y(int H, int M) { return (uint32_t)(((H + SUBY - 1) / SUBY + M - 1) / M); }
@@ -395,10 +398,10 @@ void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, 
                        const float* bg, float* out_color, float* out_invdepth, hipStream_t s);
 void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, const float* colors,
                        const float* out_color, const float* out_invdepth, const float* dL_dcolor,
-                       const float* dL_dinvdepth, hipStream_t s);
+                       const float* dL_dinvdepth, const float* bg, hipStream_t s);
 // which render kernel a forward / backward runs: 0 = one list per tile, 1 = block lists, 2 = quad sub-lists (render.hip)
 int render_fwd_variant(int block, int64_t R, int P);
-int render_bwd_variant(int block, int64_t R, int P);
+int render_bwd_variant(int block, int64_t R, int P);  // 0 tile, 1 block, 2 quad, 3 / 4 MFMA experiments, 5 back to front
 struct GaussBwdArgs {
   int P, H, W;
   const float *means3D, *scales, *rotations, *cov3D_precomp, *opacities, *viewmatrix, *projmatrix;

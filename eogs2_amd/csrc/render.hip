@@ -727,6 +727,145 @@ __global__ __launch_bounds__(RBLK) void render_bwd_kernel(
 
 
 // ------------------------------------------------------------------------------------------------------
+// Backward, back to front: the reference's own recursion (DGR/cuda_rasterizer/backward.cu:536-643), per-tile lists
+// ------------------------------------------------------------------------------------------------------
+// render_bwd_kernel / render_bwd_quad_kernel walk the list front to back and take the sum behind a Gaussian as "rendered total
+// minus running prefix": one dot product per pair, no division chain — and an absolute error of an ulp of the TOTAL in a
+// quantity that, hundreds of entries deep under opaque Gaussians, is orders of magnitude smaller. When the
+// Gaussians list a tenth of the image each (token bit 60) the lists are exactly that deep, and this kernel runs instead: last
+// contributor first, T recovered by T /= (1 - alpha) from the forward's final transmittance, the colour behind a Gaussian
+// carried as the reference's accum_rec recursion per channel, the background term from T_final. Same records, same
+// transposition rounds (the order of the entries inside a round does not enter any sum). It costs a division and ten more
+// multiply-adds per pair and is never chosen for footprints of a few tiles.
+template <bool HAVE_INV>
+__global__ __launch_bounds__(RBLK) void render_bwd_btf_kernel(
+    const uint2* __restrict__ ranges, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles,
+    const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib, const float* __restrict__ final_T,
+    const float* __restrict__ bg, const float* __restrict__ dL_dpix, const float* __restrict__ dL_dinv,
+    float* __restrict__ records, uint8_t* __restrict__ live_flag) {
+  __shared__ __attribute__((aligned(16))) float s_slab[RBLK / 64][64 * ENT];
+  __shared__ __attribute__((aligned(16))) float s_round[RBLK / 64][KSURV * 8];
+  __shared__ __attribute__((aligned(16))) float s_uv[RBLK / 64][UV_PITCH + UV_SIZE];
+  __shared__ __attribute__((aligned(16))) float s_pix[RBLK / 64][64 * 8 + 32];
+  __shared__ uint32_t s_slot[RBLK / 64][64];
+  const int lane = threadIdx.x & 63;
+  const int tile = tile_of_wave();
+  if (tile >= ntiles) return;
+  const int w = RBLK == 64 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float* slab = s_slab[w];
+  float* su = s_uv[w];
+  float* sv = s_uv[w] + UV_PITCH;
+  float* spix = s_pix[w];
+  uint32_t* sslot = s_slot[w];
+  float* rb = s_round[w];
+  const int tx0 = (tile % gsx) * SUBX, ty0 = (tile / gsx) * SUBY;
+  const int px = tx0 + (lane & 7), py = ty0 + (lane >> 3);
+  const bool inside = px < W && py < H;
+  const uint32_t pix_id = (uint32_t)py * (uint32_t)W + (uint32_t)px;
+  const float pxf = (float)px, pyf = (float)py;
+  const uint2 range = ranges[tile];  // the tile's own list
+  const size_t HW = (size_t)H * W;
+
+  float g[NCH] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  float ginv = 0.f, Tfin = 1.f, bgdot = 0.f;
+  uint32_t ncontrib = 0;
+  if (inside) {
+    ncontrib = n_contrib[pix_id];
+    Tfin = final_T[pix_id];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ch++) {
+      g[ch] = dL_dpix[ch * HW + pix_id];
+      bgdot += bg[ch] * g[ch];  // backward.cu:527-529
+    }
+    if (HAVE_INV) ginv = dL_dinv[pix_id];
+  }
+  {
+    float* d = spix + lane * 8 + 4 * (lane >> 3);
+    *reinterpret_cast<float4*>(d) = make_float4(g[0], g[1], g[2], g[3]);
+    d[4] = g[4];
+  }
+  const uint32_t tile_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(ncontrib));
+  const uint32_t n = min(range.y - range.x, tile_last);  // entries behind every pixel's last contributor are dead
+  if (n == 0u) return;
+  const float kx = LN2 * 0.5f * W, ky = LN2 * 0.5f * H;
+  const float bx0 = (float)tx0, by0 = (float)ty0;
+  float T = Tfin, last_alpha = 0.f, arec_inv = 0.f, last_inv = 0.f;
+  float arec[NCH] = {0.f, 0.f, 0.f, 0.f, 0.f}, lastc[NCH] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  float* const uvlane = su + uv_index(0, lane);
+  int k = 0, kstashed = 0;
+  unsigned long long kj = 0ull;
+  for (int c = (int)((n - 1u) / 64u) * 64; c >= 0; c -= 64) {  // chunks of 64 list entries, the last one first
+    wave_lds_sync();
+    const Cand cur = gather_cand<1>(peek_cand<1>(range.x + (uint32_t)c + lane, range.x + n, nullptr, point_list), 0u, packed);
+    const int jn = park(slab, sslot, lane, cur, 0);
+    wave_lds_sync();
+    auto stash = [&](int from, int to) {
+      if (lane >= from && lane < to) {
+        const uint32_t jk = (uint32_t)(kj >> (8 * lane)) & 63u;
+        const float4 a = *reinterpret_cast<const float4*>(slab + jk * ENT);
+        const float2 b = *reinterpret_cast<const float2*>(slab + jk * ENT + 4);
+        *reinterpret_cast<float4*>(rb + lane * 8) = a;
+        *reinterpret_cast<float4*>(rb + lane * 8 + 4) = make_float4(b.x, b.y, __uint_as_float(sslot[jk]), 0.f);
+      }
+    };
+    for (int j = jn - 1; j >= 0; j--) {
+      const Ent e = fetch(slab, j);
+      const float dx = e.q0.x - pxf, dy = e.q0.y - pyf;
+      const float p = power_of(e, dx, dy);
+      const float G = __builtin_amdgcn_exp2f(p);
+      const float alpha = fminf(e.q1.y * G, 0.99f);
+      // (contributor >= last_contributor: skip, backward.cu:561-563; then the forward's own two tests)
+      const bool valid = ((uint32_t)(c + j) < ncontrib) && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);
+      if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;
+      const float one_m = 1.f - alpha;
+      const float Tn = T / one_m;  // backward.cu:573
+      const float cc[NCH] = {e.q1.z, e.q1.w, e.q2.x, e.q2.y, e.q2.z};
+      float dLda = 0.f;
+#pragma unroll
+      for (int ch = 0; ch < NCH; ch++) {  // backward.cu:586-599
+        const float ar = last_alpha * lastc[ch] + (1.f - last_alpha) * arec[ch];
+        dLda += (cc[ch] - ar) * g[ch];
+        arec[ch] = valid ? ar : arec[ch];
+        lastc[ch] = valid ? cc[ch] : lastc[ch];
+      }
+      if (HAVE_INV) {  // backward.cu:602-609
+        const float ar = last_alpha * last_inv + (1.f - last_alpha) * arec_inv;
+        dLda += (e.q2.w - ar) * ginv;
+        arec_inv = valid ? ar : arec_inv;
+        last_inv = valid ? e.q2.w : last_inv;
+      }
+      dLda *= Tn;
+      dLda += (-Tfin / one_m) * bgdot;  // backward.cu:617-620
+      // pixels that skip this Gaussian: weight 0, v = 0, state unchanged (selects: exp2 may have overflowed there)
+      float* const uv = uvlane + k * 33;
+      uv[0] = valid ? alpha * Tn : 0.f;
+      uv[UV_PITCH] = valid ? G * dLda : 0.f;
+      T = valid ? Tn : T;
+      last_alpha = valid ? alpha : last_alpha;
+      kj |= (unsigned long long)j << (8 * k);
+      if (++k == KSURV) {
+        stash(kstashed, KSURV);
+        wave_lds_sync();
+        transpose_round(KSURV, lane, rb, su, sv, spix, bx0, by0, kx, ky, records, live_flag);
+        wave_lds_sync();
+        k = 0;
+        kstashed = 0;
+        kj = 0ull;
+      }
+    }
+    if (k > kstashed) {
+      stash(kstashed, k);
+      kstashed = k;
+    }
+  }
+  if (k) {
+    wave_lds_sync();
+    transpose_round(k, lane, rb, su, sv, spix, bx0, by0, kx, ky, records, live_flag);
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------------
 // Backward with quad sub-lists (per-tile lists, small footprints)
 // ------------------------------------------------------------------------------------------------------
 // Same decomposition as render_fwd_quad_kernel: every quad (16 lanes, 4x4 pixels) walks its own sub-list of the chunk's
@@ -1376,15 +1515,22 @@ static double quad_bwd_switch() {  // EOGS_QUAD_BWD_SWITCH=<listed tiles per Gau
 
 int render_bwd_variant(int block, int64_t R, int P) {
   if (block > 1) return 1;
+  if (nr_btf(R)) return 5;
   if (!(quad_bwd_switch() > 0.0 && (double)nr_slots(R) <= quad_bwd_switch() * (double)P)) return 0;
   return bwd_mfma_on() == 1 ? 3 : (bwd_mfma_on() == 2 ? 4 : 2);
 }
 
 void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, const float* colors,
                        const float* out_color, const float* out_invdepth, const float* dL_dcolor,
-                       const float* dL_dinvdepth, hipStream_t s) {
+                       const float* dL_dinvdepth, const float* bg, hipStream_t s) {
   const int gsx = (W + SUBX - 1) / SUBX, gsy = (H + SUBY - 1) / SUBY, ntiles = gsx * gsy;
   const int variant = render_bwd_variant(b.block, R, P);
+  if (variant == 5) {
+    auto* kb = dL_dinvdepth ? render_bwd_btf_kernel<true> : render_bwd_btf_kernel<false>;
+    hipLaunchKernelGGL(kb, dim3(render_grid(ntiles)), dim3(RBLK), 0, s, im.ranges, b.point_list, W, H, gsx, ntiles, g.packed,
+                       im.n_contrib, im.final_T, bg, dL_dcolor, dL_dinvdepth, b.records, b.live);
+    return;
+  }
   auto* kern = variant == 1 ? (dL_dinvdepth ? render_bwd_kernel<BLOCK_BIG, true> : render_bwd_kernel<BLOCK_BIG, false>)
                             : (dL_dinvdepth ? render_bwd_kernel<1, true> : render_bwd_kernel<1, false>);
   if (variant == 2) kern = dL_dinvdepth ? render_bwd_quad_kernel<true, 0> : render_bwd_quad_kernel<false, 0>;

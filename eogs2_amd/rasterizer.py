@@ -136,7 +136,7 @@ def speculation_stats(reset=False):
 GRAPH_SLACK = 0.25
 _peak = {}  # (device, P, H, W, raw) -> token with the largest slot and entry counts seen, flags of the latest forward
 _recording = None  # the record_captured scope of the capture in progress
-_SLOTS, _ENTRIES = 0x7FFFFFFF, 0x1FFFFFFF << 32  # csrc/common.h nr_slots / nr_entries
+_SLOTS, _ENTRIES = 0x7FFFFFFF, 0x0FFFFFFF << 32  # csrc/common.h nr_slots / nr_entries
 
 
 def _merge_counts(peak, exact):

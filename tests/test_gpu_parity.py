@@ -113,7 +113,7 @@ def test_long_block_lists_against_oracle(dev, P, label, exact_counts):
     case = {k: v.numpy() for k, v in sc.items()}
     case.update(H=H, W=W, antialiasing=False)
     got = run_case(case, dev, GaussianRasterizer, GaussianRasterizationSettings)
-    entries = (got["_num_rendered"] >> 32) & 0x1FFFFFFF
+    entries = (got["_num_rendered"] >> 32) & 0x0FFFFFFF
     per_block = entries / 16.0
     assert {"8-item LDS path": 2800 < per_block <= 6000, "streaming path": per_block > 6000,
             "4-item LDS path": per_block <= 2800}[label], per_block

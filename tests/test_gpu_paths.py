@@ -21,17 +21,22 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 # name -> environment. The switches are thresholds in listed tiles per Gaussian (csrc/api.hip, csrc/render.hip).
+# EOGS_BTF_SWITCH: fraction of the image's tiles a Gaussian lists on average from which a forward takes per-tile lists and the
+# back-to-front backward (0 = never; the default 0.1 would take the image-sized sweep cases out of the other forced paths).
 FORCED = {  # (the default switches run in-process: tests/test_gpu_parity.py, same cases, same comparison)
-    "tile": {"EOGS_BLOCK_SWITCH": "1000", "EOGS_DEPTH_SWITCH": "0", "EOGS_QUAD_SWITCH": "0", "EOGS_QUAD_BWD_SWITCH": "0"},
-    "block": {"EOGS_BLOCK_SWITCH": "0.5", "EOGS_DEPTH_SWITCH": "0.001"},
+    "tile": {"EOGS_BLOCK_SWITCH": "1000", "EOGS_DEPTH_SWITCH": "0", "EOGS_QUAD_SWITCH": "0", "EOGS_QUAD_BWD_SWITCH": "0",
+             "EOGS_BTF_SWITCH": "0"},
+    "block": {"EOGS_BLOCK_SWITCH": "0.5", "EOGS_DEPTH_SWITCH": "0.001", "EOGS_BTF_SWITCH": "0"},
     "quad": {"EOGS_BLOCK_SWITCH": "1000", "EOGS_DEPTH_SWITCH": "0", "EOGS_QUAD_SWITCH": "1000", "EOGS_QUAD_BWD_SWITCH": "1000",
-             "EOGS_BWD_MFMA": "0"},
+             "EOGS_BWD_MFMA": "0", "EOGS_BTF_SWITCH": "0"},
     "quad_mfma": {"EOGS_BLOCK_SWITCH": "1000", "EOGS_DEPTH_SWITCH": "0", "EOGS_QUAD_SWITCH": "1000",
-                  "EOGS_QUAD_BWD_SWITCH": "1000", "EOGS_BWD_MFMA": "1"},
+                  "EOGS_QUAD_BWD_SWITCH": "1000", "EOGS_BWD_MFMA": "1", "EOGS_BTF_SWITCH": "0"},
     "quad_mfma_t": {"EOGS_BLOCK_SWITCH": "1000", "EOGS_DEPTH_SWITCH": "0", "EOGS_QUAD_SWITCH": "1000",
-                    "EOGS_QUAD_BWD_SWITCH": "1000", "EOGS_BWD_MFMA": "2"},
+                    "EOGS_QUAD_BWD_SWITCH": "1000", "EOGS_BWD_MFMA": "2", "EOGS_BTF_SWITCH": "0"},
+    # the reference's own back-to-front recursion on per-tile lists (render_bwd_btf_kernel), forced for every case
+    "btf": {"EOGS_BTF_SWITCH": "1e-9", "EOGS_QUAD_SWITCH": "1000"},
 }
-KERNEL_NAMES = {0: "tile", 1: "block", 2: "quad", 3: "quad_mfma", 4: "quad_mfma_t"}
+KERNEL_NAMES = {0: "tile", 1: "block", 2: "quad", 3: "quad_mfma", 4: "quad_mfma_t", 5: "btf"}
 
 
 @pytest.fixture(scope="module")
@@ -99,11 +104,13 @@ def test_every_kernel_path_matches_oracle(dev, case_dir, tmp_path):
             assert all(p == (8, 2, 3) for p in paths), report[tag]
         if tag == "quad_mfma_t":
             assert all(p == (8, 2, 4) for p in paths), report[tag]
+        if tag == "btf":  # (a forward that lists nothing has no token bits to carry the choice)
+            assert all(tuple(v["path"]) == (8, 2, 5) for v in res.values() if v["path"][1] >= 0 and v["listed"]), report[tag]
         seen_fwd |= {p[1] for p in paths}
         seen_bwd |= {p[2] for p in paths}
     print("kernel paths compared with the oracle:", json.dumps(report))
     assert seen_fwd == {0, 1, 2}, report
-    assert seen_bwd == {0, 1, 2, 3, 4}, report
+    assert seen_bwd == {0, 1, 2, 3, 4, 5}, report
 
 
 def _full_size_case(P, H, W, seed, opacity, **kw):
