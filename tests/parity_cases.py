@@ -14,6 +14,7 @@ pixel holds several near pairs that flipped differently, lie inside the interval
 outside must be explained by the oracle's own ill-conditioning (sensitivity map) or the test fails. The number of accepted
 elements per tensor is capped: a regression cannot hide behind the mechanism.
 """
+import os
 import numpy as np
 import torch
 
@@ -68,7 +69,8 @@ def sweep_case(seed):
     case.update(H=H, W=W, antialiasing=aa)
     if dgrad:
         case["dL_dinvdepth"] = (torch.randn(1, H, W, generator=g) / (H * W) * 100).numpy()
-    stress = scale_mult >= 6.0 and aniso >= 0.7  # cancellation-heavy gradient sums: tests/util.py GRAD_RTOL
+    # (the label only selects a tolerance where the back-to-front backward is switched off: tests/util.py GRAD_RTOL)
+    stress = scale_mult >= 6.0 and aniso >= 0.7
     return case, ("seed15" if stress else f"sweep{seed}")
 
 

@@ -37,7 +37,7 @@ def main(case_dir, out_json):
             P = case["means3D"].shape[0]
             path = list(abi.path_info(P, got.get("_num_rendered", 0))) if P else [0, -1, -1]
             flips = compare(got, ref, label, case, cache=os.path.join(case_dir, "cache", name))
-            res[name] = {"ok": True, "path": path, "flips": flips, "listed": bool(got.get("_num_rendered", 0))}
+            res[name] = {"ok": True, "path": path, "flips": flips, "listed": bool(int(got.get("_num_rendered", 0)) & 0x7FFFFFFF)}
         except Exception as e:  # noqa: BLE001 - reported to the parent test
             res[name] = {"ok": False, "error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()[-1500:]}
     json.dump(res, open(out_json, "w"))
