@@ -239,7 +239,9 @@ int eogs_rast_profile_get(int slot, double* total_ms, int64_t* launches, const c
  *   *list_block_px  8 (per-tile lists) or 32 (block lists)
  *   *fwd_kernel / *bwd_kernel  0 = one list per tile (render_*_kernel<1>), 1 = block lists (render_*_kernel<4>),
  *                              2 = quad sub-lists (render_*_quad_kernel); backward only: 3 = quad sub-lists with the
- *                              entry-indexed MFMA reduction, 4 = quad sub-lists with the MFMA transposition
+ *                              entry-indexed MFMA reduction, 4 = quad sub-lists with the MFMA transposition,
+ *                              5 = back to front on per-tile lists: the reference's own recursion
+ *                              (DGR/cuda_rasterizer/backward.cu:536-643), chosen for image-sized Gaussians
  * The oracle reports 16 / -1 / -1 (the reference's 16-px tiles, no kernel variants). */
 int eogs_rast_path_info(int P, int64_t num_rendered, int* list_block_px, int* fwd_kernel, int* bwd_kernel);
 /* Runs the library's wave64 primitive self-test (DPP reduction, readlane broadcast) on `stream` and returns,
