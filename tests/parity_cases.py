@@ -181,7 +181,10 @@ IMAGE_KEYS = ("out_color", "out_invdepth")
 # accepted out-of-tolerance elements per tensor: at most this fraction of its elements (and never fewer than MIN allowed)
 ATTR_FRAC, ATTR_MIN = 5e-3, 32
 # elements explained only by the implementation's own dL/dalpha formulation (formulation_delta): count and size
-FORM_MAX, FORM_RTOL = 2, 1e-3
+# the allowance for the front-to-back dL/dalpha of the fast backward kernels (check_close, 3.): only in processes that switch
+# the back-to-front kernel off to force those kernels onto the stress cases (tests/test_gpu_paths.py); 0 everywhere else —
+# the default suite and the extended sweeps pass without it (profiles/r03_sweeps.txt)
+FORM_MAX, FORM_RTOL = (2 if os.environ.get("EOGS_BTF_SWITCH") == "0" else 0), 1e-3
 
 
 class Attribution:
@@ -303,7 +306,7 @@ def check_close(got, ref, what, rtol, attribution=None, key=None, sens_rtol=1e-1
             print(f"{what}: {n_sens} elements attributed to ill-conditioning (oracle moves by >= err/{SENS_FACTOR:g} under "
                   f"{SENS_ULPS:g}-ulp input perturbation), max err {float(err[unexplained & sens_ok].max()):.3e}")
         unexplained = unexplained & ~sens_ok
-    if bool(unexplained.any()) and key.startswith("g_"):
+    if FORM_MAX and bool(unexplained.any()) and key.startswith("g_"):
         fd = attribution.formulation(key).reshape(err.shape) / scale
         form_ok = unexplained & (err <= SENS_FACTOR * fd + rtol) & (err <= FORM_RTOL)
         if bool(form_ok.any()) and int(form_ok.sum()) <= FORM_MAX:
