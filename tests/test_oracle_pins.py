@@ -158,3 +158,35 @@ def test_threshold_nudge_moves_exactly_the_near_threshold_decision(oracle_backen
     assert all(np.array_equal(base[k], v) for k, v in nudged_run(case, sign_map=m).items())
     m[8, 8] = 1
     assert all(np.array_equal(up[k], v) for k, v in nudged_run(case, sign_map=m).items())
+
+
+@pytest.mark.parametrize("P,H,W,seed,opacity,scale_mult", [(1500, 32, 32, 3, 0.6, 10.0), (2000, 40, 48, 7, 0.95, 15.0)])
+def test_back_to_front_recursion_is_the_accurate_form_for_image_sized_gaussians(P, H, W, seed, opacity, scale_mult, oracle_backend):
+    """Why forwards of image-sized opaque Gaussians run the back-to-front backward (render_bwd_btf_kernel): against
+    the independent dense autograd renderer the reference's recursion (backward.cu:586-620) is an order of magnitude closer
+    than the front-to-back form the fast kernels use (sum behind a Gaussian = rendered total minus running prefix;
+    eogs_oracle_suffix_by_subtraction(1) evaluates it inside the oracle). Ordinary footprints show no difference."""
+    sc = make_scene(P, H, W, seed=seed, opacity=opacity, scale_mult=scale_mult)
+    _, _, _, gd = _dense_run(sc, H, W, False, None)
+    err = {}
+    for mode in (0, 1):
+        oracle_backend.cdll.eogs_oracle_suffix_by_subtraction(mode)
+        try:
+            _, _, _, g = _oracle_run(sc, H, W, False, None, oracle_backend)
+        finally:
+            oracle_backend.cdll.eogs_oracle_suffix_by_subtraction(0)
+        err[mode] = {k: _rel(g[k], gd[k]) for k in ("opacities", "means2D", "means3D", "scales")}
+    for k in err[0]:
+        assert err[0][k] < 2e-5, (k, err)          # the reference's form: at the level of fp32 rounding
+        assert err[1][k] > 2.0 * err[0][k], (k, err)  # the front-to-back form: visibly worse on every gradient
+    assert err[1]["opacities"] > 2e-5, err
+    # an ordinary scene (footprints of a few tiles): both forms agree with the dense renderer alike
+    sc = make_scene(400, 64, 64, seed=0, opacity="trained", scale_mult=1.0)
+    _, _, _, gd = _dense_run(sc, 64, 64, False, None)
+    for mode in (0, 1):
+        oracle_backend.cdll.eogs_oracle_suffix_by_subtraction(mode)
+        try:
+            _, _, _, g = _oracle_run(sc, 64, 64, False, None, oracle_backend)
+        finally:
+            oracle_backend.cdll.eogs_oracle_suffix_by_subtraction(0)
+        assert all(_rel(g[k], gd[k]) < 2e-5 for k in ("opacities", "means2D", "means3D")), mode
