@@ -231,3 +231,21 @@ def test_config4_2M_1024_properties(dev):
     crop = render_dense(c["means3D"], c["opacities"], c["colors"], c["bg"], c["viewmatrix"], H, W, scales=c["scales"],
                         rotations=c["rotations"], block=64, crop=(y0, x0, S, S))[0]
     assert_close(c1[:, y0:y0 + S, x0:x0 + S], crop, "2M crop")
+
+
+def test_image_sized_gaussians_select_the_back_to_front_backward(dev):
+    """The choice itself (csrc/api.hip token_from_counts): a forward whose Gaussians list a tenth of the image's tiles each
+    carries bit 60 — per-tile lists, backward kernel 5 — and ordinary footprints never do. Both against the oracle."""
+    from eogs2_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib
+    from parity_cases import compare, oracle_run, seeded_case
+
+    abi = _lib.get()
+    big, label = seeded_case(400, 200, 168, 15, "trained", 14.0, False, False)   # rects > 64 internal tiles each
+    got = run_case(big, dev, GaussianRasterizer, GaussianRasterizationSettings)
+    assert (got["_num_rendered_exact"] >> 60) & 1 == 1
+    assert abi.path_info(400, got["_num_rendered"]) == (8, 2, 5)
+    compare(got, oracle_run(big), label, big)
+    small, label = seeded_case(5000, 160, 208, 10, "init", 2.0, False, False)
+    got = run_case(small, dev, GaussianRasterizer, GaussianRasterizationSettings)
+    assert (got["_num_rendered_exact"] >> 60) & 1 == 0 and abi.path_info(5000, got["_num_rendered"])[2] == 2
+    compare(got, oracle_run(small), label, small)
