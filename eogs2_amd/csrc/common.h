@@ -287,6 +287,7 @@ struct BinWS {
   uint8_t* live;    // backward scratch: 1 = the pair's record was written (dead pairs are never touched)
   SortWS sort;      // entry sort of a forward whose entries did not fit the caller's scratch (nr_sorted(R) == 0)
   int block;
+  uint32_t cap_slots, cap_entries;  // what the token sized these arrays for (a forward that needs more has built no lists)
   size_t bytes;
 };
 
@@ -329,6 +330,8 @@ static inline BinWS bin_layout(char* base, int H, int W, int64_t R) {
   const size_t ne = (size_t)nr_entries(R), nslots = (size_t)nr_slots(R);
   size_t o = 0;
   b.block = nr_block(R);
+  b.cap_slots = (uint32_t)nslots;
+  b.cap_entries = (uint32_t)ne;
   o = ws_carve(base, o, b.point_list, b.block > 1 ? ne : nslots);
   o = ws_carve(base, o, b.sorted_keys, b.block > 1 ? ne : (size_t)0);
   o = ws_carve(base, o, b.records, nslots * REC);

@@ -391,10 +391,16 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
     float* __restrict__ dL_dmeans2D, float* __restrict__ dL_dcolors, float* __restrict__ dL_dopacity,
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscales,
     float* __restrict__ dL_drotations, bool want_T, bool want_vm, float* __restrict__ vmpart, uint32_t blk0,
-    float* __restrict__ dL_dcolors_lead, int lead_cols) {
+    float* __restrict__ dL_dcolors_lead, int lead_cols, const uint32_t* __restrict__ misc, uint32_t cap_slots,
+    uint32_t cap_entries) {
   __shared__ float s_m[3 * BLK];
   __shared__ float s_s[3 * BLK];
   __shared__ float s_red[BLK / 64][18];
+  // A forward queued on a capacity token (EOGS_FLAG_DEFER_COUNTS) that needed more than its workspaces hold has built no
+  // lists (binning.hip block_lists_kernel) and wrote no record: its slots would lie beyond `records` / `live`. The same
+  // comparison here: such a backward reads none of them and returns zero gradients (the host repeats the forward).
+  const bool fits = misc[MISC_TOTAL_HI] == 0u && misc[MISC_MACRO_HI] == 0u && misc[MISC_TOTAL_LO] <= cap_slots &&
+                    misc[MISC_MACRO_LO] <= cap_entries;
   const int t = threadIdx.x;
   const uint32_t blk = blk0 + blockIdx.x;  // workgroup index over ALL Gaussians (the launch may cover a range of them)
   const size_t row0 = (size_t)blk * BLK;
@@ -418,7 +424,7 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
     if (visible) {
       // fixed-order sum of this Gaussian's (tile,Gaussian) records: deterministic, no atomics
       const uint4 bi1 = binfo[2 * idx + 1];
-      const uint32_t n = bi1.x;
+      const uint32_t n = fits ? bi1.x : 0u;
       const size_t s0 = (size_t)pblock[blk] + bi1.y;  // Gaussian-id order: a wave reads one contiguous region
       const float4* r4 = reinterpret_cast<const float4*>(records + s0 * REC);
       // Two memory round trips instead of 2n dependent ones: first all live flags of this Gaussian (independent byte
@@ -684,7 +690,7 @@ void launch_gaussian_bwd(const GaussBwdArgs& a, const GeomWS& g, const BinWS& b,
                        a.cov3D_precomp, a.opacities, a.viewmatrix, a.projmatrix, a.alt_affine, a.radii, a.scale_modifier,
                        (int)a.antialiasing, g.binfo, g.pblock, b.records, b.live, a.dL_dmeans2D, a.dL_dcolors, a.dL_dopacity,
                        a.dL_dmeans3D, a.dL_dcov3D, a.dL_dscales, a.dL_drotations, want_T, want_vm, g.vmpart, blk0,
-                       a.dL_dcolors_lead, a.lead_cols);
+                       a.dL_dcolors_lead, a.lead_cols, g.misc, b.cap_slots, b.cap_entries);
   if ((want_T || want_vm) && p_end == a.P)
     hipLaunchKernelGGL(camera_sum_kernel, dim3(1), dim3(BLK), 0, s, g.vmpart, nblk_all, a.dL_dT_sum, a.dL_dvm_mean);
 }

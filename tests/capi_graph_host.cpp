@@ -238,6 +238,11 @@ int main() {
     for (size_t i = 0; i < (size_t)H * W; i++)
       if (r.color[(size_t)ch * H * W + i] != huge.bg[ch]) { all_bg = false; break; }
   CHECK(all_bg, "nothing was blended into the undersized workspaces: the image is the background");
+  bool zero_grads = true;
+  for (const std::vector<float>* v : {&r.g_m2, &r.g_col, &r.g_op, &r.g_m3, &r.g_sc, &r.g_rot})
+    for (float x : *v)
+      if (x != 0.f) { zero_grads = false; break; }
+  CHECK(zero_grads, "and its backward read no record slot beyond them: every gradient is zero");
   int64_t exact_huge = 0;
   const Result eager_huge = eager_step(b, st, &exact_huge);
   CHECK(ex == exact_huge, "the counts it reported are the eager counts");

@@ -96,6 +96,9 @@ def test_replay_that_outgrows_the_recorded_workspaces_is_recorded_again(dev):
     assert not g.fits()  # detected ...
     bg = st.rs.bg
     assert torch.equal(g.outputs[0], bg[:, None, None].expand_as(g.outputs[0]))  # ... and nothing was blended
+    # ... nor read: the backward of an outgrown forward touches no record slot (they would lie beyond the workspace) and
+    # hands back zeros
+    assert all(bool((t == 0).all()) for t in g.outputs[3:])
     got = st.results(g())  # replay -> does not fit -> recorded again with room -> replay
     assert g.recaptures == 1
     _same(got, st.results(st()))
