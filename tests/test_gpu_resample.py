@@ -111,3 +111,45 @@ def test_resample_entry_point_and_errors(dev):
         resample(direct, torch.eye(4, device=dev), uva)
     with pytest.raises(RuntimeError):
         resample(direct, torch.eye(3, device=dev), uva[..., :2])
+
+
+# ---- vectors from the REFERENCE's own render_resample_virtual_camera (tests/golden/make_golden_resample.py) ----
+import glob  # noqa: E402
+import os  # noqa: E402
+
+from util import GOLDEN_DIR  # noqa: E402
+
+RESAMPLE_FIXTURES = sorted(glob.glob(os.path.join(GOLDEN_DIR, "resample_*.npz")))
+
+
+@pytest.mark.parametrize("path", RESAMPLE_FIXTURES, ids=lambda p: os.path.basename(p)[9:-4])
+def test_resample_matches_reference_vectors(dev, path):
+    """The HIP resample (forward and backward through the C-ABI) against what the reference's function returned and what
+    autograd gave for it: RGB / altitude samples with the -100 fill, coordinates, d/d virtual render, d/d altitude."""
+    from test_resample_oracle import compare, load, run
+
+    from eogs2_amd.resample import resample
+
+    c = load(path)
+    compare(run(resample, c, dev), c, rtol=1e-4)
+
+
+def test_entry_point_matches_reference_vectors_with_a_stub_render(dev, monkeypatch):
+    """eogs2_amd.resample.render_resample_virtual_camera (the reference's signature) with step 1 replaced by the fixture's
+    virtual render, exactly as the fixture was produced."""
+    from test_resample_oracle import compare, load
+
+    import eogs2_amd.render as R
+    from eogs2_amd.resample import render_resample_virtual_camera
+
+    c = load(RESAMPLE_FIXTURES[1])
+    vr = c["virtual_render"].to(dev).requires_grad_(True)
+    alt = c["altitude"].to(dev).requires_grad_(True)
+    monkeypatch.setattr(R, "render", lambda cam, pc, pipe, bg: {"render": vr})
+    uva = torch.stack((c["U"].to(dev), c["V"].to(dev), alt), dim=-1)
+    rgb, a, uv, extra = render_resample_virtual_camera(None, c["cam2virt"].to(dev), uva, None, None, None, return_extra=True)
+    assert extra is vr
+    ((rgb * c["w_rgb"].to(dev)).sum() + (a * c["w_alt"].to(dev)).sum() + (uv * c["w_uv"].to(dev)).sum()).backward()
+    got = dict(rgb_sample=rgb.detach().cpu(), altitude_sample=a.detach().cpu(), virtual_uv=uv.detach().cpu(),
+               g_virtual_render=vr.grad.cpu(), g_altitude=alt.grad.cpu())
+    compare(got, c, rtol=1e-4)

@@ -99,3 +99,35 @@ def test_full_size_properties(dev):
     assert torch.allclose(b._weight_vol, 2 * a._weight_vol, rtol=1e-6, atol=0)
     assert torch.allclose(b._tsdf_vol, a._tsdf_vol, rtol=0, atol=2e-6)
     assert float(a._tsdf_vol.max()) <= 1.0 and float(a._tsdf_vol[touched].min()) >= -1.0 - 1e-6
+
+
+# ---- vectors from the REFERENCE's own tsdf.py (tests/golden/make_golden_tsdf.py; tests/test_tsdf_oracle.py pins the restatement) ----
+import glob  # noqa: E402
+import os  # noqa: E402
+
+from util import GOLDEN_DIR  # noqa: E402
+
+TSDF_FIXTURES = sorted(glob.glob(os.path.join(GOLDEN_DIR, "tsdf_*.npz")))
+
+
+@pytest.mark.parametrize("path", TSDF_FIXTURES, ids=lambda p: os.path.basename(p)[5:-4])
+def test_integrate_matches_reference_vectors(dev, path):
+    """eogs2_amd.tsdf.TSDFVolume (constructor + one HIP kernel per view) against the volumes the reference's
+    TSDFVolume.integrate produced after every accumulated view, NaN voxels of the zero-weight region included."""
+    from eogs2_amd.tsdf import TSDFVolume
+
+    z = np.load(path)
+    c = {k: z[k] for k in z.files}
+    vol = TSDFVolume(c["vol_bounds"], float(c["vox_size"]), float(c["trunc_margin_fact"]), device=dev)
+    assert tuple(vol.num_voxels_per_dimension) == tuple(int(x) for x in c["num_voxels"])
+    for i in range(3):
+        assert torch.equal(vol.axes[i].cpu(), torch.as_tensor(c[f"axis{i}"]))
+    t = lambda k: torch.as_tensor(c[k]).to(dev)
+    for v in range(int(c["n_views"])):
+        ri = types.SimpleNamespace(affine_model=(t(f"v{v}_coef"), t(f"v{v}_intercept")), model_scale=float(c["model_scale"]),
+                                   altitude_img=t(f"v{v}_altitude"), get_weights=lambda v=v: t(f"v{v}_weights"))
+        vol.integrate(ri)
+        assert_same(vol._tsdf_vol, torch.as_tensor(c[f"v{v}_tsdf_vol"]), 2e-5, f"view {v}: tsdf vs the reference's volume")
+        assert_same(vol._weight_vol, torch.as_tensor(c[f"v{v}_weight_vol"]), 2e-5, f"view {v}: weights vs the reference's volume")
+    if "outside" in path:
+        assert torch.equal(vol._tsdf_vol, torch.ones_like(vol._tsdf_vol)) and float(vol._weight_vol.abs().max()) == 0.0
