@@ -13,6 +13,13 @@ with that per-pixel map, and every output and gradient must then agree with THAT
 pixel holds several near pairs that flipped differently, lie inside the interval the four oracle runs span). What is still
 outside must be explained by the oracle's own ill-conditioning (sensitivity map) or the test fails. The number of accepted
 elements per tensor is capped: a regression cannot hide behind the mechanism.
+
+"1e-4" is meant PER QUANTITY (round 4): the scale an error is measured against is the largest reference magnitude of the
+element's own channel for [C, H, W] images and of its own column for [P, k] per-Gaussian gradients, not of the whole tensor.
+`out_color` is [r, g, b, altitude, opacity] (renderer.py:88-95: features = [rgb, altitude, 1]) — altitude is 350 z, its
+channel peaks at 17-52 in the fixtures where RGB peaks below 1, and the photometric loss consumes RGB alone
+(utils/loss_utils.py:18-85); under a per-tensor scale RGB was only held to 0.2-1.5 % of its own range. Same for the columns of
+g_means3D (z an order below x / y), g_means2D, g_scales, g_rotations, g_colors, g_cov3D_precomp.
 """
 import os
 import numpy as np
@@ -178,6 +185,32 @@ def sensitivity_map(case, base=None):
 
 
 IMAGE_KEYS = ("out_color", "out_invdepth")
+
+
+def quantity_scale(ref):
+    """The scale |got - ref| is measured against, broadcastable to ref: per channel for [C, H, W] images, per column for
+    [P, k] tensors, one number otherwise. A quantity that is identically zero in the reference (g_means2D's unused third
+    column) gets 1e-30: only an exact zero passes."""
+    b = torch.as_tensor(np.asarray(ref), dtype=torch.float64)
+    if b.numel() == 0:
+        return torch.ones((), dtype=torch.float64)
+    if b.ndim == 3:
+        sc = b.abs().amax(dim=(1, 2), keepdim=True)
+    elif b.ndim == 2 and b.shape[1] > 1:
+        sc = b.abs().amax(dim=0, keepdim=True)
+    else:
+        sc = b.abs().max().reshape(())
+    return sc.clamp_min(1e-30)
+
+
+# one row per check_close call, appended as JSON lines to $EOGS_PARITY_STATS when set (profiles/r04_sweeps.txt is made from it)
+def _record(row):
+    f = os.environ.get("EOGS_PARITY_STATS")
+    if f:
+        import json
+
+        with open(f, "a") as fh:
+            fh.write(json.dumps(row) + "\n")
 # accepted out-of-tolerance elements per tensor: at most this fraction of its elements (and never fewer than MIN allowed)
 ATTR_FRAC, ATTR_MIN = 5e-3, 32
 # elements explained only by the implementation's own dL/dalpha formulation (formulation_delta): count and size
@@ -220,8 +253,8 @@ class Attribution:
                     if k in self.out and k in r:
                         a = self.out[k].detach().cpu().double().numpy().reshape(-1, H, W)
                         b = np.asarray(r[k], dtype=np.float64).reshape(-1, H, W)
-                        scale = max(float(np.abs(np.asarray(self.ref[k])).max()), 1e-30)
-                        e = np.maximum(e, np.abs(a - b).max(0) / scale)
+                        scale = quantity_scale(np.asarray(self.ref[k]).reshape(-1, H, W)).numpy()  # per channel
+                        e = np.maximum(e, (np.abs(a - b) / scale).max(0))
                 err[sgn] = e
             sign = np.zeros((H, W), dtype=np.int8)
             better_m, better_p = err[-1] < err[0], err[1] < err[0]
@@ -264,8 +297,12 @@ class Attribution:
         return torch.from_numpy(self._form[key])
 
 
-def check_close(got, ref, what, rtol, attribution=None, key=None, sens_rtol=1e-1):
-    """|got - ref| <= rtol * max|ref| elementwise. Elements beyond it must be explained, in this order:
+SENS_RTOL = 1e-1
+
+
+def check_close(got, ref, what, rtol, attribution=None, key=None, sens_rtol=None):
+    """|got - ref| <= rtol * max|ref of the element's own quantity| (quantity_scale: channel of an image, column of a
+    per-Gaussian gradient) elementwise. Elements beyond it must be explained, in this order:
       1. by a moved blend / stop decision: the element agrees to rtol with the oracle re-run whose per-pixel threshold
          nudges reproduce the HIP image, or lies (to rtol) inside the interval spanned by the oracle runs with the thresholds
          at -k, 0, +k ulp and that matched run;
@@ -278,13 +315,17 @@ def check_close(got, ref, what, rtol, attribution=None, key=None, sens_rtol=1e-1
     assert tuple(a.shape) == tuple(b.shape), f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
     if b.numel() == 0:
         return 0.0, 0
-    scale = max(float(b.abs().max()), 1e-30)
+    sens_rtol = SENS_RTOL if sens_rtol is None else sens_rtol
+    scale = quantity_scale(b)
     err = (a - b).abs() / scale
     bad = err > rtol
     nbad = int(bad.sum())
+    row = dict(what=what, n=int(b.numel()), max_err=float(err.max()), nbad=nbad, max_err_per_tensor=float((a - b).abs().max() / scale.max()))
     if nbad == 0:
+        _record(row)
         return float(err.max()), 0
-    assert attribution is not None and key is not None, f"{what}: max err {float(err.max()):.3e} (x scale {scale:.3e}), {nbad} elements beyond {rtol:g}"
+    assert attribution is not None and key is not None, (
+        f"{what}: max err {float(err.max()):.3e} of its quantity's scale (scales {scale.flatten().tolist()}), {nbad} elements beyond {rtol:g}")
     cap = max(ATTR_MIN, int(ATTR_FRAC * b.numel()))
     assert nbad <= cap, f"{what}: {nbad} of {b.numel()} elements beyond {rtol:g} (max {float(err.max()):.3e}): more than attribution may accept ({cap})"
     m, hull = attribution.matched()
@@ -293,6 +334,7 @@ def check_close(got, ref, what, rtol, attribution=None, key=None, sens_rtol=1e-1
     hi = torch.as_tensor(hull[key][1]).reshape(a.shape) + rtol * scale
     ok = ((a - mm).abs() / scale <= rtol) | ((a >= lo) & (a <= hi))
     unexplained = bad & ~ok
+    row.update(n_decision=int((bad & ok).sum()))
     if bool((bad & ok).any()):
         print(f"{what}: {int((bad & ok).sum())} elements explained by moved blend / stop decisions "
               f"(max err vs the un-nudged oracle {float(err[bad & ok].max()):.3e})")
@@ -300,6 +342,7 @@ def check_close(got, ref, what, rtol, attribution=None, key=None, sens_rtol=1e-1
         delta = attribution.sensitivity(key).reshape(err.shape) / scale
         sens_ok = err <= SENS_FACTOR * delta + rtol
         n_sens = int((unexplained & sens_ok).sum())
+        row.update(n_sens=n_sens, max_sens_err=float(err[unexplained & sens_ok].max()) if n_sens else 0.0)
         if n_sens:
             assert float(err[unexplained & sens_ok].max()) <= sens_rtol, (
                 f"{what}: sensitivity-attributed error {float(err[unexplained & sens_ok].max()):.3e} exceeds {sens_rtol:g}")
@@ -312,10 +355,14 @@ def check_close(got, ref, what, rtol, attribution=None, key=None, sens_rtol=1e-1
         if bool(form_ok.any()) and int(form_ok.sum()) <= FORM_MAX:
             print(f"{what}: {int(form_ok.sum())} element(s) at the precision limit of the front-to-back dL/dalpha formulation "
                   f"(DESIGN.md 5), max err {float(err[form_ok].max()):.3e} — accepted under the separate allowance")
+            row.update(n_form=int(form_ok.sum()))
             unexplained = unexplained & ~form_ok
+    row.update(n_unexplained=int(unexplained.sum()))
+    _record(row)
     assert not bool(unexplained.any()), (
         f"{what}: {int(unexplained.sum())} of {nbad} out-of-tolerance elements are explained neither by a moved blend / stop "
-        f"decision nor by ill-conditioning (max unexplained err {float(err[unexplained].max()):.3e}, rtol {rtol:g}, scale {scale:.3e})")
+        f"decision nor by ill-conditioning (max unexplained err {float(err[unexplained].max()):.3e}, rtol {rtol:g}, "
+        f"scales {[f'{x:.3e}' for x in scale.flatten().tolist()]})")
     return float(err.max()), nbad
 
 
@@ -344,6 +391,14 @@ def compare(out, ref, name, case, stats=None, cache=None):
         scale = max(float((m3.t() @ g2).max()), float(g2.sum(0).max()), float(rt.abs().max()), 1e-30)
         lim = GRAD_RTOL.get(name, RTOL)
         err = float((v.cpu().double() - rt).abs().max()) / scale
+        # (with a white-noise dL/dcolor over ~1 M Gaussians the magnitude sum is ~1e3 x the value, so this bound says little
+        # about the value itself there; it is the structured gradient of config 3 — test_config3_camera_gradient_with_warped_loss —
+        # where it is a statement about the camera gradient. The error relative to max|value| is recorded beside it.)
+        err_of_value = float((v.cpu().double() - rt).abs().max()) / max(float(rt.abs().max()), 1e-30)
+        _record(dict(what=f"{name}:g_viewmatrix", n=16, max_err=err, max_err_of_value=err_of_value, nbad=int(err > lim),
+                     magnitude_sum_over_value=scale / max(float(rt.abs().max()), 1e-30)))
+        print(f"{name}:g_viewmatrix: {err:.3e} of the magnitude sum, {err_of_value:.3e} of max|value| "
+              f"(magnitude sum / value = {scale / max(float(rt.abs().max()), 1e-30):.1f})")
         if err > lim and flips:
             # decisions moved somewhere in the image move these 16 global sums: the matched oracle run is the reference then
             mt = torch.as_tensor(np.asarray(att.matched()[0]["g_viewmatrix"])).double()
