@@ -107,6 +107,12 @@ def graph_extras(a):
     del gs
     if not a.no_train_iter:
         out["train_iter_fused_graphed"] = train_iteration(sc, P, H, W, dev, fused=True, graphed=True, iters=20)
+        try:  # the same graph with its three renders as parallel branches (eogs2_amd.graph.Branches)
+            out["train_iter_fused_graphed_parallel"] = train_iteration(sc, P, H, W, dev, fused=True, graphed=True, parallel=True, iters=20)
+            out["train_iter_fused_graphed_parallel_sun_altitude_only"] = train_iteration(
+                sc, P, H, W, dev, fused=True, graphed=True, parallel=True, iters=20, sun_altitude_only=True)
+        except Exception as e:  # noqa: BLE001 (an extra must never cost the line)
+            out["train_iter_fused_graphed_parallel"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     print(json.dumps(out), flush=True)
 
 
@@ -117,7 +123,7 @@ def graph_extras_from_child(a, kernel_sum_ms):
            "--opacity", str(a.opacity), "--steps", str(a.steps), "--warmup", str(a.warmup)]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
     try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=150)
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
         rows = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if r.returncode != 0 or not rows:
             return {"graphed_step": {"error": f"child exited {r.returncode}: {r.stderr[-300:]}"}}
@@ -305,7 +311,8 @@ def _ssim_window(dev, C=3):
     return w1.mm(w1.t()).float().expand(C, 1, 11, 11).contiguous().to(dev)
 
 
-def train_iteration(sc, P, H, W, dev, fused, iters=5, dist=None, view_seed=0, algo="all_reduce", graphed=False):
+def train_iteration(sc, P, H, W, dev, fused, iters=5, dist=None, view_seed=0, algo="all_reduce", graphed=False, parallel=False,
+                    sun_altitude_only=False):
     """Extra, reported beside the headline: one synthetic EOGS++ training iteration as the reference schedules it after
     iteration 1000 (GS/train_pan.py:278,305-316,375-391): three renders of the same Gaussians — the view (H x W), the
     sun camera (2H x 2W, affine_cameras.py:366-367) and a random virtual camera (H x W) — each forward + backward,
@@ -321,7 +328,10 @@ def train_iteration(sc, P, H, W, dev, fused, iters=5, dist=None, view_seed=0, al
     optimizer step — the reference's iteration (train_pan.py:278,308,469,664-690) under view-sharded data parallelism.
     Reported: ms per iteration (max over ranks), the same without the exchange, and the exchange alone.
     graphed (one rank, fused): the three renders, the loss and their backward passes are recorded once into a HIP graph
-    (eogs2_amd.graph.GraphedStep) and replayed; the optimizer step stays outside (its bias correction is host arithmetic)."""
+    (eogs2_amd.graph.GraphedStep) and replayed; the optimizer step stays outside (its bias correction is host arithmetic).
+    parallel (with graphed): the three renders are independent branches of that graph (eogs2_amd.graph.Branches).
+    sun_altitude_only (fused): the 2H x 2W sun-camera render blends its altitude channel alone (EOGS_FLAG_ALT_ONLY) — what the
+    reference's shipped configuration consumes of it (train_pan.py:305-324, gs_config/train.yaml:123)."""
     from eogs2_amd import GaussianRasterizer
     from eogs2_amd.fused import rasterize_raw
     from eogs2_amd.losses import photometric_loss
@@ -352,31 +362,49 @@ def train_iteration(sc, P, H, W, dev, fused, iters=5, dist=None, view_seed=0, al
         views.append((settings_for(dict(sc, viewmatrix=vm), h, w), vm[:, 2].contiguous(), torch.zeros(P, 3, device=dev), dL))
     gt = torch.rand(3, H, W, generator=torch.Generator().manual_seed(5)).to(dev)
 
+    branches = None
+    if parallel:
+        from eogs2_amd.graph import Branches
+
+        branches = Branches(len(views), device=dev)
+
     def it(exchange=True, step=True):
         if graphed and bucket is not None:
             bucket.zero_()  # the gradients live in the exchange buffer: the same tensors in every replay
         else:
             opt.zero_grad(set_to_none=True)
-        for vi, (rs, alt, m2, dL) in enumerate(views):
-            if fused:
-                color, _, _ = rasterize_raw(params["xyz"], m2, params["f_dc"], params["opacity"], params["scaling"],
-                                            params["rotation"], alt, rs)
-            else:
-                rgb = (params["f_dc"] * C0 + 0.5).squeeze(1)
-                altitude = (params["xyz"] @ rs.viewmatrix[:3, :3] + rs.viewmatrix[3, :3])[..., 2].unsqueeze(-1)
-                colors = torch.cat([rgb, altitude, torch.ones_like(altitude)], dim=-1)
-                color, _, _ = GaussianRasterizer(rs)(
-                    params["xyz"], m2, torch.sigmoid(params["opacity"]), colors_precomp=colors,
-                    scales=torch.exp(params["scaling"]), rotations=torch.nn.functional.normalize(params["rotation"]))
-            if vi == 0:
-                loss = photometric_loss(color[:3], gt, 0.2)[0] if fused else _torch_photometric(color[:3], gt, win)
-                (loss + (color[3:] * dL[3:]).sum()).backward()
-            else:
-                torch.autograd.backward([color], [dL])
+        if branches is not None:
+            branches.run([lambda vi=vi: one_view(vi) for vi in range(len(views))])
+        else:
+            for vi in range(len(views)):
+                one_view(vi)
         if bucket is not None and exchange:
             bucket.all_reduce()
         if step:
             opt.step()
+
+    def one_view(vi):
+        rs, alt, m2, dL = views[vi]
+        if fused and sun_altitude_only and vi == 1:
+            color, _, _ = rasterize_raw(params["xyz"], m2, params["f_dc"], params["opacity"], params["scaling"],
+                                        params["rotation"], alt, rs, altitude_only=True)
+            torch.autograd.backward([color], [dL[3:4]])
+            return
+        if fused:
+            color, _, _ = rasterize_raw(params["xyz"], m2, params["f_dc"], params["opacity"], params["scaling"],
+                                        params["rotation"], alt, rs)
+        else:
+            rgb = (params["f_dc"] * C0 + 0.5).squeeze(1)
+            altitude = (params["xyz"] @ rs.viewmatrix[:3, :3] + rs.viewmatrix[3, :3])[..., 2].unsqueeze(-1)
+            colors = torch.cat([rgb, altitude, torch.ones_like(altitude)], dim=-1)
+            color, _, _ = GaussianRasterizer(rs)(
+                params["xyz"], m2, torch.sigmoid(params["opacity"]), colors_precomp=colors,
+                scales=torch.exp(params["scaling"]), rotations=torch.nn.functional.normalize(params["rotation"]))
+        if vi == 0:
+            loss = photometric_loss(color[:3], gt, 0.2)[0] if fused else _torch_photometric(color[:3], gt, win)
+            (loss + (color[3:] * dL[3:]).sum()).backward()
+        else:
+            torch.autograd.backward([color], [dL])
 
     graph_info = {}
     if graphed:
@@ -790,6 +818,51 @@ def cpu_baseline(P_full, S_full):
     return out
 
 
+def regime_scan(dev, steps=20):
+    """The step in the regimes the headline does not show: same pipeline, same timing rule (steps
+    bracketed by synchronize, HBM-resident inputs), 20 steps each after 5 untimed ones. `frac` is the pipeline's algorithmic
+    bytes (432 P + 268 R + 64 HW) over the step time against the 8 TB/s HBM peak, R = the library's own pair count."""
+    from eogs2_amd import GaussianRasterizer
+    from eogs2_amd.synthetic import make_scene, settings_for
+
+    out = {}
+    for name, P, S, op in (("trained_1M_1024", 1 << 20, 1024, "trained"), ("opacity0.1_1M_1024", 1 << 20, 1024, 0.1),
+                           ("opacity0.01_1M_2048", 1 << 20, 2048, "init"), ("opacity0.1_2M_1024", 2_000_000, 1024, 0.1)):
+        try:
+            sc = make_scene(P, S, S, seed=0, opacity=op, device=dev)
+            rast = GaussianRasterizer(settings_for(sc, S, S))
+            params = {k: sc[k].clone().requires_grad_(True) for k in ("means3D", "colors", "opacities", "scales", "rotations")}
+            m2 = torch.zeros(P, 3, device=dev, requires_grad=True)
+
+            def step():
+                for p in params.values():
+                    p.grad = None
+                m2.grad = None
+                c, _, _ = rast(params["means3D"], m2, params["opacities"], colors_precomp=params["colors"],
+                               scales=params["scales"], rotations=params["rotations"])
+                torch.autograd.backward([c], [sc["dL_dcolor"]])
+                return c
+
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                c = step()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            nr = int(getattr(c.grad_fn, "num_rendered_exact", getattr(c.grad_fn, "num_rendered", -1)))
+            R = nr & 0x7FFFFFFF
+            by = 432 * P + 268 * R + 64 * S * S
+            out[name] = {"gaussians": P, "size": S, "opacity": op, "steps": steps, "ms_per_step": ms, "views_per_s": 1e3 / ms,
+                         "num_rendered": R, "list_block_px": 32 if (nr >> 62) & 1 else 8, "algorithmic_bytes": by,
+                         "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            del sc, rast, params, m2, c
+        except Exception as e:  # a regime must never cost the line
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    return out
+
+
 def main():
     a = parse()
     # read by the HSA runtime when it initialises: must be in the environment before the first torch.cuda call
@@ -961,7 +1034,7 @@ def main():
     nr = int(getattr(color.grad_fn, "num_rendered_exact", getattr(color.grad_fn, "num_rendered", -1)))
     # the API's num_rendered packs both counts: (tile, Gaussian) record slots below, (32-px block, Gaussian) list entries
     # above (csrc/common.h nr_pack)
-    R, R_entries = (nr & 0x7FFFFFFF, (nr >> 32) & 0x0FFFFFFF) if nr >= 0 else (-1, -1)
+    R, R_entries = (nr & 0x7FFFFFFF, (nr >> 32) & 0x07FFFFFF) if nr >= 0 else (-1, -1)
 
     ti_dist = None
     if use_dist and not a.no_train_iter:
@@ -1059,10 +1132,14 @@ def main():
         if world == 1 and not use_dist and not a.no_train_iter:
             line["train_iter"] = train_iteration(sc, P, H, W, dev, fused=False)
             line["train_iter_fused"] = train_iteration(sc, P, H, W, dev, fused=True)
+            line["train_iter_fused_sun_altitude_only"] = train_iteration(sc, P, H, W, dev, fused=True, sun_altitude_only=True)
             # The same step and the same iteration recorded into HIP graphs and replayed (eogs2_amd/graph.py): beside the
             # headline, never the headline — `value` stays the eager call through the reference's API. Measured in a child
             # process started after everything above is done: a failed capture must not cost this line.
             line.update(graph_extras_from_child(a, line["host"]["kernel_sum_ms"]))
+            # the regimes beside the headline (worst case included): opacity 0.1, trained opacities, the 2048^2 sun-camera
+            # size, 2 M Gaussians — `value` / `config` stay the headline's
+            line["regimes"] = regime_scan(dev)
             line["photometric_loss"] = photometric_loss_bench(abi, dev, H, W)
             line["optimizer"] = optimizer_bench(abi, dev, P)
             line["resample"] = resample_bench(abi, dev, H, W)

@@ -22,6 +22,7 @@ FLAG_DEBUG = 2
 FLAG_RAW_PARAMS = 4
 FLAG_DEFER_COUNTS = 8
 FLAG_NO_READBACK = 16
+FLAG_ALT_ONLY = 32  # include/eogs_rast.h EOGS_FLAG_ALT_ONLY: an altitude-only render
 MIRROR_BYTES = 64
 LOSS_L1 = 1
 LOSS_SSIM = 2

@@ -15,7 +15,7 @@ namespace {
 thread_local char g_err[512] = "";
 thread_local uint32_t* g_pinned = nullptr;  // MISC_WORDS u32, pinned host memory (one per calling thread)
 // the forward_prepare whose count readback is still pending on this thread (EOGS_FLAG_DEFER_COUNTS)
-struct PendingCounts { bool valid; int P, H, W; bool have_scratch; uint32_t sort_cap; hipStream_t side; };
+struct PendingCounts { bool valid; int P, H, W; bool have_scratch; uint32_t sort_cap; hipStream_t side; bool alt; };
 thread_local PendingCounts g_pending_counts = {false, 0, 0, 0, false, 0u, nullptr};
 
 // per calling thread and device: a non-blocking side stream + event for the num_rendered readback
@@ -229,7 +229,7 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
   }
   LAUNCH_TRY(s, debug, "entry_sort");
   if (!readback) return EOGS_OK;  // (the caller reads the counts itself: eogs_rast_read_counts)
-  g_pending_counts = PendingCounts{true, P, H, W, have_scratch, sw.cap, sd->stream};
+  g_pending_counts = PendingCounts{true, P, H, W, have_scratch, sw.cap, sd->stream, (flags & EOGS_FLAG_ALT_ONLY) != 0};
   if (flags & EOGS_FLAG_DEFER_COUNTS) return EOGS_OK;  // the caller asks for the token later (eogs_rast_forward_counts)
   return eogs_rast_forward_counts(num_rendered);
 }
@@ -237,7 +237,7 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
 }  // extern "C"
 namespace {
 // exact token of a forward from its count words (host copy of GeomWS::misc)
-int token_from_counts(const uint32_t* m, int P, int H, int W, bool have_scratch, uint32_t sort_cap, int64_t* num_rendered) {
+int token_from_counts(const uint32_t* m, int P, int H, int W, bool have_scratch, uint32_t sort_cap, int64_t* num_rendered, bool alt) {
   const uint64_t total = (uint64_t)m[MISC_TOTAL_LO] | ((uint64_t)m[MISC_TOTAL_HI] << 32);
   const uint64_t entries = (uint64_t)m[MISC_MACRO_LO] | ((uint64_t)m[MISC_MACRO_HI] << 32);
   // List granularity the render kernels read (common.h "blocks"). Per-tile lists while footprints are small: every entry a
@@ -273,14 +273,17 @@ int token_from_counts(const uint32_t* m, int P, int H, int W, bool have_scratch,
     const char* e = getenv("EOGS_BTF_SWITCH");
     return e ? atof(e) : 0.1;
   }();
-  const bool btf = P > 0 && btf_switch > 0.0 && (double)total >= btf_switch * (double)P * ntiles8;
-  const int block = btf ? 1 : ((by_footprint || by_depth) ? BLOCK_BIG : 1);
+  // (an altitude-only forward — EOGS_FLAG_ALT_ONLY — runs the quad kernels' one-channel variants: per-tile lists, front to back)
+  const bool btf = !alt && P > 0 && btf_switch > 0.0 && (double)total >= btf_switch * (double)P * ntiles8;
+  const int block = (btf || alt) ? 1 : ((by_footprint || by_depth) ? BLOCK_BIG : 1);
   if (m[MISC_ERR] & 1u) return fail(EOGS_ERR_ALTITUDE, "Point is too high: altitude > 200");
-  if (total >= ((uint64_t)1 << 31) || entries >= ((uint64_t)1 << 28)) return fail(EOGS_ERR_OVERFLOW, "num_rendered overflows 31 bits");
+  if (total >= ((uint64_t)1 << 31) || entries >= ((uint64_t)1 << 27)) return fail(EOGS_ERR_OVERFLOW, "num_rendered overflows 31 bits");
   // block_lists_kernel's 8-item build pays when the average block holds 2800 ... 6000 entries (csrc/binning.hip)
   const double per_block = (double)entries / ((double)macro_grid_x(W, BLOCK_BIG) * (double)macro_grid_y(H, BLOCK_BIG));
-  *num_rendered = nr_pack((uint32_t)total, (uint32_t)entries, block, have_scratch && entries <= (uint64_t)sort_cap,
-                          per_block > 2800.0 && per_block <= 6000.0, btf);
+  // (nothing listed: the token is 0, as include/eogs_rast.h says — callers test it whole, every R > 0 shortcut applies)
+  // (... except for an altitude-only forward, whose token must still say so: the render launches pick their variant by it)
+  *num_rendered = (total == 0 && entries == 0 && !alt) ? 0 : nr_pack((uint32_t)total, (uint32_t)entries, block, have_scratch && entries <= (uint64_t)sort_cap,
+                          per_block > 2800.0 && per_block <= 6000.0, btf, alt);
   return EOGS_OK;
 }
 
@@ -297,7 +300,7 @@ int eogs_rast_forward_counts(int64_t* num_rendered) {
   g_pending_counts.valid = false;
   const int P = pc.P, H = pc.H, W = pc.W;
   HIP_TRY(hipStreamSynchronize(pc.side));
-  return token_from_counts(g_pinned, P, H, W, pc.have_scratch, pc.sort_cap, num_rendered);
+  return token_from_counts(g_pinned, P, H, W, pc.have_scratch, pc.sort_cap, num_rendered, pc.alt);
 }
 
 int eogs_rast_read_counts(int P, int H, int W, const void* geom, size_t geom_bytes, int have_scratch, void* stream,
@@ -312,7 +315,7 @@ int eogs_rast_read_counts(int P, int H, int W, const void* geom, size_t geom_byt
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipMemcpyAsync(m, g.misc, MISC_READBACK * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  return token_from_counts(m, P, H, W, have_scratch != 0, ent_cap(P), num_rendered);
+  return token_from_counts(m, P, H, W, (have_scratch & 1) != 0, ent_cap(P), num_rendered, (have_scratch & 2) != 0);
 }
 
 static_assert(MISC_READBACK * sizeof(uint32_t) <= EOGS_MIRROR_BYTES, "mirror buffer");
@@ -341,13 +344,18 @@ int eogs_rast_mirror_token(int P, int H, int W, const void* host, int have_scrat
   if (P <= 0 || H <= 0 || W <= 0 || !host || !num_rendered || !arrived) return fail(EOGS_ERR_INVALID_ARG, "mirror_token: bad argument");
   *arrived = 0;
   const volatile uint32_t* v = (const volatile uint32_t*)host;
-  // the first and the last 64-bit count both there (the copy is 40 bytes inside one 64-byte line)
-  if (v[MISC_TOTAL_HI] == MIRROR_PENDING || v[MISC_OPW_HI] == MIRROR_PENDING || v[MISC_MACRO_HI] == MIRROR_PENDING) return EOGS_OK;
+  // Arrived = EVERY word of the 40-byte copy has replaced its sentinel, so nothing rests on the copy landing as one
+  // transaction. None of them can legitimately hold the sentinel — the high words of counts below 2^31, low words
+  // of counts that would otherwise be refused as overflow, a few error bits, MISC_TAG_VALUE, a positive float's bits — except
+  // MISC_KEY_NMIN (~min depth key = ~0 for a depth of exactly 0.0f), which sits between two checked words of its 16 bytes.
+  for (int i = 0; i < MISC_READBACK; i++)
+    if (i != MISC_KEY_NMIN && v[i] == MIRROR_PENDING) return EOGS_OK;
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
   uint32_t m[MISC_READBACK];
   for (int i = 0; i < MISC_READBACK; i++) m[i] = v[i];
+  if (m[MISC_TAG] != MISC_TAG_VALUE) return fail(EOGS_ERR_INVALID_ARG, "mirror_token: the mirrored words are not a forward's counts");
   *arrived = 1;
-  return token_from_counts(m, P, H, W, have_scratch != 0, ent_cap(P), num_rendered);
+  return token_from_counts(m, P, H, W, (have_scratch & 1) != 0, ent_cap(P), num_rendered, (have_scratch & 2) != 0);
 }
 
 int eogs_rast_capacity_token(int P, int64_t num_rendered, double slack, int have_scratch, int64_t exact, int64_t* capacity,
@@ -356,11 +364,17 @@ int eogs_rast_capacity_token(int P, int64_t num_rendered, double slack, int have
   uint64_t slots = (uint64_t)((double)nr_slots(num_rendered) * (1.0 + slack)) + 4096u;
   uint64_t ents = (uint64_t)((double)nr_entries(num_rendered) * (1.0 + slack)) + 1024u;
   if (slots > 0x7FFFFFFFull) slots = 0x7FFFFFFFull;
-  if (ents > 0x0FFFFFFFull) ents = 0x0FFFFFFFull;
+  if (ents > 0x07FFFFFFull) ents = 0x07FFFFFFull;
   // "sorted in scratch" only if every forward that fits this capacity also fits the scratch (then forward_prepare did sort)
-  const int sorted = have_scratch && ents <= (uint64_t)ent_cap(P);
-  *capacity = nr_pack((uint32_t)slots, (uint32_t)ents, nr_block(num_rendered), sorted, nr_wide(num_rendered), nr_btf(num_rendered));
-  if (fits) *fits = exact > 0 && nr_slots(exact) <= slots && nr_entries(exact) <= ents;
+  const int sorted = (have_scratch & 1) && ents <= (uint64_t)ent_cap(P);
+  const int alt = (have_scratch & 2) != 0 || nr_alt(num_rendered);  // (an altitude-only forward: per-tile lists, never back to front)
+  *capacity = nr_pack((uint32_t)slots, (uint32_t)ents, alt ? 1 : nr_block(num_rendered), sorted, nr_wide(num_rendered),
+                      alt ? 0 : nr_btf(num_rendered), alt);
+  // A capacity token carries the list granularity, the 8-item build and the back-to-front choice of the EARLIER forward. The
+  // first two are speed only. The third is not quite: a forward of image-sized opaque Gaussians needs the back-to-front
+  // backward to hold 1e-4, so a forward that asks for it does not "fit" a token counted on one that did not
+  //  and is redone / recorded again with its own flags; the converse is harmless (that kernel is always right).
+  if (fits) *fits = exact >= 0 && nr_slots(exact) <= slots && nr_entries(exact) <= ents && !(nr_btf(exact) && !nr_btf(num_rendered));
   return EOGS_OK;
 }
 
@@ -372,6 +386,10 @@ int eogs_rast_forward_render(int P, int H, int W, int64_t R, const float* bg, un
   if (P < 0 || H <= 0 || W <= 0 || R < 0 || !out_color || !bg || !image)
     return fail(EOGS_ERR_INVALID_ARG, "forward_render: bad argument");
   if (R > 0 && (P == 0 || !geom || !binning)) return fail(EOGS_ERR_INVALID_ARG, "forward_render: NULL workspace");
+  if (((flags & EOGS_FLAG_ALT_ONLY) != 0) != (nr_alt(R) != 0))
+    return fail(EOGS_ERR_INVALID_ARG, "forward_render: EOGS_FLAG_ALT_ONLY and the token disagree (the flag goes to forward_prepare too; "
+                                      "tokens built without flags take it as have_scratch | 2)");
+  if (nr_alt(R) && (nr_block(R) > 1 || nr_btf(R))) return fail(EOGS_ERR_INVALID_ARG, "forward_render: malformed altitude-only token");
   hipStream_t s = (hipStream_t)stream;
   const bool debug = flags & EOGS_FLAG_DEBUG;
   char* ibase = ws_base(image);
@@ -445,6 +463,10 @@ int eogs_rast_backward_range(int P, int H, int W, int64_t R, const float* bg, co
     return fail(EOGS_ERR_INVALID_ARG, "backward: EOGS_FLAG_RAW_PARAMS needs scales, rotations and alt_affine");
   if (R > 0 && !binning) return fail(EOGS_ERR_INVALID_ARG, "backward: NULL binning workspace");
   if (R > 0 && nr_btf(R) && !bg) return fail(EOGS_ERR_INVALID_ARG, "backward: bg is required (back-to-front backward)");
+  if (R > 0 && nr_alt(R) && dL_dout_invdepth)
+    return fail(EOGS_ERR_INVALID_ARG, "backward: an altitude-only render (EOGS_FLAG_ALT_ONLY) has no inverse-depth output");
+  if (R > 0 && nr_alt(R) && (nr_block(R) > 1 || nr_btf(R)))
+    return fail(EOGS_ERR_INVALID_ARG, "backward: malformed altitude-only token");
   if (dL_dcolors_lead && (lead_cols <= 0 || lead_cols > (raw ? 3 : NCH))) return fail(EOGS_ERR_INVALID_ARG, "backward: bad lead_cols");
 
   char* gb = ws_base(geom);
@@ -469,7 +491,7 @@ int eogs_rast_backward_range(int P, int H, int W, int64_t R, const float* bg, co
                  viewmatrix, projmatrix, radii, scale_modifier, (flags & EOGS_FLAG_ANTIALIASING) != 0,
                  dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, have_sr ? dL_dscales : nullptr,
                  have_sr ? dL_drotations : nullptr, dL_dT_sum, dL_dvm_mean, raw, alt_affine, dL_dcolors_lead,
-                 dL_dcolors_lead ? lead_cols : 0};
+                 dL_dcolors_lead ? lead_cols : 0, nr_alt(R) != 0};
   { ProfScope ps(PS_GAUSS_BWD, s); launch_gaussian_bwd(a, g, b, p_begin, p_end, s); }
   LAUNCH_TRY(s, debug, "gaussian_bwd");
   return EOGS_OK;

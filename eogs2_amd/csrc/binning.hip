@@ -174,6 +174,7 @@ __global__ __launch_bounds__(PS_T) void pblock_scan_kernel(uint32_t* __restrict_
       er |= s_err[i];
     }
     misc[MISC_ERR] = er;  // every word the host or a later kernel reads is written here: the workspace needs no clearing
+    misc[MISC_TAG] = MISC_TAG_VALUE;
     misc[MISC_OPW_LO] = (uint32_t)ow;
     misc[MISC_OPW_HI] = (uint32_t)(ow >> 32);
     misc[MISC_MACRO_LO] = (uint32_t)carry_e;
@@ -639,6 +640,106 @@ __global__ __launch_bounds__(ES_T) void entry_colscan_kernel(uint32_t* __restric
   }
 }
 
+// =====================================================================================================================
+// Tile schedule of the render launches
+// =====================================================================================================================
+// The render kernels run one wave per 8 x 8 tile and the dispatcher deals workgroup b to XCD b % 8. Rounds 1-3 gave every XCD
+// a contiguous band of tile rows: equal tile COUNTS, and with them whatever imbalance the scene has — at the headline scene
+// (nothing in the outer 5 % of the image) the two border XCDs hold 61 % of the others' pairs and idle for the last third of
+// both render launches, and the launches end with full tiles still starting (wave traces: profiles/r04_wave_trace.txt).
+// This body — ONE workgroup of 1024 threads, run as the EXTRA workgroup of the entry sort's scatter launch: it needs what the
+// column scan before that launch left in bpairs, nothing of the scatter, and nobody needs it before block_lists_kernel, so it
+// costs no launch of its own (a dependent one-workgroup launch is 6-9 us here) and no time on the stream — orders the
+// 32 x 32-px blocks for the render launches:
+//   * blocks with fewer than an eighth of the mean pair count are LIGHT (the empty rim of a scene); every XCD's sequence is its
+//     share of the other blocks, then of the light ones: a launch ends on cheap tiles, not on full ones;
+//   * the other blocks, in row-major order, are dealt to the XCDs in UNITS of `unit` consecutive blocks (4: a 128 x 32-px strip),
+//     round-robin: every XCD draws from every region of the image, so its share of the work is right whatever a tile's cost
+//     depends on — a cut into eight contiguous runs of equal PAIRS (the first version) was right at opacity 0.01 and left two XCDs
+//     15 % behind with trained opacities, where the blocks at the rim of the scene blend all they list and the interior ones
+//     stop early; inside a unit neighbouring blocks still share their Gaussians' records in the XCD's L2;
+//   * the light blocks are dealt one by one.
+// Output: sched[x] = blocks in XCD x's sequence, where[b] = XCD << 24 | position of block b. block_lists_kernel then writes the
+// descriptors of its block's 16 tiles (tile, list range) at that place of ImgWS::desc, so a render workgroup finds its tile AND
+// its list with one 16-byte load. Results never depend on the schedule (a tile's wave does the same arithmetic wherever it runs).
+#define SCHED_T 1024
+#define SCHED_ITEMS ((int)SCHED_MAX_BLOCKS / SCHED_T)
+namespace {
+// exclusive prefix over the workgroup of two 32-bit sums per thread; totals returned through `total`. All threads call.
+__device__ inline uint2 sched_scan(uint2 v, uint2* s_w, uint2& total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint2 inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t nx = (uint32_t)__shfl_up((int)inc.x, d, 64), ny = (uint32_t)__shfl_up((int)inc.y, d, 64);
+    if (lane >= d) { inc.x += nx; inc.y += ny; }
+  }
+  __syncthreads();
+  if (lane == 63) s_w[w] = inc;
+  __syncthreads();
+  uint2 base = make_uint2(0u, 0u), tot = make_uint2(0u, 0u);
+#pragma unroll
+  for (int k = 0; k < SCHED_T / 64; k++) {
+    const uint2 c = s_w[k];
+    if (k < w) { base.x += c.x; base.y += c.y; }
+    tot.x += c.x; tot.y += c.y;
+  }
+  total = tot;
+  return make_uint2(base.x + inc.x - v.x, base.y + inc.y - v.y);
+}
+
+__device__ __forceinline__ void tile_sched_body(const uint32_t* __restrict__ bpairs, uint32_t nblocks, uint32_t lg, uint32_t unit,
+                                                uint32_t* __restrict__ sched, uint32_t* __restrict__ where) {
+  __shared__ uint2 s_w[SCHED_T / 64];
+  const int t = threadIdx.x;
+  // thread t holds blocks t * SCHED_ITEMS ... in block (row-major) order; the pair sum fits 32 bits (pairs < 2^31, api.hip)
+  uint32_t wk[SCHED_ITEMS];
+  uint2 v = make_uint2(0u, 0u);
+#pragma unroll
+  for (int i = 0; i < SCHED_ITEMS; i++) {
+    const uint32_t b = (uint32_t)t * SCHED_ITEMS + i;
+    wk[i] = b < nblocks ? bpairs[b] : 0u;
+    v.x += wk[i];
+  }
+  uint2 tot;
+  (void)sched_scan(v, s_w, tot);
+  const unsigned long long total_pairs = tot.x;
+  bool light[SCHED_ITEMS];
+  v = make_uint2(0u, 0u);
+#pragma unroll
+  for (int i = 0; i < SCHED_ITEMS; i++) {
+    const uint32_t b = (uint32_t)t * SCHED_ITEMS + i;
+    light[i] = 8ull * wk[i] * nblocks < total_pairs;  // fewer pairs than an eighth of the mean (compared as products)
+    if (b < nblocks) { if (light[i]) v.y++; else v.x++; }
+  }
+  uint2 run = sched_scan(v, s_w, tot);  // blocks of either kind before this thread's
+  const uint32_t n0 = tot.x, n1 = tot.y, round = 8u * unit;
+  // blocks of the first kind in XCD x's sequence: whole rounds of `unit` each, then what the last round leaves for x
+  auto heavy_in = [&](uint32_t x) {
+    const uint32_t rem = n0 % round;
+    return (n0 / round) * unit + (rem > x * unit ? (rem - x * unit < unit ? rem - x * unit : unit) : 0u);
+  };
+  if (t < 8) sched[t] = heavy_in((uint32_t)t) + n1 / 8u + ((uint32_t)t < n1 % 8u ? 1u : 0u);
+  if (t >= 8 && t < 16) sched[t] = 0u;
+#pragma unroll
+  for (int i = 0; i < SCHED_ITEMS; i++) {
+    const uint32_t b = (uint32_t)t * SCHED_ITEMS + i;
+    if (b >= nblocks) continue;
+    uint32_t x, pos;
+    if (!light[i]) {
+      const uint32_t r = run.x++;
+      x = (r / unit) % 8u;
+      pos = (r / round) * unit + r % unit;
+    } else {
+      const uint32_t r = run.y++;
+      x = r % 8u;
+      pos = heavy_in(x) + r / 8u;
+    }
+    where[b] = (x << 24) | (pos < lg ? pos : lg - 1u);  // (pos < lg by construction: common.h sched_capacity)
+  }
+}
+}  // namespace
+
 // kernel 3: stable scatter. Ranking as in radix_scatter_body (wave-private ballot match, NBITS ballots per 64 entries,
 // 16-bit wave counters: a wave holds 512 entries). The workgroup's entries are then brought into sorted order through an
 // LDS window, ES_WIN entries per round, and written so that consecutive lanes write consecutive addresses inside each
@@ -657,9 +758,16 @@ template <int NBITS, int T_>
 __global__ __launch_bounds__(T_, (NBITS <= 10 && T_ == 1024 ? ES_WAVES : 1)) void entry_scatter_kernel(const uint4* __restrict__ in, uint4* __restrict__ out,
                                                              const uint32_t* __restrict__ misc, uint32_t cap, int shift,
                                                              const uint32_t* __restrict__ hist,
-                                                             const uint32_t* __restrict__ dtotal) {
+                                                             const uint32_t* __restrict__ dtotal,
+                                                             const uint32_t* __restrict__ bpairs, uint32_t sched_blocks,
+                                                             uint32_t sched_lg, uint32_t* __restrict__ sched,
+                                                             uint32_t* __restrict__ where) {
   constexpr int ES_ITEMS_ = ES_TILE / T_, ES_NW_ = T_ / 64;
   constexpr uint32_t nb = 1u << NBITS, mask = nb - 1u;
+  if (T_ == SCHED_T && sched_blocks && blockIdx.x == gridDim.x - 1) {  // the launch's extra workgroup: the tile schedule
+    tile_sched_body(bpairs, sched_blocks, sched_lg & 0xFFFFFFu, sched_lg >> 24, sched, where);
+    return;
+  }
   const uint32_t n = entries_on_device(misc, cap);
   const uint32_t tile0 = blockIdx.x * (uint32_t)ES_TILE;
   if (tile0 >= n) return;
@@ -787,25 +895,40 @@ __global__ __launch_bounds__(BLK) void clear_counts_kernel(uint32_t* __restrict_
   if (i < n) { a[i] = 0u; b[i] = 0u; }
 }
 
+// the tile schedule rides in the scatter launch when that has 1024-thread workgroups (up to 2048 blocks); with 512-thread
+// ones (4096 blocks: 2048^2 images) it is a one-workgroup launch of its own
+struct SchedArgs {
+  const uint32_t* bpairs;
+  uint32_t blocks, lg;  // blocks == 0: no schedule
+  uint32_t* sched;
+  uint32_t* where;
+};
+__global__ __launch_bounds__(SCHED_T) void tile_sched_kernel(const uint32_t* __restrict__ bpairs, uint32_t nblocks, uint32_t lg,
+                                                             uint32_t* __restrict__ sched, uint32_t* __restrict__ where) {
+  tile_sched_body(bpairs, nblocks, lg & 0xFFFFFFu, lg >> 24, sched, where);
+}
 template <int NBITS>
 static void launch_entry_scatter_n(uint32_t nblk, hipStream_t s, const uint4* in, uint4* out, const uint32_t* misc, uint32_t cap,
-                                   int shift, const uint32_t* hist, const uint32_t* dtotal) {
+                                   int shift, const uint32_t* hist, const uint32_t* dtotal, const SchedArgs& sa) {
   constexpr int T_ = NBITS <= 11 ? 1024 : 512;
-  hipLaunchKernelGGL((entry_scatter_kernel<NBITS, T_>), dim3(nblk), dim3(T_), 0, s, in, out, misc, cap, shift, hist, dtotal);
+  const bool ride = sa.blocks != 0u && T_ == SCHED_T;
+  if (sa.blocks != 0u && !ride)
+    hipLaunchKernelGGL(tile_sched_kernel, dim3(1), dim3(SCHED_T), 0, s, sa.bpairs, sa.blocks, sa.lg, sa.sched, sa.where);
+  hipLaunchKernelGGL((entry_scatter_kernel<NBITS, T_>), dim3(nblk + (ride ? 1u : 0u)), dim3(T_), 0, s, in, out, misc, cap, shift,
+                     hist, dtotal, sa.bpairs, ride ? sa.blocks : 0u, sa.lg, sa.sched, sa.where);
 }
 static void launch_entry_scatter(int bits, uint32_t nblk, hipStream_t s, const uint4* in, uint4* out, const uint32_t* misc,
-                                 uint32_t cap, int shift, const uint32_t* hist, const uint32_t* dtotal) {
+                                 uint32_t cap, int shift, const uint32_t* hist, const uint32_t* dtotal, const SchedArgs& sa) {
   switch (bits) {  // the ballot loop of the ranking is unrolled for the digit width
-#define ES_CASE(N) case N: launch_entry_scatter_n<N>(nblk, s, in, out, misc, cap, shift, hist, dtotal); break;
+#define ES_CASE(N) case N: launch_entry_scatter_n<N>(nblk, s, in, out, misc, cap, shift, hist, dtotal, sa); break;
     ES_CASE(1) ES_CASE(2) ES_CASE(3) ES_CASE(4) ES_CASE(5) ES_CASE(6) ES_CASE(7) ES_CASE(8) ES_CASE(9) ES_CASE(10) ES_CASE(11)
-    default: launch_entry_scatter_n<12>(nblk, s, in, out, misc, cap, shift, hist, dtotal); break;
+    default: launch_entry_scatter_n<12>(nblk, s, in, out, misc, cap, shift, hist, dtotal, sa); break;
 #undef ES_CASE
   }
 }
 
 void launch_entry_sort(const GeomWS& g, const SortWS& w, int P, int H, int W, hipStream_t s) {
   const uint32_t gmx = macro_grid_x(W, BLOCK_BIG), nblocks = gmx * macro_grid_y(H, BLOCK_BIG);
-  (void)nblocks;
   hipLaunchKernelGGL(expand_entries_kernel<BLOCK_BIG>, dim3(g.nblkE), dim3(BLK), 0, s, g.binfo, g.bext, g.pblock, g.pblockE,
                      g.misc, w.cap, (uint32_t)P, gmx, w.entA);
   int passes, bits;
@@ -819,7 +942,10 @@ void launch_entry_sort(const GeomWS& g, const SortWS& w, int P, int H, int W, hi
     hipLaunchKernelGGL(entry_hist_kernel, dim3(w.nblk), dim3(ES_T), 0, s, in, g.misc, w.cap, shift, mask, w.hist, histp);
     hipLaunchKernelGGL(entry_colscan_kernel, dim3((mask + 64u) / 64u), dim3(ES_T), 0, s, w.hist, histp, g.misc, w.cap, mask + 1u,
                        passes == 1 ? g.bcount : w.dtotal, g.bpairs);
-    launch_entry_scatter(bits, w.nblk, s, in, out, g.misc, w.cap, shift, w.hist, passes == 1 ? g.bcount : w.dtotal);
+    // (one pass <=> at most SCHED_MAX_BLOCKS blocks) the render launches' tile schedule goes with this launch
+    // (lg travels with the unit size in its top byte: both are launch constants of the schedule)
+    const SchedArgs sa{g.bpairs, (passes == 1 && sched_enabled()) ? nblocks : 0u, sched_capacity(nblocks) | (sched_unit() << 24), g.sched, g.where};
+    launch_entry_scatter(bits, w.nblk, s, in, out, g.misc, w.cap, shift, w.hist, passes == 1 ? g.bcount : w.dtotal, sa);
     const uint4* t = in; in = out; out = const_cast<uint4*>(t);
   }
   if (passes > 1) {
@@ -874,7 +1000,8 @@ __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __res
                                                               uint32_t gsy, uint2* __restrict__ point_list,
                                                               uint32_t* __restrict__ sorted_keys, uint2* __restrict__ ranges,
                                                               uint8_t* __restrict__ live, uint32_t cap_slots,
-                                                              uint32_t cap_entries) {
+                                                              uint32_t cap_entries, const uint32_t* __restrict__ where,
+                                                              uint4* __restrict__ desc, uint32_t lg16) {
   constexpr int BL_CH = BL_T * BL_ITEMS;  // entries per chunk of a pass = longest list the LDS path takes
   __shared__ uint16_t s_wcnt[BL_NW][256];
   __shared__ uint32_t s_base[256], s_cb[256], s_h[256], s_hn[256];
@@ -884,6 +1011,14 @@ __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __res
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const uint32_t b = blockIdx.x;
   const int npass = (int)misc[MISC_DEPTH_PASSES];
+  // The render workgroup that takes internal tile `sub` of this block finds tile and list in ONE 16-byte descriptor at the
+  // block's place in the tile schedule (tile_sched_body): XCD x's sequence starts at desc[x * lg16], 16 descriptors per block.
+  auto put_desc = [&](uint32_t sub, uint32_t tx, uint32_t ty, uint32_t begin, uint32_t end) {
+    if (desc == nullptr) return;
+    const uint32_t wh = where[b];
+    desc[(size_t)(wh >> 24) * lg16 + (size_t)(wh & 0xFFFFFFu) * 16u + sub] =
+        make_uint4((tx < gsx && ty < gsy) ? (tx | (ty << 16)) : 0xFFFFFFFFu, begin, end, 0u);
+  };
   {
     // The workspaces may have been sized before the host knew this forward's counts (EOGS_FLAG_DEFER_COUNTS): a forward
     // that does not fit them (or lists nothing: the entry sort then left the per-block counts alone) gets empty lists —
@@ -892,11 +1027,11 @@ __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __res
     const uint32_t ne = misc[MISC_MACRO_LO];
     const bool fits = misc[MISC_TOTAL_HI] == 0u && misc[MISC_MACRO_HI] == 0u && misc[MISC_TOTAL_LO] <= cap_slots && ne <= cap_entries;
     if (!fits || ne == 0u) {  // (uniform over the grid)
-      if (MODE != 1) {
-        if (t == 0) ranges[b] = make_uint2(0u, 0u);
-      } else if (t < 16) {
+      if (MODE != 1 && t == 0) ranges[b] = make_uint2(0u, 0u);
+      if (t < 16) {
         const uint32_t tx = (b % gmx) * BLOCK_BIG + (uint32_t)(t % BLOCK_BIG), ty = (b / gmx) * BLOCK_BIG + (uint32_t)(t / BLOCK_BIG);
-        if (tx < gsx && ty < gsy) ranges[ty * gsx + tx] = make_uint2(0u, 0u);
+        if (MODE == 1 && tx < gsx && ty < gsy) ranges[ty * gsx + tx] = make_uint2(0u, 0u);
+        put_desc((uint32_t)t, tx, ty, 0u, 0u);
       }
       return;
     }
@@ -916,6 +1051,8 @@ __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __res
     if (MODE == 1) pairs_before = bl_sum(vp, s_red);
   }
   if (MODE != 1 && t == 0) ranges[b] = make_uint2(s0, s0 + n);
+  if (MODE != 1 && t < 16)  // block lists: every tile of the block reads the block's list
+    put_desc((uint32_t)t, (b % gmx) * BLOCK_BIG + (uint32_t)(t % BLOCK_BIG), (b / gmx) * BLOCK_BIG + (uint32_t)(t / BLOCK_BIG), s0, s0 + n);
   if (t < 256) s_h[t] = 0;
   if (t < 16) s_tc[t] = 0;
   __syncthreads();
@@ -1153,6 +1290,7 @@ __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __res
     s_tb[t] = pre;
     const uint32_t tx = (b % gmx) * BLOCK_BIG + (uint32_t)(t % BLOCK_BIG), ty = (b / gmx) * BLOCK_BIG + (uint32_t)(t / BLOCK_BIG);
     if (tx < gsx && ty < gsy) ranges[ty * gsx + tx] = make_uint2(pre, pre + s_tc[t]);
+    put_desc((uint32_t)t, tx, ty, pre, pre + s_tc[t]);
   }
   {
     // live flags of this block's pairs: which records get written depends only on forward state (lists and n_contrib),
@@ -1235,10 +1373,10 @@ void launch_block_lists(const GeomWS& g, const SortWS& w, const BinWS& b, const 
     (void)hipMemsetAsync(b.live, 0, (size_t)nr_slots(R), s);
     auto* kern = wide ? block_lists_kernel<BLOCK_BIG, 8> : block_lists_kernel<BLOCK_BIG, 4>;
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(BL_T), 0, s, ent, ki, g.bcount, g.bpairs, g.misc, gmx, gsx, gsy, b.point_list,
-                       b.sorted_keys, im.ranges, b.live, cap_slots, cap_entries);
+                       b.sorted_keys, im.ranges, b.live, cap_slots, cap_entries, g.where, im.desc, 16u * im.sched_lg);
   } else {
     auto* kern = wide ? block_lists_kernel<1, 8> : block_lists_kernel<1, 4>;
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(BL_T), 0, s, ent, ki, g.bcount, g.bpairs, g.misc, gmx, gsx, gsy, b.point_list,
-                       b.sorted_keys, im.ranges, b.live, cap_slots, cap_entries);
+                       b.sorted_keys, im.ranges, b.live, cap_slots, cap_entries, g.where, im.desc, 16u * im.sched_lg);
   }
 }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 
 #include "eogs_rast.h"
 #include "eogs_loss.h"
@@ -23,6 +24,7 @@
 #define BLK 256                 // threads per workgroup everywhere (4 wave64)
 #define NFEAT 6                 // staged per-Gaussian features: 5 colours + 1/depth
 #ifndef REC
+#define REC_ALT 8               // ... of an altitude-only render: 32 bytes {mean2D.x, .y, conic.a, opacity | conic.b, conic.c, colour3, -}
 #define REC 12                  // floats per (tile,Gaussian) gradient record: 48 bytes, three 16-byte quarters, 11 floats used
 #endif                          //   [0..3]   dL/dmean2D.x, .y (NDC units), dL/dconic.a, dL/dopacity
                                 //   [4..7]   dL/dconic.b, dL/dconic.c, dL/dcolour0, dL/dcolour1
@@ -34,6 +36,9 @@ static_assert(REC == 12, "record quarters");
 #define MISC_TOTAL_LO 0  // sum of tiles_touched (u64, lo/hi)
 #define MISC_TOTAL_HI 1
 #define MISC_ERR 2       // bit0: altitude > 200
+#define MISC_TAG 3       // a constant the count scan writes with the counts (MISC_TAG_VALUE): lets a host that watches a
+                         // mirrored copy arrive (eogs_rast_mirror_token) see that the FIRST 16 bytes are there as a whole
+#define MISC_TAG_VALUE 0x0C0FFEE0u
 #define MISC_KEY_MAX 4   // max depth key over listed Gaussians
 #define MISC_KEY_NMIN 5  // max of ~key = ~min depth key (zero-initialised like the rest of misc)
 #define MISC_MACRO_LO 6  // number of (macro block, Gaussian) list entries (u64, lo/hi)
@@ -43,6 +48,30 @@ static_assert(REC == 12, "record quarters");
 #define MISC_READBACK 10 // words copied to the host by forward_prepare
 #define MISC_DEPTH_PASSES 10  // 8-bit digits that cover the varying bits of the listed Gaussians' depth keys (0..4)
 #define MISC_WORDS 64
+
+// Tile schedule of the render launches (binning.hip tile_sched_body). It is computed by one workgroup that
+// holds every block's pair count: images up to 4096 blocks of 32 x 32 px (2048^2); larger ones keep the band mapping.
+#define SCHED_MAX_BLOCKS 4096u
+// Blocks are dealt to the XCDs in units of SCHED_UNIT consecutive blocks (EOGS_SCHED_UNIT=1..32 overrides: tuning aid); an
+// XCD's sequence holds at most ceil(heavy / (8 unit)) unit + ceil(light / 8) <= nblocks / 8 + unit + 1 blocks.
+#define SCHED_UNIT 4u
+static inline uint32_t sched_unit() {
+  static const uint32_t v = [] {
+    const char* e = getenv("EOGS_SCHED_UNIT");
+    const long u = e ? atol(e) : (long)SCHED_UNIT;
+    return (uint32_t)(u < 1 ? 1 : (u > 32 ? 32 : u));
+  }();
+  return v;
+}
+static inline uint32_t sched_capacity(uint32_t nblocks) { return nblocks / 8u + sched_unit() + 2u; }
+// EOGS_TILE_SCHED=0 switches the schedule off (A/B: the XCD band mapping of rounds 1-3)
+static inline bool sched_enabled() {
+  static const bool v = [] {
+    const char* e = getenv("EOGS_TILE_SCHED");
+    return !(e && e[0] == '0');
+  }();
+  return v;
+}
 
 // ---- radix sort geometry ----
 #define SORTP_ITEMS 8    // generic u32 key + u32 payload sort (knn.hip's Morton order): 2048 keys per workgroup
@@ -222,6 +251,8 @@ struct GeomWS {
   uint32_t* bcount;     // [MAX_BLOCKS] per 32 x 32-px block: list entries (their sum over the blocks before b = where
                         // block b's entries start in the block-sorted entry array)
   uint32_t* bpairs;     // [MAX_BLOCKS] per block: listed (internal tile, Gaussian) pairs
+  uint32_t* sched;      // [16] tile schedule of the render launches (binning.hip tile_sched_body): [0..8) blocks in XCD x's sequence
+  uint32_t* where;      // [SCHED_MAX_BLOCKS] block b's place in that schedule: XCD << 24 | position in the XCD's sequence
   uint32_t* misc;       // MISC_WORDS
   float* vmpart;        // backward: per-workgroup partials of the 18 camera-gradient sums [ceil(P/256)][18]
   uint32_t nblkE;
@@ -240,6 +271,8 @@ static inline GeomWS geom_layout(char* base, int P) {
   o = ws_carve(base, o, g.pbkey, (size_t)g.nblkE * 4);
   o = ws_carve(base, o, g.bcount, (size_t)MAX_BLOCKS);
   o = ws_carve(base, o, g.bpairs, (size_t)MAX_BLOCKS);
+  o = ws_carve(base, o, g.sched, (size_t)16);
+  o = ws_carve(base, o, g.where, (size_t)SCHED_MAX_BLOCKS);
   o = ws_carve(base, o, g.misc, MISC_WORDS);
   o = ws_carve(base, o, g.vmpart, (size_t)g.nblkE * 18);
   g.bytes = ws_align(o) + 256;  // slack so a base that is only 1-aligned still fits after rounding
@@ -262,7 +295,7 @@ struct SortWS {
 };
 static inline uint32_t ent_cap(int P) {
   const uint64_t c = 6ull * (uint64_t)(P < 0 ? 0 : P);
-  return c < 4096ull ? 4096u : (c > 0x0FFFFFFFull ? 0x0FFFFFFFu : (uint32_t)c);
+  return c < 4096ull ? 4096u : (c > 0x07FFFFFFull ? 0x07FFFFFFu : (uint32_t)c);
 }
 static inline SortWS sort_layout(char* base, uint32_t cap) {
   SortWS w;
@@ -298,21 +331,23 @@ static inline int ceil_log2_u32(uint32_t n) {  // smallest b with (1<<b) >= n
 }
 
 // num_rendered as handed across the C-ABI packs what a forward decided: the record slots (one per listed internal tile,
-// backward scratch) in bits 0..30, the list entries (one per listed 32 x 32-px block) in bits 32..60, bit 61 = the
+// backward scratch) in bits 0..30, the list entries (one per listed 32 x 32-px block) in bits 32..58, bit 59 = an altitude-only
+// forward (EOGS_FLAG_ALT_ONLY: per-tile lists, the quad kernels' one-channel variants, 32-byte gradient records), bit 61 = the
 // entries were sorted in the caller's scratch by forward_prepare, bit 62 = the render kernels read block lists
 // (BLOCK_BIG) instead of per-tile lists, bit 31 = a block holds 2800 ... 6000 entries on average (block_lists_kernel's
 // 8-item build; a property of the forward the token was counted on, carried over into capacity tokens), bit 60 = the
 // Gaussians list a tenth of the image's tiles each on average: per-tile lists and the back-to-front backward
 // (render_bwd_btf_kernel).
 static inline uint32_t nr_slots(int64_t R) { return (uint32_t)((uint64_t)R & 0x7FFFFFFFull); }
-static inline uint32_t nr_entries(int64_t R) { return (uint32_t)(((uint64_t)R >> 32) & 0x0FFFFFFFull); }
+static inline uint32_t nr_entries(int64_t R) { return (uint32_t)(((uint64_t)R >> 32) & 0x07FFFFFFull); }
+static inline int nr_alt(int64_t R) { return (int)(((uint64_t)R >> 59) & 1ull); }  // altitude-only forward (EOGS_FLAG_ALT_ONLY)
 static inline int nr_btf(int64_t R) { return (int)(((uint64_t)R >> 60) & 1ull); }
 static inline int nr_sorted(int64_t R) { return (int)(((uint64_t)R >> 61) & 1ull); }
 static inline int nr_block(int64_t R) { return (((uint64_t)R >> 62) & 1ull) ? BLOCK_BIG : 1; }
 static inline int nr_wide(int64_t R) { return (int)(((uint64_t)R >> 31) & 1ull); }
-static inline int64_t nr_pack(uint32_t slots, uint32_t entries, int block, int sorted, int wide, int btf) {
+static inline int64_t nr_pack(uint32_t slots, uint32_t entries, int block, int sorted, int wide, int btf, int alt = 0) {
   return (int64_t)(((uint64_t)(block > 1) << 62) | ((uint64_t)(sorted != 0) << 61) | ((uint64_t)(btf != 0) << 60) |
-                   ((uint64_t)entries << 32) | ((uint64_t)(wide != 0) << 31) | slots);
+                   ((uint64_t)(alt != 0) << 59) | ((uint64_t)(entries & 0x07FFFFFFu) << 32) | ((uint64_t)(wide != 0) << 31) | slots);
 }
 static inline uint32_t macro_grid_x(int W, int M) { return (uint32_t)(((W + SUBX - 1) / SUBX + M - 1) / M); }
 static inline uint32_t macro_grid_y(int H, int M) { return (uint32_t)(((H + SUBY - 1) / SUBY + M - 1) / M); }
@@ -351,6 +386,10 @@ struct ImgWS {
   uint2* ranges;       // per block (M x M internal tiles, M chosen per forward) [start,end) into point_list
   float* final_T;      // transmittance after the last blended Gaussian
   uint32_t* n_contrib; // 1 + list index of the last blended Gaussian
+  uint4* desc;         // one descriptor per dispatched render workgroup (nullptr without a tile schedule): XCD x's i-th workgroup
+                       // reads desc[x * 16 sched_lg + i] = {tile tx | ty << 16 (0xFFFFFFFF: outside the image), list begin, list end, -},
+                       // written by block_lists_kernel at its block's place in the schedule (GeomWS::where)
+  uint32_t sched_lg;   // capacity of one XCD's sequence in blocks: the render grid is 8 x 16 x sched_lg workgroups
   size_t bytes;
 };
 
@@ -358,9 +397,16 @@ static inline ImgWS img_layout(char* base, int H, int W) {
   ImgWS im;
   size_t n = (size_t)H * W, o = 0;
   size_t T = (size_t)macro_grid_x(W, 1) * macro_grid_y(H, 1);  // enough for either block size
+  const uint32_t nblocks = macro_grid_x(W, BLOCK_BIG) * macro_grid_y(H, BLOCK_BIG);
   o = ws_carve(base, o, im.ranges, T);
   o = ws_carve(base, o, im.final_T, n);
   o = ws_carve(base, o, im.n_contrib, n);
+  im.desc = nullptr;
+  im.sched_lg = 0;
+  if (nblocks <= SCHED_MAX_BLOCKS && sched_enabled()) {
+    im.sched_lg = sched_capacity(nblocks);
+    o = ws_carve(base, o, im.desc, (size_t)8 * 16 * im.sched_lg);
+  }
   im.bytes = ws_align(o) + 256;
   return im;
 }
@@ -417,6 +463,7 @@ struct GaussBwdArgs {
   const float* alt_affine;
   float* dL_dcolors_lead;  // second destination of the colour gradient's first lead_cols columns (or NULL)
   int lead_cols;
+  bool alt_only;           // the records are those of an altitude-only render (REC_ALT)
 };
 // per-Gaussian backward over rows [p_begin, p_end) (p_begin a multiple of BLK); the camera sums are finished by the call
 // whose p_end == P

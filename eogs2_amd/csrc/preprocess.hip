@@ -380,7 +380,11 @@ void launch_preprocess_fwd(const FwdPrepArgs& a, const GeomWS& g, hipStream_t s)
 // ------------------------------------------------------------------------------------------------------
 // Backward, per Gaussian.
 // ------------------------------------------------------------------------------------------------------
-template <bool RAW>
+#ifndef GB_DIRECT
+#define GB_DIRECT 4u  // listed tiles up to which a Gaussian's flags and records are read in one trip (see the kernel)
+#endif
+// ALT: the records of an altitude-only render (32 bytes, common.h REC_ALT): only colour 3 has a gradient.
+template <bool RAW, bool ALT>
 __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
     int P, int H, int W,
     const float* __restrict__ means3D, const float* __restrict__ scales, const float* __restrict__ rotations,
@@ -420,17 +424,61 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
     float acc[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) acc[k] = 0.f;
-    const bool visible = radii[idx] > 0;
+    // Round 4: everything that does not depend on another load is requested up front (the kernel waited 45 % of its wave
+    // time, profiles/r03_v30: radii -> binfo -> flags -> records -> rotation / opacity was a chain of five dependent round
+    // trips per workgroup): radii, the binning record, the workgroup's first slot and the per-Gaussian inputs of the math
+    // below are independent loads in flight together; a Gaussian with at most GB_DIRECT listed tiles (the usual case: four)
+    // then reads its flags AND its records in ONE trip — a dead pair's record is read and discarded: never-written memory,
+    // but only ever selected away — and only longer lists take the two-trip form (flags, then the live records alone).
+    const int radius_in = radii[idx];
+    const uint4 bi1 = binfo[2 * idx + 1];
+    const uint32_t pb = pblock[blk];
+    float4 rot_in = make_float4(1.f, 0.f, 0.f, 0.f);
+    float op_raw = 0.f;
+    if (!cov3D_precomp) rot_in = reinterpret_cast<const float4*>(rotations)[idx];
+    if (RAW || antialiasing) op_raw = opacities[idx];
+    const bool visible = radius_in > 0;
     if (visible) {
       // fixed-order sum of this Gaussian's (tile,Gaussian) records: deterministic, no atomics
-      const uint4 bi1 = binfo[2 * idx + 1];
       const uint32_t n = fits ? bi1.x : 0u;
-      const size_t s0 = (size_t)pblock[blk] + bi1.y;  // Gaussian-id order: a wave reads one contiguous region
-      const float4* r4 = reinterpret_cast<const float4*>(records + s0 * REC);
+      const size_t s0 = (size_t)pb + bi1.y;  // Gaussian-id order: a wave reads one contiguous region
+      constexpr int RS = ALT ? REC_ALT : REC;  // floats per record
+      const float4* r4 = reinterpret_cast<const float4*>(records + s0 * RS);
+      uint32_t q_first = 0;
+      if (n <= GB_DIRECT) {
+        float4 ra[GB_DIRECT], rb[GB_DIRECT];
+        float3 rc[GB_DIRECT];
+        bool lv[GB_DIRECT];
+#pragma unroll
+        for (uint32_t u = 0; u < GB_DIRECT; u++) {
+          const uint32_t qq = u < n ? u : 0u;  // (n == 0: slot s0 itself may lie past the arrays — never dereferenced)
+          lv[u] = false;
+          if (u < n) {
+            lv[u] = live[s0 + qq] != 0;
+            ra[u] = r4[(RS / 4) * qq];
+            rb[u] = r4[(RS / 4) * qq + 1];
+            if (!ALT) rc[u] = reinterpret_cast<const float3*>(r4 + (RS / 4) * qq + 2)[0];
+          }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < GB_DIRECT; u++) {
+          if (lv[u]) {
+            acc[0] += ra[u].x; acc[1] += ra[u].y; acc[2] += ra[u].z; acc[5] += ra[u].w;
+            acc[3] += rb[u].x; acc[4] += rb[u].y;
+            if (ALT) {
+              acc[9] += rb[u].z;
+            } else {
+              acc[6] += rb[u].z; acc[7] += rb[u].w;
+              acc[8] += rc[u].x; acc[9] += rc[u].y; acc[10] += rc[u].z;
+            }
+          }
+        }
+        q_first = n;  // done
+      }
       // Two memory round trips instead of 2n dependent ones: first all live flags of this Gaussian (independent byte
       // loads -> a register bitmask), then the live records (independent loads driven by the mask). Dead pairs
       // (behind every pixel's last contributor) were never written and are never read.
-      for (uint32_t q0 = 0; q0 < n; q0 += 32) {
+      for (uint32_t q0 = q_first; q0 < n; q0 += 32) {
         const uint32_t m_n = n - q0 < 32u ? n - q0 : 32u;
         uint32_t m = 0;
 #pragma unroll 4
@@ -449,16 +497,21 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             const uint32_t qq = have[u] ? q[u] : q[0];  // a valid address either way
-            ra[u] = r4[(REC / 4) * qq];
-            rb[u] = r4[(REC / 4) * qq + 1];
-            rc[u] = reinterpret_cast<const float3*>(r4 + (REC / 4) * qq + 2)[0];
+            ra[u] = r4[(RS / 4) * qq];
+            rb[u] = r4[(RS / 4) * qq + 1];
+            if (!ALT) rc[u] = reinterpret_cast<const float3*>(r4 + (RS / 4) * qq + 2)[0];
           }
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             if (have[u]) {  // record (common.h REC) -> acc: 0,1 mean2D  2,3,4 conic  5 opacity  6..10 colour
               acc[0] += ra[u].x; acc[1] += ra[u].y; acc[2] += ra[u].z; acc[5] += ra[u].w;
-              acc[3] += rb[u].x; acc[4] += rb[u].y; acc[6] += rb[u].z; acc[7] += rb[u].w;
-              acc[8] += rc[u].x; acc[9] += rc[u].y; acc[10] += rc[u].z;
+              acc[3] += rb[u].x; acc[4] += rb[u].y;
+              if (ALT) {
+                acc[9] += rb[u].z;
+              } else {
+                acc[6] += rb[u].z; acc[7] += rb[u].w;
+                acc[8] += rc[u].x; acc[9] += rc[u].y; acc[10] += rc[u].z;
+              }
             }
           }
         }
@@ -478,13 +531,13 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
       float q[4] = {1.f, 0.f, 0.f, 0.f};
       float s3[3] = {0.f, 0.f, 0.f};
       float q_inv = 1.f, op_in = 0.f;
-      if (RAW || antialiasing) op_in = RAW ? sigmoidf(opacities[idx]) : opacities[idx];
+      if (RAW || antialiasing) op_in = RAW ? sigmoidf(op_raw) : op_raw;
       if (cov3D_precomp) {
         const float2* c2 = reinterpret_cast<const float2*>(cov3D_precomp + 6 * idx);
         float2 a = c2[0], b = c2[1], c = c2[2];
         c6[0] = a.x; c6[1] = a.y; c6[2] = b.x; c6[3] = b.y; c6[4] = c.x; c6[5] = c.y;
       } else {
-        const float4 qq = reinterpret_cast<const float4*>(rotations)[idx];
+        const float4 qq = rot_in;
         q[0] = qq.x; q[1] = qq.y; q[2] = qq.z; q[3] = qq.w;
         s3[0] = s_s[3 * t]; s3[1] = s_s[3 * t + 1]; s3[2] = s_s[3 * t + 2];
         if (RAW) q_inv = raw_activate(s3, q);
@@ -684,7 +737,8 @@ void launch_gaussian_bwd(const GaussBwdArgs& a, const GeomWS& g, const BinWS& b,
   const uint32_t nblk_all = ceil_div_u32((uint64_t)a.P, BLK);
   const uint32_t blk0 = (uint32_t)p_begin / BLK, nblk = ceil_div_u32((uint64_t)(p_end - p_begin), BLK);
   const bool want_T = a.dL_dT_sum != nullptr, want_vm = a.dL_dvm_mean != nullptr;
-  auto* kern = a.raw ? gaussian_bwd_kernel<true> : gaussian_bwd_kernel<false>;
+  auto* kern = a.raw ? gaussian_bwd_kernel<true, false> : gaussian_bwd_kernel<false, false>;
+  if (a.alt_only) kern = a.raw ? gaussian_bwd_kernel<true, true> : gaussian_bwd_kernel<false, true>;
   if (nblk)
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(BLK), 0, s, a.P, a.H, a.W, a.means3D, a.scales, a.rotations,
                        a.cov3D_precomp, a.opacities, a.viewmatrix, a.projmatrix, a.alt_affine, a.radii, a.scale_modifier,

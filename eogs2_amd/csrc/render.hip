@@ -81,14 +81,49 @@ __device__ inline void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// XCD-aware tile of this wave: workgroup b runs on XCD b % 8 (round-robin dispatch; speed only, never
-// correctness), so XCD x gets the contiguous run of tile groups [x*per, (x+1)*per). gridDim.x is a multiple of 8.
-__device__ inline int tile_of_wave() {
+// XCD-aware tile of this wave: workgroup b runs on XCD b % 8 (round-robin dispatch; speed only, never correctness).
+//   * with a tile schedule (binning.hip tile_sched_body): XCD x walks ITS sequence of 32 x 32-px blocks, which
+//     the schedule cut so that the eight sequences hold equal WORK (listed pairs), long blocks first and the near-empty ones
+//     last; the 16 tiles of a block are 16 consecutive workgroups of its XCD. The workgroup's descriptor — written by
+//     block_lists_kernel at the block's place in the schedule — holds the tile AND its list range: one 16-byte load where
+//     rounds 1-3 computed the tile and loaded ranges[tile]. Workgroups past an XCD's count, or on tiles outside the image, leave.
+//   * without one (images beyond 4096 blocks, or a forward that lists nothing): XCD x gets the contiguous run of tile groups
+//     [x*per, (x+1)*per); gridDim.x is a multiple of 8; `range` is left for the caller to load.
+__device__ inline int tile_of_wave(const uint4* __restrict__ desc, const uint32_t* __restrict__ sched, int lg16, int gsx, uint2& range) {
+  if (RBLK == 64 && desc != nullptr) {
+    const uint32_t x = blockIdx.x & 7u, i = blockIdx.x >> 3;
+    const uint32_t cnt = sched[x];                          // (independent loads: one round trip)
+    const uint4 d = desc[(size_t)x * (uint32_t)lg16 + i];
+    if ((i >> 4) >= cnt || d.x == 0xFFFFFFFFu) return 0x7FFFFFFF;
+    range = make_uint2(d.y, d.z);
+    return (int)(d.x >> 16) * gsx + (int)(d.x & 0xFFFFu);
+  }
   const int per = gridDim.x >> 3;
   const int grp = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   // the wave index is uniform across the wave: tell the compiler, so tile, list range and loop control live in SGPRs
   return grp * (RBLK / 64) + (RBLK == 64 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)));
 }
+
+// -DEOGS_WAVE_TRACE: per tile {start, end} of its wave on the constant-rate clock, the shader-clock ticks between them, and where
+// it ran (HW_ID, XCC_ID): tools/wave_trace.py turns them into resident waves over time, per-XCD work and finish times, slot
+// idle gaps, ramp and tail. Diagnostics only (profiles/r04_wave_trace.txt).
+#ifdef EOGS_WAVE_TRACE
+#define WTRACE_TILES 65536
+__device__ unsigned long long g_wave_trace[2][WTRACE_TILES][4];
+#define WTRACE_BEGIN const unsigned long long wt_r0 = __builtin_amdgcn_s_memrealtime(), wt_c0 = __builtin_amdgcn_s_memtime()
+#define WTRACE_END(dir, tile)                                                                                                \
+  do {                                                                                                                         \
+    if ((threadIdx.x & 63) == 0 && (tile) < WTRACE_TILES) {                                                                    \
+      g_wave_trace[dir][tile][0] = wt_r0;                                                                                      \
+      g_wave_trace[dir][tile][1] = __builtin_amdgcn_s_memrealtime();                                                           \
+      g_wave_trace[dir][tile][2] = __builtin_amdgcn_s_memtime() - wt_c0;                                                       \
+      g_wave_trace[dir][tile][3] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32); \
+    }                                                                                                                          \
+  } while (0)
+#else
+#define WTRACE_BEGIN
+#define WTRACE_END(dir, tile)
+#endif
 
 // One list entry as gathered by a lane: the Gaussian's 64-byte render record written by preprocess_fwd_kernel
 // (conic pre-scaled by log2 e: alpha = o 2^p, p = (A dx - B dy) dx + C dy^2).
@@ -174,13 +209,14 @@ __device__ inline Ent fetch(const float* slab, int j) {
 
 template <int MACRO>
 __global__ __launch_bounds__(RBLK) void render_fwd_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx,
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx, const uint4* __restrict__ desc, const uint32_t* __restrict__ sched, int lg16,
     const float4* __restrict__ packed, const float* __restrict__ bg,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
     float* __restrict__ out_invdepth) {
   __shared__ __attribute__((aligned(16))) float s_slab[RBLK / 64][FWD_CAP * ENT];
   const int lane = threadIdx.x & 63;
-  const int tile = tile_of_wave();
+  uint2 range = make_uint2(0u, 0u);
+  const int tile = tile_of_wave(desc, sched, lg16, gsx, range);
   if (tile >= ntiles) return;  // wave-uniform; waves never synchronise with each other
   float* slab = s_slab[RBLK == 64 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
   const int px = (tile % gsx) * SUBX + (lane & 7), py = (tile / gsx) * SUBY + (lane >> 3);
@@ -188,7 +224,7 @@ __global__ __launch_bounds__(RBLK) void render_fwd_kernel(
   const uint32_t pix_id = (uint32_t)py * (uint32_t)W + (uint32_t)px;
   const float pxf = (float)px, pyf = (float)py;
   const int ftx = tile % gsx, fty = tile / gsx;
-  const uint2 range = ranges[(fty / MACRO) * gmx + ftx / MACRO];  // the macro block's list
+  if (desc == nullptr) range = ranges[(fty / MACRO) * gmx + ftx / MACRO];  // the macro block's list
   const uint32_t sub = (uint32_t)((fty % MACRO) * MACRO + ftx % MACRO);
 
   float T = 1.0f;
@@ -324,9 +360,11 @@ __device__ inline void quad_append(uint32_t* sidx, int lane, bool hit, int pos, 
 
 }  // namespace
 
-template <int MACRO>
+// ALT: an altitude-only render (EOGS_FLAG_ALT_ONLY): only feature channel 3 is blended and stored — out_color is ONE plane
+// f32[H, W], out_invdepth is not written — and a trip reads 28 of the entry's 48 bytes.
+template <int MACRO, bool ALT>
 __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_FW, EOGS_FW))) void render_fwd_quad_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx,
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx, const uint4* __restrict__ desc, const uint32_t* __restrict__ sched, int lg16,
     const float4* __restrict__ packed, const float* __restrict__ bg,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
     float* __restrict__ out_invdepth) {
@@ -336,8 +374,10 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_FW, E
   __shared__ __attribute__((aligned(16))) float s_slab[RBLK / 64][(FQ_CAP + 1) * ENT];
   __shared__ __attribute__((aligned(16))) uint32_t s_idx[RBLK / 64][4 * QCAP];
   const int lane = threadIdx.x & 63;
-  const int tile = tile_of_wave();
+  uint2 range = make_uint2(0u, 0u);
+  const int tile = tile_of_wave(desc, sched, lg16, gsx, range);
   if (tile >= ntiles) return;  // wave-uniform; waves never synchronise with each other
+  WTRACE_BEGIN;
   const int w = RBLK == 64 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   float* slab = s_slab[w];
   uint32_t* sidx = s_idx[w];
@@ -350,7 +390,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_FW, E
   const uint32_t pix_id = (uint32_t)py * (uint32_t)W + (uint32_t)px;
   const float pxf = (float)px, pyf = (float)py;
   const float bx0 = (float)tx0, by0 = (float)ty0;
-  const uint2 range = ranges[tile];
+  if (desc == nullptr) range = ranges[tile];
   const int myq = lane >> 4;
   const uint32_t* myidx = sidx + myq * QCAP;
   // stale elements are read (never used) by the pipelined loop: make them valid slab offsets
@@ -394,7 +434,14 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_FW, E
     auto fetch_off = [&](uint32_t off) {
       const float4* e4 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(slab) + off);
       Ent e;
-      e.q0 = e4[0]; e.q1 = e4[1]; e.q2 = e4[2];
+      e.q0 = e4[0];
+      if (ALT) {  // C, opacity and the altitude feature: 12 of the other 32 bytes
+        const float2 co = *reinterpret_cast<const float2*>(e4 + 1);
+        e.q1 = make_float4(co.x, co.y, 0.f, 0.f);
+        e.q2 = make_float4(0.f, reinterpret_cast<const float*>(e4 + 2)[1], 0.f, 0.f);
+      } else {
+        e.q1 = e4[1]; e.q2 = e4[2];
+      }
       return e;
     };
     auto blend = [&](const Ent& e, uint32_t off) {
@@ -407,9 +454,13 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_FW, E
       done = done || stop;    // this Gaussian is NOT blended; the pixel is finished
       valid = valid != stop;  // (stop implies valid: one mask xor instead of a second compare)
       const float wgt = valid ? alpha * T : 0.f;
-      C[0] += e.q1.z * wgt; C[1] += e.q1.w * wgt;
-      C[2] += e.q2.x * wgt; C[3] += e.q2.y * wgt; C[4] += e.q2.z * wgt;
-      invd += e.q2.w * wgt;
+      if (ALT) {
+        C[3] += e.q2.y * wgt;
+      } else {
+        C[0] += e.q1.z * wgt; C[1] += e.q1.w * wgt;
+        C[2] += e.q2.x * wgt; C[3] += e.q2.y * wgt; C[4] += e.q2.z * wgt;
+        invd += e.q2.w * wgt;
+      }
       T = valid ? test_T : T;
       last_off = valid ? off : last_off;
     };
@@ -455,10 +506,15 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_FW, E
     const size_t HW = (size_t)H * W;
     final_T[pix_id] = T;
     n_contrib[pix_id] = last_contributor;
+    if (ALT) {
+      out_color[pix_id] = C[3] + T * bg[3];
+    } else {
 #pragma unroll
-    for (int ch = 0; ch < NCH; ch++) out_color[ch * HW + pix_id] = C[ch] + T * bg[ch];
-    if (out_invdepth) out_invdepth[pix_id] = invd;
+      for (int ch = 0; ch < NCH; ch++) out_color[ch * HW + pix_id] = C[ch] + T * bg[ch];
+      if (out_invdepth) out_invdepth[pix_id] = invd;
+    }
   }
+  WTRACE_END(0, tile);
 }
 
 // Quad sub-lists: the trip count falls to the longest sub-list (0.6 of the tile's list at four listed tiles per Gaussian)
@@ -475,12 +531,17 @@ static double quad_switch() {
   return v;
 }
 
-static inline uint32_t render_grid(int ntiles) {
+// grid of a render launch: with a tile schedule 8 XCD sequences x lg blocks x 16 tiles, else the tiles rounded up to a multiple of 8
+// (a forward that lists nothing has built no descriptors: launch_block_lists returned before its kernel)
+static inline const uint4* render_desc(const ImgWS& im, int64_t R) { return (RBLK == 64 && nr_entries(R) > 0) ? im.desc : nullptr; }
+static inline uint32_t render_grid(int ntiles, const ImgWS& im, int64_t R) {
+  if (render_desc(im, R)) return 8u * 16u * im.sched_lg;
   const uint32_t groups = ceil_div_u32((uint64_t)ntiles, RBLK / 64);
   return ((groups + 7u) / 8u) * 8u;  // multiple of 8 for the XCD band mapping
 }
 
 int render_fwd_variant(int block, int64_t R, int P) {
+  if (nr_alt(R)) return 2;  // altitude-only: the quad kernel's one-channel variant (the token carries per-tile lists)
   if (block > 1) return 1;
   return (quad_switch() > 0.0 && (double)nr_slots(R) <= quad_switch() * (double)P) ? 2 : 0;
 }
@@ -489,9 +550,10 @@ void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, 
                        const float* bg, float* out_color, float* out_invdepth, hipStream_t s) {
   const int gsx = (W + SUBX - 1) / SUBX, gsy = (H + SUBY - 1) / SUBY, ntiles = gsx * gsy;
   const int variant = render_fwd_variant(b.block, R, P);
-  auto* kern = variant == 1 ? render_fwd_kernel<BLOCK_BIG> : (variant == 2 ? render_fwd_quad_kernel<1> : render_fwd_kernel<1>);
-  hipLaunchKernelGGL(kern, dim3(render_grid(ntiles)), dim3(RBLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H, gsx,
-                     ntiles, (int)macro_grid_x(W, b.block), g.packed, bg, im.final_T, im.n_contrib, out_color, out_invdepth);
+  auto* kern = variant == 1 ? render_fwd_kernel<BLOCK_BIG> : (variant == 2 ? (nr_alt(R) ? render_fwd_quad_kernel<1, true> : render_fwd_quad_kernel<1, false>) : render_fwd_kernel<1>);
+  hipLaunchKernelGGL(kern, dim3(render_grid(ntiles, im, R)), dim3(RBLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H, gsx,
+                     ntiles, (int)macro_grid_x(W, b.block), render_desc(im, R), g.sched, (int)(16u * im.sched_lg), g.packed, bg, im.final_T, im.n_contrib,
+                     out_color, out_invdepth);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -520,6 +582,16 @@ namespace {
                "v_add_f32_dpp %10, %10, %10 " CTRL                                                                \
                : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), \
                  "+v"(c[8]), "+v"(c[9]), "+v"(c[10]))
+#define DPP_STEP7(CTRL)                                                                                          \
+  asm volatile("s_nop 1\n\t"                                                                                     \
+               "v_add_f32_dpp %0, %0, %0 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %1, %1, %1 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %2, %2, %2 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %3, %3, %3 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %4, %4, %4 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %5, %5, %5 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %6, %6, %6 " CTRL                                                                   \
+               : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]))
 __device__ inline void group8_sum11(float (&c)[11]) {
   DPP_STEP11("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1");
   DPP_STEP11("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1");
@@ -583,7 +655,7 @@ __device__ inline void transpose_round(int nsurv, int lane, const float* rb, con
 // renderer.py:101 never consumes invdepths; here the common case compiles the term away).
 template <int MACRO, bool HAVE_INV>
 __global__ __launch_bounds__(RBLK) void render_bwd_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx,
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx, const uint4* __restrict__ desc, const uint32_t* __restrict__ sched, int lg16,
     const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ out_color, const float* __restrict__ out_invdepth, const float* __restrict__ dL_dpix,
     const float* __restrict__ dL_dinv, float* __restrict__ records, uint8_t* __restrict__ live_flag) {
@@ -594,7 +666,8 @@ __global__ __launch_bounds__(RBLK) void render_bwd_kernel(
   __shared__ __attribute__((aligned(16))) float s_pix[RBLK / 64][64 * 8 + 32];
   __shared__ uint32_t s_slot[RBLK / 64][64];
   const int lane = threadIdx.x & 63;
-  const int tile = tile_of_wave();
+  uint2 range = make_uint2(0u, 0u);
+  const int tile = tile_of_wave(desc, sched, lg16, gsx, range);
   if (tile >= ntiles) return;
   const int w = RBLK == 64 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   float* slab = s_slab[w];
@@ -609,7 +682,7 @@ __global__ __launch_bounds__(RBLK) void render_bwd_kernel(
   const uint32_t pix_id = (uint32_t)py * (uint32_t)W + (uint32_t)px;
   const float pxf = (float)px, pyf = (float)py;
   const int ftx = tile % gsx, fty = tile / gsx;
-  const uint2 range = ranges[(fty / MACRO) * gmx + ftx / MACRO];  // the macro block's list
+  if (desc == nullptr) range = ranges[(fty / MACRO) * gmx + ftx / MACRO];  // the macro block's list
   const uint32_t sub = (uint32_t)((fty % MACRO) * MACRO + ftx % MACRO);
   const size_t HW = (size_t)H * W;
   constexpr bool have_inv = HAVE_INV;
@@ -740,6 +813,7 @@ __global__ __launch_bounds__(RBLK) void render_bwd_kernel(
 template <bool HAVE_INV>
 __global__ __launch_bounds__(RBLK) void render_bwd_btf_kernel(
     const uint2* __restrict__ ranges, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles,
+    const uint4* __restrict__ desc, const uint32_t* __restrict__ sched, int lg16,
     const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib, const float* __restrict__ final_T,
     const float* __restrict__ bg, const float* __restrict__ dL_dpix, const float* __restrict__ dL_dinv,
     float* __restrict__ records, uint8_t* __restrict__ live_flag) {
@@ -749,7 +823,8 @@ __global__ __launch_bounds__(RBLK) void render_bwd_btf_kernel(
   __shared__ __attribute__((aligned(16))) float s_pix[RBLK / 64][64 * 8 + 32];
   __shared__ uint32_t s_slot[RBLK / 64][64];
   const int lane = threadIdx.x & 63;
-  const int tile = tile_of_wave();
+  uint2 range = make_uint2(0u, 0u);
+  const int tile = tile_of_wave(desc, sched, lg16, gsx, range);
   if (tile >= ntiles) return;
   const int w = RBLK == 64 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   float* slab = s_slab[w];
@@ -763,7 +838,7 @@ __global__ __launch_bounds__(RBLK) void render_bwd_btf_kernel(
   const bool inside = px < W && py < H;
   const uint32_t pix_id = (uint32_t)py * (uint32_t)W + (uint32_t)px;
   const float pxf = (float)px, pyf = (float)py;
-  const uint2 range = ranges[tile];  // the tile's own list
+  if (desc == nullptr) range = ranges[tile];  // the tile's own list
   const size_t HW = (size_t)H * W;
 
   float g[NCH] = {0.f, 0.f, 0.f, 0.f, 0.f};
@@ -887,7 +962,9 @@ namespace {
                   // against bank conflicts) in floats [0, 288), channel 4 at PIXB + pixel + (pixel >> 3)
 #define STG 12    // floats per staged (trip, quad) partial: 11 used
 
-// Transposition of one round of `nk` trips (trips 8 r .. 8 r + nk - 1 of the chunk).
+// Transposition of one round of `nk` trips (trips 8 r .. 8 r + nk - 1 of the chunk). ALT (altitude-only render): the one
+// colour sum of channel 3, whose pixel gradients sit in the single plane at s_pix + PIXB; 7 partials per (trip, quad).
+template <bool ALT>
 __device__ inline void transpose_round_quad(int nk, int r, int lane, const uint32_t* sidx, const float* slab, float* s_u,
                                             const float* s_v, const float* s_pix, float bx0, float by0) {
   const int k = lane >> 3, o = lane & 7, q = o >> 1, h = o & 1;
@@ -904,13 +981,27 @@ __device__ inline void transpose_round_quad(int nk, int r, int lane, const uint3
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     const float u = urow[i], v = vrow[i];
-    const float4 ga = *reinterpret_cast<const float4*>(pa + i * 4);
     const float gb = pb[i];
     const float dx = gxr - (float)(i & 3);
     const float t1 = v * dx;
     if (i < 4) { S0a += v; Sxa += t1; Sxxa += t1 * dx; }
     else { S0b += v; Sxb += t1; Sxxb += t1 * dx; }
-    c0 += u * ga.x; c1 += u * ga.y; c2 += u * ga.z; c3 += u * ga.w; c4 += u * gb;
+    if (!ALT) {
+      const float4 ga = *reinterpret_cast<const float4*>(pa + i * 4);
+      c0 += u * ga.x; c1 += u * ga.y; c2 += u * ga.z; c3 += u * ga.w;
+    }
+    c4 += u * gb;
+  }
+  if (ALT) {
+    float c[7] = {S0a + S0b, Sxa + Sxb, dy0 * S0a + dy1 * S0b, Sxxa + Sxxb, dy0 * Sxa + dy1 * Sxb,
+                  dy0 * dy0 * S0a + dy1 * dy1 * S0b, c4};
+    DPP_STEP7("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1");  // lane h = 1 += lane h = 0
+    if (h == 1 && k < nk) {
+      float4* st = reinterpret_cast<float4*>(s_u + (k * 4 + q) * STG);
+      st[0] = make_float4(c[0], c[1], c[2], c[3]);
+      st[1] = make_float4(c[4], c[5], c[6], 0.f);
+    }
+    return;
   }
   float c[11] = {S0a + S0b, Sxa + Sxb, dy0 * S0a + dy1 * S0b, Sxxa + Sxxb, dy0 * Sxa + dy1 * Sxb,
                  dy0 * dy0 * S0a + dy1 * dy1 * S0b, c0, c1, c2, c3, c4};
@@ -999,9 +1090,13 @@ __device__ unsigned long long g_bwd_phase[PHASE_TILES][6];  // per tile (wave): 
 #define PHASE(i)
 #define PHASE_FLUSH
 #endif
-template <bool HAVE_INV, int RED>
+// ALT (with RED = 0, HAVE_INV = false): the backward of an altitude-only render (EOGS_FLAG_ALT_ONLY). out_color and dL_dpix are
+// single planes (channel 3); one product instead of a five-term dot per pair, one colour sum instead of five in the
+// transposition, 7 instead of 11 values through the DPP merge, the staging area and the owner pull, and a 32-byte record
+// {mean2D.x, .y, conic.a, opacity | conic.b, conic.c, colour3, -} (REC_ALT) that gaussian_bwd_kernel<., true> reads.
+template <bool HAVE_INV, int RED, bool ALT>
 __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(4, 4))) void render_bwd_quad_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx,
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx, const uint4* __restrict__ desc, const uint32_t* __restrict__ sched, int lg16,
     const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ out_color, const float* __restrict__ out_invdepth, const float* __restrict__ dL_dpix,
     const float* __restrict__ dL_dinv, float* __restrict__ records, uint8_t* __restrict__ live_flag) {
@@ -1015,8 +1110,10 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
   static_assert(PIXB + 72 <= 6 * 64, "both pixel-gradient planes fit");
   static_assert(32 * STG <= UV_SIZE && 32 * STG <= 8 * URS, "the staging area lives inside the u matrix");
   const int lane = threadIdx.x & 63;
-  const int tile = tile_of_wave();
+  uint2 range = make_uint2(0u, 0u);
+  const int tile = tile_of_wave(desc, sched, lg16, gsx, range);
   if (tile >= ntiles) return;
+  WTRACE_BEGIN;
   const int w = RBLK == 64 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   float* slab = s_slab[w];
   float* su = s_uv[w];
@@ -1030,7 +1127,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
   const bool inside = px < W && py < H;
   const uint32_t pix_id = (uint32_t)py * (uint32_t)W + (uint32_t)px;
   const float pxf = (float)px, pyf = (float)py;
-  const uint2 range = ranges[tile];
+  if (desc == nullptr) range = ranges[tile];
   const size_t HW = (size_t)H * W;
   const int myq = lane >> 4;
   const uint32_t* myidx = sidx + myq * QB;
@@ -1038,12 +1135,18 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
   float g[NCH] = {0.f, 0.f, 0.f, 0.f, 0.f};
   float ginv = 0.f, Dfinal = 0.f;
   uint32_t ncontrib = 0;
+  static_assert(!ALT || (RED == 0 && !HAVE_INV), "the altitude-only variant exists for the VALU transposition without inverse depth");
   if (inside) {
     ncontrib = n_contrib[pix_id];
+    if (ALT) {  // single planes: the altitude image and its gradient
+      g[3] = dL_dpix[pix_id];
+      Dfinal = g[3] * out_color[pix_id];
+    } else {
 #pragma unroll
-    for (int ch = 0; ch < NCH; ch++) {
-      g[ch] = dL_dpix[ch * HW + pix_id];
-      Dfinal += g[ch] * out_color[ch * HW + pix_id];
+      for (int ch = 0; ch < NCH; ch++) {
+        g[ch] = dL_dpix[ch * HW + pix_id];
+        Dfinal += g[ch] * out_color[ch * HW + pix_id];
+      }
     }
     if (HAVE_INV) {
       ginv = dL_dinv[pix_id];
@@ -1071,6 +1174,8 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
       const float y = (float)(4 * h + kk);
       fyv[h] = ey == 0 ? 1.f : (ey == 1 ? y : y * y);
     }
+  } else if (ALT) {  // the one plane the altitude-only transposition reads
+    spix[PIXB + lane + (lane >> 3)] = g[3];
   } else {  // pixel gradients for the transposition rounds (pixel index = lane): see PIXB
     *reinterpret_cast<float4*>(spix + lane * 4 + 4 * (lane >> 3)) = make_float4(g[0], g[1], g[2], g[3]);
     spix[PIXB + lane + (lane >> 3)] = g[4];
@@ -1126,6 +1231,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     }
     // contributing list positions of this pixel, relative to the chunk, as a slab byte offset
     const uint32_t nc_off = min(ncontrib - min(ncontrib, jbase), 64u) * (uint32_t)(4 * ENT);
+    constexpr int NACC = ALT ? 7 : 11;
     float acc[11];
 #pragma unroll
     for (int t = 0; t < 11; t++) acc[t] = 0.f;
@@ -1135,7 +1241,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
       PHASE(1);
       wave_lds_sync();
       if (RED) mfma_round_quad(nk, lane, su, fxv, fyv, au_row);
-      else transpose_round_quad(nk, r, lane, sidx, slab, su, sv, spix, bx0, by0);
+      else transpose_round_quad<ALT>(nk, r, lane, sidx, slab, su, sv, spix, bx0, by0);
       wave_lds_sync();
       PHASE(2);
 #pragma unroll
@@ -1143,10 +1249,14 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         const uint32_t rk = myranks >> (8 * q);  // bits 7..3: the round of quad q's trip (31: never), bits 2..0: its slot
         if (((rk >> 3) & 31u) == (uint32_t)r) {
           const float4* st = reinterpret_cast<const float4*>(su + ((rk & 7u) * 4u + (uint32_t)q) * STG);
-          const float4 a0 = st[0], a1 = st[1], a2 = st[2];
+          const float4 a0 = st[0], a1 = st[1];
           acc[0] += a0.x; acc[1] += a0.y; acc[2] += a0.z; acc[3] += a0.w;
-          acc[4] += a1.x; acc[5] += a1.y; acc[6] += a1.z; acc[7] += a1.w;
-          acc[8] += a2.x; acc[9] += a2.y; acc[10] += a2.z;
+          acc[4] += a1.x; acc[5] += a1.y; acc[6] += a1.z;
+          if (!ALT) {
+            const float4 a2 = st[2];
+            acc[7] += a1.w;
+            acc[8] += a2.x; acc[9] += a2.y; acc[10] += a2.z;
+          }
         }
       }
       wave_lds_sync();  // the next trips overwrite the u matrix
@@ -1155,7 +1265,14 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     auto fetch_off = [&](uint32_t off) {
       const float4* e4 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(slab) + off);
       Ent e;
-      e.q0 = e4[0]; e.q1 = e4[1]; e.q2 = e4[2];
+      e.q0 = e4[0];
+      if (ALT) {  // C, opacity and the altitude feature: 12 of the other 32 bytes
+        const float2 co = *reinterpret_cast<const float2*>(e4 + 1);
+        e.q1 = make_float4(co.x, co.y, 0.f, 0.f);
+        e.q2 = make_float4(0.f, reinterpret_cast<const float*>(e4 + 2)[1], 0.f, 0.f);
+      } else {
+        e.q1 = e4[1]; e.q2 = e4[2];
+      }
       return e;
     };
     // one (pixel, entry) evaluation; `slot` = trip & 7 selects the row of the u/v matrices
@@ -1165,7 +1282,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
       const float G = __builtin_amdgcn_exp2f(p);
       const float alpha = fminf(e.q1.y * G, 0.99f);
       const bool valid = (off < nc_off) && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);  // (the dummy: alpha = 0)
-      float gc = g[0] * e.q1.z + g[1] * e.q1.w + g[2] * e.q2.x + g[3] * e.q2.y + g[4] * e.q2.z;
+      float gc = ALT ? g[3] * e.q2.y : g[0] * e.q1.z + g[1] * e.q1.w + g[2] * e.q2.x + g[3] * e.q2.y + g[4] * e.q2.z;
       if (HAVE_INV) gc += ginv * e.q2.w;
       const float a_eff = valid ? alpha : 0.f;
       const float G_eff = valid ? G : 0.f;
@@ -1219,7 +1336,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
       // entry `lane`: accumulated moments -> record (backward.cu:624-640, as in transpose_round)
       bool any = false;
 #pragma unroll
-      for (int t = 0; t < 11; t++) any = any || acc[t] != 0.f;
+      for (int t = 0; t < NACC; t++) any = any || acc[t] != 0.f;
       if (lane < jn && any) {
         const float4 q0 = *reinterpret_cast<const float4*>(slab + lane * ENT);
         const float2 q1 = *reinterpret_cast<const float2*>(slab + lane * ENT + 4);
@@ -1237,10 +1354,14 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         const float m2x = op * kx * (2.f * A * acc[1] - B * acc[2]);
         const float m2y = op * ky * (2.f * Cq * acc[2] - B * acc[1]);
         const float ho = -0.5f * op;
-        float4* dst = reinterpret_cast<float4*>(records + (size_t)cur_slot * REC);  // layout: common.h REC
+        float4* dst = reinterpret_cast<float4*>(records + (size_t)cur_slot * (ALT ? REC_ALT : REC));  // layout: common.h REC / REC_ALT
         dst[0] = make_float4(m2x, m2y, ho * acc[3], acc[0]);
-        dst[1] = make_float4(ho * acc[4], ho * acc[5], acc[6], acc[7]);
-        reinterpret_cast<float3*>(dst + 2)[0] = make_float3(acc[8], acc[9], acc[10]);
+        if (ALT) {
+          reinterpret_cast<float3*>(dst + 1)[0] = make_float3(ho * acc[4], ho * acc[5], acc[6]);
+        } else {
+          dst[1] = make_float4(ho * acc[4], ho * acc[5], acc[6], acc[7]);
+          reinterpret_cast<float3*>(dst + 2)[0] = make_float3(acc[8], acc[9], acc[10]);
+        }
         live_flag[cur_slot] = 1;
       }
     }
@@ -1248,6 +1369,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     PHASE(4);
   }
   PHASE_FLUSH;
+  WTRACE_END(1, tile);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1279,7 +1401,7 @@ namespace {
 
 template <bool HAVE_INV>
 __global__ __launch_bounds__(RBLK) void render_bwd_mfma_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx,
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx, const uint4* __restrict__ desc, const uint32_t* __restrict__ sched, int lg16,
     const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ out_color, const float* __restrict__ out_invdepth, const float* __restrict__ dL_dpix,
     const float* __restrict__ dL_dinv, float* __restrict__ records, uint8_t* __restrict__ live_flag) {
@@ -1289,7 +1411,8 @@ __global__ __launch_bounds__(RBLK) void render_bwd_mfma_kernel(
   __shared__ __attribute__((aligned(16))) uint8_t s_idx[RBLK / 64][4 * QBM];
   static_assert(6 * 64 <= 2 * MUV, "the colour-gradient staging lives inside the window matrices");
   const int lane = threadIdx.x & 63;
-  const int tile = tile_of_wave();
+  uint2 range = make_uint2(0u, 0u);
+  const int tile = tile_of_wave(desc, sched, lg16, gsx, range);
   if (tile >= ntiles) return;
   const int w = RBLK == 64 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   float* slab = s_slab[w];
@@ -1303,7 +1426,7 @@ __global__ __launch_bounds__(RBLK) void render_bwd_mfma_kernel(
   const bool inside = px < W && py < H;
   const uint32_t pix_id = (uint32_t)py * (uint32_t)W + (uint32_t)px;
   const float pxf = (float)px, pyf = (float)py;
-  const uint2 range = ranges[tile];
+  if (desc == nullptr) range = ranges[tile];
   const size_t HW = (size_t)H * W;
   const int myq = lane >> 4;
   const uint8_t* myidx = sidx + myq * QBM;
@@ -1514,6 +1637,7 @@ static double quad_bwd_switch() {  // EOGS_QUAD_BWD_SWITCH=<listed tiles per Gau
 }
 
 int render_bwd_variant(int block, int64_t R, int P) {
+  if (nr_alt(R)) return 6;  // altitude-only: the quad backward's one-channel variant
   if (block > 1) return 1;
   if (nr_btf(R)) return 5;
   if (!(quad_bwd_switch() > 0.0 && (double)nr_slots(R) <= quad_bwd_switch() * (double)P)) return 0;
@@ -1527,18 +1651,19 @@ void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, 
   const int variant = render_bwd_variant(b.block, R, P);
   if (variant == 5) {
     auto* kb = dL_dinvdepth ? render_bwd_btf_kernel<true> : render_bwd_btf_kernel<false>;
-    hipLaunchKernelGGL(kb, dim3(render_grid(ntiles)), dim3(RBLK), 0, s, im.ranges, b.point_list, W, H, gsx, ntiles, g.packed,
-                       im.n_contrib, im.final_T, bg, dL_dcolor, dL_dinvdepth, b.records, b.live);
+    hipLaunchKernelGGL(kb, dim3(render_grid(ntiles, im, R)), dim3(RBLK), 0, s, im.ranges, b.point_list, W, H, gsx, ntiles, render_desc(im, R),
+                       g.sched, (int)(16u * im.sched_lg), g.packed, im.n_contrib, im.final_T, bg, dL_dcolor, dL_dinvdepth, b.records, b.live);
     return;
   }
   auto* kern = variant == 1 ? (dL_dinvdepth ? render_bwd_kernel<BLOCK_BIG, true> : render_bwd_kernel<BLOCK_BIG, false>)
                             : (dL_dinvdepth ? render_bwd_kernel<1, true> : render_bwd_kernel<1, false>);
-  if (variant == 2) kern = dL_dinvdepth ? render_bwd_quad_kernel<true, 0> : render_bwd_quad_kernel<false, 0>;
+  if (variant == 2) kern = dL_dinvdepth ? render_bwd_quad_kernel<true, 0, false> : render_bwd_quad_kernel<false, 0, false>;
+  if (variant == 6) kern = render_bwd_quad_kernel<false, 0, true>;  // altitude-only (no inverse-depth gradient: api.hip checks)
   if (variant == 3) kern = dL_dinvdepth ? render_bwd_mfma_kernel<true> : render_bwd_mfma_kernel<false>;
-  if (variant == 4) kern = dL_dinvdepth ? render_bwd_quad_kernel<true, 1> : render_bwd_quad_kernel<false, 1>;
-  hipLaunchKernelGGL(kern, dim3(render_grid(ntiles)), dim3(RBLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H, gsx,
-                     ntiles, (int)macro_grid_x(W, b.block), g.packed, im.n_contrib, out_color, out_invdepth, dL_dcolor,
-                     dL_dinvdepth, b.records, b.live);
+  if (variant == 4) kern = dL_dinvdepth ? render_bwd_quad_kernel<true, 1, false> : render_bwd_quad_kernel<false, 1, false>;
+  hipLaunchKernelGGL(kern, dim3(render_grid(ntiles, im, R)), dim3(RBLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H, gsx,
+                     ntiles, (int)macro_grid_x(W, b.block), render_desc(im, R), g.sched, (int)(16u * im.sched_lg), g.packed, im.n_contrib, out_color,
+                     out_invdepth, dL_dcolor, dL_dinvdepth, b.records, b.live);
 }
 
 #ifdef EOGS_BWD_PHASES
@@ -1556,6 +1681,15 @@ extern "C" int eogs_debug_bwd_phases(unsigned long long* out8, int reset) {
     if (hipMemset(dptr, 0, sizeof(host)) != hipSuccess) return -1;
   }
   return 0;
+}
+#endif
+
+#ifdef EOGS_WAVE_TRACE
+// out: [tiles][4] = {start, end (100 MHz), shader-clock ticks, HW_ID | XCC_ID << 32} of the last launch in direction dir
+extern "C" int eogs_debug_wave_trace(unsigned long long* out, int dir, int tiles) {
+  if (dir < 0 || dir > 1 || tiles < 0 || tiles > WTRACE_TILES) return -1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_trace), sizeof(unsigned long long) * 4 * (size_t)tiles,
+                             sizeof(unsigned long long) * 4 * WTRACE_TILES * (size_t)dir) == hipSuccess ? 0 : -1;
 }
 #endif
 

@@ -19,7 +19,9 @@ What a recorded forward freezes besides its capacities is the list granularity (
 DESIGN.md §2.3) of the last eager forward of that shape: an eager loop re-decides it per forward, so near the switch the two
 loops take different — equally valid, individually oracle-tested — kernel variants and their gradients differ at the
 level of threshold flips (examples/train_synthetic.py at 200 k / 512²: identical loss curves with the switch disabled,
-0.00815 against 0.00844 after 200 iterations with it).
+0.00815 against 0.00844 after 200 iterations with it). The choice of the back-to-front backward (image-sized opaque
+Gaussians) is frozen the same way, with a guard: a replay whose forward asks for it while the graph was
+recorded without it counts as not fitting (`CapturedForward.fits`) and is recorded again.
 
 `fn` follows the rules of torch.cuda.graph: it reads its inputs from tensors that exist before the capture, allocates
 everything else itself, and never waits for the device. Gradients: set them to None at the start of `fn`
@@ -30,6 +32,39 @@ replaces it; returning them from `fn` keeps a handle either way.
 import torch
 
 from . import rasterizer
+
+
+class Branches:
+    """Independent pieces of one step — the renders of a training iteration (train_pan.py:278,305-316,375-391: the view, the
+    sun camera, a random camera, all of the same Gaussians) — queued on streams of their own, forked from and joined back into
+    the current stream. Recorded inside `GraphedStep` they become parallel branches of the HIP graph: one render's
+    launch-floor kernels (count scan, histogram, column scan: a workgroup or sixteen) and the tail of its blend kernels
+    (profiles/r04_wave_trace.txt: a fifth of a render launch runs at half occupancy) run beside another render's large
+    ones. Results are those of the serial order bit for bit: every piece does the same arithmetic, and gradients of shared
+    parameters accumulate in the order the pieces were queued (autograd accumulates on the stream the parameter was first
+    used on; each `backward()` call has queued its accumulation before it returns).
+
+        br = Branches(3)
+        def fn():
+            br.run([lambda v=v: render_and_backward(v) for v in views])
+    """
+
+    def __init__(self, n, device=None):
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(n)]
+
+    def run(self, fns):
+        fns = list(fns)
+        if len(fns) > len(self.streams):
+            raise ValueError(f"Branches({len(self.streams)}) asked to run {len(fns)} pieces")
+        cur = torch.cuda.current_stream()
+        outs = []
+        for s, fn in zip(self.streams, fns):
+            s.wait_stream(cur)  # fork: the piece sees everything queued so far
+            with torch.cuda.stream(s):
+                outs.append(fn())
+        for s in self.streams[:len(fns)]:
+            cur.wait_stream(s)  # join
+        return outs
 
 
 class CapacityExceeded(RuntimeError):
@@ -59,12 +94,15 @@ class GraphedStep:
             for _ in range(warmup):
                 fn()
         cur.wait_stream(side)
+        rasterizer.clear_scratch(stream=side)  # (the warm-up stream is never used again: do not keep its entry-sort buffer)
         self._capture()
 
     def _capture(self):
         torch.cuda.current_stream().synchronize()  # (a replay of the graph being replaced may still be running)
         self.graph = None  # (frees the previous graph's pool before the new capture allocates)
         self.outputs = None
+        self.forwards = []  # (each holds its graph's geometry workspace: the old pool is only released without them; the
+        #                      counts they read are already merged into rasterizer._peak by fits())
         graph = torch.cuda.CUDAGraph()
         with rasterizer.record_captured(self._mirror) as forwards:
             with torch.cuda.graph(graph):
@@ -103,4 +141,4 @@ class GraphedStep:
         return self.outputs
 
 
-__all__ = ["GraphedStep", "CapacityExceeded"]
+__all__ = ["GraphedStep", "Branches", "CapacityExceeded"]

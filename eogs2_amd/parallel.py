@@ -420,7 +420,7 @@ def view_sharded_schedule(opt, world=None, strict=False):
                 d[k] = v * math.sqrt(world)
 
     walk(out)
-    missing = [k for k in _EXPECTED if k not in seen]
+    missing = [k for k in _EXPECTED if k not in seen] if world > 1 else []  # (world 1 scales nothing: nothing to miss)
     if missing:
         msg = f"view_sharded_schedule: settings lack {missing}: not the reference's `optimization` section? (those stay unscaled)"
         if strict:

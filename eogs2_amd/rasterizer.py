@@ -26,7 +26,8 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._abi import FLAG_ANTIALIASING, FLAG_DEBUG, FLAG_DEFER_COUNTS, FLAG_NO_READBACK, FLAG_RAW_PARAMS, MIRROR_BYTES, RastError
+from ._abi import (FLAG_ALT_ONLY, FLAG_ANTIALIASING, FLAG_DEBUG, FLAG_DEFER_COUNTS, FLAG_NO_READBACK, FLAG_RAW_PARAMS, MIRROR_BYTES,
+                   RastError)
 
 NUM_CHANNELS = 5  # DGR/cuda_rasterizer/config.h:15
 
@@ -136,7 +137,7 @@ def speculation_stats(reset=False):
 GRAPH_SLACK = 0.25
 _peak = {}  # (device, P, H, W, raw) -> token with the largest slot and entry counts seen, flags of the latest forward
 _recording = None  # the record_captured scope of the capture in progress
-_SLOTS, _ENTRIES = 0x7FFFFFFF, 0x0FFFFFFF << 32  # csrc/common.h nr_slots / nr_entries
+_SLOTS, _ENTRIES = 0x7FFFFFFF, 0x07FFFFFF << 32  # csrc/common.h nr_slots / nr_entries
 
 
 def _merge_counts(peak, exact):
@@ -154,7 +155,8 @@ class CapturedForward:
     POLL_SECONDS = 0.05  # then wait for the stream instead (after which the copy has landed by definition)
 
     def __init__(self, abi, key, geom, capacity, have_scratch, mirror=None):
-        self.abi, self.key, self.geom, self.capacity, self.have_scratch = abi, key, geom, capacity, have_scratch
+        # have_scratch: bit 0 = a scratch buffer went with the forward, bit 1 = an altitude-only forward (include/eogs_rast.h)
+        self.abi, self.key, self.geom, self.capacity, self.have_scratch = abi, key, geom, capacity, int(have_scratch)
         self.mirror = mirror  # ctypes.c_void_p or None
 
     def arm(self):
@@ -162,7 +164,7 @@ class CapturedForward:
             self.abi.check(self.abi.mirror_arm(self.mirror))
 
     def fits(self):
-        dev, P, H, W, _ = self.key
+        dev, P, H, W = self.key[:4]
         R, arrived = ctypes.c_int64(), ctypes.c_int(0)
         if self.mirror is not None:
             deadline = time.perf_counter() + self.POLL_SECONDS
@@ -182,7 +184,10 @@ class CapturedForward:
         exact = R.value
         _peak[self.key] = _merge_counts(_peak.get(self.key), exact)
         _spec[self.key] = _last_exact[dev] = exact
-        return (exact & _SLOTS) <= (self.capacity & _SLOTS) and (exact & _ENTRIES) <= (self.capacity & _ENTRIES)
+        # (a forward that asks for the back-to-front backward — bit 60, image-sized opaque Gaussians — does not fit a graph
+        # recorded without it: eogs_rast_capacity_token; the next capture takes the flags of this forward from _peak)
+        btf_ok = not ((exact >> 60) & 1 and not (self.capacity >> 60) & 1)
+        return (exact & _SLOTS) <= (self.capacity & _SLOTS) and (exact & _ENTRIES) <= (self.capacity & _ENTRIES) and btf_ok
 
 
 class record_captured:
@@ -227,9 +232,24 @@ def _scratch_for(abi, dev, stream_id, P, H, W):
     key = (dev, stream_id)
     with _scratch_lock:
         t = _scratch.get(key)
-        if t is None or t.numel() < n.value:
+        # grown on demand; given back when the scene shrank to less than half of it (pruning) instead of staying at its peak
+        if t is None or t.numel() < n.value or t.numel() > 2 * (n.value + n.value // 4):
             t = _scratch[key] = torch.empty((n.value + n.value // 4,), dtype=torch.uint8, device=dev)
     return t
+
+
+def clear_scratch(device=None, stream=None):
+    """Drops cached entry-sort buffers (192 B per Gaussian + 25 %, one per device and stream that has run a forward): all of
+    them, those of one device, or the one of a stream. They are transient — the next forward on a stream allocates its own
+    again — so this is safe whenever no forward is being queued concurrently."""
+    with _scratch_lock:
+        for key in list(_scratch):
+            dev, sid = key
+            if device is not None and torch.device(device) != dev:
+                continue
+            if stream is not None and (stream.device != dev or stream.cuda_stream != sid):
+                continue
+            del _scratch[key]
 
 
 def rasterize_gaussians(
@@ -257,11 +277,13 @@ def rasterize_gaussians(
     )
 
 
-def _run_forward(rs, viewmat, means3D, colors, opacities, scales, rotations, cov3Ds_precomp, alt_affine=None, raw=False):
+def _run_forward(rs, viewmat, means3D, colors, opacities, scales, rotations, cov3Ds_precomp, alt_affine=None, raw=False,
+                 alt_only=False):
     """Marshalling of DGR/rasterize_points.cu:35-131 over the C-ABI.
 
     Returns (num_rendered, color, radii, invdepths, geom, binning, img). With `raw` the per-Gaussian tensors are the
-    model's raw parameters (EOGS_FLAG_RAW_PARAMS, include/eogs_rast.h) and `colors` is f_dc [P,3].
+    model's raw parameters (EOGS_FLAG_RAW_PARAMS, include/eogs_rast.h) and `colors` is f_dc [P,3]. With `alt_only`
+    (EOGS_FLAG_ALT_ONLY) only feature channel 3 is rendered: `color` is [1, H, W] and `invdepths` is not written.
     """
     abi = _backend()
     # DGR/rasterize_points.cu:58-60
@@ -270,12 +292,12 @@ def _run_forward(rs, viewmat, means3D, colors, opacities, scales, rotations, cov
     dev = means3D.device
     P = means3D.shape[0]
     H, W = int(rs.image_height), int(rs.image_width)
-    flags = _flags(rs) | (FLAG_RAW_PARAMS if raw else 0)
+    flags = _flags(rs) | (FLAG_RAW_PARAMS if raw else 0) | (FLAG_ALT_ONLY if alt_only else 0)
     ncol = 3 if raw else NUM_CHANNELS
 
     with _Ctx(abi, dev) as cx:
         # outputs as DGR/rasterize_points.cu:69-76 (zero images when P == 0: forward is skipped)
-        color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+        color = torch.empty((1 if alt_only else NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
         invdepths = torch.empty((1, H, W), dtype=torch.float32, device=dev)
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
         empty_u8 = torch.empty((0,), dtype=torch.uint8, device=dev)
@@ -338,7 +360,7 @@ def _run_forward(rs, viewmat, means3D, colors, opacities, scales, rotations, cov
                     abi.forward_render(
                         P, H, W, token, _ptr(bg), flags,
                         _ptr(geom), geom.numel(), _ptr(ws), ws.numel(), _ptr(img), img.numel(),
-                        _ptr(scratch), n_scratch, _ptr(color), _ptr(invdepths), cx.stream,
+                        _ptr(scratch), n_scratch, _ptr(color), None if alt_only else _ptr(invdepths), cx.stream,
                     )
                 )
                 return ws
@@ -347,8 +369,11 @@ def _run_forward(rs, viewmat, means3D, colors, opacities, scales, rotations, cov
             # does the first forward of a shape here. Later forwards of the same shape size the binning workspace from the
             # previous one's counts plus slack and queue the whole forward before asking for the counts
             # (EOGS_FLAG_DEFER_COUNTS): the device builds no lists when the guess does not hold them, and the forward is then
-            # repeated with the exact counts. The results do not depend on which way a forward went.
-            key = (dev, P, H, W, bool(raw))
+            # repeated with the exact counts. Which way a forward went changes the kernel variants it runs (a capacity token
+            # keeps the earlier forward's list granularity), never what it computes, with one guarded exception: a forward
+            # that needs the back-to-front backward does not fit a token counted without it and is redone.
+            key = (dev, P, H, W, bool(raw), bool(alt_only))
+            hs = lambda: int(scratch is not None) | (2 if alt_only else 0)  # `have_scratch` of the token-building calls
             last = _spec.get(key) if (_speculate and abi.backend != "cpu-oracle") else None
             if capturing:
                 # Recorded into a graph: nothing may wait. The workspaces hold GRAPH_SLACK more than any eager forward of
@@ -360,7 +385,7 @@ def _run_forward(rs, viewmat, means3D, colors, opacities, scales, rotations, cov
                 if flags & FLAG_DEBUG:
                     raise RuntimeError("debug=True waits for the stream after every kernel: not inside a graph capture")
                 cap = ctypes.c_int64()
-                abi.check(abi.capacity_token(P, peak, GRAPH_SLACK, int(scratch is not None), 0, ctypes.byref(cap), None))
+                abi.check(abi.capacity_token(P, peak, GRAPH_SLACK, hs(), 0, ctypes.byref(cap), None))
                 prepare(FLAG_DEFER_COUNTS | FLAG_NO_READBACK)
                 exact = num_rendered = cap.value
                 binning = render(num_rendered)
@@ -368,7 +393,7 @@ def _run_forward(rs, viewmat, means3D, colors, opacities, scales, rotations, cov
                     slot = _recording.take_slot()
                     if slot is not None:  # the counts reach the host while the rest of the graph runs
                         abi.check(abi.mirror_counts(P, _ptr(geom), geom.numel(), slot, cx.stream))
-                    _recording.forwards.append(CapturedForward(abi, key, geom, num_rendered, scratch is not None, slot))
+                    _recording.forwards.append(CapturedForward(abi, key, geom, num_rendered, hs(), slot))
             elif last is None:
                 prepare(0)
                 exact = num_rendered = R.value
@@ -377,11 +402,11 @@ def _run_forward(rs, viewmat, means3D, colors, opacities, scales, rotations, cov
             else:
                 prepare(FLAG_DEFER_COUNTS)
                 cap, fits = ctypes.c_int64(), ctypes.c_int()
-                abi.check(abi.capacity_token(P, last, SPECULATION_SLACK, int(scratch is not None), 0, ctypes.byref(cap), None))
+                abi.check(abi.capacity_token(P, last, SPECULATION_SLACK, hs(), 0, ctypes.byref(cap), None))
                 binning = render(cap.value)
                 abi.check(abi.forward_counts(ctypes.byref(R)))
                 exact = R.value
-                abi.check(abi.capacity_token(P, last, SPECULATION_SLACK, int(scratch is not None), exact, ctypes.byref(cap), ctypes.byref(fits)))
+                abi.check(abi.capacity_token(P, last, SPECULATION_SLACK, hs(), exact, ctypes.byref(cap), ctypes.byref(fits)))
                 if fits.value:
                     num_rendered = cap.value
                     _spec_stats["hit"] += 1
@@ -447,7 +472,8 @@ def chunk_ranges(P, chunks):
 
 
 def _run_backward(rs, num_rendered, grad_out_color, grad_out_depth, means3D, colors, opacities, scales, rotations,
-                  cov3Ds_precomp, radii, geom, binning, img, color, invdepths, want_vm, alt_affine=None, raw=False):
+                  cov3Ds_precomp, radii, geom, binning, img, color, invdepths, want_vm, alt_affine=None, raw=False,
+                  alt_only=False):
     """Marshalling of DGR/rasterize_points.cu:133-224 over the C-ABI (P > 0).
 
     Returns (d_means2D, d_colors, d_opacity[P,1], d_means3D, d_cov3D|None, d_scales|None, d_rot|None, grad_viewmatrix|None).
@@ -464,7 +490,11 @@ def _run_backward(rs, num_rendered, grad_out_color, grad_out_depth, means3D, col
     with _Ctx(abi, dev) as cx:
         g_color = _f32(grad_out_color, dev)
         if g_color is None:
-            g_color = torch.zeros((NUM_CHANNELS, H, W), **f32)
+            g_color = torch.zeros((1 if alt_only else NUM_CHANNELS, H, W), **f32)
+        if g_color.numel() != (1 if alt_only else NUM_CHANNELS) * H * W:
+            raise RuntimeError("backward: the image gradient does not have the forward's shape")
+        if alt_only and grad_out_depth is not None:
+            raise RuntimeError("an altitude-only render has no inverse-depth output to differentiate")
         # the reference always receives a materialised (usually all-zero) invdepth gradient;
         # here an unused invdepth output arrives as None and its work is skipped
         g_depth = _f32(grad_out_depth, dev)

@@ -39,7 +39,11 @@ def _camera_matrices(cam):
 
 
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_sh=False, override_color=None,
-           use_trained_exp=False, fallback=None):
+           use_trained_exp=False, fallback=None, altitude_only=False):
+    """`altitude_only=True` (not in the reference's signature; `eogs2_amd.fused.rasterize_raw`): "render" is the altitude image
+    [1,H,W] alone — for a render whose RGB nobody consumes (the sun camera before `iterstart_L_sun_resample`)."""
+    if altitude_only and (use_trained_exp or not fusable(viewpoint_camera, pipe, override_color)):
+        raise NotImplementedError("altitude_only renders exist on the raw-parameter path only, without per-image exposure")
     if not fusable(viewpoint_camera, pipe, override_color):
         if fallback is None:
             raise NotImplementedError(
@@ -60,7 +64,7 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_
     # altitude channel = xyz @ affine[:3, 2] + affine[3, 2]   (scene/cameras/affine_cameras.py:432-438)
     alt_affine = viewpoint_camera.affine[:, 2].detach().to(torch.float32).contiguous()
     image, radii, _ = rasterize_raw(pc._xyz, viewspace_points, pc._features_dc, pc._opacity, pc._scaling, pc._rotation,
-                                    alt_affine, settings)
+                                    alt_affine, settings, altitude_only=altitude_only)
     if use_trained_exp:  # per-image 3x4 exposure on the rgb planes (renderer.py:112-120)
         e = pc.get_exposure_from_name(viewpoint_camera.image_name)
         image = torch.einsum("chw,cd->dhw", image, e[:3, :3]) + e[:3, 3].reshape(3, 1, 1)

@@ -71,11 +71,24 @@ def resample(virtual_render, cam2virt, rendered_uva, n_out=4, fill_channel=3, fi
     return _Resample.apply(virtual_render, rendered_uva, cam2virt, n_out, fill_channel, fill_value)
 
 
-def render_resample_virtual_camera(virtual_camera, cam2virt, rendered_uva, gaussians, pipe, background, return_extra=False):
+def render_resample_virtual_camera(virtual_camera, cam2virt, rendered_uva, gaussians, pipe, background, return_extra=False,
+                                   altitude_only=False):
     """renderer_cc_shadow.py:5-60: render the virtual camera, reproject the true camera's (u, v, altitude) grid into it,
-    sample the virtual image there. Returns (rgb_sample[3,H,W], altitude_sample[H,W], virtual_uv[H,W,2])."""
+    sample the virtual image there. Returns (rgb_sample[3,H,W], altitude_sample[H,W], virtual_uv[H,W,2]).
+
+    `altitude_only=True` (not in the reference's signature): for a caller that does not consume `rgb_sample` — the sun camera
+    while `iterstart_L_sun_resample` has not been reached, i.e. always with the shipped configuration (train_pan.py:305-324,
+    gs_config/train.yaml:123) — the virtual camera renders its altitude channel alone (EOGS_FLAG_ALT_ONLY: one blended
+    channel instead of five, forward and backward, on the iteration's largest render) and one plane is resampled;
+    `rgb_sample` comes back as None. The altitude sample, the coordinates and every gradient equal the full call's."""
     from .render import render
 
+    if altitude_only:
+        virtual_render = render(virtual_camera, gaussians, pipe, background, altitude_only=True)["render"]  # [1, Hv, Wv]
+        sample, virtual_uv = resample(virtual_render, cam2virt, rendered_uva, n_out=1, fill_channel=0)
+        if return_extra:
+            return None, sample[0], virtual_uv, virtual_render
+        return None, sample[0], virtual_uv
     virtual_render = render(virtual_camera, gaussians, pipe, background)["render"]
     sample, virtual_uv = resample(virtual_render, cam2virt, rendered_uva)
     if return_extra:

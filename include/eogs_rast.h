@@ -78,6 +78,18 @@ extern "C" {
  * may be recorded into a HIP graph (hipStreamBeginCapture). eogs_rast_forward_counts is not available for such a forward;
  * after the stream's work (or a replay of the graph) has been queued, eogs_rast_read_counts returns its counts. */
 #define EOGS_FLAG_NO_READBACK 16u
+/* forward_prepare: an ALTITUDE-ONLY render. The reference's training iteration renders the sun camera at 2H x 2W and, by
+ * default, consumes that render through its altitude channel alone (GS/train_pan.py:305-324 with
+ * gs_config/train.yaml:123 `iterstart_L_sun_resample: 9999999999`; renderer_cc_shadow.py:28-50): the most expensive
+ * render of the iteration blends five channels to use one. With this flag the forward blends and stores only feature
+ * channel 3: `out_color` of forward_render and `out_color` / `dL_dout_color` of backward are then SINGLE planes f32[H,W]
+ * (the altitude image and its gradient), the backward's per-pair work and records shrink accordingly, and dL_dcolors
+ * comes back with column 3 alone non-zero (raw mode: a zero f_dc gradient; the altitude's dependence on xyz is chained).
+ * The choice travels in the token (bit 59): pass the flag to forward_prepare, hand `have_scratch | 2` to the calls that
+ * build a token without flags (read_counts, mirror_token, capacity_token). Such a forward always takes per-tile lists and
+ * the front-to-back quad kernels. Equal to the full render's channel 3 / to a full backward with zero upstream gradient
+ * on the other channels (tests/test_gpu_altonly.py). */
+#define EOGS_FLAG_ALT_ONLY 32u
 
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char* eogs_rast_last_error(void);
@@ -139,8 +151,11 @@ int eogs_rast_mirror_arm(void* host);
 int eogs_rast_mirror_counts(int P, const void* geom, size_t geom_bytes, void* host, void* stream);
 int eogs_rast_mirror_token(int P, int H, int W, const void* host, int have_scratch, int64_t* num_rendered, int* arrived);
 /* A token whose workspaces hold `slack` (e.g. 0.25) more record slots and list entries than `num_rendered` (an exact token
- * of an earlier forward with the same P, H, W) describes, for a deferred-count forward; *fits (optional) receives whether an
- * exact token `exact` (0: not asked) fits inside it. have_scratch: the caller passes a scratch buffer to both calls. */
+ * of an earlier forward with the same P, H, W) describes, for a deferred-count forward; *fits (optional; pass NULL when there
+ * is no exact token yet) receives whether the exact token `exact` fits inside it — its counts do (0 = nothing listed always
+ * does) and it does not ask for the back-to-front backward while `num_rendered` was counted without it (the capacity token
+ * keeps the earlier forward's list granularity and backward variant; that one choice matters for parity).
+ * have_scratch: the caller passes a scratch buffer to both calls. */
 int eogs_rast_capacity_token(int P, int64_t num_rendered, double slack, int have_scratch, int64_t exact,
                              int64_t* capacity, int* fits);
 

@@ -10,6 +10,17 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long GPU cases (experiment kernels, 2 M Gaussians, two-rank runs) that -m gpu only "
+                                       "runs with EOGS_FULL=1 in the environment, to keep the default GPU suite under five minutes")
+
+
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get("EOGS_FULL") == "1":
+        return
+    skip = pytest.mark.skip(reason="slow case: set EOGS_FULL=1 to run it")
+    for item in items:
+        if "slow" in item.keywords:
+            item.add_marker(skip)
 
 
 @pytest.fixture

@@ -97,6 +97,17 @@ def oracle_run(case, backend=None):
     return {k: v.cpu().numpy() for k, v in ref.items() if not k.startswith("_")}
 
 
+_ORACLE_CACHE = {}
+
+
+def oracle_cached(key, case):
+    """oracle_run with its result kept for the rest of the test process under `key` (the seeded table and the sweep seeds are
+    compared in tests/test_gpu_parity.py and again, per forced kernel path, in tests/test_gpu_paths.py: one oracle run each)."""
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = oracle_run(case)
+    return _ORACLE_CACHE[key]
+
+
 SENS_ULPS, SENS_DRAWS, SENS_FACTOR = 4.0, 4, 4.0
 
 
@@ -194,7 +205,9 @@ def quantity_scale(ref):
     b = torch.as_tensor(np.asarray(ref), dtype=torch.float64)
     if b.numel() == 0:
         return torch.ones((), dtype=torch.float64)
-    if b.ndim == 3:
+    if b.ndim == 3 and b.shape[1] == 1 and b.shape[0] > 1:  # [P, 1, k] (f_dc and its gradient): per-Gaussian rows, not an image
+        sc = b.abs().amax(dim=(0, 1), keepdim=True)
+    elif b.ndim == 3:
         sc = b.abs().amax(dim=(1, 2), keepdim=True)
     elif b.ndim == 2 and b.shape[1] > 1:
         sc = b.abs().amax(dim=0, keepdim=True)
@@ -286,9 +299,11 @@ class Attribution:
                 t0 = time.perf_counter()
                 self._sens = sensitivity_map(self.case, self.ref)
                 print(f"sensitivity map: {time.perf_counter() - t0:.1f} s")
-                if f:
+                if f:  # (written whole, then renamed: the path children run two at a time and share this cache)
                     os.makedirs(os.path.dirname(f), exist_ok=True)
-                    np.savez(f, **self._sens)
+                    tmp = f"{f}.{os.getpid()}.tmp.npz"
+                    np.savez(tmp, **self._sens)
+                    os.replace(tmp, f)
         return torch.from_numpy(self._sens[key])
 
     def formulation(self, key):
@@ -297,7 +312,10 @@ class Attribution:
         return torch.from_numpy(self._form[key])
 
 
-SENS_RTOL = 1e-1
+# bound on an error attributed to the oracle's own ill-conditioning, relative to its quantity's scale. Rounds 1-3: 1e-1 of the
+# TENSOR's scale. Round 4, per quantity: the default suite needs 6.5e-2 (sweep216, g_rotations, 7 elements: strongly anisotropic
+# Gaussians, the oracle itself moves by 0.13 there under 4-ulp perturbations), every other case stays below 3e-2 (profiles/r04_sweeps.txt).
+SENS_RTOL = 7e-2
 
 
 def check_close(got, ref, what, rtol, attribution=None, key=None, sens_rtol=None):

@@ -76,7 +76,7 @@ def test_capacity_token_and_counts_without_a_pending_forward(hip_lib):
     last = pack(1_000_000, 200_000, 0, 1)
     hip_lib.check(hip_lib.capacity_token(P, last, 0.25, 1, pack(1_200_000, 250_000, 0, 1), ctypes.byref(cap), ctypes.byref(fits)))
     c = cap.value
-    assert (c & 0x7FFFFFFF) == 1_250_000 + 4096 and ((c >> 32) & 0x0FFFFFFF) == 250_000 + 1024
+    assert (c & 0x7FFFFFFF) == 1_250_000 + 4096 and ((c >> 32) & 0x07FFFFFF) == 250_000 + 1024
     assert (c >> 61) & 1 == 1 and (c >> 62) & 1 == 0 and fits.value == 1
     hip_lib.check(hip_lib.capacity_token(P, last, 0.25, 1, pack(1_254_097, 250_000, 0, 1), ctypes.byref(cap), ctypes.byref(fits)))
     assert fits.value == 0

@@ -123,7 +123,8 @@ def test_count_bookkeeping_of_deferred_and_captured_forwards():
     assert m == tok(1000, 50)  # max of each count, flags of the later one
     m = rz._merge_counts(tok(400, 50), tok(1000, 10, block=1, wide=1))
     assert m == tok(1000, 50, block=1, wide=1)
-    assert (tok(0x7FFFFFFF, 0x0FFFFFFF) & rz._SLOTS) == 0x7FFFFFFF and (tok(0, 0x0FFFFFFF) & rz._ENTRIES) >> 32 == 0x0FFFFFFF
+    assert (tok(0x7FFFFFFF, 0x07FFFFFF) & rz._SLOTS) == 0x7FFFFFFF and (tok(0, 0x07FFFFFF) & rz._ENTRIES) >> 32 == 0x07FFFFFF
+    assert ((1 << 59) & (rz._SLOTS | rz._ENTRIES)) == 0  # bit 59: an altitude-only forward (csrc/common.h nr_alt)
     old = rz.set_speculation(True)
     try:
         assert rz.set_speculation(False) is True and rz.set_speculation(True, forget=True) is False and not rz._spec

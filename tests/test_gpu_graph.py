@@ -183,3 +183,54 @@ def test_fused_training_step_in_a_graph(dev):
         target.mul_(0.5)
     got = [t.clone() for t in g()]
     _same(got, [t.clone() for t in fn()])
+
+
+def test_three_renders_as_parallel_branches_equal_the_serial_graph(dev):
+    """The renders of one training iteration (view, 2H x 2W sun camera, random camera: train_pan.py:278,305-316,375-391) as
+    parallel branches of one graph (eogs2_amd.graph.Branches): the accumulated gradients are bit-identical to the serial
+    graph's and to the eager iteration's, also after the parameters moved."""
+    from eogs2_amd.fused import rasterize_raw
+    from eogs2_amd.graph import Branches, GraphedStep
+    from eogs2_amd.synthetic import make_camera, make_scene, settings_for
+
+    P, H, W = 20000, 160, 192
+    sc = make_scene(P, H, W, seed=23, opacity="trained", device=dev)
+    leaves = dict(xyz=sc["means3D"].clone(), f_dc=torch.logit(sc["colors"][:, :3].clamp(0.01, 0.99)),
+                  opl=torch.logit(sc["opacities"].clamp(1e-4, 1 - 1e-4)), lsc=sc["scales"].log(), rot=sc["rotations"].clone())
+    for v in leaves.values():
+        v.requires_grad_(True)
+    views = []
+    for seed, (h, w) in ((1, (H, W)), (2, (2 * H, 2 * W)), (3, (H, W))):
+        vm = make_camera(h, w, seed=seed, device=dev)
+        dL = torch.randn(5, h, w, device=dev) / (h * w)
+        views.append((settings_for(dict(sc, viewmatrix=vm), h, w), vm[:, 2].contiguous(), torch.zeros(P, 3, device=dev, requires_grad=True), dL))
+
+    def one(vi):
+        rs, alt, m2, dL = views[vi]
+        color, _, _ = rasterize_raw(leaves["xyz"], m2, leaves["f_dc"], leaves["opl"], leaves["lsc"], leaves["rot"], alt, rs)
+        torch.autograd.backward([color], [dL])
+        return color.detach()
+
+    br = Branches(3, device=dev)
+
+    def fn(parallel):
+        for v in leaves.values():
+            v.grad = None
+        for _, _, m2, _ in views:
+            m2.grad = None
+        cols = br.run([lambda vi=vi: one(vi) for vi in range(3)]) if parallel else [one(vi) for vi in range(3)]
+        return tuple(cols) + tuple(v.grad for v in leaves.values()) + tuple(m2.grad for _, _, m2, _ in views)
+
+    eager = [t.clone() for t in fn(False)]
+    serial = GraphedStep(lambda: fn(False), warmup=1)
+    _same([t.clone() for t in serial()], eager)
+    par = GraphedStep(lambda: fn(True), warmup=1)
+    assert len(par.forwards) == 3
+    _same([t.clone() for t in par()], eager)
+    with torch.no_grad():
+        leaves["xyz"].add_(0.003)
+        leaves["opl"].sub_(0.2)
+    want = [t.clone() for t in fn(False)]
+    _same([t.clone() for t in par()], want)
+    _same([t.clone() for t in serial()], want)
+    _same([t.clone() for t in fn(True)], want)  # the eager iteration on three streams as well

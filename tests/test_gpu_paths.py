@@ -36,6 +36,11 @@ FORCED = {  # (the default switches run in-process: tests/test_gpu_parity.py, sa
     # the reference's own back-to-front recursion on per-tile lists (render_bwd_btf_kernel), forced for every case
     "btf": {"EOGS_BTF_SWITCH": "1e-9", "EOGS_QUAD_SWITCH": "1000"},
 }
+# The two MFMA backward variants are a recorded experiment (parity-green, slower, never selected by default):
+# their 2 x 40 oracle comparisons run only with EOGS_FULL=1, like every `slow` test (tests/conftest.py).
+EXPERIMENT_PATHS = ("quad_mfma", "quad_mfma_t")
+if os.environ.get("EOGS_FULL") != "1":
+    FORCED = {k: v for k, v in FORCED.items() if k not in EXPERIMENT_PATHS}
 KERNEL_NAMES = {0: "tile", 1: "block", 2: "quad", 3: "quad_mfma", 4: "quad_mfma_t", 5: "btf"}
 
 
@@ -70,8 +75,10 @@ def case_dir(tmp_path_factory):
     for seed in range(200, 224):
         c, label = sweep_case(seed)
         cases.append((f"sweep_{seed}", label, c, None))
+    from parity_cases import oracle_cached
+
     for fname, label, ins, ref in cases:
-        ref = ref if ref is not None else _oracle(ins)
+        ref = ref if ref is not None else oracle_cached(fname, ins)  # (shared with tests/test_gpu_parity.py in this process)
         np.savez(os.path.join(str(d), fname + ".npz"), label=label, **{"in_" + k: v for k, v in ins.items()},
                  **{"ref_" + k: v for k, v in ref.items()})
     return str(d), len(cases)
@@ -80,11 +87,25 @@ def case_dir(tmp_path_factory):
 def test_every_kernel_path_matches_oracle(dev, case_dir, tmp_path):
     d, ncases = case_dir
     seen_fwd, seen_bwd, report = set(), set(), {}
+    # the children are started two at a time (each is one process on the card and mostly CPU-side comparison; the GPU box
+    # allows six processes on its card and has 16 cores): exactly the processes started here are waited for
+    tags, procs = list(FORCED), {}
+    for i in range(0, len(tags), 2):
+        for tag in tags[i:i + 2]:
+            out = os.path.join(str(tmp_path), f"{tag}.json")
+            procs[tag] = (subprocess.Popen([sys.executable, os.path.join(HERE, "path_child.py"), d, out],
+                                           env=dict(os.environ, **FORCED[tag]), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True), out)
+        for tag in tags[i:i + 2]:
+            try:
+                _, err = procs[tag][0].communicate(timeout=1500)
+            except subprocess.TimeoutExpired:
+                for q, _o in procs.values():
+                    if q.poll() is None:
+                        q.kill()
+                raise
+            assert procs[tag][0].returncode == 0, f"{tag}: {err[-2000:]}"
     for tag, env_extra in FORCED.items():
-        out = os.path.join(str(tmp_path), f"{tag}.json")
-        r = subprocess.run([sys.executable, os.path.join(HERE, "path_child.py"), d, out], env=dict(os.environ, **env_extra),
-                           capture_output=True, text=True, timeout=1500)
-        assert r.returncode == 0, f"{tag}: {r.stderr[-2000:]}"
+        out = procs[tag][1]
         res = json.load(open(out))
         assert len(res) == ncases
         bad = {k: v["error"] for k, v in res.items() if not v["ok"]}
@@ -111,7 +132,7 @@ def test_every_kernel_path_matches_oracle(dev, case_dir, tmp_path):
         seen_bwd |= {p[2] for p in paths}
     print("kernel paths compared with the oracle:", json.dumps(report))
     assert seen_fwd == {0, 1, 2}, report
-    assert seen_bwd == {0, 1, 2, 3, 4, 5}, report
+    assert seen_bwd == ({0, 1, 2, 3, 4, 5} if os.environ.get("EOGS_FULL") == "1" else {0, 1, 2, 5}), report
 
 
 def _full_size_case(P, H, W, seed, opacity, **kw):

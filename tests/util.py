@@ -34,14 +34,18 @@ def load_golden(name):
     return {k: z[k] for k in z.files}
 
 
-def closeness(a, b):
-    """(max error, fraction of elements beyond RTOL, largest scale), the error of an element measured against the largest
-    reference magnitude of its own QUANTITY: the channel of a [C, H, W] image, the column of a [P, k] tensor (round 4; the
-    altitude channel of out_color is 20-150x the RGB channels, tests/parity_cases.py quantity_scale)."""
+def closeness(a, b, with_items=False):
+    """(max error, fraction of ITEMS beyond RTOL, largest scale[, number of items]). The error of an element is measured
+    against the largest reference magnitude of its own QUANTITY: the channel of a [C, H, W] image, the column of a [P, k]
+    tensor (round 4; the altitude channel of out_color is 20-150x the RGB channels, tests/parity_cases.py quantity_scale).
+    An item is what one moved blend decision touches as a whole: a pixel (all its channels) of an image, a row (one
+    Gaussian) of a [P, k] tensor, an element otherwise."""
     a = torch.as_tensor(a, dtype=torch.float64).cpu()
     b = torch.as_tensor(b, dtype=torch.float64).cpu()
     if b.numel() == 0:
-        return 0.0, 0.0, 0.0
+        return (0.0, 0.0, 0.0, 0) if with_items else (0.0, 0.0, 0.0)
+    if b.ndim == 3 and b.shape[1] == 1 and b.shape[0] > 1:  # [P, 1, k] (f_dc and its gradient): per-Gaussian rows, not an image
+        a, b = a.reshape(b.shape[0], -1), b.reshape(b.shape[0], -1)
     if b.ndim == 3:
         scale = b.abs().amax(dim=(1, 2), keepdim=True)
     elif b.ndim == 2 and b.shape[1] > 1:
@@ -50,21 +54,26 @@ def closeness(a, b):
         scale = b.abs().max().reshape(())
     scale = scale.clamp_min(1e-30)
     err = (a - b).abs() / scale
-    return float(err.max()), float((err > RTOL).double().mean()), float(scale.max())
+    bad = err > RTOL
+    if b.ndim == 3:
+        bad = bad.any(dim=0)
+    elif b.ndim == 2 and b.shape[1] > 1:
+        bad = bad.any(dim=1)
+    out = (float(err.max()), float(bad.double().mean()), float(scale.max()))
+    return out + (int(bad.numel()),) if with_items else out
 
 
 def assert_close(a, b, what, rtol=RTOL, allow_flips=True, flip_floor=0, flip_rtol=FLIP_RTOL):
-    """flip_floor: number of threshold-flip elements tolerated regardless of tensor size (used where the two sides
-    evaluate the activations with different exp implementations, so opacities differ by an ulp).
-    flip_rtol: bound on the size of such an outlier, relative to the tensor's scale."""
+    """flip_floor: number of threshold-flip items (pixels / Gaussians) tolerated regardless of tensor size (used where the
+    two sides evaluate the activations with different exp implementations, so opacities differ by an ulp).
+    flip_rtol: bound on the size of such an outlier, relative to its quantity's scale."""
     assert tuple(a.shape) == tuple(b.shape), f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
-    mx, frac, scale = closeness(a, b)
+    mx, frac, scale, n = closeness(a, b, with_items=True)
     if allow_flips:
-        n = max(int(torch.as_tensor(b).numel()), 1)
-        ok = (mx <= rtol) or (frac <= max(FLIP_FRAC, (flip_floor + 0.5) / n) and mx <= flip_rtol)
+        ok = (mx <= rtol) or (frac <= max(FLIP_FRAC, (flip_floor + 0.5) / max(n, 1)) and mx <= flip_rtol)
     else:
         ok = mx <= rtol
-    assert ok, f"{what}: max err {mx:.3e} (x scale {scale:.3e}), fraction beyond {RTOL:g}: {frac:.3e}"
+    assert ok, f"{what}: max err {mx:.3e} (largest scale {scale:.3e}), fraction of pixels / rows beyond {RTOL:g}: {frac:.3e}"
     return mx
 
 
