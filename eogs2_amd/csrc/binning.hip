@@ -653,7 +653,7 @@ __global__ __launch_bounds__(ES_T) void entry_colscan_kernel(uint32_t* __restric
 // 32 x 32-px blocks for the render launches:
 //   * blocks with fewer than an eighth of the mean pair count are LIGHT (the empty rim of a scene); every XCD's sequence is its
 //     share of the other blocks, then of the light ones: a launch ends on cheap tiles, not on full ones;
-//   * the other blocks, in row-major order, are dealt to the XCDs in UNITS of `unit` consecutive blocks (4: a 128 x 32-px strip),
+//   * the other blocks, in row-major order, are dealt to the XCDs in UNITS of `unit` consecutive blocks (2: a 64 x 32-px strip),
 //     round-robin: every XCD draws from every region of the image, so its share of the work is right whatever a tile's cost
 //     depends on — a cut into eight contiguous runs of equal PAIRS (the first version) was right at opacity 0.01 and left two XCDs
 //     15 % behind with trained opacities, where the blocks at the rim of the scene blend all they list and the interior ones

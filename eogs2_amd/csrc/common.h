@@ -31,6 +31,17 @@
                                 //   [8..11]  dL/dcolour2..4, -
                                 // (64-byte slots with zero padding in rounds 1-2: a quarter of the backward's record traffic)
 static_assert(REC == 12, "record quarters");
+// Where quarter q (16 bytes) of the record in slot `slot` lives, in float4 units: record-major (a record's 48 bytes side by
+// side). -DEOGS_REC_SOA=1 builds the quarter-major alternative — three planes of `plane` = capacity slots — tried in round 4 on
+// the idea that gaussian_bwd's lanes (one Gaussian each, its records 48 x tiles-per-Gaussian bytes from the neighbour lane's)
+// would coalesce better 16 x tiles apart: measured WORSE (gaussian_bwd 0.094 -> 0.111 ms, render_bwd 0.288 -> 0.300: a lane's
+// three quarters then sit in three cache lines instead of one or two; profiles/r04_experiments/ab_rec_soa.txt). Kept as a switch.
+#ifndef EOGS_REC_SOA
+#define EOGS_REC_SOA 0
+#endif
+__host__ __device__ inline size_t rec_q(size_t slot, int q, size_t plane, int quarters) {
+  return EOGS_REC_SOA ? (size_t)q * plane + slot : slot * (size_t)quarters + (size_t)q;
+}
 
 // ---- misc[] slots (u32) in the geometry workspace ----
 #define MISC_TOTAL_LO 0  // sum of tiles_touched (u64, lo/hi)
@@ -52,9 +63,10 @@ static_assert(REC == 12, "record quarters");
 // Tile schedule of the render launches (binning.hip tile_sched_body). It is computed by one workgroup that
 // holds every block's pair count: images up to 4096 blocks of 32 x 32 px (2048^2); larger ones keep the band mapping.
 #define SCHED_MAX_BLOCKS 4096u
-// Blocks are dealt to the XCDs in units of SCHED_UNIT consecutive blocks (EOGS_SCHED_UNIT=1..32 overrides: tuning aid); an
+// Blocks are dealt to the XCDs in units of SCHED_UNIT consecutive blocks (2: measured against 1, 4, 8 and 32 in six regimes,
+// profiles/r04_sched_units.txt; EOGS_SCHED_UNIT=1..32 overrides: tuning aid); an
 // XCD's sequence holds at most ceil(heavy / (8 unit)) unit + ceil(light / 8) <= nblocks / 8 + unit + 1 blocks.
-#define SCHED_UNIT 4u
+#define SCHED_UNIT 2u
 static inline uint32_t sched_unit() {
   static const uint32_t v = [] {
     const char* e = getenv("EOGS_SCHED_UNIT");

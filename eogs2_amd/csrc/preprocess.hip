@@ -442,8 +442,8 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
       // fixed-order sum of this Gaussian's (tile,Gaussian) records: deterministic, no atomics
       const uint32_t n = fits ? bi1.x : 0u;
       const size_t s0 = (size_t)pb + bi1.y;  // Gaussian-id order: a wave reads one contiguous region
-      constexpr int RS = ALT ? REC_ALT : REC;  // floats per record
-      const float4* r4 = reinterpret_cast<const float4*>(records + s0 * RS);
+      constexpr int RQ = (ALT ? REC_ALT : REC) / 4;  // quarters per record (common.h rec_q: quarter-major planes of cap_slots)
+      const float4* r4 = reinterpret_cast<const float4*>(records);
       uint32_t q_first = 0;
       if (n <= GB_DIRECT) {
         float4 ra[GB_DIRECT], rb[GB_DIRECT];
@@ -455,9 +455,9 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
           lv[u] = false;
           if (u < n) {
             lv[u] = live[s0 + qq] != 0;
-            ra[u] = r4[(RS / 4) * qq];
-            rb[u] = r4[(RS / 4) * qq + 1];
-            if (!ALT) rc[u] = reinterpret_cast<const float3*>(r4 + (RS / 4) * qq + 2)[0];
+            ra[u] = r4[rec_q(s0 + qq, 0, cap_slots, RQ)];
+            rb[u] = r4[rec_q(s0 + qq, 1, cap_slots, RQ)];
+            if (!ALT) rc[u] = reinterpret_cast<const float3*>(r4 + rec_q(s0 + qq, 2, cap_slots, RQ))[0];
           }
         }
 #pragma unroll
@@ -497,9 +497,9 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
 #pragma unroll
           for (int u = 0; u < 4; u++) {
             const uint32_t qq = have[u] ? q[u] : q[0];  // a valid address either way
-            ra[u] = r4[(RS / 4) * qq];
-            rb[u] = r4[(RS / 4) * qq + 1];
-            if (!ALT) rc[u] = reinterpret_cast<const float3*>(r4 + (RS / 4) * qq + 2)[0];
+            ra[u] = r4[rec_q(s0 + qq, 0, cap_slots, RQ)];
+            rb[u] = r4[rec_q(s0 + qq, 1, cap_slots, RQ)];
+            if (!ALT) rc[u] = reinterpret_cast<const float3*>(r4 + rec_q(s0 + qq, 2, cap_slots, RQ))[0];
           }
 #pragma unroll
           for (int u = 0; u < 4; u++) {

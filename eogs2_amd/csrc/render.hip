@@ -611,7 +611,7 @@ __device__ inline void group8_sum11(float (&c)[11]) {
 // survived), so a round may span several list chunks.
 __device__ inline void transpose_round(int nsurv, int lane, const float* rb, const float* s_u, const float* s_v,
                                        const float* s_pix, float bx0, float by0, float kx, float ky,
-                                       float* __restrict__ records, uint8_t* __restrict__ live_flag) {
+                                       float* __restrict__ records, uint8_t* __restrict__ live_flag, uint32_t rec_plane) {
   const int k = lane >> 3, o = lane & 7;
   const bool live = k < nsurv;
   const float4 q0 = *reinterpret_cast<const float4*>(rb + k * 8);      // gx gy A B
@@ -641,10 +641,10 @@ __device__ inline void transpose_round(int nsurv, int lane, const float* rb, con
     const float m2y = op * ky * (2.f * Cq * acc[2] - B * acc[1]);  // -c = 2C/log2e
     const float ho = -0.5f * op;
     const uint32_t slot = __float_as_uint(q1.z);
-    float4* dst = reinterpret_cast<float4*>(records + (size_t)slot * REC);  // layout: common.h REC
-    dst[0] = make_float4(m2x, m2y, ho * acc[3], acc[0]);
-    dst[1] = make_float4(ho * acc[4], ho * acc[5], acc[6], acc[7]);
-    reinterpret_cast<float3*>(dst + 2)[0] = make_float3(acc[8], acc[9], acc[10]);
+    float4* r4 = reinterpret_cast<float4*>(records);  // layout: common.h REC, rec_q
+    r4[rec_q(slot, 0, rec_plane, REC / 4)] = make_float4(m2x, m2y, ho * acc[3], acc[0]);
+    r4[rec_q(slot, 1, rec_plane, REC / 4)] = make_float4(ho * acc[4], ho * acc[5], acc[6], acc[7]);
+    reinterpret_cast<float3*>(r4 + rec_q(slot, 2, rec_plane, REC / 4))[0] = make_float3(acc[8], acc[9], acc[10]);
     live_flag[slot] = 1;  // pairs that never get here keep the 0 of the memset and are skipped by gaussian_bwd
   }
 }
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(RBLK) void render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx, const uint4* __restrict__ desc, const uint32_t* __restrict__ sched, int lg16,
     const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ out_color, const float* __restrict__ out_invdepth, const float* __restrict__ dL_dpix,
-    const float* __restrict__ dL_dinv, float* __restrict__ records, uint8_t* __restrict__ live_flag) {
+    const float* __restrict__ dL_dinv, float* __restrict__ records, uint8_t* __restrict__ live_flag, uint32_t rec_plane) {
   __shared__ __attribute__((aligned(16))) float s_slab[RBLK / 64][64 * ENT];
   __shared__ __attribute__((aligned(16))) float s_round[RBLK / 64][KSURV * 8];
   // u and v matrices of a wave sit UV_PITCH floats (a multiple of 64 dwords) apart: one ds_write2st64_b32 stores both
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(RBLK) void render_bwd_kernel(
       if (++k == KSURV) {
         stash(kstashed, KSURV);
         wave_lds_sync();
-        transpose_round(KSURV, lane, rb, su, sv, spix, bx0, by0, kx, ky, records, live_flag);
+        transpose_round(KSURV, lane, rb, su, sv, spix, bx0, by0, kx, ky, records, live_flag, rec_plane);
         wave_lds_sync();
         k = 0;
         kstashed = 0;
@@ -793,7 +793,7 @@ __global__ __launch_bounds__(RBLK) void render_bwd_kernel(
   }
   if (k) {  // the last, partial round
     wave_lds_sync();
-    transpose_round(k, lane, rb, su, sv, spix, bx0, by0, kx, ky, records, live_flag);
+    transpose_round(k, lane, rb, su, sv, spix, bx0, by0, kx, ky, records, live_flag, rec_plane);
   }
 }
 
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(RBLK) void render_bwd_btf_kernel(
     const uint4* __restrict__ desc, const uint32_t* __restrict__ sched, int lg16,
     const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib, const float* __restrict__ final_T,
     const float* __restrict__ bg, const float* __restrict__ dL_dpix, const float* __restrict__ dL_dinv,
-    float* __restrict__ records, uint8_t* __restrict__ live_flag) {
+    float* __restrict__ records, uint8_t* __restrict__ live_flag, uint32_t rec_plane) {
   __shared__ __attribute__((aligned(16))) float s_slab[RBLK / 64][64 * ENT];
   __shared__ __attribute__((aligned(16))) float s_round[RBLK / 64][KSURV * 8];
   __shared__ __attribute__((aligned(16))) float s_uv[RBLK / 64][UV_PITCH + UV_SIZE];
@@ -921,7 +921,7 @@ __global__ __launch_bounds__(RBLK) void render_bwd_btf_kernel(
       if (++k == KSURV) {
         stash(kstashed, KSURV);
         wave_lds_sync();
-        transpose_round(KSURV, lane, rb, su, sv, spix, bx0, by0, kx, ky, records, live_flag);
+        transpose_round(KSURV, lane, rb, su, sv, spix, bx0, by0, kx, ky, records, live_flag, rec_plane);
         wave_lds_sync();
         k = 0;
         kstashed = 0;
@@ -935,7 +935,7 @@ __global__ __launch_bounds__(RBLK) void render_bwd_btf_kernel(
   }
   if (k) {
     wave_lds_sync();
-    transpose_round(k, lane, rb, su, sv, spix, bx0, by0, kx, ky, records, live_flag);
+    transpose_round(k, lane, rb, su, sv, spix, bx0, by0, kx, ky, records, live_flag, rec_plane);
   }
 }
 
@@ -1099,7 +1099,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx, const uint4* __restrict__ desc, const uint32_t* __restrict__ sched, int lg16,
     const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ out_color, const float* __restrict__ out_invdepth, const float* __restrict__ dL_dpix,
-    const float* __restrict__ dL_dinv, float* __restrict__ records, uint8_t* __restrict__ live_flag) {
+    const float* __restrict__ dL_dinv, float* __restrict__ records, uint8_t* __restrict__ live_flag, uint32_t rec_plane) {
   // slab position 64 holds a DUMMY entry (opacity 0 -> alpha = 0 -> never valid): shorter sub-lists are padded with it
   __shared__ __attribute__((aligned(16))) float s_slab[RBLK / 64][65 * ENT];
   __shared__ __attribute__((aligned(16))) float s_uv[RBLK / 64][RED ? 2 * UV_PITCH : UV_PITCH + UV_SIZE];
@@ -1354,13 +1354,14 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
         const float m2x = op * kx * (2.f * A * acc[1] - B * acc[2]);
         const float m2y = op * ky * (2.f * Cq * acc[2] - B * acc[1]);
         const float ho = -0.5f * op;
-        float4* dst = reinterpret_cast<float4*>(records + (size_t)cur_slot * (ALT ? REC_ALT : REC));  // layout: common.h REC / REC_ALT
-        dst[0] = make_float4(m2x, m2y, ho * acc[3], acc[0]);
+        constexpr int RQ = (ALT ? REC_ALT : REC) / 4;  // layout: common.h REC / REC_ALT, rec_q
+        float4* r4 = reinterpret_cast<float4*>(records);
+        r4[rec_q(cur_slot, 0, rec_plane, RQ)] = make_float4(m2x, m2y, ho * acc[3], acc[0]);
         if (ALT) {
-          reinterpret_cast<float3*>(dst + 1)[0] = make_float3(ho * acc[4], ho * acc[5], acc[6]);
+          reinterpret_cast<float3*>(r4 + rec_q(cur_slot, 1, rec_plane, RQ))[0] = make_float3(ho * acc[4], ho * acc[5], acc[6]);
         } else {
-          dst[1] = make_float4(ho * acc[4], ho * acc[5], acc[6], acc[7]);
-          reinterpret_cast<float3*>(dst + 2)[0] = make_float3(acc[8], acc[9], acc[10]);
+          r4[rec_q(cur_slot, 1, rec_plane, RQ)] = make_float4(ho * acc[4], ho * acc[5], acc[6], acc[7]);
+          reinterpret_cast<float3*>(r4 + rec_q(cur_slot, 2, rec_plane, RQ))[0] = make_float3(acc[8], acc[9], acc[10]);
         }
         live_flag[cur_slot] = 1;
       }
@@ -1404,7 +1405,7 @@ __global__ __launch_bounds__(RBLK) void render_bwd_mfma_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx, const uint4* __restrict__ desc, const uint32_t* __restrict__ sched, int lg16,
     const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ out_color, const float* __restrict__ out_invdepth, const float* __restrict__ dL_dpix,
-    const float* __restrict__ dL_dinv, float* __restrict__ records, uint8_t* __restrict__ live_flag) {
+    const float* __restrict__ dL_dinv, float* __restrict__ records, uint8_t* __restrict__ live_flag, uint32_t rec_plane) {
   __shared__ __attribute__((aligned(16))) float s_slab[RBLK / 64][64 * ENT];
   __shared__ __attribute__((aligned(16))) float s_uv[RBLK / 64][2 * MUV];
   __shared__ uint32_t s_slot[RBLK / 64][64];
@@ -1606,13 +1607,14 @@ __global__ __launch_bounds__(RBLK) void render_bwd_mfma_kernel(
         } else {               // c1 c2 c3 c4
           out = make_float4(a0, a1, a2, a3);
         }
-        float* const rec = records + (size_t)slot * REC;  // every lane group stores its own pieces of the 48-byte record
-        if (kk == 0) *reinterpret_cast<float4*>(rec) = out;
-        else if (kk == 1) rec[4] = out.x;
-        else if (kk == 2) { rec[5] = out.x; rec[6] = out.y; }  // (8-byte store: misaligned at float 5)
+        float4* r4 = reinterpret_cast<float4*>(records);  // every lane group stores its own pieces of the 48-byte record
+        float* const q1p = reinterpret_cast<float*>(r4 + rec_q(slot, 1, rec_plane, REC / 4));
+        if (kk == 0) r4[rec_q(slot, 0, rec_plane, REC / 4)] = out;
+        else if (kk == 1) q1p[0] = out.x;
+        else if (kk == 2) { q1p[1] = out.x; q1p[2] = out.y; }  // (8-byte store: misaligned at float 5)
         else {
-          rec[7] = out.x;
-          *reinterpret_cast<float3*>(rec + 8) = make_float3(out.y, out.z, out.w);
+          q1p[3] = out.x;
+          *reinterpret_cast<float3*>(r4 + rec_q(slot, 2, rec_plane, REC / 4)) = make_float3(out.y, out.z, out.w);
         }
       }
     }
@@ -1652,7 +1654,7 @@ void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, 
   if (variant == 5) {
     auto* kb = dL_dinvdepth ? render_bwd_btf_kernel<true> : render_bwd_btf_kernel<false>;
     hipLaunchKernelGGL(kb, dim3(render_grid(ntiles, im, R)), dim3(RBLK), 0, s, im.ranges, b.point_list, W, H, gsx, ntiles, render_desc(im, R),
-                       g.sched, (int)(16u * im.sched_lg), g.packed, im.n_contrib, im.final_T, bg, dL_dcolor, dL_dinvdepth, b.records, b.live);
+                       g.sched, (int)(16u * im.sched_lg), g.packed, im.n_contrib, im.final_T, bg, dL_dcolor, dL_dinvdepth, b.records, b.live, b.cap_slots);
     return;
   }
   auto* kern = variant == 1 ? (dL_dinvdepth ? render_bwd_kernel<BLOCK_BIG, true> : render_bwd_kernel<BLOCK_BIG, false>)
@@ -1663,7 +1665,7 @@ void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, 
   if (variant == 4) kern = dL_dinvdepth ? render_bwd_quad_kernel<true, 1, false> : render_bwd_quad_kernel<false, 1, false>;
   hipLaunchKernelGGL(kern, dim3(render_grid(ntiles, im, R)), dim3(RBLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H, gsx,
                      ntiles, (int)macro_grid_x(W, b.block), render_desc(im, R), g.sched, (int)(16u * im.sched_lg), g.packed, im.n_contrib, out_color,
-                     out_invdepth, dL_dcolor, dL_dinvdepth, b.records, b.live);
+                     out_invdepth, dL_dcolor, dL_dinvdepth, b.records, b.live, b.cap_slots);
 }
 
 #ifdef EOGS_BWD_PHASES

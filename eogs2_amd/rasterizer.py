@@ -549,8 +549,10 @@ def _run_backward(rs, num_rendered, grad_out_color, grad_out_depth, means3D, col
             # DGR/diff_gaussian_rasterization/__init__.py:174-202, on the reduced sums.
             # (NCD2Screen @ dL_dT^T).sum(0): row k of the (3,2) result is scaled by NCD2Screen[k,k].
             with torch.no_grad():
-                ncd = torch.tensor([W / 2, H / 2, 1.0], **f32)
-                dL_dA = ncd[:, None] * dT_sum.view(2, 3).t()
+                # (scalars, not a host-built tensor: a host-to-device copy is not allowed while a HIP graph is being recorded)
+                dL_dA = dT_sum.view(2, 3).t().clone()
+                dL_dA[0] *= W / 2
+                dL_dA[1] *= H / 2
                 grad_viewmatrix[:3, :2] += dL_dA.to(grad_viewmatrix.dtype)
                 grad_viewmatrix[:3, :3] += dvm_mean[:9].view(3, 3).to(grad_viewmatrix.dtype)
                 grad_viewmatrix[-1, :3] += dvm_mean[9:].to(grad_viewmatrix.dtype)

@@ -68,12 +68,17 @@ def test_altitude_only_equals_channel_3_of_the_full_render(dev, P, H, W, seed, o
     assert torch.equal(a["out_radii"], b["out_radii"])
     assert torch.equal(a["altitude"], b["altitude"]), "forward: the same products in the same order"
     assert float(a["g_f_dc"].abs().max()) == 0.0 and float(b["g_f_dc"].abs().max()) == 0.0
+    # Same kernels' arithmetic on both sides (front-to-back quad backward): equal to rounding. A full render whose Gaussians
+    # list a tenth of the image each runs the reference's back-to-front recursion instead (token bit 60): the same
+    # gradient in the other formulation, which the front-to-back form follows to a few 1e-4 on such scenes (the allowance the
+    # forced front-to-back path tests carry, tests/util.py GRAD_RTOL_FRONT_TO_BACK) — outside a sun camera's operating range.
+    btf = (b["_token"] >> 60) & 1
+    assert btf or scale_mult < 8
     for k in a:
         if k.startswith("g_") and k != "g_viewmatrix":
-            # (the full render of image-sized Gaussians runs the back-to-front recursion: the same gradient, another formulation)
-            assert_close(a[k], b[k], f"alt-only vs full:{k}", rtol=1e-4 if scale_mult >= 10 else 2e-6, allow_flips=False)
+            assert_close(a[k], b[k], f"alt-only vs full:{k}", rtol=1e-3 if btf else 2e-6, allow_flips=False)
     scale = float((scene["means3D"].abs().t() @ b["g_means2D"].abs()).max())
-    assert float((a["g_viewmatrix"] - b["g_viewmatrix"]).abs().max()) <= 1e-5 * scale
+    assert float((a["g_viewmatrix"] - b["g_viewmatrix"]).abs().max()) <= (1e-3 if btf else 1e-5) * scale
 
 
 def test_altitude_only_matches_oracle(dev, monkeypatch):
