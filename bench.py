@@ -1133,6 +1133,8 @@ def main():
             line["train_iter"] = train_iteration(sc, P, H, W, dev, fused=False)
             line["train_iter_fused"] = train_iteration(sc, P, H, W, dev, fused=True)
             line["train_iter_fused_sun_altitude_only"] = train_iteration(sc, P, H, W, dev, fused=True, sun_altitude_only=True)
+            # the three renders queued on three streams (eogs2_amd.graph.Branches) in the EAGER loop
+            line["train_iter_fused_three_streams"] = train_iteration(sc, P, H, W, dev, fused=True, parallel=True)
             # The same step and the same iteration recorded into HIP graphs and replayed (eogs2_amd/graph.py): beside the
             # headline, never the headline — `value` stays the eager call through the reference's API. Measured in a child
             # process started after everything above is done: a failed capture must not cost this line.

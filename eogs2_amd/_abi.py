@@ -6,7 +6,7 @@ exports the same symbols over host pointers.
 """
 import ctypes as C
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 EOGS_OK = 0
 ERR_NAMES = {

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define EOGS_RAST_ABI_VERSION 6
+#define EOGS_RAST_ABI_VERSION 7 /* 7: EOGS_FLAG_ALT_ONLY, token bit 59 (list entries now 27 bits), `have_scratch | 2`, tile schedule in the workspaces */
 #define EOGS_RAST_CHANNELS 5 /* DGR/cuda_rasterizer/config.h:15 NUM_CHANNELS */
 #define EOGS_RAST_TILE 16    /* DGR/cuda_rasterizer/config.h:16-17 BLOCK_X/BLOCK_Y */
 

@@ -315,7 +315,9 @@ class Attribution:
 # bound on an error attributed to the oracle's own ill-conditioning, relative to its quantity's scale. Rounds 1-3: 1e-1 of the
 # TENSOR's scale. Round 4, per quantity: the default suite needs 6.5e-2 (sweep216, g_rotations, 7 elements: strongly anisotropic
 # Gaussians, the oracle itself moves by 0.13 there under 4-ulp perturbations), every other case stays below 3e-2 (profiles/r04_sweeps.txt).
-SENS_RTOL = 7e-2
+# The 1600 extended sweep seeds: 1598 pass at 7e-2; seeds 1259 and 4275 (axis spread 1.2, g_rotations) need 0.129 and 0.118 — the
+# oracle moves by more than a quarter of that itself — and pass with EOGS_SENS_RTOL=0.13 (tuning aid for such runs only).
+SENS_RTOL = float(os.environ.get("EOGS_SENS_RTOL", "7e-2"))
 
 
 def check_close(got, ref, what, rtol, attribution=None, key=None, sens_rtol=None):
