@@ -652,90 +652,198 @@ __global__ __launch_bounds__(ES_T) void entry_colscan_kernel(uint32_t* __restric
 // costs no launch of its own (a dependent one-workgroup launch is 6-9 us here) and no time on the stream — orders the
 // 32 x 32-px blocks for the render launches:
 //   * blocks with fewer than an eighth of the mean pair count are LIGHT (the empty rim of a scene); every XCD's sequence is its
-//     share of the other blocks, then of the light ones: a launch ends on cheap tiles, not on full ones;
-//   * the other blocks, in row-major order, are dealt to the XCDs in UNITS of `unit` consecutive blocks (2: a 64 x 32-px strip),
-//     round-robin: every XCD draws from every region of the image, so its share of the work is right whatever a tile's cost
-//     depends on — a cut into eight contiguous runs of equal PAIRS (the first version) was right at opacity 0.01 and left two XCDs
-//     15 % behind with trained opacities, where the blocks at the rim of the scene blend all they list and the interior ones
-//     stop early; inside a unit neighbouring blocks still share their Gaussians' records in the XCD's L2;
-//   * the light blocks are dealt one by one.
+//     share of the other blocks, then of the light ones: a launch ends on cheap tiles, not on full ones (without this class
+//     every variant below loses 3-4 %);
+//   * the other blocks, in row-major order, are cut into eight CONTIGUOUS runs — an XCD's blocks stay neighbours and its L2
+//     keeps serving the records neighbouring tiles share — of equal WORK, where a block's work is its listed pairs up to a cap:
+//     a tile stops blending once all its pixels are saturated, after about SCHED_K / (mean pair opacity) list entries, whatever
+//     its list still holds. With opacities of 0.1 and below nothing saturates and the runs hold equal pairs; with trained
+//     opacities every interior block is at the cap and the runs hold equal counts. (Equal pairs alone left two XCDs 15 % behind
+//     at trained opacities; dealing the blocks round-robin in units of 1-8 balanced every regime but cost the saturating ones
+//     2-3 % against contiguous runs — their footprints span 3 x 3 tiles and want their neighbours on the same XCD;
+//     profiles/r04_sched_units.txt, profiles/r04_experiments/ab_sched_modes*.txt);
+//   * the light blocks are dealt one by one;
+//   * a sequence holds at most lg blocks (the render grid is fixed before this runs): the blocks beyond are handed, in order,
+//     to the free places at the end of the other XCDs' sequences.
 // Output: sched[x] = blocks in XCD x's sequence, where[b] = XCD << 24 | position of block b. block_lists_kernel then writes the
 // descriptors of its block's 16 tiles (tile, list range) at that place of ImgWS::desc, so a render workgroup finds its tile AND
 // its list with one 16-byte load. Results never depend on the schedule (a tile's wave does the same arithmetic wherever it runs).
+// Five workgroup scans, no atomics (8 k same-address LDS atomics made the first version 10 us), no 64-bit division (the
+// scatter launch that carries it is compiled for 64 VGPRs).
 #define SCHED_T 1024
 #define SCHED_ITEMS ((int)SCHED_MAX_BLOCKS / SCHED_T)
+#define SCHED_C0 10u     // fixed cost of a tile's wave, in list entries
+#ifndef SCHED_K
+#define SCHED_K 60.0f    // list entries x mean pair opacity after which a tile counts as saturated. Bracketed by measurement: at
+#endif                   // opacity 0.1 (555 entries per tile) runs of equal PAIRS win by 2.5 % -> K >= 55; at opacity 0.3 (680
+                         // entries) runs of equal COUNT win by 4 % -> K <= 60 (profiles/r04_experiments/ab_sched_*.txt)
 namespace {
-// exclusive prefix over the workgroup of two 32-bit sums per thread; totals returned through `total`. All threads call.
-__device__ inline uint2 sched_scan(uint2 v, uint2* s_w, uint2& total) {
+__device__ inline uint4 u4_add(const uint4& a, const uint4& b) { return make_uint4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+// exclusive prefix over the workgroup of four 32-bit sums per thread; totals returned through `total`. All threads call.
+__device__ inline uint4 sched_scan(uint4 v, uint4* s_w, uint4& total) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  uint2 inc = v;
+  uint4 inc = v;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t nx = (uint32_t)__shfl_up((int)inc.x, d, 64), ny = (uint32_t)__shfl_up((int)inc.y, d, 64);
-    if (lane >= d) { inc.x += nx; inc.y += ny; }
+    const uint4 n = make_uint4((uint32_t)__shfl_up((int)inc.x, d, 64), (uint32_t)__shfl_up((int)inc.y, d, 64),
+                               (uint32_t)__shfl_up((int)inc.z, d, 64), (uint32_t)__shfl_up((int)inc.w, d, 64));
+    if (lane >= d) inc = u4_add(inc, n);
   }
   __syncthreads();
   if (lane == 63) s_w[w] = inc;
   __syncthreads();
-  uint2 base = make_uint2(0u, 0u), tot = make_uint2(0u, 0u);
+  uint4 base = make_uint4(0u, 0u, 0u, 0u), tot = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
   for (int k = 0; k < SCHED_T / 64; k++) {
-    const uint2 c = s_w[k];
-    if (k < w) { base.x += c.x; base.y += c.y; }
-    tot.x += c.x; tot.y += c.y;
+    const uint4 c = s_w[k];
+    if (k < w) base = u4_add(base, c);
+    tot = u4_add(tot, c);
   }
   total = tot;
-  return make_uint2(base.x + inc.x - v.x, base.y + inc.y - v.y);
+  return make_uint4(base.x + inc.x - v.x, base.y + inc.y - v.y, base.z + inc.z - v.z, base.w + inc.w - v.w);
+}
+// floor(8 a / b) for a < b, as the number of k in 1..7 with 8 a >= k b (b == 0: 0)
+__device__ inline uint32_t eighth_of(uint32_t a, uint32_t b) {
+  const unsigned long long a8 = 8ull * a;
+  uint32_t x = 0;
+#pragma unroll
+  for (uint32_t k = 1; k < 8; k++) x += (b != 0u && a8 >= (unsigned long long)k * b) ? 1u : 0u;
+  return x;
 }
 
-__device__ __forceinline__ void tile_sched_body(const uint32_t* __restrict__ bpairs, uint32_t nblocks, uint32_t lg, uint32_t unit,
-                                                uint32_t* __restrict__ sched, uint32_t* __restrict__ where) {
-  __shared__ uint2 s_w[SCHED_T / 64];
+__device__ __forceinline__ void tile_sched_body(const uint32_t* __restrict__ bpairs, const uint32_t* __restrict__ misc,
+                                                uint32_t nblocks, uint32_t lg, uint32_t flags, uint32_t* __restrict__ sched,
+                                                uint32_t* __restrict__ where) {
+  __shared__ uint4 s_w[SCHED_T / 64];
+  __shared__ uint32_t s_first[8], s_n0[8], s_nE[8], s_cnt[8], s_spill[8], s_free[9];
   const int t = threadIdx.x;
-  // thread t holds blocks t * SCHED_ITEMS ... in block (row-major) order; the pair sum fits 32 bits (pairs < 2^31, api.hip)
+  // thread t holds blocks t * SCHED_ITEMS ... in block (row-major) order; the sums below fit 32 bits (pairs < 2^31, api.hip)
   uint32_t wk[SCHED_ITEMS];
-  uint2 v = make_uint2(0u, 0u);
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
   for (int i = 0; i < SCHED_ITEMS; i++) {
     const uint32_t b = (uint32_t)t * SCHED_ITEMS + i;
     wk[i] = b < nblocks ? bpairs[b] : 0u;
     v.x += wk[i];
   }
-  uint2 tot;
+  uint4 tot;
   (void)sched_scan(v, s_w, tot);
   const unsigned long long total_pairs = tot.x;
+  // pairs of a block beyond which its tiles have saturated: 16 tiles x SCHED_K / (mean pair opacity), the mean pair opacity
+  // being sum(round(64 opacity)) / (64 pairs) over the listed pairs (misc[MISC_OPW], written by the count scan)
+  const float opw = (float)misc[MISC_OPW_LO] + 4294967296.0f * (float)misc[MISC_OPW_HI];
+  const float capf = (opw > 0.f && !(flags & 0x20u)) ? 16.0f * 64.0f * SCHED_K * (float)tot.x / opw : 4.0e9f;
+  const uint32_t cap = capf < 4.0e9f ? (uint32_t)capf : 0xFFFFFFFFu;
+  // raw[] keeps the pairs; wk[] becomes the block's WORK: its pairs up to the cap
+  uint32_t raw[SCHED_ITEMS];
+  v = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+  for (int i = 0; i < SCHED_ITEMS; i++) {
+    raw[i] = wk[i];
+    wk[i] = wk[i] < cap ? wk[i] : cap;
+    v.x += wk[i];
+  }
+  (void)sched_scan(v, s_w, tot);
+  const unsigned long long total_work = tot.x;
+  (void)total_pairs;
+  // light: less than an eighth of the mean work (compared as products). By WORK, not pairs: where tiles saturate early a rim
+  // block that blends all of its few pairs costs as much as an interior one and must not wait for the end of the launch
   bool light[SCHED_ITEMS];
-  v = make_uint2(0u, 0u);
+  v = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
   for (int i = 0; i < SCHED_ITEMS; i++) {
     const uint32_t b = (uint32_t)t * SCHED_ITEMS + i;
-    light[i] = 8ull * wk[i] * nblocks < total_pairs;  // fewer pairs than an eighth of the mean (compared as products)
-    if (b < nblocks) { if (light[i]) v.y++; else v.x++; }
+    light[i] = 8ull * wk[i] * nblocks < total_work;
+    if (b < nblocks && !light[i]) { v.x += raw[i]; v.y++; }
   }
-  uint2 run = sched_scan(v, s_w, tot);  // blocks of either kind before this thread's
-  const uint32_t n0 = tot.x, n1 = tot.y, round = 8u * unit;
-  // blocks of the first kind in XCD x's sequence: whole rounds of `unit` each, then what the last round leaves for x
-  auto heavy_in = [&](uint32_t x) {
-    const uint32_t rem = n0 % round;
-    return (n0 / round) * unit + (rem > x * unit ? (rem - x * unit < unit ? rem - x * unit : unit) : 0u);
-  };
-  if (t < 8) sched[t] = heavy_in((uint32_t)t) + n1 / 8u + ((uint32_t)t < n1 % 8u ? 1u : 0u);
-  if (t >= 8 && t < 16) sched[t] = 0u;
+  (void)sched_scan(v, s_w, tot);
+  // EDGE blocks (saturating regimes only: the mean block is beyond the cap): a block that lists clearly fewer pairs than its
+  // peers — under three quarters of their mean — but more than the cap is a block the scene covers only partly: the pixels the
+  // scene does not reach never saturate, its tiles walk their whole lists, and they are the launch's stragglers (wave traces
+  // at trained opacities: tiles of 90-130 us among a mean of 37, profiles/r04_wave_trace.txt). They start FIRST, dealt one by one.
+  const unsigned long long heavy_pairs = tot.x, heavy_n = tot.y;
+  const bool saturating = !(flags & 0x40u) && (unsigned long long)cap * heavy_n < heavy_pairs;
+  bool edge[SCHED_ITEMS];
+  v = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+  for (int i = 0; i < SCHED_ITEMS; i++) {
+    const uint32_t b = (uint32_t)t * SCHED_ITEMS + i;
+    edge[i] = saturating && !light[i] && raw[i] > cap && 4ull * raw[i] * heavy_n < 3ull * heavy_pairs;
+    wk[i] += 16u * SCHED_C0;
+    if (b < nblocks) {
+      if (light[i]) v.w++;
+      else if (edge[i]) v.z++;
+      else { v.x += wk[i]; v.y++; }
+    }
+  }
+  uint4 run = sched_scan(v, s_w, tot);  // before this thread's blocks: {work, count} of the run blocks, edge blocks, light blocks
+  const uint32_t nE = tot.z, n1 = tot.w;
+  uint32_t xcd[SCHED_ITEMS], crank[SCHED_ITEMS];
+  uint4 c0x = make_uint4(0u, 0u, 0u, 0u);  // run blocks per XCD, 16 bits each: x = {xcd 0, 1}, y = {2, 3}, z = {4, 5}, w = {6, 7}
+#pragma unroll
+  for (int i = 0; i < SCHED_ITEMS; i++) {
+    const uint32_t b = (uint32_t)t * SCHED_ITEMS + i;
+    xcd[i] = 0; crank[i] = 0;
+    if (b >= nblocks) continue;
+    if (light[i]) {
+      xcd[i] = run.w % 8u;
+      crank[i] = run.w++ / 8u;
+    } else if (edge[i]) {
+      xcd[i] = run.z % 8u;
+      crank[i] = run.z++ / 8u;
+    } else {
+      xcd[i] = eighth_of(run.x + wk[i] / 2u, tot.x);  // by the block's centre of work
+      crank[i] = run.y;
+      run.x += wk[i]; run.y++;
+      const uint32_t one = 1u << (16u * (xcd[i] & 1u));
+      c0x.x += (xcd[i] >> 1) == 0u ? one : 0u; c0x.y += (xcd[i] >> 1) == 1u ? one : 0u;
+      c0x.z += (xcd[i] >> 1) == 2u ? one : 0u; c0x.w += (xcd[i] >> 1) == 3u ? one : 0u;
+    }
+  }
+  uint4 c0tot;
+  (void)sched_scan(c0x, s_w, c0tot);  // (at most 4096 blocks: a 16-bit field cannot overflow into its neighbour)
+  if (t == 0) {
+    uint32_t first0 = 0, a = 0, f = 0;
+    for (uint32_t x = 0; x < 8; x++) {
+      const uint32_t pair = x >> 1 == 0 ? c0tot.x : (x >> 1 == 1 ? c0tot.y : (x >> 1 == 2 ? c0tot.z : c0tot.w));
+      const uint32_t n0x = (pair >> (16u * (x & 1u))) & 0xFFFFu;
+      const uint32_t nEx = nE / 8u + (x < nE % 8u ? 1u : 0u);
+      s_first[x] = first0;  // (the XCD rises with the rank among the run blocks: a run is contiguous in rank)
+      s_nE[x] = nEx;
+      s_n0[x] = n0x;
+      first0 += n0x;
+      const uint32_t c = nEx + n0x + n1 / 8u + (x < n1 % 8u ? 1u : 0u);
+      s_cnt[x] = c < lg ? c : lg;  // the XCD's own blocks that stay
+      s_spill[x] = a;              // spilled blocks of the XCDs before x
+      s_free[x] = f;               // free places of the XCDs before x
+      a += c > lg ? c - lg : 0u;
+      f += c < lg ? lg - c : 0u;
+    }
+    s_free[8] = f;
+    for (uint32_t x = 0; x < 8; x++) {  // final length of XCD x's sequence: its own blocks + the spilled ones that land in its free places
+      const uint32_t fr = s_free[x + 1] - s_free[x];
+      const uint32_t take = a > s_free[x] ? (a - s_free[x] < fr ? a - s_free[x] : fr) : 0u;
+      sched[x] = s_cnt[x] + take;
+      sched[8 + x] = 0u;
+    }
+  }
+  __syncthreads();
 #pragma unroll
   for (int i = 0; i < SCHED_ITEMS; i++) {
     const uint32_t b = (uint32_t)t * SCHED_ITEMS + i;
     if (b >= nblocks) continue;
-    uint32_t x, pos;
-    if (!light[i]) {
-      const uint32_t r = run.x++;
-      x = (r / unit) % 8u;
-      pos = (r / round) * unit + r % unit;
-    } else {
-      const uint32_t r = run.y++;
-      x = r % 8u;
-      pos = heavy_in(x) + r / 8u;
+    const uint32_t x = xcd[i];
+    // an XCD's sequence: its edge blocks, its run, its light blocks
+    uint32_t pos = light[i] ? s_nE[x] + s_n0[x] + crank[i] : (edge[i] ? crank[i] : s_nE[x] + crank[i] - s_first[x]);
+    uint32_t dst = x;
+    if (pos >= lg) {  // spilled: the r-th spilled block overall takes the r-th free place (8 lg >= nblocks: there is one)
+      const uint32_t r = s_spill[x] + (pos - lg);
+      uint32_t y = 0;
+      for (int k = 1; k < 8; k++) y += (r >= s_free[k]) ? 1u : 0u;
+      dst = y;
+      pos = s_cnt[y] + (r - s_free[y]);
     }
-    where[b] = (x << 24) | (pos < lg ? pos : lg - 1u);  // (pos < lg by construction: common.h sched_capacity)
+    where[b] = (dst << 24) | pos;
   }
 }
 }  // namespace
@@ -765,7 +873,7 @@ __global__ __launch_bounds__(T_, (NBITS <= 10 && T_ == 1024 ? ES_WAVES : 1)) voi
   constexpr int ES_ITEMS_ = ES_TILE / T_, ES_NW_ = T_ / 64;
   constexpr uint32_t nb = 1u << NBITS, mask = nb - 1u;
   if (T_ == SCHED_T && sched_blocks && blockIdx.x == gridDim.x - 1) {  // the launch's extra workgroup: the tile schedule
-    tile_sched_body(bpairs, sched_blocks, sched_lg & 0xFFFFFFu, sched_lg >> 24, sched, where);
+    tile_sched_body(bpairs, misc, sched_blocks, sched_lg & 0xFFFFFFu, sched_lg >> 24, sched, where);
     return;
   }
   const uint32_t n = entries_on_device(misc, cap);
@@ -903,9 +1011,10 @@ struct SchedArgs {
   uint32_t* sched;
   uint32_t* where;
 };
-__global__ __launch_bounds__(SCHED_T) void tile_sched_kernel(const uint32_t* __restrict__ bpairs, uint32_t nblocks, uint32_t lg,
-                                                             uint32_t* __restrict__ sched, uint32_t* __restrict__ where) {
-  tile_sched_body(bpairs, nblocks, lg & 0xFFFFFFu, lg >> 24, sched, where);
+__global__ __launch_bounds__(SCHED_T) void tile_sched_kernel(const uint32_t* __restrict__ bpairs, const uint32_t* __restrict__ misc,
+                                                             uint32_t nblocks, uint32_t lg, uint32_t* __restrict__ sched,
+                                                             uint32_t* __restrict__ where) {
+  tile_sched_body(bpairs, misc, nblocks, lg & 0xFFFFFFu, lg >> 24, sched, where);
 }
 template <int NBITS>
 static void launch_entry_scatter_n(uint32_t nblk, hipStream_t s, const uint4* in, uint4* out, const uint32_t* misc, uint32_t cap,
@@ -913,7 +1022,7 @@ static void launch_entry_scatter_n(uint32_t nblk, hipStream_t s, const uint4* in
   constexpr int T_ = NBITS <= 11 ? 1024 : 512;
   const bool ride = sa.blocks != 0u && T_ == SCHED_T;
   if (sa.blocks != 0u && !ride)
-    hipLaunchKernelGGL(tile_sched_kernel, dim3(1), dim3(SCHED_T), 0, s, sa.bpairs, sa.blocks, sa.lg, sa.sched, sa.where);
+    hipLaunchKernelGGL(tile_sched_kernel, dim3(1), dim3(SCHED_T), 0, s, sa.bpairs, misc, sa.blocks, sa.lg, sa.sched, sa.where);
   hipLaunchKernelGGL((entry_scatter_kernel<NBITS, T_>), dim3(nblk + (ride ? 1u : 0u)), dim3(T_), 0, s, in, out, misc, cap, shift,
                      hist, dtotal, sa.bpairs, ride ? sa.blocks : 0u, sa.lg, sa.sched, sa.where);
 }
@@ -943,8 +1052,8 @@ void launch_entry_sort(const GeomWS& g, const SortWS& w, int P, int H, int W, hi
     hipLaunchKernelGGL(entry_colscan_kernel, dim3((mask + 64u) / 64u), dim3(ES_T), 0, s, w.hist, histp, g.misc, w.cap, mask + 1u,
                        passes == 1 ? g.bcount : w.dtotal, g.bpairs);
     // (one pass <=> at most SCHED_MAX_BLOCKS blocks) the render launches' tile schedule goes with this launch
-    // (lg travels with the unit size in its top byte: both are launch constants of the schedule)
-    const SchedArgs sa{g.bpairs, (passes == 1 && sched_enabled()) ? nblocks : 0u, sched_capacity(nblocks) | (sched_unit() << 24), g.sched, g.where};
+    // (lg travels with the experiment switches in its top byte)
+    const SchedArgs sa{g.bpairs, (passes == 1 && sched_enabled()) ? nblocks : 0u, sched_capacity(nblocks) | (sched_flags() << 24), g.sched, g.where};
     launch_entry_scatter(bits, w.nblk, s, in, out, g.misc, w.cap, shift, w.hist, passes == 1 ? g.bcount : w.dtotal, sa);
     const uint4* t = in; in = out; out = const_cast<uint4*>(t);
   }

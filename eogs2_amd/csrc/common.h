@@ -63,19 +63,16 @@ __host__ __device__ inline size_t rec_q(size_t slot, int q, size_t plane, int qu
 // Tile schedule of the render launches (binning.hip tile_sched_body). It is computed by one workgroup that
 // holds every block's pair count: images up to 4096 blocks of 32 x 32 px (2048^2); larger ones keep the band mapping.
 #define SCHED_MAX_BLOCKS 4096u
-// Blocks are dealt to the XCDs in units of SCHED_UNIT consecutive blocks (2: measured against 1, 4, 8 and 32 in six regimes,
-// profiles/r04_sched_units.txt; EOGS_SCHED_UNIT=1..32 overrides: tuning aid); an
-// XCD's sequence holds at most ceil(heavy / (8 unit)) unit + ceil(light / 8) <= nblocks / 8 + unit + 1 blocks.
-#define SCHED_UNIT 2u
-static inline uint32_t sched_unit() {
+// An XCD's sequence holds up to 1.25 x its fair share of the blocks (+1): the equal-work cut gives an XCD whose blocks are
+// light more of them; what exceeds the capacity spills into the other XCDs' free places.
+static inline uint32_t sched_capacity(uint32_t nblocks) { return (nblocks + 7u) / 8u + (nblocks + 31u) / 32u + 1u; }
+static inline uint32_t sched_flags() {  // EOGS_SCHED_FLAGS: experiment switch of tile_sched_body (0x20 = no saturation cap), default 0
   static const uint32_t v = [] {
-    const char* e = getenv("EOGS_SCHED_UNIT");
-    const long u = e ? atol(e) : (long)SCHED_UNIT;
-    return (uint32_t)(u < 1 ? 1 : (u > 32 ? 32 : u));
+    const char* e = getenv("EOGS_SCHED_FLAGS");
+    return (uint32_t)(e ? strtoul(e, nullptr, 0) : 0ul) & 0xE0u;
   }();
   return v;
 }
-static inline uint32_t sched_capacity(uint32_t nblocks) { return nblocks / 8u + sched_unit() + 2u; }
 // EOGS_TILE_SCHED=0 switches the schedule off (A/B: the XCD band mapping of rounds 1-3)
 static inline bool sched_enabled() {
   static const bool v = [] {
