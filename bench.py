@@ -820,7 +820,7 @@ def cpu_baseline(P_full, S_full):
 
 def regime_scan(dev, steps=20):
     """The step in the regimes the headline does not show: same pipeline, same timing rule (steps
-    bracketed by synchronize, HBM-resident inputs), 20 steps each after 5 untimed ones. `frac` is the pipeline's algorithmic
+    bracketed by synchronize, HBM-resident inputs), the median of three windows of 20 steps each after 5 untimed ones. `frac` is the pipeline's algorithmic
     bytes (432 P + 268 R + 64 HW) over the step time against the 8 TB/s HBM peak, R = the library's own pair count."""
     from eogs2_amd import GaussianRasterizer
     from eogs2_amd.synthetic import make_scene, settings_for
@@ -843,20 +843,29 @@ def regime_scan(dev, steps=20):
                 torch.autograd.backward([c], [sc["dL_dcolor"]])
                 return c
 
+            t_ramp = time.perf_counter()  # the scene was built on the host: the GPU's clocks have dropped meanwhile
+            while time.perf_counter() - t_ramp < 0.4:
+                step()
+                torch.cuda.synchronize()
             for _ in range(5):
                 step()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                c = step()
-            torch.cuda.synchronize()
-            ms = (time.perf_counter() - t0) / steps * 1e3
+            # three windows of `steps` steps, the median reported: one host hiccup (the eager forward blocks on its count
+            # readback, so a 10 ms stall of the host is 10 ms of idle GPU) would otherwise be a regime's whole number
+            windows = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    c = step()
+                torch.cuda.synchronize()
+                windows.append((time.perf_counter() - t0) / steps * 1e3)
+            ms = sorted(windows)[1]
             nr = int(getattr(c.grad_fn, "num_rendered_exact", getattr(c.grad_fn, "num_rendered", -1)))
             R = nr & 0x7FFFFFFF
             by = 432 * P + 268 * R + 64 * S * S
             out[name] = {"gaussians": P, "size": S, "opacity": op, "steps": steps, "ms_per_step": ms, "views_per_s": 1e3 / ms,
                          "num_rendered": R, "list_block_px": 32 if (nr >> 62) & 1 else 8, "algorithmic_bytes": by,
-                         "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                         "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "windows_ms": windows}
             del sc, rast, params, m2, c
         except Exception as e:  # a regime must never cost the line
             out[name] = {"error": f"{type(e).__name__}: {e}"[:200]}
@@ -1005,9 +1014,11 @@ def main():
     abi.profile_select(1 << slots.index("render_bwd"))
     abi.profile_reset()
     abi.profile_enable(1)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
+    stamps = [0.0] * (a.steps + 1)  # host clock after each step's calls returned (no synchronisation: diagnostics only)
+    t0 = stamps[0] = time.perf_counter()
+    for i in range(a.steps):
         step()
+        stamps[i + 1] = time.perf_counter()
     fence()
     dt = time.perf_counter() - t0
     abi.profile_enable(0)
@@ -1118,8 +1129,13 @@ def main():
         # of the run obtained their counts (eogs2_amd/rasterizer.py: "hit" = queued whole on the previous forward's counts)
         from eogs2_amd import rasterizer as _rz
         ksum = float(sum(kern.values()))
+        # An eager forward blocks on its count readback (as the reference's does, rasterizer_impl.cu:284), so the host is never
+        # more than one step ahead and a stall of the host idles the GPU: the per-step host intervals of the timed region say
+        # whether `ms_per_step` is the steady state (median = mean) or carries a hiccup (max >> median).
+        iv = sorted((stamps[i + 1] - stamps[i]) * 1e3 for i in range(a.steps))
         line["host"] = {"kernel_sum_ms": ksum, "step_over_kernel_sum": ms_step / ksum if ksum > 0 else None,
-                        "count_readback": _rz.speculation_stats()}
+                        "count_readback": _rz.speculation_stats(),
+                        "timed_step_intervals_ms": {"median": iv[len(iv) // 2], "min": iv[0], "max": iv[-1]} if iv else None}
         if exchange is not None:
             exchange["backend"] = a.backend + (" (rehearsal: ranks share one GPU)" if a.share_gpu else "")
             line["exchange"] = exchange

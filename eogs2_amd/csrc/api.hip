@@ -17,6 +17,10 @@ thread_local uint32_t* g_pinned = nullptr;  // MISC_WORDS u32, pinned host memor
 // the forward_prepare whose count readback is still pending on this thread (EOGS_FLAG_DEFER_COUNTS)
 struct PendingCounts { bool valid; int P, H, W; bool have_scratch; uint32_t sort_cap; hipStream_t side; bool alt; };
 thread_local PendingCounts g_pending_counts = {false, 0, 0, 0, false, 0u, nullptr};
+// the side stream of a count copy into g_pinned that nobody has waited for yet (a deferred forward whose counts were never
+// asked for): the next forward_prepare drains it before it arms g_pinned again, or the old copy would land as the new counts
+thread_local hipStream_t g_copy_in_flight = nullptr;
+#define MIRROR_PENDING 0xFFFFFFFFu  // sentinel of a count word that has not arrived (never a legitimate high word of a count below 2^31)
 
 // per calling thread and device: a non-blocking side stream + event for the num_rendered readback
 struct Side { int dev; hipStream_t stream; hipEvent_t ev; };
@@ -219,9 +223,16 @@ int eogs_rast_forward_prepare(int P, int H, int W, const float* means3D, const f
   if (readback) {
     sd = side_for_current_device();
     if (!sd) return fail(EOGS_ERR_DEVICE, "forward_prepare: cannot create the readback stream");
+    // The host does not sleep on this copy (hipStreamSynchronize parks the thread after a short spin, and the wake-up — an
+    // interrupt plus the scheduler — is on the critical path of every eager forward: a late host is an idle GPU). It arms the
+    // pinned words with a sentinel here and polls them in eogs_rast_forward_counts, as a graph's host does with its mirror.
+    if (g_copy_in_flight) { HIP_TRY(hipStreamSynchronize(g_copy_in_flight)); g_copy_in_flight = nullptr; }
+    for (int i = 0; i < MISC_READBACK; i++) reinterpret_cast<volatile uint32_t*>(g_pinned)[i] = MIRROR_PENDING;
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
     HIP_TRY(hipEventRecord(sd->ev, s));
     HIP_TRY(hipStreamWaitEvent(sd->stream, sd->ev, 0));
     HIP_TRY(hipMemcpyAsync(g_pinned, g.misc, MISC_READBACK * sizeof(uint32_t), hipMemcpyDeviceToHost, sd->stream));
+    g_copy_in_flight = sd->stream;
   }
   if (have_scratch) {
     ProfScope ps(PS_BINNING, s);
@@ -299,8 +310,30 @@ int eogs_rast_forward_counts(int64_t* num_rendered) {
   const PendingCounts pc = g_pending_counts;
   g_pending_counts.valid = false;
   const int P = pc.P, H = pc.H, W = pc.W;
-  HIP_TRY(hipStreamSynchronize(pc.side));
-  return token_from_counts(g_pinned, P, H, W, pc.have_scratch, pc.sort_cap, num_rendered, pc.alt);
+  // Poll the armed words (forward_prepare); every 256 looks ask the stream, so a failed copy or a faulted kernel ends the wait
+  // with its error instead of spinning for ever. Arrived = every word replaced (eogs_rast_mirror_token's rule) and the tag.
+  const volatile uint32_t* v = g_pinned;
+  for (uint32_t spin = 1;; spin++) {
+    bool arrived = true;
+    for (int i = 0; i < MISC_READBACK; i++)
+      if (i != MISC_KEY_NMIN && v[i] == MIRROR_PENDING) { arrived = false; break; }
+    if (arrived) break;
+    if ((spin & 255u) == 0u) {
+      const hipError_t q = hipStreamQuery(pc.side);
+      if (q == hipSuccess) {  // the copy is done: its words are in memory
+        HIP_TRY(hipStreamSynchronize(pc.side));
+        break;
+      }
+      if (q != hipErrorNotReady) HIP_TRY(q);
+    }
+    __builtin_ia32_pause();
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  g_copy_in_flight = nullptr;
+  uint32_t m[MISC_READBACK];
+  for (int i = 0; i < MISC_READBACK; i++) m[i] = v[i];
+  if (m[MISC_TAG] != MISC_TAG_VALUE) return fail(EOGS_ERR_DEVICE, "forward_counts: the count words did not arrive");
+  return token_from_counts(m, P, H, W, pc.have_scratch, pc.sort_cap, num_rendered, pc.alt);
 }
 
 int eogs_rast_read_counts(int P, int H, int W, const void* geom, size_t geom_bytes, int have_scratch, void* stream,
@@ -319,7 +352,6 @@ int eogs_rast_read_counts(int P, int H, int W, const void* geom, size_t geom_byt
 }
 
 static_assert(MISC_READBACK * sizeof(uint32_t) <= EOGS_MIRROR_BYTES, "mirror buffer");
-#define MIRROR_PENDING 0xFFFFFFFFu  // (never a legitimate high word of a 64-bit count below 2^31)
 
 int eogs_rast_mirror_arm(void* host) {
   if (!host || ((uintptr_t)host & 63u)) return fail(EOGS_ERR_INVALID_ARG, "mirror_arm: NULL or unaligned host buffer");
