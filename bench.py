@@ -872,6 +872,28 @@ def regime_scan(dev, steps=20):
     return out
 
 
+def train_example_bench(P, S, iters=24):
+    """Extra (SURVEY.md §8 f, BASELINE's "train iters/s"): examples/train_synthetic.py at the headline size — the reference's
+    whole iteration with the shipped configuration (train_pan.py:262-400,663-690): view render, sun camera at 2H x 2W consumed
+    through its altitude alone, random virtual camera, both resampled onto the view, colour correction + shadow map + tint,
+    photometric loss, masked consistency pair, translucent-shadow regulariser, FusedAdam on the Gaussians + Adam on the camera —
+    eager and as a replayed HIP graph. ms per iteration over the last half of `iters` iterations (no prune inside)."""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import train_synthetic
+
+    out = {"gaussians": P, "size": S, "iters_timed": max(1, iters // 2),
+           "what": "3 renders (view, 2x sun altitude-only, random camera) + 2 resamples + render pipeline + losses + FusedAdam + camera Adam"}
+    for tag, extra in (("eager", []), ("graphed", ["--graph"])):
+        try:
+            train_synthetic.main(["--gaussians", str(P), "--size", str(S), "--iters", str(iters), "--quiet", "--no-prune",
+                                  "--sun-altitude-only", "--random-camera"] + extra)
+            ms = train_synthetic.main.last_ms_per_iter
+            out[tag] = {"ms_per_iter": ms, "iters_per_s": 1e3 / ms}
+        except Exception as e:  # an extra must never cost the line
+            out[tag] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    return out
+
+
 def main():
     a = parse()
     # read by the HSA runtime when it initialises: must be in the environment before the first torch.cuda call
@@ -1158,6 +1180,7 @@ def main():
             # the regimes beside the headline (worst case included): opacity 0.1, trained opacities, the 2048^2 sun-camera
             # size, 2 M Gaussians — `value` / `config` stay the headline's
             line["regimes"] = regime_scan(dev)
+            line["train_example"] = train_example_bench(P, H)
             line["photometric_loss"] = photometric_loss_bench(abi, dev, H, W)
             line["optimizer"] = optimizer_bench(abi, dev, P)
             line["resample"] = resample_bench(abi, dev, H, W)

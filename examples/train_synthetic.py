@@ -27,8 +27,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eogs2_amd.losses import photometric_loss  # noqa: E402
 from eogs2_amd.optim import FusedAdam, prune_optimizer  # noqa: E402
 from eogs2_amd.render import render  # noqa: E402
-from eogs2_amd.resample import resample  # noqa: E402
-from eogs2_amd.shade import render_pipeline, suncamera_l, translucentshadows_l  # noqa: E402
+from eogs2_amd.resample import render_resample_virtual_camera  # noqa: E402
+from eogs2_amd.shade import randomcam_l, render_pipeline, suncamera_l, translucentshadows_l  # noqa: E402
 from eogs2_amd.synthetic import make_camera, make_scene  # noqa: E402
 from simple_knn._C import distCUDA2  # noqa: E402
 
@@ -84,6 +84,14 @@ def main(argv=None):
     ap.add_argument("--graph", action="store_true",
                     help="record renders + losses + backward once into a HIP graph and replay it (eogs2_amd.graph.GraphedStep); "
                          "the optimizers stay outside, the graph is recorded again after every prune")
+    ap.add_argument("--sun-altitude-only", action="store_true",
+                    help="the sun camera renders and resamples its altitude channel alone — what the reference's shipped "
+                         "configuration consumes of it (iterstart_L_sun_resample is never reached, gs_config/train.yaml:123); "
+                         "the sun-camera RGB consistency term is then absent, as it is there")
+    ap.add_argument("--random-camera", action="store_true",
+                    help="third render of the iteration: a random virtual camera at the view's size, resampled onto the view, "
+                         "with the masked altitude / RGB consistency pair (train_pan.py:375-391, loss/main_loss.py:151-164)")
+    ap.add_argument("--no-prune", action="store_true", help="keep every Gaussian (timing runs)")
     a = ap.parse_args(argv)
     dev = torch.device("cuda:0")
     P, H, W = a.gaussians, a.size, a.size
@@ -92,6 +100,9 @@ def main(argv=None):
     sun = Camera(make_camera(2 * H, 2 * W, seed=5, device=dev), 2 * H, 2 * W)
     cam2sun = torch.eye(3, device=dev)
     cam2sun[:2, 2] = (sun.affine[2, :2] - cam.affine[2, :2]) / 350.0  # altitude-dependent shift between the two views
+    rnd = Camera(make_camera(H, W, seed=9, device=dev), H, W)
+    cam2rnd = torch.eye(3, device=dev)
+    cam2rnd[:2, 2] = (rnd.affine[2, :2] - cam.affine[2, :2]) / 350.0
     pipe = types.SimpleNamespace(debug=False, antialiasing=False, compute_cov3D_python=False, require_radii=True)
     bg = sc["bg"]
     U, V = torch.meshgrid(torch.linspace(-1, 1, W, device=dev), torch.linspace(-1, 1, H, device=dev), indexing="xy")
@@ -100,11 +111,16 @@ def main(argv=None):
         """train_pan.py:279-330: view render, sun render resampled onto the view, camera render pipeline."""
         out = render(cam, m, pipe, bg)
         img, altitude = out["render"][:3], out["render"][3]
-        sun_img = render(sun, m, pipe, bg)["render"]
-        sample, sun_uv = resample(sun_img, cam2sun, torch.stack((U, V, altitude / 350.0), dim=-1))
-        sun_altitude_diff = altitude - sample[3]
+        uva = torch.stack((U, V, altitude / 350.0), dim=-1)
+        sun_rgb, sun_alt, sun_uv = render_resample_virtual_camera(sun, cam2sun, uva, m, pipe, bg,
+                                                                  altitude_only=a.sun_altitude_only)
+        sun_altitude_diff = altitude - sun_alt
         shaded = render_pipeline(cc_cam, img, sun_altitude_diff)
-        return out, img, sample, sun_uv, sun_altitude_diff, shaded
+        new = None
+        if a.random_camera:  # train_pan.py:375-391 / loss/main_loss.py:123-164
+            new_rgb, new_alt, new_uv = render_resample_virtual_camera(rnd, cam2rnd, uva, m, pipe, bg)
+            new = (altitude - new_alt, new_rgb, new_uv)
+        return out, img, sun_rgb, sun_uv, sun_altitude_diff, shaded, new
 
     def colour_camera(perturb):
         c = types.SimpleNamespace(use_cc=True, use_exposure=False, use_shadow=True)
@@ -133,10 +149,15 @@ def main(argv=None):
         """Everything between two optimizer steps; reads the model's and the camera's parameter tensors in place."""
         model.optimizer.zero_grad(set_to_none=True)
         camera_optimizer.zero_grad(set_to_none=True)
-        out, img, sample, sun_uv, sun_altitude_diff, shaded = view(model, cc_cam)
+        out, img, sun_rgb, sun_uv, sun_altitude_diff, shaded, new = view(model, cc_cam)
         loss, _ = photometric_loss(shaded["final"], gt, 0.2)
-        L_sun_alt, L_sun_rgb = suncamera_l(img, sample[:3], sun_altitude_diff, sun_uv)
-        loss = loss + 1e-4 * L_sun_alt + 1e-3 * L_sun_rgb + 1e-3 * translucentshadows_l(shaded["shadowmap"])
+        loss = loss + 1e-3 * translucentshadows_l(shaded["shadowmap"])
+        if sun_rgb is not None:
+            L_sun_alt, L_sun_rgb = suncamera_l(img, sun_rgb, sun_altitude_diff, sun_uv)
+            loss = loss + 1e-4 * L_sun_alt + 1e-3 * L_sun_rgb
+        if new is not None:
+            L_new_alt, L_new_rgb = randomcam_l(new[0], img, new[1], new[2])
+            loss = loss + 1e-4 * L_new_alt + 1e-3 * L_new_rgb
         loss.backward()
         return loss.detach(), out["radii"]
 
@@ -144,7 +165,12 @@ def main(argv=None):
     step = None  # the recorded graph of fwd_bwd for the current set of Gaussians
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    t_steady = None  # (the clock of the last `timed` iterations: without the first ones, which allocate and record)
+    timed = max(1, a.iters // 2)
     for it in range(1, a.iters + 1):
+        if it == a.iters - timed + 1:
+            torch.cuda.synchronize()
+            t_steady = time.perf_counter()
         if a.graph:
             if step is None:
                 from eogs2_amd.graph import GraphedStep
@@ -157,7 +183,7 @@ def main(argv=None):
         camera_optimizer.step()
         with torch.no_grad():
             model.max_radii2D = torch.maximum(model.max_radii2D, radii.float())
-            if it % 50 == 0:  # train_pan.py:673-678
+            if it % 50 == 0 and not a.no_prune:  # train_pan.py:673-678
                 keep = model._opacity.squeeze() >= math.log(0.005 / 0.995)
                 if not bool(keep.all()):
                     model.prune(keep)
@@ -169,9 +195,12 @@ def main(argv=None):
             if not a.quiet:
                 print(f"iter {it:4d}  loss {v:.5f}  gaussians {model._xyz.shape[0]}")
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    dt = t1 - t0
+    main.last_ms_per_iter = (t1 - t_steady) / timed * 1e3  # steady state: the last half of the run
     if not a.quiet:
-        print(f"{a.iters} iterations in {dt:.2f} s ({dt / a.iters * 1e3:.2f} ms/iter, 2 renders + resample + render pipeline + losses + Adam each)")
+        print(f"{a.iters} iterations in {dt:.2f} s ({dt / a.iters * 1e3:.2f} ms/iter over all, {main.last_ms_per_iter:.2f} ms/iter over the "
+              f"last {timed}; {3 if a.random_camera else 2} renders + resample + render pipeline + losses + Adam each)")
     return first, last, model._xyz.shape[0]
 
 

@@ -131,6 +131,35 @@ def nudged_run(case, uniform=0, sign_map=None):
         lib.eogs_oracle_threshold_nudge(0, None, 0, None)
 
 
+_PREFETCH = {}
+
+
+def _nudged_job(case, uniform):
+    return nudged_run(case, uniform=uniform)
+
+
+def prefetch_nudges(case):
+    """Starts the two uniform nudged oracle runs of `case` in two worker processes (spawned: they import numpy, torch-CPU and
+    the oracle library, never the GPU) while the caller computes the un-nudged run and the HIP result. Only for the cases whose
+    oracle run takes tens of seconds (1 M Gaussians / 1024^2: 25 s per run, four runs in a row otherwise); the oracle's nudge
+    switch is process-global, so threads cannot do this. `Attribution.matched()` collects the results."""
+    import multiprocessing as mp
+
+    pool = mp.get_context("spawn").Pool(2)
+    _PREFETCH[id(case)] = (pool, {u: pool.apply_async(_nudged_job, (case, u)) for u in (-1, 1)})
+
+
+def _take_prefetched(case):
+    h = _PREFETCH.pop(id(case), None)
+    if h is None:
+        return None
+    pool, jobs = h
+    try:
+        return {u: j.get(timeout=600) for u, j in jobs.items()}
+    finally:
+        pool.terminate()
+
+
 def formulation_delta(case, base):
     """|oracle evaluated with the HIP path's formulation of dL/dalpha - oracle|: front to back, the sum behind a Gaussian
     taken as (rendered total - running prefix) instead of the reference's back-to-front recursion (render.hip; algebraically
@@ -257,7 +286,9 @@ class Attribution:
 
         if self._matched is None:
             t0 = time.perf_counter()
-            runs = {-1: nudged_run(self.case, uniform=-1), 0: self.ref, 1: nudged_run(self.case, uniform=1)}
+            pre = _take_prefetched(self.case)
+            runs = {-1: pre[-1] if pre else nudged_run(self.case, uniform=-1), 0: self.ref,
+                    1: pre[1] if pre else nudged_run(self.case, uniform=1)}
             H, W = int(self.case["H"]), int(self.case["W"])
             err = {}
             for sgn, r in runs.items():
@@ -435,6 +466,9 @@ def compare(out, ref, name, case, stats=None, cache=None):
                   f"(oracle moves by {float(delta.max()):.3e})")
             err = lim
         assert err <= lim, f"{name}:g_viewmatrix: {err:.3e} of the magnitude sum (limit {lim:g})"
+    leftover = _PREFETCH.pop(id(case), None)  # prefetched nudged runs nobody needed: every element was within tolerance
+    if leftover is not None:
+        leftover[0].terminate()
     if stats is not None:
         stats[name] = flips
     return flips

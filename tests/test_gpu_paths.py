@@ -150,7 +150,10 @@ def test_headline_1M_1024_matches_oracle(dev):
 
     import time
 
+    from parity_cases import prefetch_nudges
+
     case = _full_size_case(1 << 20, 1024, 1024, 0, "init")
+    prefetch_nudges(case)  # the two uniform nudged runs beside the un-nudged one: 100 s -> 50 s of wall time
     got = run_case(case, dev, GaussianRasterizer, GaussianRasterizationSettings)
     assert _lib.get().path_info(1 << 20, got["_num_rendered"]) == (8, 2, 2)  # the bench's kernels
     t0 = time.perf_counter()

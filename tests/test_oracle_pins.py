@@ -158,6 +158,15 @@ def test_threshold_nudge_moves_exactly_the_near_threshold_decision(oracle_backen
     assert all(np.array_equal(base[k], v) for k, v in nudged_run(case, sign_map=m).items())
     m[8, 8] = 1
     assert all(np.array_equal(up[k], v) for k, v in nudged_run(case, sign_map=m).items())
+    # the same two uniform runs taken in worker processes (prefetch_nudges: what the 1 M-Gaussian comparison does to halve its
+    # wall time) are the in-process ones, and an unused prefetch is dropped by compare()
+    from parity_cases import _PREFETCH, _take_prefetched, prefetch_nudges
+
+    prefetch_nudges(case)
+    pre = _take_prefetched(case)
+    assert id(case) not in _PREFETCH
+    for k in base:
+        assert np.array_equal(pre[-1][k], down[k]) and np.array_equal(pre[1][k], up[k]), k
 
 
 @pytest.mark.parametrize("P,H,W,seed,opacity,scale_mult", [(1500, 32, 32, 3, 0.6, 10.0), (2000, 40, 48, 7, 0.95, 15.0)])
