@@ -57,6 +57,11 @@ def parse():
                     help="collective backend; gloo + --share-gpu rehearses the N-rank path on a one-GPU box (not a measurement)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--graph-extras", action="store_true", help="child mode: the graph-replay measurements only")
+    ap.add_argument("--traffic-child", action="store_true",
+                    help="child mode (run under rocprofv3 --pmc by live_traffic()): a few steps of the headline workload, nothing else")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="skip the two rocprofv3 --pmc child runs that observe the dominant kernel's HBM traffic in this run "
+                         "(roofline.traffic then comes from the committed profile of the same kernel sources, or is null)")
     ap.add_argument("--graph-train-iter", action="store_true",
                     help="N ranks: also report the training iteration with its compute recorded into a HIP graph (opt-in)")
     ap.add_argument("--dry-run", action="store_true",
@@ -244,6 +249,90 @@ def measured_traffic(kernel, a):
         if hit:
             return int(total), os.path.relpath(d, ROOT)
     return None, None
+
+
+def live_traffic(a, kernels=("render_bwd", "render_fwd", "gaussian_bwd", "preprocess_fwd", "depth_sort", "binning")):
+    """HBM bytes per launch OBSERVED IN THIS RUN: two child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE and
+    WRITE_SIZE do not fit one pass; counters only, no trace domain beside them), a few steps of the same workload each, the
+    mean counter value per dispatch of each kernel. Corrections per MI355X_MICROARCH.md (its HBM / rocprofv3 section): both
+    counters are in KiB, FETCH_SIZE counts 128-byte requests as 64 bytes on gfx950 -> doubled. The children are started as
+    child processes from /tmp (the profiler writes there), the program itself after `--`. Returns ({kernel group: bytes},
+    note); ({}, reason) when the profiler is not there or a pass fails — the caller falls back to the committed profile."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {}, "rocprofv3 not found"
+    means = {}
+    t0 = time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="eogs_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+               "--traffic-child", "--gaussians", str(a.gaussians), "--size", str(a.size), "--opacity", str(a.opacity)]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT, timeout=180)
+            if r.returncode != 0:
+                return {}, f"rocprofv3 --pmc {counter}: exit {r.returncode}"
+            agg = collections.defaultdict(list)
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] == counter:
+                        agg[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+            if not agg:
+                return {}, f"rocprofv3 --pmc {counter}: no counter rows"
+            means[counter] = {k: sum(v) / len(v) for k, v in agg.items()}
+        except Exception as e:
+            return {}, f"rocprofv3 --pmc {counter}: {type(e).__name__}: {e}"[:160]
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    res = {}
+    groups = {"depth_sort": ("block_lists_kernel",),  # a launch group of the library (kernels_ms key) -> its kernels, once per step each
+              "binning": ("pblock_scan_kernel", "expand_entries_kernel", "entry_hist_kernel", "entry_colscan_kernel", "entry_scatter_kernel")}
+    for g in kernels:
+        names = groups.get(g, (g + "_kernel", g + "_quad_kernel"))
+        tot, hit = 0.0, 0
+        for nm in names:
+            pick = lambda c: [v for k, v in means[c].items() if k.replace("void ", "").startswith(nm)]
+            f, w = pick("FETCH_SIZE"), pick("WRITE_SIZE")
+            if f and w:  # (one variant of a kernel runs per workload)
+                tot += (2.0 * max(f) + max(w)) * 1024
+                hit += 1
+        if hit and (g in groups or hit == 1):
+            res[g] = int(tot)
+    return res, f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two child runs of this command's workload ({time.perf_counter() - t0:.0f} s)"
+
+
+def traffic_child(a):
+    """The workload of live_traffic()'s children: 2 + 4 steps of the bench step, no clock ramp (counters, not time)."""
+    from eogs2_amd import GaussianRasterizer
+    from eogs2_amd.synthetic import make_camera, make_scene, settings_for
+
+    dev = torch.device("cuda", 0)
+    P, H, W = a.gaussians, a.size, a.size
+    try:
+        opacity = float(a.opacity)
+    except ValueError:
+        opacity = a.opacity
+    sc = make_scene(P, H, W, seed=0, opacity=opacity, device=dev)
+    sc["viewmatrix"] = make_camera(H, W, seed=0, device=dev)
+    rast = GaussianRasterizer(settings_for(sc, H, W))
+    params = {k: sc[k].clone().requires_grad_(True) for k in ("means3D", "colors", "opacities", "scales", "rotations")}
+    m2 = torch.zeros(P, 3, device=dev, requires_grad=True)
+    for _ in range(6):
+        for p in params.values():
+            p.grad = None
+        m2.grad = None
+        c, _, _ = rast(params["means3D"], m2, params["opacities"], colors_precomp=params["colors"], scales=params["scales"],
+                       rotations=params["rotations"])
+        torch.autograd.backward([c], [sc["dL_dcolor"]])
+    torch.cuda.synchronize()
+    return 0
 
 
 def _profile_is_current(pmc_json):
@@ -911,6 +1000,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
     if a.graph_extras:
         return graph_extras(a)
+    if a.traffic_child:
+        return traffic_child(a)
     dev = torch.device("cuda", 0 if a.share_gpu else local_rank)
     torch.cuda.set_device(dev)
     dist = None
@@ -1097,9 +1188,13 @@ def main():
             "gaussian_bwd": 300 * P,
         }
         roof = None
+        live = {}
         if dom:
             ach = alg[dom] / (kern[dom] * 1e-3) / 1e9
-            traffic, tsrc = measured_traffic(dom, a)
+            # observed in this run (rocprofv3 --pmc children) where the profiler is there; else the committed profile of the
+            # same kernel sources; else null
+            live, live_note = ({}, "disabled") if (a.no_live_traffic or use_dist) else live_traffic(a)
+            traffic, tsrc = (live[dom], live_note) if dom in live else measured_traffic(dom, a)
             roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                     "algorithmic_bytes": alg[dom], "kernel_ms": kern[dom]}
@@ -1126,7 +1221,7 @@ def main():
         per_kernel = {}
         for k, ms in kern.items():
             if k in alg and ms > 0:
-                tr, _ = measured_traffic(k, a)
+                tr = live[k] if (dom and k in live) else measured_traffic(k, a)[0]
                 per_kernel[k] = {"algorithmic_bytes": alg[k], "achieved": alg[k] / (ms * 1e-3) / 1e9,
                                  "frac": alg[k] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tr}
         pipe_bytes = 432 * P + 268 * R + 64 * npx

@@ -1094,8 +1094,11 @@ __device__ unsigned long long g_bwd_phase[PHASE_TILES][6];  // per tile (wave): 
 // single planes (channel 3); one product instead of a five-term dot per pair, one colour sum instead of five in the
 // transposition, 7 instead of 11 values through the DPP merge, the staging area and the owner pull, and a 32-byte record
 // {mean2D.x, .y, conic.a, opacity | conic.b, conic.c, colour3, -} (REC_ALT) that gaussian_bwd_kernel<., true> reads.
+#ifndef EOGS_BW
+#define EOGS_BW 4  // waves per SIMD the quad backward is compiled for (10 KB of LDS per wave: four fit)
+#endif
 template <bool HAVE_INV, int RED, bool ALT>
-__global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(4, 4))) void render_bwd_quad_kernel(
+__global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, EOGS_BW))) void render_bwd_quad_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx, const uint4* __restrict__ desc, const uint32_t* __restrict__ sched, int lg16,
     const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ out_color, const float* __restrict__ out_invdepth, const float* __restrict__ dL_dpix,

@@ -72,6 +72,11 @@ def test_one_gpu_bench_line_and_its_graph_extras():
         assert k in line, k
     assert line["n_gpus"] == 1 and line["steps"] == 5 and line["dtype"] == "f32" and line["vs_baseline"] is None
     assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
+    # HBM traffic of the dominant kernel observed in THIS run (two rocprofv3 --pmc children, bench.live_traffic)
+    assert str(line["roofline"]["traffic_source"]).startswith("live"), line["roofline"]
+    assert line["roofline"]["traffic"] > 0
+    te = line["train_example"]
+    assert te["eager"]["ms_per_iter"] > 0 and te["graphed"]["ms_per_iter"] > 0, te
     host = line["host"]
     assert host["kernel_sum_ms"] > 0 and host["count_readback"]["hit"] == 0  # the eager headline waits for its counts
     gs = line["graphed_step"]

@@ -4,7 +4,7 @@
 IFS='|' read -ra ENVS <<< "$1"; IFS='|' read -ra ARGS <<< "$2"; OUT=gpurun_out/ab3.txt; : > $OUT
 for a in "${ARGS[@]}"; do
   for e in "${ENVS[@]}"; do
-    env $e python bench.py --no-cpu-baseline --no-train-iter --steps 60 $a > gpurun_out/ab_tmp.json 2>/dev/null || exit 1
+    env $e python bench.py --no-cpu-baseline --no-train-iter --no-live-traffic --steps 60 $a > gpurun_out/ab_tmp.json 2>/dev/null || exit 1
     python - "[$e] [$a]" >> $OUT <<'PY'
 import json,sys
 d=json.loads(open('gpurun_out/ab_tmp.json').read().strip().splitlines()[-1])

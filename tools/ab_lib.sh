@@ -6,7 +6,7 @@ cp eogs2_amd/libeogs_rast_hip.so /tmp/eogs_keep.so
 for a in "${ARGS[@]}"; do
   for l in "${LIBS[@]}"; do
     cp eogs2_amd/variants/$l.so eogs2_amd/libeogs_rast_hip.so
-    python bench.py --no-cpu-baseline --no-train-iter --steps 60 $a > gpurun_out/ab_tmp.json 2>/dev/null || { cp /tmp/eogs_keep.so eogs2_amd/libeogs_rast_hip.so; exit 1; }
+    python bench.py --no-cpu-baseline --no-train-iter --no-live-traffic --steps 60 $a > gpurun_out/ab_tmp.json 2>/dev/null || { cp /tmp/eogs_keep.so eogs2_amd/libeogs_rast_hip.so; exit 1; }
     python - "[$l] [$a]" >> $OUT <<'PY'
 import json,sys
 d=json.loads(open('gpurun_out/ab_tmp.json').read().strip().splitlines()[-1])

@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O="$R/gpurun_out/prof_$TAG"
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train-iter $BENCH_ARGS"
+B="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train-iter --no-live-traffic $BENCH_ARGS"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- $B > "$O/stats.log" 2>&1
 [ -n "$KEEP_TRACE" ] || find "$O/stats" -name "*kernel_trace.csv" -delete   # tens of MB; gpurun_out is capped at 64 MiB
 if [ -z "$STATS_ONLY" ]; then

@@ -3,7 +3,7 @@
 # kernel against the two forced alternatives, over Gaussian count, image size and opacity. Output: gpurun_out/regime_scan.txt
 OUT=gpurun_out/regime_scan.txt; mkdir -p gpurun_out; : > $OUT
 run() {  # $1 = env assignments, $2 = bench args
-  env $1 python bench.py --no-cpu-baseline --no-train-iter --steps 60 $2 2>/dev/null | python -c "
+  env $1 python bench.py --no-cpu-baseline --no-train-iter --no-live-traffic --steps 60 $2 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); c=d['config']
 print('%.3f blk %d tiles/G %.2f' % (d['ms_per_step'], c['list_block_px'], c['num_rendered']/c['gaussians']))"
