@@ -60,8 +60,10 @@ __global__ __launch_bounds__(BLK) void resample_fwd_kernel(int C, int Hv, int Wv
 // dL/duva needs only per-pixel data. dL/dvirtual_render is a scatter of four taps per output pixel; global fp32 atomics
 // sustain only ~26 G/s here (0.7 ms for a 1024^2 grid), so the scatter is turned into a gather by VIRTUAL tile:
 //   pixel kernel : per 16x16 output tile, dL/duva and the bounding box of the cells its pixels touch;
-//   tile kernel  : one workgroup per 64x32 virtual tile accumulates, in LDS, the taps of every output tile whose box
-//                  meets it (recomputing the few coordinates involved), then writes its tile with plain stores.
+//   tile kernel  : one workgroup per virtual tile collects the taps of every output tile whose box meets it (recomputing the
+//                  few coordinates involved), then writes its tile with plain stores. Two forms: resample_bwd_tile_kernel
+//                  (round 2: ds_add_f32 into an LDS image of the tile) and resample_bwd_gather_kernel (round 4, the default:
+//                  pixels bucketed by tap cell with integer atomics, cells gather their buckets; profiles/r04_resample_bwd.txt).
 // No global atomics, no memset; every virtual pixel is written exactly once.
 constexpr int OT = 16;  // output tile edge (256 pixels = one workgroup)
 
@@ -213,6 +215,198 @@ __global__ __launch_bounds__(BLK) void resample_bwd_tile_kernel(int C, int Hv, i
   }
 }
 
+// ---- tile kernel, second form (round 4): bucketed gather, no float atomics ----
+// The first form spends its time in ds_add_f32: four taps x n_out channels per output pixel, ~2 LDS cycles per lane each
+// (profiles/r04 resample probes: 72-107 us per backward at 1024^2). Here a pixel that lands in the tile costs two INTEGER LDS
+// atomics: the workgroup takes its candidate output tiles four at a time (1024 pixels),
+//   count : every pixel whose north-west tap cell (x0, y0) lies in [vx0-1, vx0+VTX) x [vy0-1, vy0+VTY) — the cells whose taps can
+//           reach the tile — adds one to the counter of that cell's BUCKET;
+//   scan  : exclusive prefix of the (VTX+1) x (VTY+1) counters;
+//   fill  : the same pixels again, each takes the next place of its bucket and parks {wx1, wy1, g[0..3]} there;
+//   gather: every virtual cell (cx, cy) of the tile — a few per thread, accumulators in registers — adds the entries of its four
+//           buckets (x0, y0) in {cx-1, cx} x {cy-1, cy} with the tap weight that cell has in them,
+// and writes its cells once with plain stores. Every tap of every pixel is counted exactly once, by the tile that owns its
+// cell; taps outside the virtual image have no cell. The order of the few entries of a bucket is the order of the atomics, so
+// — like the first form, and like grid_sample's backward in the reference — sums are reproducible to rounding, not bit for bit.
+template <int NACC, int VX, int VY>
+__global__ __launch_bounds__(BLK) void resample_bwd_gather_kernel(int C, int Hv, int Wv, int H, int W, int n_out,
+                                                                  const float* __restrict__ uva, const float* __restrict__ M,
+                                                                  int fill_channel, const float* __restrict__ gs,
+                                                                  const int4* __restrict__ bbox, int ntx, int nty,
+                                                                  float* __restrict__ gvr) {
+  constexpr int BXN = VX + 1, BYN = VY + 1, NB = BXN * BYN;  // buckets: north-west cells x0 = vx0-1 .. vx0+VX-1
+  constexpr int CHT = NACC == 1 ? 8 : 4;                       // candidate output tiles per chunk
+  // boxes per scan round, each thread's loads independent. One channel: the whole 1024^2 grid in one round (38.9 us against
+  // 46.5 with rounds of 1024 at 2048^2); four channels: rounds of 1024 — the parked entries already take 24 KB of LDS and the
+  // larger candidate list costs the fourth resident workgroup (70.9 -> 78.2 us, 31.8 -> 39.1 at 1024^2)
+  constexpr int RB = NACC == 1 ? 4096 : 1024;
+  constexpr int CAP = CHT * OT * OT;                           // entries a chunk can park
+  constexpr int PAY = 2 + NACC;                                // floats per entry: wx1, wy1, g[NACC]
+  constexpr int CPT = VX * VY / BLK;                           // cells per thread
+  static_assert(VX * VY % BLK == 0 && BLK == OT * OT, "cells dealt evenly; one thread per pixel of an output tile");
+  __shared__ uint32_t s_cnt[NB + 1];
+  __shared__ uint32_t s_start[NB + 1];
+  __shared__ float s_pay[CAP * PAY];
+  __shared__ uint16_t s_list[RB];  // candidates of the round, as offsets into it
+  __shared__ uint32_t s_n;
+  __shared__ uint32_t s_wsum[BLK / 64];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int vx0 = blockIdx.x * VX, vy0 = blockIdx.y * VY;
+  const int HW = H * W;
+  const int nt = ntx * nty;
+  float acc[CPT][NACC];
+#pragma unroll
+  for (int c = 0; c < CPT; c++)
+#pragma unroll
+    for (int ch = 0; ch < NACC; ch++) acc[c][ch] = 0.f;
+  for (int e = t; e <= NB; e += BLK) s_cnt[e] = 0u;
+
+  for (int scanned = 0; scanned < nt; scanned += RB) {  // candidate output tiles: RB boxes per round (one round at 1024^2)
+    if (t == 0) s_n = 0;
+    __syncthreads();
+    {
+      int4 bb[RB / BLK];
+#pragma unroll
+      for (int i = 0; i < RB / BLK; i++) {
+        const int k = scanned + i * BLK + t;
+        bb[i] = k < nt ? bbox[k] : make_int4(1, 1, 0, 0);  // (empty box: x0 > x1)
+      }
+#pragma unroll
+      for (int i = 0; i < RB / BLK; i++)
+        if (bb[i].x <= bb[i].z && bb[i].x <= vx0 + VX - 1 && bb[i].z >= vx0 && bb[i].y <= vy0 + VY - 1 && bb[i].w >= vy0)
+          s_list[atomicAdd(&s_n, 1u)] = (uint16_t)(i * BLK + t);
+    }
+    __syncthreads();
+    const uint32_t n = s_n;
+    for (uint32_t k0 = 0; k0 < n; k0 += CHT) {
+      const uint32_t kn = min(n - k0, (uint32_t)CHT);
+      // This thread's pixel of each of the chunk's candidate tiles. The loads of all CHT pixels are issued before anything
+      // waits for one of them (the first version walked the candidates one by one and spent its time in four dependent
+      // round trips per pass: 98 us per backward at 2048^2 against 113 for the atomics it had been written to avoid).
+      size_t pix[CHT];
+      float ua[CHT], ub[CHT], uc[CHT];
+      bool in_img[CHT];
+#pragma unroll
+      for (int k = 0; k < CHT; k++) {
+        const int tile = (uint32_t)k < kn ? scanned + (int)s_list[k0 + k] : 0;
+        const int x = (tile % ntx) * OT + (t & (OT - 1)), y = (tile / ntx) * OT + (t >> 4);
+        in_img[k] = (uint32_t)k < kn && x < W && y < H;
+        pix[k] = in_img[k] ? (size_t)y * W + x : 0;
+        ua[k] = uva[3 * pix[k]]; ub[k] = uva[3 * pix[k] + 1]; uc[k] = uva[3 * pix[k] + 2];
+      }
+      int bucket[CHT];
+      float wx1[CHT], wy1[CHT];
+      bool outside[CHT];
+      // count
+#pragma unroll
+      for (int k = 0; k < CHT; k++) {
+        const float u = M[0] * ua[k] + M[1] * ub[k] + M[2] * uc[k], v = M[3] * ua[k] + M[4] * ub[k] + M[5] * uc[k];
+        const Taps tp = make_taps(u, v, Wv, Hv);
+        const int lx = tp.x0 - vx0, ly = tp.y0 - vy0;
+        const bool lands = in_img[k] && lx >= -1 && lx < VX && ly >= -1 && ly < VY;
+        bucket[k] = lands ? (ly + 1) * BXN + (lx + 1) : -1;
+        wx1[k] = tp.wx1; wy1[k] = tp.wy1;
+        outside[k] = fabsf(u) > 1.f || fabsf(v) > 1.f;
+        if (lands) atomicAdd(&s_cnt[bucket[k]], 1u);
+      }
+      // the gradients the fill pass parks: requested now, used after the scan
+      float gq[CHT][NACC];
+#pragma unroll
+      for (int k = 0; k < CHT; k++)
+#pragma unroll
+        for (int ch = 0; ch < NACC; ch++) {
+          float g = (bucket[k] >= 0 && ch < n_out) ? gs[(size_t)ch * HW + pix[k]] : 0.f;
+          if (ch == fill_channel && outside[k]) g = 0.f;  // the value was overwritten by a constant
+          gq[k][ch] = g;
+        }
+      __syncthreads();
+      // exclusive scan of the NB counters: thread t owns a contiguous run, waves chained through s_wsum
+      {
+        constexpr int PER = (NB + BLK - 1) / BLK;
+        uint32_t loc[PER], sum = 0;
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+          const int e = t * PER + i;
+          loc[i] = e < NB ? s_cnt[e] : 0u;
+          sum += loc[i];
+        }
+        uint32_t inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t nb2 = __shfl_up(inc, o, 64);
+          if (lane >= o) inc += nb2;
+        }
+        if (lane == 63) s_wsum[wv] = inc;
+        __syncthreads();
+        uint32_t pre = inc - sum;
+#pragma unroll
+        for (int k = 0; k < BLK / 64; k++)
+          if (k < wv) pre += s_wsum[k];
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+          const int e = t * PER + i;
+          if (e < NB) { s_start[e] = pre; s_cnt[e] = 0u; }
+          pre += loc[i];
+        }
+      }
+      __syncthreads();
+      // fill
+#pragma unroll
+      for (int k = 0; k < CHT; k++) {
+        if (bucket[k] >= 0) {
+          const uint32_t pos = s_start[bucket[k]] + atomicAdd(&s_cnt[bucket[k]], 1u);
+          float* e = s_pay + pos * PAY;
+          e[0] = wx1[k]; e[1] = wy1[k];
+#pragma unroll
+          for (int ch = 0; ch < NACC; ch++) e[2 + ch] = gq[k][ch];
+        }
+      }
+      __syncthreads();
+      // gather: cell (lx, ly) <- buckets (lx + dx, ly + dy), dx, dy in {0, 1}: bucket column lx holds x0 = cell - 1 (the cell is
+      // the EAST tap: weight wx1), column lx + 1 holds x0 = cell (WEST tap: 1 - wx1); rows likewise
+#pragma unroll
+      for (int c = 0; c < CPT; c++) {
+        const int cell = c * BLK + t, lx = cell % VX, ly = cell / VX;
+#pragma unroll
+        for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+          for (int dx = 0; dx < 2; dx++) {
+            const int bk = (ly + dy) * BXN + lx + dx;
+            const uint32_t cnt = s_cnt[bk];
+            if (cnt == 0u) continue;
+            const uint32_t st = s_start[bk];
+            for (uint32_t e = st; e < st + cnt; e++) {
+              const float* q = s_pay + e * PAY;
+              const float wx = dx ? 1.f - q[0] : q[0], wy = dy ? 1.f - q[1] : q[1];
+              const float wgt = wx * wy;
+#pragma unroll
+              for (int ch = 0; ch < NACC; ch++) acc[c][ch] += q[2 + ch] * wgt;
+            }
+          }
+      }
+      __syncthreads();
+      for (int e = t; e <= NB; e += BLK) s_cnt[e] = 0u;  // (ordered against the next count pass by the barrier that follows)
+      __syncthreads();
+    }
+  }
+  // every virtual pixel of the tile, every channel (channels >= n_out get zeros): plain coalesced stores
+  const size_t plane = (size_t)Hv * Wv;
+#pragma unroll
+  for (int c = 0; c < CPT; c++) {
+    const int cell = c * BLK + t, lx = cell % VX, ly = cell / VX;
+    const int gx = vx0 + lx, gy = vy0 + ly;
+    if (gx < Wv && gy < Hv) {
+      for (int ch = 0; ch < C; ch++) {
+        float v = 0.f;
+#pragma unroll
+        for (int a = 0; a < NACC; a++)
+          if (a == ch && ch < n_out) v = acc[c][a];
+        gvr[ch * plane + (size_t)gy * Wv + gx] = v;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 void launch_resample_fwd(int C, int Hv, int Wv, int H, int W, int n_out, const float* vr, const float* uva,
@@ -240,6 +434,20 @@ void launch_resample_bwd(int C, int Hv, int Wv, int H, int W, int n_out, const f
   int4* bbox = reinterpret_cast<int4*>(ws_base(ws));
   hipLaunchKernelGGL(resample_bwd_pixel_kernel<false>, dim3(ntx, nty), dim3(BLK), 0, s, Hv, Wv, H, W, n_out, vr, uva, M,
                      fill_channel, gs, guv, gvr, guva, bbox);
-  hipLaunchKernelGGL(resample_bwd_tile_kernel<4>, dim3((Wv + VTX - 1) / VTX, (Hv + VTY - 1) / VTY), dim3(BLK), 0, s, C, Hv, Wv,
-                     H, W, n_out, uva, M, fill_channel, gs, bbox, ntx, nty, gvr);
+  static const int form = [] {  // EOGS_RESAMPLE_BWD=1: the first form (LDS float atomics); default: the bucketed gather
+    const char* e = getenv("EOGS_RESAMPLE_BWD");
+    return e ? atoi(e) : 2;
+  }();
+  if (form == 1) {
+    hipLaunchKernelGGL(resample_bwd_tile_kernel<4>, dim3((Wv + VTX - 1) / VTX, (Hv + VTY - 1) / VTY), dim3(BLK), 0, s, C, Hv, Wv,
+                       H, W, n_out, uva, M, fill_channel, gs, bbox, ntx, nty, gvr);
+    return;
+  }
+  // virtual tile 64 x 32 for large virtual images, 32 x 32 below 1.5 M cells (a 1024^2 image would be 512 workgroups on 256 CUs)
+  const bool big = (size_t)Hv * Wv > 1500000;
+  auto* kern = n_out == 1 ? (big ? resample_bwd_gather_kernel<1, 64, 32> : resample_bwd_gather_kernel<1, 32, 32>)
+                          : (big ? resample_bwd_gather_kernel<4, 64, 32> : resample_bwd_gather_kernel<4, 32, 32>);
+  const int vx = big ? 64 : 32, vy = 32;
+  hipLaunchKernelGGL(kern, dim3((Wv + vx - 1) / vx, (Hv + vy - 1) / vy), dim3(BLK), 0, s, C, Hv, Wv, H, W, n_out, uva, M,
+                     fill_channel, gs, bbox, ntx, nty, gvr);
 }

@@ -131,7 +131,9 @@ int eogs_rast_forward_prepare(
     int64_t* num_rendered, void* stream);
 
 /* Exact token of the last eogs_rast_forward_prepare(..., EOGS_FLAG_DEFER_COUNTS) on this thread: waits for its count
- * readback. Errors as forward_prepare reports them (EOGS_ERR_ALTITUDE, EOGS_ERR_OVERFLOW). */
+ * readback — by polling the pinned words the copy lands in (the calling thread spins, it is never parked; the stream is
+ * asked every 256 looks, so a failed copy or a faulted kernel ends the wait with EOGS_ERR_DEVICE). A forward_prepare
+ * WITHOUT the flag ends in this same wait. Errors as forward_prepare reports them (EOGS_ERR_ALTITUDE, EOGS_ERR_OVERFLOW). */
 int eogs_rast_forward_counts(int64_t* num_rendered);
 /* Exact token (and error state, as forward_prepare reports it) of the forward that last ran over `geom`: copies its count
  * words back on `stream` and WAITS for the stream. For forwards queued with EOGS_FLAG_NO_READBACK — a replayed graph — whose
