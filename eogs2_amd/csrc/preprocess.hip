@@ -405,6 +405,15 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
   // comparison here: such a backward reads none of them and returns zero gradients (the host repeats the forward).
   const bool fits = misc[MISC_TOTAL_HI] == 0u && misc[MISC_MACRO_HI] == 0u && misc[MISC_TOTAL_LO] <= cap_slots &&
                     misc[MISC_MACRO_LO] <= cap_entries;
+  // Where tiles saturate (trained opacities: a tile's pixels stop after a tenth of its list) most listed pairs are DEAD — behind
+  // every pixel's last contributor, never written — and the one-trip read below fetches records only to discard them: there a
+  // Gaussian reads its flags first unless it lists a single tile (gaussian_bwd 0.087 -> 0.080 ms at 1 M trained; with live
+  // pairs the one-trip read wins: opacity 0.1 0.193 against 0.194 two-trip, and against 0.169 with eight records in one
+  // trip, which costs the headline 7 % in registers — profiles/r04_experiments/ab_gb_direct.txt). "Saturating" as the tile
+  // schedule defines it (binning.hip): mean list depth x mean pair opacity beyond SCHED_K = 60 entries.
+  const float opw = (float)misc[MISC_OPW_LO] + 4294967296.0f * (float)misc[MISC_OPW_HI];
+  const float ntiles8 = (float)((W + SUBX - 1) / SUBX) * (float)((H + SUBY - 1) / SUBY);
+  const uint32_t dlim = opw > 64.0f * 60.0f * ntiles8 ? 1u : GB_DIRECT;
   const int t = threadIdx.x;
   const uint32_t blk = blk0 + blockIdx.x;  // workgroup index over ALL Gaussians (the launch may cover a range of them)
   const size_t row0 = (size_t)blk * BLK;
@@ -445,7 +454,7 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
       constexpr int RQ = (ALT ? REC_ALT : REC) / 4;  // quarters per record (common.h rec_q: quarter-major planes of cap_slots)
       const float4* r4 = reinterpret_cast<const float4*>(records);
       uint32_t q_first = 0;
-      if (n <= GB_DIRECT) {
+      if (n <= dlim) {
         float4 ra[GB_DIRECT], rb[GB_DIRECT];
         float3 rc[GB_DIRECT];
         bool lv[GB_DIRECT];

@@ -153,3 +153,20 @@ def test_entry_point_matches_reference_vectors_with_a_stub_render(dev, monkeypat
     got = dict(rgb_sample=rgb.detach().cpu(), altitude_sample=a.detach().cpu(), virtual_uv=uv.detach().cpu(),
                g_virtual_render=vr.grad.cpu(), g_altitude=alt.grad.cpu())
     compare(got, c, rtol=1e-4)
+
+
+def test_first_form_of_the_backward_tile_kernel_still_matches_the_oracle(dev):
+    """EOGS_RESAMPLE_BWD=1 (read once per process) selects the round-2 tile kernel (LDS float atomics) instead of the bucketed
+    gather: the oracle comparisons above, in a child process with it set."""
+    import os
+    import subprocess
+    import sys
+
+    if os.environ.get("EOGS_RESAMPLE_BWD") == "1":
+        pytest.skip("already the child")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_resample.py"), "-m", "gpu", "-q", "-x",
+                        "-k", "matches_oracle or matches_reference_ops"], env=dict(os.environ, EOGS_RESAMPLE_BWD="1"),
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
