@@ -35,6 +35,22 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 HBM_ACHIEVABLE_GBS = {"read": 6500.0, "copy": 5700.0, "write": 4800.0, "source": "profiles/r03_hbm_stream.txt (tools/hbm_stream.hip)"}
 
 
+def median_window_ms(run, iters, windows=3):
+    """ms per call of `run`: `windows` timed windows of `iters` calls each, bracketed by synchronize, the MEDIAN window reported
+    — the extra sections below time a few milliseconds of host-driven work each, and one stall of the box's host thread
+    (profiles/r04_experiments/ab_session2_summary.txt: 4 ms once per ~500 steps on some boxes) would otherwise be a section's
+    whole number (the same section read 0.36, 0.52 and 0.93 ms on three boxes before this)."""
+    ws = []
+    for _ in range(windows):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            run()
+        torch.cuda.synchronize()
+        ws.append((time.perf_counter() - t0) / iters * 1e3)
+    return sorted(ws)[len(ws) // 2]
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -511,8 +527,9 @@ def train_iteration(sc, P, H, W, dev, fused, iters=5, dist=None, view_seed=0, al
 
     def timed(fn, n):
         fn()
-        if dist is not None:
-            dist.barrier()
+        if dist is None:  # one rank: the median of three windows (a stall of the host thread is not the iteration's time)
+            return median_window_ms(fn, n) * 1e-3
+        dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n):
@@ -562,16 +579,13 @@ def photometric_loss_bench(abi, dev, H, W, iters=20):
         return _torch_photometric(img, gt, win)
 
     def timed(fn):
+        def run():
+            img.grad = None
+            fn().backward()
+
         for _ in range(3):
-            img.grad = None
-            fn().backward()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            img.grad = None
-            fn().backward()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / iters * 1e3
+            run()
+        return median_window_ms(run, iters)
 
     t_ref = timed(torch_ops)
     v_ref = float(torch_ops())
@@ -579,7 +593,7 @@ def photometric_loss_bench(abi, dev, H, W, iters=20):
     abi.profile_enable(1)
     t_fused = timed(lambda: photometric_loss(img, gt, 0.2)[0])
     abi.profile_enable(0)
-    kern = {k: ms / (iters + 3) for k, (ms, n) in abi.profile().items() if n and k.startswith("loss_")}
+    kern = {k: ms / n for k, (ms, n) in abi.profile().items() if n and k.startswith("loss_")}
     v_fused = float(photometric_loss(img, gt, 0.2)[0])
     alg = {"loss_fwd": 20 * 3 * H * W, "loss_bwd": 24 * 3 * H * W}  # B: fwd reads 2 images, writes 3 maps; bwd reads 5, writes 1
     return {"workload": f"3x{H}x{W}, lambda_dssim=0.2, fwd+bwd", "fused_ms": t_fused, "torch_ops_ms": t_ref,
@@ -616,12 +630,7 @@ def resample_bench(abi, dev, H, W, iters=20):
                 ((s * w).sum() + uv.sum()).backward()
             for _ in range(3):
                 run()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(iters):
-                run()
-            torch.cuda.synchronize()
-            out[f"{name}_{tag}"] = (time.perf_counter() - t0) / iters * 1e3
+            out[f"{name}_{tag}"] = median_window_ms(run, iters)
             if tag == "fused_ms":
                 abi.profile_reset()
                 abi.profile_enable(1)
@@ -680,12 +689,7 @@ def shade_bench(abi, dev, H, W, iters=20):
             return v
         for _ in range(3):
             v = run()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            run()
-        torch.cuda.synchronize()
-        res[tag] = (time.perf_counter() - t0) / iters * 1e3
+        res[tag] = median_window_ms(run, iters)
         res["value_" + tag[:-3]] = float(v.detach())
         if tag == "fused_ms":
             abi.profile_reset()
@@ -752,12 +756,7 @@ def tsdf_bench(abi, dev, iters=10):
         t, w = torch.ones(dims, device=dev), torch.zeros(dims, device=dev)
         fn(t, w)
         vols[tag] = (t.clone(), w.clone())
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            fn(t, w)
-        torch.cuda.synchronize()
-        res[tag] = (time.perf_counter() - t0) / iters * 1e3
+        res[tag] = median_window_ms(lambda: fn(t, w), iters)
     res["max_abs_diff_tsdf"] = float((vols["torch_ops_ms"][0] - vols["fused_ms"][0]).abs().max())
     abi.profile_reset()
     abi.profile_enable(1)
@@ -790,12 +789,7 @@ def optimizer_bench(abi, dev, P, iters=20):
 
     def timed(fn, n=iters):
         fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / n * 1e3
+        return median_window_ms(fn, n)
 
     out = {}
     for name, ctor in (("torch_adam_ms", lambda l: torch.optim.Adam(l, lr=0.0, eps=1e-15)),

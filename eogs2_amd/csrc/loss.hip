@@ -44,52 +44,80 @@ __global__ __launch_bounds__(LTHREADS) void loss_fwd_kernel(int H, int W, const 
   const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
   const size_t pbase = (size_t)plane * H * W;
 
-  for (int e = t; e < LW * LW; e += LTHREADS) {
-    const int r = e / LW, c = e - r * LW;
-    const int gy = y0 + r - HALO, gx = x0 + c - HALO;
-    float a = 0.f, b = 0.f;
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-      a = img[pbase + (size_t)gy * W + gx];
-      b = gt[pbase + (size_t)gy * W + gx];
+  {
+    // all of the patch's loads in flight before the first one is stored (seven dependent round trips otherwise)
+    constexpr int NE = (LW * LW + LTHREADS - 1) / LTHREADS;
+    float a[NE], b[NE];
+#pragma unroll
+    for (int i = 0; i < NE; i++) {
+      const int e = t + i * LTHREADS, r = e / LW, c = e - r * LW;
+      const int gy = y0 + r - HALO, gx = x0 + c - HALO;
+      a[i] = 0.f; b[i] = 0.f;
+      if (e < LW * LW && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        a[i] = img[pbase + (size_t)gy * W + gx];
+        b[i] = gt[pbase + (size_t)gy * W + gx];
+      }
     }
-    s_x[r][c] = a;
-    s_y[r][c] = b;
+#pragma unroll
+    for (int i = 0; i < NE; i++) {
+      const int e = t + i * LTHREADS, r = e / LW, c = e - r * LW;
+      if (e < LW * LW) { s_x[r][c] = a[i]; s_y[r][c] = b[i]; }
+    }
   }
   __syncthreads();
 
   if (WITH_SSIM) {
-    // horizontal pass: 42 rows x 32 columns x 5 moments
-    for (int e = t; e < LW * LT; e += LTHREADS) {
-      const int r = e / LT, c = e - r * LT;
-      float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+    // horizontal pass: 42 rows x 32 columns x 5 moments. A thread takes EIGHT adjacent columns of one row: their windows
+    // overlap, so it reads 18 + 18 staged values once instead of 8 x (11 + 11) (round 4: the kernel was bound by its LDS
+    // reads — 86 k dwords per tile, 28 k now; every output's own sum keeps its order, k ascending)
+    if (t < LW * (LT / 8)) {
+      const int r = t / (LT / 8), c0 = (t % (LT / 8)) * 8;
+      float xa[8 + LOSS_WIN - 1], ya[8 + LOSS_WIN - 1];
 #pragma unroll
-      for (int k = 0; k < LOSS_WIN; k++) {
-        const float a = s_x[r][c + k], b = s_y[r][c + k], w = win.w[k];
-        const float wa = w * a, wb = w * b;
-        m1 += wa; m2 += wb; e11 += wa * a; e22 += wb * b; e12 += wa * b;
+      for (int k = 0; k < 8 + LOSS_WIN - 1; k++) { xa[k] = s_x[r][c0 + k]; ya[k] = s_y[r][c0 + k]; }
+#pragma unroll
+      for (int o = 0; o < 8; o++) {
+        float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+        for (int k = 0; k < LOSS_WIN; k++) {
+          const float a = xa[o + k], b = ya[o + k], w = win.w[k];
+          const float wa = w * a, wb = w * b;
+          m1 += wa; m2 += wb; e11 += wa * a; e22 += wb * b; e12 += wa * b;
+        }
+        const int c = c0 + o;
+        s_h[0][r][c] = m1; s_h[1][r][c] = m2; s_h[2][r][c] = e11; s_h[3][r][c] = e22; s_h[4][r][c] = e12;
       }
-      s_h[0][r][c] = m1; s_h[1][r][c] = m2; s_h[2][r][c] = e11; s_h[3][r][c] = e22; s_h[4][r][c] = e12;
     }
     __syncthreads();
   }
 
-  const int tx = t & (LT - 1), ty = t >> 5;  // 32 x 8 threads, four rows each
+  const int tx = t & (LT - 1), ty = t >> 5;  // 32 x 8 threads, four ADJACENT rows each: 14 column values serve four windows
   float l1 = 0.f, ss = 0.f;
+  float vs[WITH_SSIM ? 5 : 1][LT / 8];
+  if (WITH_SSIM) {
+#pragma unroll
+    for (int m = 0; m < 5; m++) {
+      float col[LT / 8 + LOSS_WIN - 1];
+#pragma unroll
+      for (int i = 0; i < LT / 8 + LOSS_WIN - 1; i++) col[i] = s_h[m][(LT / 8) * ty + i][tx];
+#pragma unroll
+      for (int j = 0; j < LT / 8; j++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < LOSS_WIN; k++) acc += win.w[k] * col[j + k];
+        vs[m][j] = acc;
+      }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < LT / 8; j++) {
-    const int r = ty + 8 * j;
+    const int r = (LT / 8) * ty + j;
     const int gy = y0 + r, gx = x0 + tx;
     const bool inside = gy < H && gx < W;
     const float a = s_x[r + HALO][tx + HALO], b = s_y[r + HALO][tx + HALO];
     if (WITH_L1 && inside) l1 += fabsf(a - b);
     if (WITH_SSIM) {
-      float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
-#pragma unroll
-      for (int k = 0; k < LOSS_WIN; k++) {
-        const float w = win.w[k];
-        mu1 += w * s_h[0][r + k][tx]; mu2 += w * s_h[1][r + k][tx];
-        e11 += w * s_h[2][r + k][tx]; e22 += w * s_h[3][r + k][tx]; e12 += w * s_h[4][r + k][tx];
-      }
+      const float mu1 = vs[0][j], mu2 = vs[1][j], e11 = vs[2][j], e22 = vs[3][j], e12 = vs[4][j];
       // _ssim (loss_utils.py:58-80)
       const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
       const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
@@ -186,36 +214,68 @@ __global__ __launch_bounds__(LTHREADS) void loss_bwd_kernel(int H, int W, const 
   }
 
   if (WITH_SSIM) {
-    for (int e = t; e < LW * LW; e += LTHREADS) {
-      const int r = e / LW, c = e - r * LW;
-      const int gy = y0 + r - HALO, gx = x0 + c - HALO;
-      float a = 0.f, b = 0.f, d = 0.f;
-      if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-        const size_t o = pbase + (size_t)gy * W + gx;
-        a = maps[o];
-        b = maps[map_stride + o];
-        d = maps[2 * map_stride + o];
+    {
+      constexpr int NE = (LW * LW + LTHREADS - 1) / LTHREADS;
+      float a[NE], b[NE], d[NE];
+#pragma unroll
+      for (int i = 0; i < NE; i++) {
+        const int e = t + i * LTHREADS, r = e / LW, c = e - r * LW;
+        const int gy = y0 + r - HALO, gx = x0 + c - HALO;
+        a[i] = 0.f; b[i] = 0.f; d[i] = 0.f;
+        if (e < LW * LW && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+          const size_t o = pbase + (size_t)gy * W + gx;
+          a[i] = maps[o];
+          b[i] = maps[map_stride + o];
+          d[i] = maps[2 * map_stride + o];
+        }
       }
-      s_m[0][r][c] = a; s_m[1][r][c] = b; s_m[2][r][c] = d;
+#pragma unroll
+      for (int i = 0; i < NE; i++) {
+        const int e = t + i * LTHREADS, r = e / LW, c = e - r * LW;
+        if (e < LW * LW) { s_m[0][r][c] = a[i]; s_m[1][r][c] = b[i]; s_m[2][r][c] = d[i]; }
+      }
     }
     __syncthreads();
-    for (int e = t; e < LW * LT; e += LTHREADS) {
-      const int r = e / LT, c = e - r * LT;
-      float a = 0.f, b = 0.f, d = 0.f;
+    // (eight adjacent columns per thread, as in the forward)
+    if (t < LW * (LT / 8)) {
+      const int r = t / (LT / 8), c0 = (t % (LT / 8)) * 8;
 #pragma unroll
-      for (int k = 0; k < LOSS_WIN; k++) {
-        const float w = win.w[k];
-        a += w * s_m[0][r][c + k]; b += w * s_m[1][r][c + k]; d += w * s_m[2][r][c + k];
+      for (int m = 0; m < 3; m++) {
+        float v[8 + LOSS_WIN - 1];
+#pragma unroll
+        for (int k = 0; k < 8 + LOSS_WIN - 1; k++) v[k] = s_m[m][r][c0 + k];
+#pragma unroll
+        for (int o = 0; o < 8; o++) {
+          float a = 0.f;
+#pragma unroll
+          for (int k = 0; k < LOSS_WIN; k++) a += win.w[k] * v[o + k];
+          s_h[m][r][c0 + o] = a;
+        }
       }
-      s_h[0][r][c] = a; s_h[1][r][c] = b; s_h[2][r][c] = d;
     }
     __syncthreads();
   }
 
-  const int tx = t & (LT - 1), ty = t >> 5;
+  const int tx = t & (LT - 1), ty = t >> 5;  // four adjacent rows per thread
+  float vs[WITH_SSIM ? 3 : 1][LT / 8];
+  if (WITH_SSIM) {
+#pragma unroll
+    for (int m = 0; m < 3; m++) {
+      float col[LT / 8 + LOSS_WIN - 1];
+#pragma unroll
+      for (int i = 0; i < LT / 8 + LOSS_WIN - 1; i++) col[i] = s_h[m][(LT / 8) * ty + i][tx];
+#pragma unroll
+      for (int j = 0; j < LT / 8; j++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < LOSS_WIN; k++) acc += win.w[k] * col[j + k];
+        vs[m][j] = acc;
+      }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < LT / 8; j++) {
-    const int r = ty + 8 * j;
+    const int r = (LT / 8) * ty + j;
     const int gy = y0 + r, gx = x0 + tx;
     if (gy >= H || gx >= W) continue;
     const size_t o = pbase + (size_t)gy * W + gx;
@@ -226,12 +286,7 @@ __global__ __launch_bounds__(LTHREADS) void loss_bwd_kernel(int H, int W, const 
       g += g_l1 * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
     }
     if (WITH_SSIM) {
-      float cm = 0.f, c11 = 0.f, c12 = 0.f;
-#pragma unroll
-      for (int k = 0; k < LOSS_WIN; k++) {
-        const float w = win.w[k];
-        cm += w * s_h[0][r + k][tx]; c11 += w * s_h[1][r + k][tx]; c12 += w * s_h[2][r + k][tx];
-      }
+      const float cm = vs[0][j], c11 = vs[1][j], c12 = vs[2][j];
       g += g_ss * (cm + 2.f * x * c11 + y * c12);
     }
     dimg[o] = g;
