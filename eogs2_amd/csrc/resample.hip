@@ -44,15 +44,31 @@ __global__ __launch_bounds__(BLK) void resample_fwd_kernel(int C, int Hv, int Wv
   const size_t plane = (size_t)Hv * Wv;
   const size_t o00 = (size_t)t.y0 * Wv + t.x0;
   const bool outside = fabsf(u) > 1.f || fabsf(v) > 1.f;
-  for (int ch = 0; ch < n_out; ch++) {
-    const float* src = vr + ch * plane;
-    float s = 0.f;
-    if (t.in_y0 && t.in_x0) s += src[o00] * wnw;
-    if (t.in_y0 && t.in_x1) s += src[o00 + 1] * wne;
-    if (t.in_y1 && t.in_x0) s += src[o00 + Wv] * wsw;
-    if (t.in_y1 && t.in_x1) s += src[o00 + Wv + 1] * wse;
-    if (ch == fill_channel && outside) s = fill_value;
-    sample[(size_t)ch * HW + p] = s;
+  // the taps of up to four channels are requested together (the reference resamples four; a runtime-bounded loop made every
+  // channel wait for the previous one's four gathers)
+  for (int c0 = 0; c0 < n_out; c0 += 4) {
+    float v[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const bool on = c0 + k < n_out;
+      const float* src = vr + (size_t)(on ? c0 + k : 0) * plane;
+      v[k][0] = (on && t.in_y0 && t.in_x0) ? src[o00] : 0.f;
+      v[k][1] = (on && t.in_y0 && t.in_x1) ? src[o00 + 1] : 0.f;
+      v[k][2] = (on && t.in_y1 && t.in_x0) ? src[o00 + Wv] : 0.f;
+      v[k][3] = (on && t.in_y1 && t.in_x1) ? src[o00 + Wv + 1] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int ch = c0 + k;
+      if (ch >= n_out) break;
+      float s = 0.f;
+      if (t.in_y0 && t.in_x0) s += v[k][0] * wnw;
+      if (t.in_y0 && t.in_x1) s += v[k][1] * wne;
+      if (t.in_y1 && t.in_x0) s += v[k][2] * wsw;
+      if (t.in_y1 && t.in_x1) s += v[k][3] * wse;
+      if (ch == fill_channel && outside) s = fill_value;
+      sample[(size_t)ch * HW + p] = s;
+    }
   }
 }
 
@@ -95,30 +111,47 @@ __global__ __launch_bounds__(BLK) void resample_bwd_pixel_kernel(int Hv, int Wv,
     const size_t o00 = (size_t)t.y0 * Wv + t.x0;
     const bool outside = fabsf(u) > 1.f || fabsf(v) > 1.f;
     float gix = 0.f, giy = 0.f;
-    for (int ch = 0; ch < n_out; ch++) {
-      float g = gs[(size_t)ch * HW + p];
-      if (ch == fill_channel && outside) g = 0.f;  // the value was overwritten by a constant
-      const float* src = vr + ch * plane;
-      float* dst = gvr + ch * plane;
-      if (t.in_y0 && t.in_x0) {
-        const float val = src[o00];
-        if (ATOMIC_SCATTER) unsafeAtomicAdd(dst + o00, g * wx0 * wy0);
-        gix -= val * wy0 * g; giy -= val * wx0 * g;
+    // (gradients and taps of up to four channels requested together, as in the forward; sums in channel order as before)
+    for (int c0 = 0; c0 < n_out; c0 += 4) {
+      float gq[4], v[4][4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const bool on = c0 + k < n_out;
+        const int ch = on ? c0 + k : 0;
+        gq[k] = on ? gs[(size_t)ch * HW + p] : 0.f;
+        const float* src = vr + (size_t)ch * plane;
+        v[k][0] = (on && t.in_y0 && t.in_x0) ? src[o00] : 0.f;
+        v[k][1] = (on && t.in_y0 && t.in_x1) ? src[o00 + 1] : 0.f;
+        v[k][2] = (on && t.in_y1 && t.in_x0) ? src[o00 + Wv] : 0.f;
+        v[k][3] = (on && t.in_y1 && t.in_x1) ? src[o00 + Wv + 1] : 0.f;
       }
-      if (t.in_y0 && t.in_x1) {
-        const float val = src[o00 + 1];
-        if (ATOMIC_SCATTER) unsafeAtomicAdd(dst + o00 + 1, g * t.wx1 * wy0);
-        gix += val * wy0 * g; giy -= val * t.wx1 * g;
-      }
-      if (t.in_y1 && t.in_x0) {
-        const float val = src[o00 + Wv];
-        if (ATOMIC_SCATTER) unsafeAtomicAdd(dst + o00 + Wv, g * wx0 * t.wy1);
-        gix -= val * t.wy1 * g; giy += val * wx0 * g;
-      }
-      if (t.in_y1 && t.in_x1) {
-        const float val = src[o00 + Wv + 1];
-        if (ATOMIC_SCATTER) unsafeAtomicAdd(dst + o00 + Wv + 1, g * t.wx1 * t.wy1);
-        gix += val * t.wy1 * g; giy += val * t.wx1 * g;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int ch = c0 + k;
+        if (ch >= n_out) break;
+        float g = gq[k];
+        if (ch == fill_channel && outside) g = 0.f;  // the value was overwritten by a constant
+        float* dst = gvr + (size_t)ch * plane;
+        if (t.in_y0 && t.in_x0) {
+          const float val = v[k][0];
+          if (ATOMIC_SCATTER) unsafeAtomicAdd(dst + o00, g * wx0 * wy0);
+          gix -= val * wy0 * g; giy -= val * wx0 * g;
+        }
+        if (t.in_y0 && t.in_x1) {
+          const float val = v[k][1];
+          if (ATOMIC_SCATTER) unsafeAtomicAdd(dst + o00 + 1, g * t.wx1 * wy0);
+          gix += val * wy0 * g; giy -= val * t.wx1 * g;
+        }
+        if (t.in_y1 && t.in_x0) {
+          const float val = v[k][2];
+          if (ATOMIC_SCATTER) unsafeAtomicAdd(dst + o00 + Wv, g * wx0 * t.wy1);
+          gix -= val * t.wy1 * g; giy += val * wx0 * g;
+        }
+        if (t.in_y1 && t.in_x1) {
+          const float val = v[k][3];
+          if (ATOMIC_SCATTER) unsafeAtomicAdd(dst + o00 + Wv + 1, g * t.wx1 * t.wy1);
+          gix += val * t.wy1 * g; giy += val * t.wx1 * g;
+        }
       }
     }
     // d(ix)/du = (Wv-1)/2 (align_corners=True)
