@@ -163,6 +163,22 @@ def test_headline_1M_1024_matches_oracle(dev):
     print("headline 1M/1024^2: attributed out-of-tolerance elements:", flips)
 
 
+@pytest.mark.slow
+@pytest.mark.parametrize("name,P,S,opacity", [("trained_1M_1024", 1 << 20, 1024, "trained"), ("opacity0.1_1M_1024", 1 << 20, 1024, 0.1)])
+def test_regimes_of_the_bench_line_match_oracle(dev, name, P, S, opacity):
+    """The regimes bench.py reports beside the headline (bench.regime_scan), in full against the C oracle: trained opacities
+    (tiles saturate, most listed pairs dead: the backward's flags-first record sum) and opacity 0.1 (lists twice as long, nothing
+    saturates). Minutes of oracle time each: EOGS_FULL=1 only; outcome recorded in profiles/r04_sweeps.txt."""
+    from eogs2_amd import GaussianRasterizationSettings, GaussianRasterizer
+    from parity_cases import prefetch_nudges
+
+    case = _full_size_case(P, S, S, 0, opacity)
+    prefetch_nudges(case)
+    got = run_case(case, dev, GaussianRasterizer, GaussianRasterizationSettings)
+    flips = compare(got, _oracle(case), name, case)
+    print(f"{name}: attributed out-of-tolerance elements: {flips}")
+
+
 def test_config2_300k_800_matches_oracle(dev):
     """configs[1] (JAX_004 class): ~300 k Gaussians, 800 x 800, trained opacities, in full against the oracle."""
     from eogs2_amd import GaussianRasterizationSettings, GaussianRasterizer
