@@ -92,6 +92,10 @@ def main(argv=None):
                     help="third render of the iteration: a random virtual camera at the view's size, resampled onto the view, "
                          "with the masked altitude / RGB consistency pair (train_pan.py:375-391, loss/main_loss.py:151-164)")
     ap.add_argument("--no-prune", action="store_true", help="keep every Gaussian (timing runs)")
+    ap.add_argument("--require-radii", action="store_true",
+                    help="pipe.require_radii: every render also returns radii and `visibility_filter` = nonzero(radii > 0), which waits "
+                         "for the device (renderer.py:128-130). The reference's shipped configuration has it OFF "
+                         "(gs_config/train.yaml:39: require_radii = not only_prune, only_prune: True): off by default here too")
     a = ap.parse_args(argv)
     dev = torch.device("cuda:0")
     P, H, W = a.gaussians, a.size, a.size
@@ -103,7 +107,7 @@ def main(argv=None):
     rnd = Camera(make_camera(H, W, seed=9, device=dev), H, W)
     cam2rnd = torch.eye(3, device=dev)
     cam2rnd[:2, 2] = (rnd.affine[2, :2] - cam.affine[2, :2]) / 350.0
-    pipe = types.SimpleNamespace(debug=False, antialiasing=False, compute_cov3D_python=False, require_radii=True)
+    pipe = types.SimpleNamespace(debug=False, antialiasing=False, compute_cov3D_python=False, require_radii=a.require_radii)
     bg = sc["bg"]
     U, V = torch.meshgrid(torch.linspace(-1, 1, W, device=dev), torch.linspace(-1, 1, H, device=dev), indexing="xy")
 
@@ -159,7 +163,7 @@ def main(argv=None):
             L_new_alt, L_new_rgb = randomcam_l(new[0], img, new[1], new[2])
             loss = loss + 1e-4 * L_new_alt + 1e-3 * L_new_rgb
         loss.backward()
-        return loss.detach(), out["radii"]
+        return loss.detach(), out.get("radii")
 
     first = last = None
     step = None  # the recorded graph of fwd_bwd for the current set of Gaussians
@@ -182,7 +186,8 @@ def main(argv=None):
         model.optimizer.step()
         camera_optimizer.step()
         with torch.no_grad():
-            model.max_radii2D = torch.maximum(model.max_radii2D, radii.float())
+            if radii is not None:  # train_pan.py:681-686 (densification statistics: only with require_radii)
+                model.max_radii2D = torch.maximum(model.max_radii2D, radii.float())
             if it % 50 == 0 and not a.no_prune:  # train_pan.py:673-678
                 keep = model._opacity.squeeze() >= math.log(0.005 / 0.995)
                 if not bool(keep.all()):

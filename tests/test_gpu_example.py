@@ -28,7 +28,7 @@ def test_synthetic_training_as_replayed_graph_matches_eager():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
     import train_synthetic
 
-    args = ["--gaussians", "30000", "--size", "192", "--iters", "120", "--quiet"]
+    args = ["--gaussians", "30000", "--size", "192", "--iters", "120", "--quiet", "--require-radii"]
     eager = train_synthetic.main(args)
     graph = train_synthetic.main(args + ["--graph"])
     assert graph[2] == eager[2]  # the prune kept the same Gaussians
