@@ -292,7 +292,7 @@ def live_traffic(a, kernels=("render_bwd", "render_fwd", "gaussian_bwd", "prepro
                "--traffic-child", "--gaussians", str(a.gaussians), "--size", str(a.size), "--opacity", str(a.opacity)]
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
-                               stderr=subprocess.STDOUT, timeout=180)
+                               stderr=subprocess.STDOUT, timeout=90)
             if r.returncode != 0:
                 return {}, f"rocprofv3 --pmc {counter}: exit {r.returncode}"
             agg = collections.defaultdict(list)
