@@ -525,3 +525,18 @@ def test_render_entry_point(dev):
             assert float((res[True][k] - res[False][k]).abs().max()) <= 1e-4 * scale
         else:
             assert_close(res[True][k], res[False][k], k, flip_floor=4)
+
+
+@pytest.mark.parametrize("P,H,W", [(1, 1, 1), (2, 1, 7), (70, 5, 3), (300, 8, 8), (65, 2, 33), (1, 40, 1)])
+def test_images_smaller_than_a_tile_or_a_block(dev, P, H, W):
+    """Images of a few pixels: one partial 8 x 8 tile, one partial 32 x 32-px block, a tile schedule over a single block, Gaussians
+    larger than the image. Every output and gradient against the oracle."""
+    from parity_cases import compare, oracle_run
+    from eogs2_amd import GaussianRasterizationSettings, GaussianRasterizer
+    from eogs2_amd.synthetic import make_scene
+
+    sc = make_scene(P, H, W, seed=100 + P + H + W, opacity="trained", scale_mult=3.0)
+    case = {k: v.numpy() for k, v in sc.items()}
+    case.update(H=H, W=W, antialiasing=False)
+    got = run_case(case, dev, GaussianRasterizer, GaussianRasterizationSettings)
+    compare(got, oracle_run(case), f"tiny{P}_{H}x{W}", case)
