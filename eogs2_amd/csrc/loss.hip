@@ -12,11 +12,24 @@
 // Sums are reduced per workgroup, then in a fixed order by one small kernel: bitwise reproducible, no atomics.
 #include "common.h"
 
+// The library is built with -ffp-contract=off for the rasterizer's sake (its parity is against an fp32 restatement of the
+// reference's arithmetic). The loss has no such twin — its oracle is float64, its tolerance relative — and its window sums are
+// half of its instructions: multiply-adds may fuse here.
+#pragma clang fp contract(fast)
+
 namespace {
 
-constexpr int LT = 32;             // output tile edge
+constexpr int LT = 32;             // output tile width
+#ifndef LOSS_LTY
+#define LOSS_LTY 16
+#endif
+constexpr int LTY = LOSS_LTY;      // output tile height (round 4: 16 rows — 26 KB of LDS, six workgroups per CU instead of three)
 constexpr int HALO = LOSS_WIN / 2; // 5
-constexpr int LW = LT + 2 * HALO;  // 42 staged rows / columns
+constexpr int LW = LT + 2 * HALO;  // 42 staged columns
+constexpr int LH = LTY + 2 * HALO; // staged rows
+constexpr int RPT = LTY / 8;       // adjacent output rows per thread (32 x 8 threads)
+constexpr int HG = 4;              // adjacent output columns per thread in the horizontal pass
+static_assert(LTY % 8 == 0 && LT % HG == 0 && LH * (LT / HG) <= 256, "tile shape against 256 threads");
 constexpr int LTHREADS = 256;
 
 __device__ inline float block_sum(float v, float* s_red) {
@@ -35,25 +48,25 @@ __global__ __launch_bounds__(LTHREADS) void loss_fwd_kernel(int H, int W, const 
                                                             const float* __restrict__ gt, LossWindow win,
                                                             float* __restrict__ maps, size_t map_stride,
                                                             float* __restrict__ partial) {
-  __shared__ float s_x[LW][LW + 1];
-  __shared__ float s_y[LW][LW + 1];
-  __shared__ float s_h[WITH_SSIM ? 5 : 1][WITH_SSIM ? LW : 1][LT + 1];
+  __shared__ float s_x[LH][LW + 1];
+  __shared__ float s_y[LH][LW + 1];
+  __shared__ float s_h[WITH_SSIM ? 5 : 1][WITH_SSIM ? LH : 1][LT + 1];
   __shared__ float s_red[4];
   const int t = threadIdx.x;
   const int plane = blockIdx.z;
-  const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
+  const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LTY;
   const size_t pbase = (size_t)plane * H * W;
 
   {
     // all of the patch's loads in flight before the first one is stored (seven dependent round trips otherwise)
-    constexpr int NE = (LW * LW + LTHREADS - 1) / LTHREADS;
+    constexpr int NE = (LH * LW + LTHREADS - 1) / LTHREADS;
     float a[NE], b[NE];
 #pragma unroll
     for (int i = 0; i < NE; i++) {
       const int e = t + i * LTHREADS, r = e / LW, c = e - r * LW;
       const int gy = y0 + r - HALO, gx = x0 + c - HALO;
       a[i] = 0.f; b[i] = 0.f;
-      if (e < LW * LW && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      if (e < LH * LW && gy >= 0 && gy < H && gx >= 0 && gx < W) {
         a[i] = img[pbase + (size_t)gy * W + gx];
         b[i] = gt[pbase + (size_t)gy * W + gx];
       }
@@ -61,7 +74,7 @@ __global__ __launch_bounds__(LTHREADS) void loss_fwd_kernel(int H, int W, const 
 #pragma unroll
     for (int i = 0; i < NE; i++) {
       const int e = t + i * LTHREADS, r = e / LW, c = e - r * LW;
-      if (e < LW * LW) { s_x[r][c] = a[i]; s_y[r][c] = b[i]; }
+      if (e < LH * LW) { s_x[r][c] = a[i]; s_y[r][c] = b[i]; }
     }
   }
   __syncthreads();
@@ -70,13 +83,13 @@ __global__ __launch_bounds__(LTHREADS) void loss_fwd_kernel(int H, int W, const 
     // horizontal pass: 42 rows x 32 columns x 5 moments. A thread takes EIGHT adjacent columns of one row: their windows
     // overlap, so it reads 18 + 18 staged values once instead of 8 x (11 + 11) (round 4: the kernel was bound by its LDS
     // reads — 86 k dwords per tile, 28 k now; every output's own sum keeps its order, k ascending)
-    if (t < LW * (LT / 8)) {
-      const int r = t / (LT / 8), c0 = (t % (LT / 8)) * 8;
-      float xa[8 + LOSS_WIN - 1], ya[8 + LOSS_WIN - 1];
+    if (t < LH * (LT / HG)) {
+      const int r = t / (LT / HG), c0 = (t % (LT / HG)) * HG;
+      float xa[HG + LOSS_WIN - 1], ya[HG + LOSS_WIN - 1];
 #pragma unroll
-      for (int k = 0; k < 8 + LOSS_WIN - 1; k++) { xa[k] = s_x[r][c0 + k]; ya[k] = s_y[r][c0 + k]; }
+      for (int k = 0; k < HG + LOSS_WIN - 1; k++) { xa[k] = s_x[r][c0 + k]; ya[k] = s_y[r][c0 + k]; }
 #pragma unroll
-      for (int o = 0; o < 8; o++) {
+      for (int o = 0; o < HG; o++) {
         float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
 #pragma unroll
         for (int k = 0; k < LOSS_WIN; k++) {
@@ -93,15 +106,15 @@ __global__ __launch_bounds__(LTHREADS) void loss_fwd_kernel(int H, int W, const 
 
   const int tx = t & (LT - 1), ty = t >> 5;  // 32 x 8 threads, four ADJACENT rows each: 14 column values serve four windows
   float l1 = 0.f, ss = 0.f;
-  float vs[WITH_SSIM ? 5 : 1][LT / 8];
+  float vs[WITH_SSIM ? 5 : 1][RPT];
   if (WITH_SSIM) {
 #pragma unroll
     for (int m = 0; m < 5; m++) {
-      float col[LT / 8 + LOSS_WIN - 1];
+      float col[RPT + LOSS_WIN - 1];
 #pragma unroll
-      for (int i = 0; i < LT / 8 + LOSS_WIN - 1; i++) col[i] = s_h[m][(LT / 8) * ty + i][tx];
+      for (int i = 0; i < RPT + LOSS_WIN - 1; i++) col[i] = s_h[m][RPT * ty + i][tx];
 #pragma unroll
-      for (int j = 0; j < LT / 8; j++) {
+      for (int j = 0; j < RPT; j++) {
         float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < LOSS_WIN; k++) acc += win.w[k] * col[j + k];
@@ -110,8 +123,8 @@ __global__ __launch_bounds__(LTHREADS) void loss_fwd_kernel(int H, int W, const 
     }
   }
 #pragma unroll
-  for (int j = 0; j < LT / 8; j++) {
-    const int r = (LT / 8) * ty + j;
+  for (int j = 0; j < RPT; j++) {
+    const int r = RPT * ty + j;
     const int gy = y0 + r, gx = x0 + tx;
     const bool inside = gy < H && gx < W;
     const float a = s_x[r + HALO][tx + HALO], b = s_y[r + HALO][tx + HALO];
@@ -195,11 +208,11 @@ __global__ __launch_bounds__(LTHREADS) void loss_bwd_kernel(int H, int W, const 
                                                             const float* __restrict__ upstream,
                                                             const float* __restrict__ plane_grad,
                                                             float* __restrict__ dimg) {
-  __shared__ float s_m[WITH_SSIM ? 3 : 1][WITH_SSIM ? LW : 1][LW + 1];
-  __shared__ float s_h[WITH_SSIM ? 3 : 1][WITH_SSIM ? LW : 1][LT + 1];
+  __shared__ float s_m[WITH_SSIM ? 3 : 1][WITH_SSIM ? LH : 1][LW + 1];
+  __shared__ float s_h[WITH_SSIM ? 3 : 1][WITH_SSIM ? LH : 1][LT + 1];
   const int t = threadIdx.x;
   const int plane = blockIdx.z;
-  const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
+  const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LTY;
   const size_t pbase = (size_t)plane * H * W;
   // weights of sum|x-y| and sum SSIM of this plane in the loss
   float g_l1, g_ss;
@@ -215,14 +228,14 @@ __global__ __launch_bounds__(LTHREADS) void loss_bwd_kernel(int H, int W, const 
 
   if (WITH_SSIM) {
     {
-      constexpr int NE = (LW * LW + LTHREADS - 1) / LTHREADS;
+      constexpr int NE = (LH * LW + LTHREADS - 1) / LTHREADS;
       float a[NE], b[NE], d[NE];
 #pragma unroll
       for (int i = 0; i < NE; i++) {
         const int e = t + i * LTHREADS, r = e / LW, c = e - r * LW;
         const int gy = y0 + r - HALO, gx = x0 + c - HALO;
         a[i] = 0.f; b[i] = 0.f; d[i] = 0.f;
-        if (e < LW * LW && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        if (e < LH * LW && gy >= 0 && gy < H && gx >= 0 && gx < W) {
           const size_t o = pbase + (size_t)gy * W + gx;
           a[i] = maps[o];
           b[i] = maps[map_stride + o];
@@ -232,20 +245,20 @@ __global__ __launch_bounds__(LTHREADS) void loss_bwd_kernel(int H, int W, const 
 #pragma unroll
       for (int i = 0; i < NE; i++) {
         const int e = t + i * LTHREADS, r = e / LW, c = e - r * LW;
-        if (e < LW * LW) { s_m[0][r][c] = a[i]; s_m[1][r][c] = b[i]; s_m[2][r][c] = d[i]; }
+        if (e < LH * LW) { s_m[0][r][c] = a[i]; s_m[1][r][c] = b[i]; s_m[2][r][c] = d[i]; }
       }
     }
     __syncthreads();
     // (eight adjacent columns per thread, as in the forward)
-    if (t < LW * (LT / 8)) {
-      const int r = t / (LT / 8), c0 = (t % (LT / 8)) * 8;
+    if (t < LH * (LT / HG)) {
+      const int r = t / (LT / HG), c0 = (t % (LT / HG)) * HG;
 #pragma unroll
       for (int m = 0; m < 3; m++) {
-        float v[8 + LOSS_WIN - 1];
+        float v[HG + LOSS_WIN - 1];
 #pragma unroll
-        for (int k = 0; k < 8 + LOSS_WIN - 1; k++) v[k] = s_m[m][r][c0 + k];
+        for (int k = 0; k < HG + LOSS_WIN - 1; k++) v[k] = s_m[m][r][c0 + k];
 #pragma unroll
-        for (int o = 0; o < 8; o++) {
+        for (int o = 0; o < HG; o++) {
           float a = 0.f;
 #pragma unroll
           for (int k = 0; k < LOSS_WIN; k++) a += win.w[k] * v[o + k];
@@ -257,15 +270,15 @@ __global__ __launch_bounds__(LTHREADS) void loss_bwd_kernel(int H, int W, const 
   }
 
   const int tx = t & (LT - 1), ty = t >> 5;  // four adjacent rows per thread
-  float vs[WITH_SSIM ? 3 : 1][LT / 8];
+  float vs[WITH_SSIM ? 3 : 1][RPT];
   if (WITH_SSIM) {
 #pragma unroll
     for (int m = 0; m < 3; m++) {
-      float col[LT / 8 + LOSS_WIN - 1];
+      float col[RPT + LOSS_WIN - 1];
 #pragma unroll
-      for (int i = 0; i < LT / 8 + LOSS_WIN - 1; i++) col[i] = s_h[m][(LT / 8) * ty + i][tx];
+      for (int i = 0; i < RPT + LOSS_WIN - 1; i++) col[i] = s_h[m][RPT * ty + i][tx];
 #pragma unroll
-      for (int j = 0; j < LT / 8; j++) {
+      for (int j = 0; j < RPT; j++) {
         float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < LOSS_WIN; k++) acc += win.w[k] * col[j + k];
@@ -274,8 +287,8 @@ __global__ __launch_bounds__(LTHREADS) void loss_bwd_kernel(int H, int W, const 
     }
   }
 #pragma unroll
-  for (int j = 0; j < LT / 8; j++) {
-    const int r = (LT / 8) * ty + j;
+  for (int j = 0; j < RPT; j++) {
+    const int r = RPT * ty + j;
     const int gy = y0 + r, gx = x0 + tx;
     if (gy >= H || gx >= W) continue;
     const size_t o = pbase + (size_t)gy * W + gx;
@@ -297,7 +310,7 @@ __global__ __launch_bounds__(LTHREADS) void loss_bwd_kernel(int H, int W, const 
 
 LossWS loss_layout(char* base, int planes, int H, int W, unsigned mode) {
   LossWS w;
-  const size_t tiles = (size_t)((W + LT - 1) / LT) * ((H + LT - 1) / LT);
+  const size_t tiles = (size_t)((W + LT - 1) / LT) * ((H + LTY - 1) / LTY);
   size_t off = 0;
   auto take = [&](size_t bytes) {
     char* p = base ? base + off : nullptr;
@@ -328,7 +341,7 @@ LossWindow loss_window() {
 
 void launch_loss_fwd(const LossWS& w, int planes, int H, int W, const float* img, const float* gt, unsigned mode,
                      float w_l1, float w_ssim, float bias, float* out, float* plane_sums, hipStream_t s) {
-  const dim3 grid((W + LT - 1) / LT, (H + LT - 1) / LT, planes);
+  const dim3 grid((W + LT - 1) / LT, (H + LTY - 1) / LTY, planes);
   const LossWindow win = loss_window();
   const bool l1 = mode & EOGS_LOSS_L1, ss = mode & EOGS_LOSS_SSIM;
   auto* kern = ss ? (l1 ? loss_fwd_kernel<true, true> : loss_fwd_kernel<false, true>) : loss_fwd_kernel<true, false>;
@@ -342,7 +355,7 @@ void launch_loss_fwd(const LossWS& w, int planes, int H, int W, const float* img
 void launch_loss_bwd(const LossWS& w, int planes, int H, int W, const float* img, const float* gt, unsigned mode,
                      float w_l1, float w_ssim, const float* upstream, const float* plane_grad, float* dimg,
                      hipStream_t s) {
-  const dim3 grid((W + LT - 1) / LT, (H + LT - 1) / LT, planes);
+  const dim3 grid((W + LT - 1) / LT, (H + LTY - 1) / LTY, planes);
   const LossWindow win = loss_window();
   const float inv_n = (float)(1.0 / ((double)planes * H * W));
   const bool l1 = mode & EOGS_LOSS_L1, ss = mode & EOGS_LOSS_SSIM;
