@@ -9,7 +9,13 @@ all-reduces the 56 B/Gaussian parameter-gradient buffer over RCCL. value = views
 
 Extra objects in the JSON line:
   roofline      — dominant kernel (render_bwd): algorithmic bytes (52 B/pair + 32 B/pixel)
-                  / its mean HIP-event duration on the launch stream, vs the 8 TB/s HBM peak
+                  / its mean HIP-event duration on the launch stream, vs the 8 TB/s HBM peak; `traffic` = its HBM bytes per
+                  launch counted IN THIS RUN by two `rocprofv3 --pmc` child runs (live_traffic; --no-live-traffic skips them,
+                  the committed profile of the same kernel sources is the fallback)
+  host          — kernel sum against step time, and the per-step host intervals of the timed region (median / min / max)
+  regimes       — the same step at trained opacities, opacity 0.1, 2048^2 and 2 M Gaussians (median of three 20-step windows)
+  train_iter*   — the synthetic 3-render training iteration (torch ops / fused / graphs / parallel branches / altitude-only sun)
+  train_example — examples/train_synthetic.py at this size: the reference's whole iteration with its shipped configuration
   pipeline      — the whole fwd+bwd: (432 P + 268 R + 64 HW) bytes / step time, same peak
   kernels_ms    — mean device ms per kernel group (HIP events inside the library)
   cpu_baseline  — the pure-PyTorch dense alpha-blend (oracle/torch_dense.py, fwd+bwd through autograd) on a
