@@ -460,8 +460,8 @@ __global__ __launch_bounds__(BLK, 4) void expand_entries_kernel(const uint4* __r
   float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0;  // SpanParams of a BK_SPANS Gaussian
   uint4 ia = make_uint4(0u, 0u, 0u, 0u), ib = ia;
   if (k < P) {
-    ia = binfo[2 * (size_t)k];
-    ib = binfo[2 * (size_t)k + 1];
+    ia = binfo[(size_t)k];              // (two planes of P records: common.h GeomWS::binfo)
+    ib = binfo[(size_t)P + (size_t)k];
     it.c = ib.x ? (ib.w >> 2) : 0u;
   }
   uint32_t tot;

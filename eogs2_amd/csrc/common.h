@@ -241,7 +241,7 @@ struct GeomWS {
   float4* packed;       // 4 x float4 = one 64-byte line per Gaussian, everything the render kernels gather:
                         //   {gx, gy, A, B} {C, opacity, f0, f1} {f2, f3, f4, 1/depth} {pad}
                         //   with the conic pre-scaled by log2 e: A = -a log2e/2, B = b log2e, C = -c log2e/2
-  uint4* binfo;         // 2 x uint4 = 32 bytes per Gaussian, everything binning needs, written once by preprocess:
+  uint4* binfo;         // 2 x uint4 = 32 bytes per Gaussian in TWO PLANES of P records ([k] and [P + k]: the backward reads the second alone), everything binning needs, written once by preprocess:
                         //   [0] = {sx0 | sx1<<16, sy0 | sy1<<16 (internal-tile rect, clipped), mask lo, mask hi}
                         //   [1] = {tiles (internal tiles listed, 0 = none), lpre, depth key, kind | block entries << 2}
                         //   kind BK_MASK : mask bit (sy-sy0)*(sx1-sx0) + (sx-sx0) set <=> internal tile (sx,sy) can reach

@@ -327,8 +327,8 @@ __global__ __launch_bounds__(BLK) PP_ATTR void preprocess_fwd_kernel(
   const int w = t >> 6;
   const uint32_t pre = (w > 0 ? w0 : 0u) + (w > 1 ? w1 : 0u) + (w > 2 ? w2 : 0u);
   if (t < rows) {
-    binfo[2 * idx] = bi0;
-    binfo[2 * idx + 1] = make_uint4(my_tiles, pre + inc - my_tiles, key_bits, bkind | (my_entries << 2));
+    binfo[idx] = bi0;
+    binfo[(size_t)P + idx] = make_uint4(my_tiles, pre + inc - my_tiles, key_bits, bkind | (my_entries << 2));
   }
   // range of the depth keys of listed Gaussians (lets the host drop sort passes whose digit is constant) and the
   // workgroup's pair count: plain stores, reduced by pblock_scan_kernel (same-address atomics from 16k waves cost
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
     // then reads its flags AND its records in ONE trip — a dead pair's record is read and discarded: never-written memory,
     // but only ever selected away — and only longer lists take the two-trip form (flags, then the live records alone).
     const int radius_in = radii[idx];
-    const uint4 bi1 = binfo[2 * idx + 1];
+    const uint4 bi1 = binfo[(size_t)P + idx];  // (its own plane: this kernel reads 16 of a Gaussian's 32 bytes, and fetched all 32 while they shared a line)
     const uint32_t pb = pblock[blk];
     float4 rot_in = make_float4(1.f, 0.f, 0.f, 0.f);
     float op_raw = 0.f;
