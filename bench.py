@@ -293,10 +293,11 @@ def live_traffic(a, kernels=("render_bwd", "render_fwd", "gaussian_bwd", "prepro
     means = {}
     t0 = time.perf_counter()
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        out = tempfile.mkdtemp(prefix="eogs_pmc_", dir="/tmp")
-        cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
-               "--traffic-child", "--gaussians", str(a.gaussians), "--size", str(a.size), "--opacity", str(a.opacity)]
+        out = None
         try:
+            out = tempfile.mkdtemp(prefix="eogs_pmc_", dir="/tmp")
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+                   "--traffic-child", "--gaussians", str(a.gaussians), "--size", str(a.size), "--opacity", str(a.opacity)]
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE,
                                stderr=subprocess.STDOUT, timeout=90)
             if r.returncode != 0:
@@ -312,7 +313,8 @@ def live_traffic(a, kernels=("render_bwd", "render_fwd", "gaussian_bwd", "prepro
         except Exception as e:
             return {}, f"rocprofv3 --pmc {counter}: {type(e).__name__}: {e}"[:160]
         finally:
-            shutil.rmtree(out, ignore_errors=True)
+            if out:
+                shutil.rmtree(out, ignore_errors=True)
     res = {}
     groups = {"depth_sort": ("block_lists_kernel",),  # a launch group of the library (kernels_ms key) -> its kernels, once per step each
               "binning": ("pblock_scan_kernel", "expand_entries_kernel", "entry_hist_kernel", "entry_colscan_kernel", "entry_scatter_kernel")}
