@@ -122,12 +122,7 @@ def graph_extras(a):
     gs = GraphedStep(step, warmup=2)
     for _ in range(max(a.warmup, 10)):
         gs()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        gs()
-    torch.cuda.synchronize()
-    g_ms = (time.perf_counter() - t0) / a.steps * 1e3
+    g_ms = median_window_ms(gs, a.steps)  # (three windows of a.steps replays, the median: an extra beside the headline)
     out = {"graphed_step": {"ms_per_step": g_ms, "views_per_s": 1e3 / g_ms, "recaptures": gs.recaptures,
                             "what": "GraphedStep: fwd+bwd of the bench step as one hipGraph replay, list capacity checked "
                                     "per replay while it runs"}}
@@ -537,20 +532,21 @@ def train_iteration(sc, P, H, W, dev, fused, iters=5, dist=None, view_seed=0, al
         fn()
         if dist is None:  # one rank: the median of three windows (a stall of the host thread is not the iteration's time)
             return median_window_ms(fn, n) * 1e-3
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            fn()
-        if dist is not None:
+        # N ranks: three windows, each bracketed by a barrier + synchronize on both sides and clocked by the slowest rank
+        # (MAX over ranks); the median window is reported — every rank sees the same three numbers, so the same median
+        ws = []
+        for _ in range(3):
             dist.barrier()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / n
-        if dist is not None:  # the slowest rank's clock
-            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            dist.barrier()
+            torch.cuda.synchronize()
+            tt = torch.tensor([(time.perf_counter() - t0) / n], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-        return dt
+            ws.append(float(tt.item()))
+        return sorted(ws)[1]
 
     dt = timed(it, iters)
     extra = {}
