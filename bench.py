@@ -886,6 +886,8 @@ def cpu_baseline(P_full, S_full):
         sc = make_scene(P_full, S_full, S_full, seed=0, opacity="init")
         hip = _lib.get
         _lib.get = oracle.abi
+        # ONE core: the checker's per-pixel loops are threaded for the tests' sake (oracle/rast_oracle.c eogs_oracle_set_threads)
+        old_threads = oracle.abi().cdll.eogs_oracle_set_threads(1)
         try:
             rast = GaussianRasterizer(settings_for(sc, S_full, S_full))
             lv = {k: sc[k].clone().requires_grad_(True) for k in ("means3D", "opacities", "colors", "scales", "rotations")}
@@ -900,6 +902,7 @@ def cpu_baseline(P_full, S_full):
                                          f"{S_full}x{S_full}) = {tc:.1f} s, not extrapolated"}
         finally:
             _lib.get = hip
+            oracle.abi().cdll.eogs_oracle_set_threads(old_threads)
     except Exception as e:  # the checker library is optional for the bench line
         out["scalar_c"] = {"error": str(e)[:200]}
     return out

@@ -28,7 +28,11 @@
  * and rounded once, i.e. the order-independent value every fp32 ordering
  * approximates.
  *
- * Build: gcc -O2 -ffp-contract=off -shared -fPIC (oracle/Makefile).
+ * Build: gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC (oracle/Makefile).
+ * Threads (round 4): the two per-pixel loops run on the host's cores — the forward's pixels are independent; the backward
+ * takes its per-Gaussian double sums per band of image rows (ORACLE_BANDS, a constant) and adds the bands in ascending
+ * order — so every result is the same number whatever the thread count (eogs_oracle_set_threads; 1 = the single-core run
+ * bench.py reports as `scalar_c`). The committed fixtures regenerate bit for bit with it (tests/golden/make_golden.py).
  */
 #include <math.h>
 #include <stdint.h>
@@ -95,6 +99,25 @@ static inline float T_min(int s, uint32_t nblended) {
   return s ? 0.0001f * (1.0f + (float)s * (g_nk[2] + g_nk[3] * (float)nblended) * ORACLE_ULP) : 0.0001f;
 }
 #define ACC(a, term) do { if (g_acc_float) (a) = (double)((float)(a) + (float)(term)); else (a) += (double)(term); } while (0)
+
+/* Threads of the per-pixel loops (test infrastructure: speeds up the checker, never changes its results — forward pixels are
+ * independent, the backward's sums are taken per band of rows in a fixed order whatever the thread count). 0 = as many as the
+ * machine offers, at most 16; bench.py's single-core `scalar_c` baseline sets 1. */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#define ORACLE_BANDS 8 /* bands of image rows the backward's per-Gaussian sums are taken over (backward_activated) */
+static int g_threads = 0;
+int eogs_oracle_set_threads(int n) { const int old = g_threads; g_threads = n < 0 ? 0 : n; return old; }
+static int oracle_threads(void) {
+#ifdef _OPENMP
+  if (g_threads > 0) return g_threads;
+  const int m = omp_get_num_procs();
+  return m > 16 ? 16 : (m < 1 ? 1 : m);
+#else
+  return 1;
+#endif
+}
 
 static int fail(int code, const char* msg) {
   snprintf(g_err, sizeof g_err, "%s", msg);
@@ -451,7 +474,12 @@ int eogs_rast_forward_render(
   }
 
   /* FORWARD::renderCUDA (forward.cu:288-411), one pixel at a time; the block-level early exit
-   * (:340-342) only skips work for pixels that are all `done`, so it has no effect on results. */
+   * (:340-342) only skips work for pixels that are all `done`, so it has no effect on results.
+   * Rows are dealt to threads (OpenMP, eogs_oracle_set_threads): a pixel reads shared data and writes only its own outputs, so
+   * the results are those of the serial loop bit for bit. */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(oracle_threads())
+#endif
   for (int py = 0; py < H; py++)
     for (int px = 0; px < W; px++) {
       const uint32_t tile = (uint32_t)((py / TILE) * gx + (px / TILE));
@@ -529,20 +557,36 @@ static int backward_activated(
   const size_t HW = (size_t)H * W, n = (size_t)P;
   const int aa = (flags & EOGS_FLAG_ANTIALIASING) != 0;
 
-  /* double accumulators for the atomically-summed outputs (see header) */
-  double* acc_mean2D = (double*)calloc(n * 2, 8);
-  double* acc_conic = (double*)calloc(n * 3, 8); /* x, y, w */
-  double* acc_opac = (double*)calloc(n, 8);
-  double* acc_color = (double*)calloc(n * C_, 8);
-  double* acc_invd = (double*)calloc(n, 8); /* dL_dinvdepths: computed, consumed by nobody (backward.cu:306-307 commented) */
-  if (!acc_mean2D || !acc_conic || !acc_opac || !acc_color || !acc_invd) {
-    free(acc_mean2D); free(acc_conic); free(acc_opac); free(acc_color); free(acc_invd);
-    return fail(EOGS_ERR_DEVICE, "backward: out of host memory");
-  }
+  /* double accumulators for the atomically-summed outputs (see header).
+   * The image is cut into ORACLE_BANDS bands of rows, each with accumulators of its own; a band sums its pixels in row-major
+   * order and the bands are added in ascending order afterwards. The number of bands is a constant — never the number of
+   * threads that happen to work on them — so the result does not depend on the machine: one more fixed order of the sums the
+   * reference leaves to its atomics (backward.cu:598-640), and what lets the checker's backward use the host's cores (bands
+   * are dealt to OpenMP threads, eogs_oracle_set_threads). With fp32 accumulation switched on (eogs_oracle_accum_float: the
+   * sensitivity measurement "one sequence of atomicAdds") there is ONE band: a sequence, not a tree. */
+  const int nbands = g_acc_float ? 1 : ORACLE_BANDS;
+  const size_t per_band = n * (2 + 3 + 1 + C_ + 1);
+  double* acc_all = (double*)calloc(per_band * (size_t)nbands, 8);
+  if (!acc_all) return fail(EOGS_ERR_DEVICE, "backward: out of host memory");
+  double* acc_mean2D = acc_all;                 /* band 0: after the merge below, the totals */
+  double* acc_conic = acc_mean2D + n * 2;       /* x, y, w */
+  double* acc_opac = acc_conic + n * 3;
+  double* acc_color = acc_opac + n;
+  /* (after the colours: dL_dinvdepths, n doubles per band — computed, consumed by nobody: backward.cu:306-307 is commented out) */
 
   /* ---- BACKWARD::renderCUDA (backward.cu:457-643), back to front per pixel ---- */
   const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
-  for (int py = 0; py < H; py++)
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(oracle_threads() < nbands ? oracle_threads() : nbands)
+#endif
+  for (int band = 0; band < nbands; band++) {
+    double* const acc_mean2D = acc_all + per_band * (size_t)band; /* (shadow the totals: this band's own accumulators) */
+    double* const acc_conic = acc_mean2D + n * 2;
+    double* const acc_opac = acc_conic + n * 3;
+    double* const acc_color = acc_opac + n;
+    double* const acc_invd = acc_color + n * C_;
+    const int py0 = (int)((long long)H * band / nbands), py1 = (int)((long long)H * (band + 1) / nbands);
+  for (int py = py0; py < py1; py++)
     for (int px = 0; px < W; px++) {
       const uint32_t tile = (uint32_t)((py / TILE) * gx + (px / TILE));
       const uint32_t r0 = im.ranges[2 * tile], r1 = im.ranges[2 * tile + 1];
@@ -648,6 +692,15 @@ static int backward_activated(
       }
       free(alt);
     }
+  }
+  /* the bands' sums, in ascending band order, into band 0 (element-wise: any number of threads gives the same sums) */
+  for (int band = 1; band < nbands; band++) {
+    const double* src = acc_all + per_band * (size_t)band;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(oracle_threads())
+#endif
+    for (long long i = 0; i < (long long)per_band; i++) acc_all[i] += src[i];
+  }
 
   /* outputs zero-initialised like rasterize_points.cu:163-174 */
   memset(dL_dmeans2D, 0, n * 3 * 4);
@@ -783,7 +836,7 @@ static int backward_activated(
   if (dL_dT_sum) for (int k = 0; k < 6; k++) dL_dT_sum[k] = (float)dT_sum[k];
   if (dL_dvm_mean) for (int k = 0; k < 12; k++) dL_dvm_mean[k] = (float)vm_mean[k];
 
-  free(acc_mean2D); free(acc_conic); free(acc_opac); free(acc_color); free(acc_invd);
+  free(acc_all);
   return EOGS_OK;
 }
 

@@ -168,6 +168,8 @@ def test_headline_1M_1024_matches_oracle(dev):
 @pytest.mark.parametrize("name,P,S,opacity", [
     ("trained_1M_1024", 1 << 20, 1024, "trained"),  # (8 s: as config 4 below)
     pytest.param("opacity0.1_1M_1024", 1 << 20, 1024, 0.1, marks=pytest.mark.slow),
+    pytest.param("opacity0.01_1M_2048", 1 << 20, 2048, "init", marks=pytest.mark.slow),  # the sun camera's size (row-span listing)
+    pytest.param("opacity0.1_2M_1024", 2_000_000, 1024, 0.1, marks=pytest.mark.slow),
     ("config4_2M_1024", 2_000_000, 1024, "trained")])  # (14 s: saturating tiles end the oracle's lists early — in the default suite)
 def test_regimes_of_the_bench_line_match_oracle(dev, name, P, S, opacity):
     """The regimes bench.py reports beside the headline (bench.regime_scan), in full against the C oracle: trained opacities
@@ -179,7 +181,7 @@ def test_regimes_of_the_bench_line_match_oracle(dev, name, P, S, opacity):
     from eogs2_amd import GaussianRasterizationSettings, GaussianRasterizer
     from parity_cases import prefetch_nudges
 
-    case = _full_size_case(P, S, S, 8 if P == 2_000_000 else 0, opacity)
+    case = _full_size_case(P, S, S, 8 if name.startswith("config4") else 0, opacity)
     prefetch_nudges(case)
     got = run_case(case, dev, GaussianRasterizer, GaussianRasterizationSettings)
     flips = compare(got, _oracle(case), name, case)
