@@ -166,18 +166,17 @@ def test_headline_1M_1024_matches_oracle(dev):
 
 
 @pytest.mark.parametrize("name,P,S,opacity", [
-    ("trained_1M_1024", 1 << 20, 1024, "trained"),  # (8 s: as config 4 below)
-    pytest.param("opacity0.1_1M_1024", 1 << 20, 1024, 0.1, marks=pytest.mark.slow),
-    pytest.param("opacity0.01_1M_2048", 1 << 20, 2048, "init", marks=pytest.mark.slow),  # the sun camera's size (row-span listing)
-    pytest.param("opacity0.1_2M_1024", 2_000_000, 1024, 0.1, marks=pytest.mark.slow),
-    ("config4_2M_1024", 2_000_000, 1024, "trained")])  # (14 s: saturating tiles end the oracle's lists early — in the default suite)
+    ("trained_1M_1024", 1 << 20, 1024, "trained"),
+    ("opacity0.1_1M_1024", 1 << 20, 1024, 0.1),
+    ("opacity0.01_1M_2048", 1 << 20, 2048, "init"),  # the sun camera's size (row-span listing)
+    ("opacity0.1_2M_1024", 2_000_000, 1024, 0.1),
+    ("config4_2M_1024", 2_000_000, 1024, "trained")])
 def test_regimes_of_the_bench_line_match_oracle(dev, name, P, S, opacity):
-    """The regimes bench.py reports beside the headline (bench.regime_scan), in full against the C oracle: trained opacities
-    (tiles saturate, most listed pairs dead: the backward's flags-first record sum) and opacity 0.1 (lists twice as long, nothing
-    saturates) — and configs[3]'s per-rank workload (IARPA_001 class: 2 M Gaussians, one 1024^2 view), which the default suite
-    checked before round 4 through properties and a dense crop only (test_config4_2M_1024_properties). The opacity-0.1 regime takes
-    over a minute of oracle time (nothing saturates: every list is walked to its end): EOGS_FULL=1 only, outcome recorded in
-    profiles/r04_sweeps.txt; the two saturating ones are in the default suite."""
+    """Every regime bench.py reports beside the headline (bench.regime_scan), at its own size, in full against the C oracle:
+    trained opacities (tiles saturate, most listed pairs dead: the backward's flags-first record sum), opacity 0.1 (lists twice
+    as long, nothing saturates), the 2048^2 sun-camera size (row-span listing), 2 M Gaussians at opacity 0.1 — and configs[3]'s
+    per-rank workload (IARPA_001 class: 2 M Gaussians, trained opacities, one 1024^2 view). In the default suite since the
+    oracle's per-pixel loops use the host's cores (8-33 s each; minutes before); outcomes in profiles/r04_sweeps.txt."""
     from eogs2_amd import GaussianRasterizationSettings, GaussianRasterizer
     from parity_cases import prefetch_nudges
 
