@@ -900,6 +900,18 @@ def cpu_baseline(P_full, S_full):
             out["scalar_c"] = {"value": 1.0 / tc, "unit": "views/s", "cores": 1,
                                "sample": f"oracle/rast_oracle.c, one fwd+bwd of the full workload ({P_full} Gaussians / "
                                          f"{S_full}x{S_full}) = {tc:.1f} s, not extrapolated"}
+            # the same restatement with its per-pixel loops on all cores (OpenMP, at most 16 threads; projection, sort and the
+            # per-Gaussian passes stay serial): the strongest CPU number this repository can produce for the full workload
+            oracle.abi().cdll.eogs_oracle_set_threads(0)
+            for p in lv.values():
+                p.grad = None
+            t0 = time.perf_counter()
+            c, _, _ = rast(lv["means3D"], m2, lv["opacities"], colors_precomp=lv["colors"], scales=lv["scales"],
+                           rotations=lv["rotations"])
+            torch.autograd.backward([c], [sc["dL_dcolor"]])
+            tm = time.perf_counter() - t0
+            out["threaded_c"] = {"value": 1.0 / tm, "unit": "views/s", "cores": min(os.cpu_count() or 1, 16),
+                                 "sample": f"the same, per-pixel loops on all cores = {tm:.1f} s, not extrapolated"}
         finally:
             _lib.get = hip
             oracle.abi().cdll.eogs_oracle_set_threads(old_threads)
