@@ -50,6 +50,7 @@ CASES = [  # P, H, W, seed, opacity, scale_mult, antialiasing
     (8000, 131, 97, 62, "init", 2.5, True),       # partial tiles on both edges
     (3000, 64, 64, 63, 0.7, 8.0, False),          # long lists, early termination
     (400, 200, 168, 64, "trained", 14.0, False),  # image-sized footprints: the full render takes the back-to-front backward
+    (1 << 20, 2048, 2048, 65, "init", 1.0, False),  # the sun camera of the bench's iteration at its own size (row-span listing)
 ]
 
 
