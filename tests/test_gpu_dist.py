@@ -37,6 +37,24 @@ def test_two_rank_bench_rehearsal():
     assert ti["ms_per_iter"] > 0 and ti["compute_only_ms"] > 0 and ti["exchange_alone_ms"] > 0
 
 
+def test_four_rank_bench_rehearsal():
+    """The same with four ranks on the one card (gloo; four ranks and this process: five of the six processes the box allows
+    on its GPU): bench.py's own launcher, the per-rank view seeds, the exchange among more than two partners, the line's
+    whole-job value."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--backend", "gloo", "--share-gpu",
+                        "--steps", "3", "--warmup", "1", "--gaussians", "20000", "--size", "128", "--no-train-iter"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 4 and line["scaling"] == "weak" and line["config"]["parallelism"] == "view-dp4"
+    assert line["exchange"]["rccl_ranks"] == 4 and line["exchange"]["bytes_per_gaussian"] == 56
+    # whole-job throughput: the four ranks' views over the slowest rank's clock
+    assert abs(line["value"] - 4 * 1e3 / line["ms_per_step"]) <= 1e-6 * line["value"]
+
+
 def test_two_rank_bench_under_torchrun():
     """The driver's own launch style for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
     127.0.0.1 --master-port P bench.py --gpus N ...` — bench.py is then a rank (RANK / LOCAL_RANK / WORLD_SIZE from the
