@@ -418,6 +418,15 @@ def check_close(got, ref, what, rtol, attribution=None, key=None, sens_rtol=None
 
 
 def compare(out, ref, name, case, stats=None, cache=None):
+    try:
+        return _compare(out, ref, name, case, stats, cache)
+    finally:  # prefetched nudged runs nobody collected (every element within tolerance, or an assertion on the way): stop the workers
+        leftover = _PREFETCH.pop(id(case), None)
+        if leftover is not None:
+            leftover[0].terminate()
+
+
+def _compare(out, ref, name, case, stats=None, cache=None):
     """HIP outputs + gradients of one case against the oracle's. radii bit-exact; images and per-Gaussian gradients to
     RTOL (GRAD_RTOL for the stress fixtures); out-of-tolerance elements only where explained (check_close)."""
     assert np.array_equal(out["out_radii"].cpu().numpy(), np.asarray(ref["out_radii"])), f"{name}: radii differ"
@@ -466,9 +475,6 @@ def compare(out, ref, name, case, stats=None, cache=None):
                   f"(oracle moves by {float(delta.max()):.3e})")
             err = lim
         assert err <= lim, f"{name}:g_viewmatrix: {err:.3e} of the magnitude sum (limit {lim:g})"
-    leftover = _PREFETCH.pop(id(case), None)  # prefetched nudged runs nobody needed: every element was within tolerance
-    if leftover is not None:
-        leftover[0].terminate()
     if stats is not None:
         stats[name] = flips
     return flips
