@@ -482,7 +482,12 @@ def train_iteration(sc, P, H, W, dev, fused, iters=5, dist=None, view_seed=0, al
         else:
             opt.zero_grad(set_to_none=True)
         if branches is not None:
-            branches.run([lambda vi=vi: one_view(vi) for vi in range(len(views))])
+            # the largest render (the 2H x 2W sun camera) is queued first: its long kernels start at once and the two small
+            # renders fill in beside them, instead of the sun camera finishing alone (2.73-2.76 -> 2.58-2.63 ms with the
+            # altitude-only sun render; tools/branch_order_probe.py). Gradients accumulate in the order queued.
+            order = [int(x) for x in os.environ["EOGS_BRANCH_ORDER"].split(",")] if "EOGS_BRANCH_ORDER" in os.environ else \
+                sorted(range(len(views)), key=lambda vi: -(views[vi][3].shape[-1] * views[vi][3].shape[-2]))
+            branches.run([lambda vi=vi: one_view(vi) for vi in order])
         else:
             for vi in range(len(views)):
                 one_view(vi)
@@ -985,7 +990,7 @@ def train_example_bench(P, S, iters=24):
 
     out = {"gaussians": P, "size": S, "iters_timed": max(1, iters // 2),
            "what": "3 renders (view, 2x sun altitude-only, random camera) + 2 resamples + render pipeline + losses + FusedAdam + camera Adam"}
-    for tag, extra in (("eager", []), ("graphed", ["--graph"])):
+    for tag, extra in (("eager", []), ("graphed", ["--graph"]), ("graphed_parallel_renders", ["--graph", "--parallel-renders"])):
         try:
             train_synthetic.main(["--gaussians", str(P), "--size", str(S), "--iters", str(iters), "--quiet", "--no-prune",
                                   "--sun-altitude-only", "--random-camera"] + extra)

@@ -27,7 +27,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eogs2_amd.losses import photometric_loss  # noqa: E402
 from eogs2_amd.optim import FusedAdam, prune_optimizer  # noqa: E402
 from eogs2_amd.render import render  # noqa: E402
-from eogs2_amd.resample import render_resample_virtual_camera  # noqa: E402
+from eogs2_amd.graph import Branches  # noqa: E402
+from eogs2_amd.resample import render_resample_virtual_camera, resample  # noqa: E402
 from eogs2_amd.shade import randomcam_l, render_pipeline, suncamera_l, translucentshadows_l  # noqa: E402
 from eogs2_amd.synthetic import make_camera, make_scene  # noqa: E402
 from simple_knn._C import distCUDA2  # noqa: E402
@@ -92,6 +93,10 @@ def main(argv=None):
                     help="third render of the iteration: a random virtual camera at the view's size, resampled onto the view, "
                          "with the masked altitude / RGB consistency pair (train_pan.py:375-391, loss/main_loss.py:151-164)")
     ap.add_argument("--no-prune", action="store_true", help="keep every Gaussian (timing runs)")
+    ap.add_argument("--parallel-renders", action="store_true",
+                    help="the renders of the iteration (independent given the parameters: only the RESAMPLES need the view's "
+                         "altitude) are queued on streams of their own, the largest first (eogs2_amd.graph.Branches); with --graph "
+                         "they become parallel branches of the recorded graph, and autograd runs their backward passes on the same streams")
     ap.add_argument("--require-radii", action="store_true",
                     help="pipe.require_radii: every render also returns radii and `visibility_filter` = nonzero(radii > 0), which waits "
                          "for the device (renderer.py:128-130). The reference's shipped configuration has it OFF "
@@ -111,8 +116,31 @@ def main(argv=None):
     bg = sc["bg"]
     U, V = torch.meshgrid(torch.linspace(-1, 1, W, device=dev), torch.linspace(-1, 1, H, device=dev), indexing="xy")
 
+    branches = Branches(3, device=dev) if a.parallel_renders else None
+
     def view(m, cc_cam):
         """train_pan.py:279-330: view render, sun render resampled onto the view, camera render pipeline."""
+        if branches is not None:
+            # the three renders side by side, the 2H x 2W one first; then what render_resample_virtual_camera does with them
+            sun_img, out, rnd_img = branches.run([
+                lambda: render(sun, m, pipe, bg, altitude_only=a.sun_altitude_only)["render"],
+                lambda: render(cam, m, pipe, bg),
+                lambda: render(rnd, m, pipe, bg)["render"] if a.random_camera else None])
+            img, altitude = out["render"][:3], out["render"][3]
+            uva = torch.stack((U, V, altitude / 350.0), dim=-1)
+            if a.sun_altitude_only:
+                smp, sun_uv = resample(sun_img, cam2sun, uva, n_out=1, fill_channel=0)
+                sun_rgb, sun_alt = None, smp[0]
+            else:
+                smp, sun_uv = resample(sun_img, cam2sun, uva)
+                sun_rgb, sun_alt = smp[:3], smp[3]
+            sun_altitude_diff = altitude - sun_alt
+            shaded = render_pipeline(cc_cam, img, sun_altitude_diff)
+            new = None
+            if a.random_camera:
+                smp, new_uv = resample(rnd_img, cam2rnd, uva)
+                new = (altitude - smp[3], smp[:3], new_uv)
+            return out, img, sun_rgb, sun_uv, sun_altitude_diff, shaded, new
         out = render(cam, m, pipe, bg)
         img, altitude = out["render"][:3], out["render"][3]
         uva = torch.stack((U, V, altitude / 350.0), dim=-1)

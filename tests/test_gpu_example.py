@@ -49,6 +49,9 @@ def test_synthetic_training_three_renders_sun_altitude_only():
     assert eager[1] < 0.6 * eager[0], eager
     graph = train_synthetic.main(args + ["--graph"])
     assert graph[2] == eager[2]
+    # the three renders as parallel branches of the graph (largest first; autograd runs their backward passes on the same streams)
+    par = train_synthetic.main(args + ["--graph", "--parallel-renders"])
+    assert par[2] == eager[2] and abs(par[0] - eager[0]) <= 1e-6 * abs(eager[0]) and abs(par[1] - eager[1]) <= 5e-3 * abs(eager[1]), (eager, par)
     # the first loss is the same number; after 100 optimizer steps the curves agree to rounding amplified by the optimisation
     # (three backward passes accumulate into the same .grad tensors: the engine's order of the two additions is not the
     # recorded graph's), measured 9e-4
