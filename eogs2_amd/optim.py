@@ -8,6 +8,8 @@
 * `compact_rows(mask, tensors)` — every `tensor[mask]` of `prune_points` / `_prune_optimizer`
   (gaussian_model.py:466-505) in one scan + one gather launch and a single host sync.
 * `prune_optimizer(optimizer, mask, extra=())` — `_prune_optimizer` + the statistics of `prune_points`, on top of it.
+* `retire_rows(optimizer, keep)` / `alive_rows(optimizer)` — the same prune deferred: opacity 0 now (no shapes change, no
+  wait, a recorded graph of the iteration stays valid), compaction at a coarser interval.
 * `densify_and_clone` / `densify_and_split` / `cat_tensors_to_optimizer` — the clone / split densification of
   gaussian_model.py:507-660 (off by default in the reference, `only_prune: True`): every boolean-mask gather of a step in
   one scan + one gather, the random draw left to `torch.normal` so that it is the reference's own.
@@ -272,5 +274,35 @@ def reset_opacity(optimizer, name="opacity", cap=0.01):
     return out
 
 
+RETIRED_LOGIT = -1.0e30  # sigmoid() of it is exactly 0 in fp32; Adam's bounded updates cannot move it
+
+
+def retire_rows(optimizer, keep, name="opacity"):
+    """Deferred form of the transparent-Gaussian prune (train_pan.py:673-678 runs `prune_points` every iteration): the rows
+    NOT marked in `keep` get the opacity logit RETIRED_LOGIT instead of being removed. A retired Gaussian has opacity 0: the
+    rasterizer lists it in no tile (alpha < 1/255 everywhere, forward.cu:374-376), it receives zero gradients, and because
+    the stable compaction of `prune_optimizer` would have kept the survivors in the same relative order — the tie-break of
+    the depth sort — the renders, the gradients and the Adam updates of the survivors are those of the pruned model, bit
+    for bit. No tensor changes shape or address and nothing waits for the device: a recorded HIP graph of the iteration
+    (`eogs2_amd.graph.GraphedStep`) keeps replaying, where a prune forces a new recording. Remove the retired rows for good
+    with `prune_optimizer(optimizer, alive_rows(optimizer))` at a coarser interval — before anything that reads all rows
+    (`reset_opacity`, densification, saving the model)."""
+    for group in optimizer.param_groups:
+        if group["name"] == name:
+            p = group["params"][0]
+            with torch.no_grad():
+                p.view(-1).masked_fill_(~keep.view(-1), RETIRED_LOGIT)
+            return
+    raise KeyError(f"retire_rows: no parameter group named {name!r}")
+
+
+def alive_rows(optimizer, name="opacity"):
+    """Boolean mask of the rows `retire_rows` has not retired (a device tensor: no wait)."""
+    for group in optimizer.param_groups:
+        if group["name"] == name:
+            return group["params"][0].detach().view(-1) > 0.5 * RETIRED_LOGIT
+    raise KeyError(f"alive_rows: no parameter group named {name!r}")
+
+
 __all__ = ["FusedAdam", "compact_rows", "prune_optimizer", "reset_opacity", "cat_tensors_to_optimizer", "densify_and_clone",
-           "densify_and_split", "build_rotation"]
+           "densify_and_split", "build_rotation", "retire_rows", "alive_rows", "RETIRED_LOGIT"]

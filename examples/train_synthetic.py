@@ -25,7 +25,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from eogs2_amd.losses import photometric_loss  # noqa: E402
-from eogs2_amd.optim import FusedAdam, prune_optimizer  # noqa: E402
+from eogs2_amd.optim import FusedAdam, alive_rows, prune_optimizer, retire_rows  # noqa: E402
 from eogs2_amd.render import render  # noqa: E402
 from eogs2_amd.graph import Branches  # noqa: E402
 from eogs2_amd.resample import render_resample_virtual_camera, resample  # noqa: E402
@@ -93,6 +93,10 @@ def main(argv=None):
                     help="third render of the iteration: a random virtual camera at the view's size, resampled onto the view, "
                          "with the masked altitude / RGB consistency pair (train_pan.py:375-391, loss/main_loss.py:151-164)")
     ap.add_argument("--no-prune", action="store_true", help="keep every Gaussian (timing runs)")
+    ap.add_argument("--defer-prune", type=int, default=0, metavar="K",
+                    help="at the prune points retire the transparent Gaussians (opacity 0: eogs2_amd.optim.retire_rows) and "
+                         "compact only at every K-th of them and at the end: same renders, same updates, but no shape changes, "
+                         "no wait for the device, and a recorded graph (--graph) keeps replaying in between")
     ap.add_argument("--parallel-renders", action="store_true",
                     help="the renders of the iteration (independent given the parameters: only the RESAMPLES need the view's "
                          "altitude) are queued on streams of their own, the largest first (eogs2_amd.graph.Branches); with --graph "
@@ -218,7 +222,15 @@ def main(argv=None):
                 model.max_radii2D = torch.maximum(model.max_radii2D, radii.float())
             if it % 50 == 0 and not a.no_prune:  # train_pan.py:673-678
                 keep = model._opacity.squeeze() >= math.log(0.005 / 0.995)
-                if not bool(keep.all()):
+                last_point = it + 50 > a.iters
+                if a.defer_prune and not last_point and (it // 50) % a.defer_prune:
+                    retire_rows(model.optimizer, keep)
+                elif a.defer_prune:
+                    alive = alive_rows(model.optimizer) & keep
+                    if not bool(alive.all()):
+                        model.prune(alive)
+                        step = None
+                elif not bool(keep.all()):
                     model.prune(keep)
                     step = None  # new parameter tensors, new shapes: record again
         if it == 1 or it % 25 == 0 or it == a.iters:

@@ -56,3 +56,23 @@ def test_synthetic_training_three_renders_sun_altitude_only():
     # (three backward passes accumulate into the same .grad tensors: the engine's order of the two additions is not the
     # recorded graph's), measured 9e-4
     assert abs(graph[0] - eager[0]) <= 1e-6 * abs(eager[0]) and abs(graph[1] - eager[1]) <= 5e-3 * abs(eager[1]), (eager, graph)
+
+
+def test_deferred_prune_equals_prune():
+    """`--defer-prune K`: at the prune points the transparent Gaussians are retired (opacity 0, eogs2_amd.optim.retire_rows)
+    and compacted only at every K-th point and at the end. The stable compaction keeps the survivors' order — the depth sort's
+    tie-break — so the run is the pruned run: same losses, same survivors (and as a replayed graph it records three times
+    instead of at every prune that removes something)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import train_synthetic
+
+    args = ["--gaussians", "30000", "--size", "192", "--iters", "400", "--quiet", "--sun-altitude-only", "--random-camera"]
+    plain = train_synthetic.main(args)
+    deferred = train_synthetic.main(args + ["--defer-prune", "3"])
+    assert plain[2] < 30000, plain  # (the case prunes)
+    assert deferred == plain, (plain, deferred)  # bit for bit
+    graph = train_synthetic.main(args + ["--graph"])
+    graph_deferred = train_synthetic.main(args + ["--graph", "--defer-prune", "3"])
+    assert graph_deferred == graph, (graph, graph_deferred)
