@@ -259,10 +259,15 @@ __global__ __launch_bounds__(BLK) void resample_bwd_tile_kernel(int C, int Hv, i
 //   gather: every virtual cell (cx, cy) of the tile — a few per thread, accumulators in registers — adds the entries of its four
 //           buckets (x0, y0) in {cx-1, cx} x {cy-1, cy} with the tap weight that cell has in them,
 // and writes its cells once with plain stores. Every tap of every pixel is counted exactly once, by the tile that owns its
-// cell; taps outside the virtual image have no cell. The order of the few entries of a bucket is the order of the atomics, so
-// — like the first form, and like grid_sample's backward in the reference — sums are reproducible to rounding, not bit for bit.
+// cell; taps outside the virtual image have no cell. The sums run in a FIXED order (bit-reproducible, unlike the first form and
+// unlike grid_sample's backward in the reference): the candidate tiles are listed in tile order (ballot ranks, not an atomic
+// cursor), and inside a bucket — whose places the integer atomics hand out in any order — every entry ranks itself among the
+// bucket's pixel ids before it parks its payload, so a bucket's entries lie in pixel order.
+// (registers: held to the occupancy each variant had before the fixed-order fill — the compiler otherwise keeps a few more
+// values live across the two new barriers and drops a wave per SIMD, +50 % on the one-channel kernel)
 template <int NACC, int VX, int VY>
-__global__ __launch_bounds__(BLK) void resample_bwd_gather_kernel(int C, int Hv, int Wv, int H, int W, int n_out,
+__global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((NACC == 4 && VX == 32) ? 4 : 3)))
+void resample_bwd_gather_kernel(int C, int Hv, int Wv, int H, int W, int n_out,
                                                                   const float* __restrict__ uva, const float* __restrict__ M,
                                                                   int fill_channel, const float* __restrict__ gs,
                                                                   const int4* __restrict__ bbox, int ntx, int nty,
@@ -283,6 +288,7 @@ __global__ __launch_bounds__(BLK) void resample_bwd_gather_kernel(int C, int Hv,
   __shared__ uint16_t s_list[RB];  // candidates of the round, as offsets into it
   __shared__ uint32_t s_n;
   __shared__ uint32_t s_wsum[BLK / 64];
+  __shared__ uint32_t s_wc[64];  // candidates per (scan step, wave), then their exclusive prefix
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int vx0 = blockIdx.x * VX, vy0 = blockIdx.y * VY;
   const int HW = H * W;
@@ -295,19 +301,43 @@ __global__ __launch_bounds__(BLK) void resample_bwd_gather_kernel(int C, int Hv,
   for (int e = t; e <= NB; e += BLK) s_cnt[e] = 0u;
 
   for (int scanned = 0; scanned < nt; scanned += RB) {  // candidate output tiles: RB boxes per round (one round at 1024^2)
-    if (t == 0) s_n = 0;
-    __syncthreads();
     {
-      int4 bb[RB / BLK];
+      constexpr int RBN = RB / BLK, NW = BLK / 64;
+      static_assert(RBN * NW <= 64, "the per-wave candidate counts are scanned by one wave");
+      int4 bb[RBN];
 #pragma unroll
-      for (int i = 0; i < RB / BLK; i++) {
+      for (int i = 0; i < RBN; i++) {
         const int k = scanned + i * BLK + t;
         bb[i] = k < nt ? bbox[k] : make_int4(1, 1, 0, 0);  // (empty box: x0 > x1)
       }
+      // the candidates in tile order: per (i, wave) ballot counts, their exclusive scan, ballot ranks
+      uint32_t pred = 0;
 #pragma unroll
-      for (int i = 0; i < RB / BLK; i++)
-        if (bb[i].x <= bb[i].z && bb[i].x <= vx0 + VX - 1 && bb[i].z >= vx0 && bb[i].y <= vy0 + VY - 1 && bb[i].w >= vy0)
-          s_list[atomicAdd(&s_n, 1u)] = (uint16_t)(i * BLK + t);
+      for (int i = 0; i < RBN; i++) {
+        const bool c = bb[i].x <= bb[i].z && bb[i].x <= vx0 + VX - 1 && bb[i].z >= vx0 && bb[i].y <= vy0 + VY - 1 && bb[i].w >= vy0;
+        pred |= (c ? 1u : 0u) << i;
+        const unsigned long long m = __ballot(c);
+        if (lane == 0) s_wc[i * NW + wv] = (uint32_t)__popcll(m);
+      }
+      __syncthreads();
+      if (t < 64) {
+        const uint32_t v = t < RBN * NW ? s_wc[t] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t nb2 = __shfl_up(inc, o, 64);
+          if (lane >= o) inc += nb2;
+        }
+        if (t < RBN * NW) s_wc[t] = inc - v;
+        if (t == 63) s_n = inc;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < RBN; i++) {
+        const bool c = (pred >> i) & 1u;
+        const unsigned long long m = __ballot(c);
+        if (c) s_list[s_wc[i * NW + wv] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(i * BLK + t);
+      }
     }
     __syncthreads();
     const uint32_t n = s_n;
@@ -383,12 +413,31 @@ __global__ __launch_bounds__(BLK) void resample_bwd_gather_kernel(int C, int Hv,
         }
       }
       __syncthreads();
-      // fill
+      // fill, in pixel order inside every bucket: the atomics hand out the bucket's places to the pixel IDS (candidate k of the
+      // chunk, thread t), each pixel then counts the smaller ids of its bucket (a bucket holds a few entries; one alone skips
+      // the loop) and parks its payload at that rank
+      uint32_t* s_id = reinterpret_cast<uint32_t*>(s_pay);
+#pragma unroll
+      for (int k = 0; k < CHT; k++)
+        if (bucket[k] >= 0) s_id[(s_start[bucket[k]] + atomicAdd(&s_cnt[bucket[k]], 1u)) * PAY] = (uint32_t)(k * BLK + t);
+      __syncthreads();
+      uint32_t pos[CHT];
+#pragma unroll
+      for (int k = 0; k < CHT; k++) {
+        pos[k] = 0u;
+        if (bucket[k] >= 0) {
+          const uint32_t st = s_start[bucket[k]], cnt = s_cnt[bucket[k]], me = (uint32_t)(k * BLK + t);
+          uint32_t r = 0u;
+          if (cnt > 1u)
+            for (uint32_t e = st; e < st + cnt; e++) r += s_id[e * PAY] < me ? 1u : 0u;
+          pos[k] = st + r;
+        }
+      }
+      __syncthreads();
 #pragma unroll
       for (int k = 0; k < CHT; k++) {
         if (bucket[k] >= 0) {
-          const uint32_t pos = s_start[bucket[k]] + atomicAdd(&s_cnt[bucket[k]], 1u);
-          float* e = s_pay + pos * PAY;
+          float* e = s_pay + pos[k] * PAY;
           e[0] = wx1[k]; e[1] = wy1[k];
 #pragma unroll
           for (int ch = 0; ch < NACC; ch++) e[2 + ch] = gq[k][ch];

@@ -38,9 +38,11 @@ int eogs_resample_bytes(int H, int W, size_t* bytes);
 
 /* Backward.
  *   dL_dsample f32[n_out,H,W]; dL_duv f32[H,W,2] or NULL
- *   dL_dvirtual f32[C,Hv,Wv]: fully overwritten. The four-tap scatter is evaluated as a gather per virtual tile with the
- *     sums formed in LDS (no global atomics); like PyTorch's grid_sampler_2d_backward the summation order, hence the
- *     last bit, is not fixed run to run. With n_out > 4 or ws == NULL it falls back to global fp32 atomic adds.
+ *   dL_dvirtual f32[C,Hv,Wv]: fully overwritten. The four-tap scatter is evaluated as a gather per virtual tile (no global
+ *     atomics) whose sums run in a fixed order — candidate tiles in tile order, the pixels of a cell in pixel order — so the
+ *     result is bitwise reproducible run to run (PyTorch's grid_sampler_2d_backward, which the reference uses, is not).
+ *     Exceptions: n_out > 4 or ws == NULL fall back to global fp32 atomic adds, and the round-2 form of the tile kernel
+ *     (environment EOGS_RESAMPLE_BWD=1, a tuning aid) sums with LDS float atomics; neither fixes the last bit.
  *   dL_duva f32[H,W,3]: cam2virt[0:2,:]^T (dL_duv + the sampler's gradient with respect to the coordinates), fully overwritten
  * cam2virt itself receives no gradient (the reference derives it from fixed camera matrices). */
 int eogs_resample_backward(int C, int Hv, int Wv, int H, int W, int n_out, const float* virtual_render,

@@ -61,8 +61,9 @@ def test_synthetic_training_three_renders_sun_altitude_only():
 def test_deferred_prune_equals_prune():
     """`--defer-prune K`: at the prune points the transparent Gaussians are retired (opacity 0, eogs2_amd.optim.retire_rows)
     and compacted only at every K-th point and at the end. The stable compaction keeps the survivors' order — the depth sort's
-    tie-break — so the run is the pruned run: same losses, same survivors (and as a replayed graph it records three times
-    instead of at every prune that removes something)."""
+    tie-break — so the run is the pruned run: same losses, same survivors, bit for bit (every sum of the chain runs in a fixed
+    order: the same run twice gives the same bits); as a replayed graph it records three times instead of at every prune that
+    removes something."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
@@ -70,6 +71,7 @@ def test_deferred_prune_equals_prune():
 
     args = ["--gaussians", "30000", "--size", "192", "--iters", "400", "--quiet", "--sun-altitude-only", "--random-camera"]
     plain = train_synthetic.main(args)
+    assert train_synthetic.main(args) == plain  # reproducible
     deferred = train_synthetic.main(args + ["--defer-prune", "3"])
     assert plain[2] < 30000, plain  # (the case prunes)
     assert deferred == plain, (plain, deferred)  # bit for bit

@@ -170,3 +170,26 @@ def test_first_form_of_the_backward_tile_kernel_still_matches_the_oracle(dev):
                        capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_backward_is_reproducible_bit_for_bit(dev):
+    """The gather sums in a fixed order (candidate tiles in tile order, a bucket's entries in pixel order): repeated backward
+    passes over the same inputs give the same bits — at 1:1 and under minification, where several true-camera pixels land in one
+    virtual cell and the order of the sum is visible, one plane and four."""
+    from eogs2_amd.resample import resample
+
+    for f, H, W, n_out in ((1, 300, 420, 4), (1, 300, 420, 1)):
+        vr, alt, UV, M, w_s, w_uv = _case(H, W, f, seed=7, shift=0.2)
+        M = M.clone()
+        M[0, 0], M[1, 1] = 0.45, 0.6  # several pixels per virtual cell
+        grads = []
+        for _ in range(6):
+            v = vr[:5 if n_out == 4 else 1].to(dev).requires_grad_(True)
+            a = alt.to(dev).requires_grad_(True)
+            uva = torch.stack((UV[0].to(dev), UV[1].to(dev), a), dim=-1)
+            s, uv = resample(v, M.to(dev), uva, n_out=n_out, fill_channel=n_out - 1)
+            ((s * w_s[:n_out].to(dev)).sum() + (uv * w_uv.to(dev)).sum()).backward()
+            grads.append((v.grad.clone(), a.grad.clone()))
+        assert float(grads[0][0].abs().max()) > 0
+        for gv, ga in grads[1:]:
+            assert torch.equal(gv, grads[0][0]) and torch.equal(ga, grads[0][1])
