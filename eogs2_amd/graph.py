@@ -87,14 +87,39 @@ class GraphedStep:
         # pinned host slots the graph copies each forward's counts into (include/eogs_rast.h eogs_rast_mirror_counts):
         # fits() polls them instead of waiting for the whole replay
         self._mirror = torch.empty((64 * (self.MAX_MIRRORED + 1),), dtype=torch.uint8, pin_memory=True)
+        # Every recording of this step allocates from ONE private pool: what the previous recording held is reused by the next
+        # instead of going back to the device. (It also has to: with parallel branches in the graph, about half of what a
+        # released graph pool hands to hipFree stays with the runtime on this stack — tools/graph_leak_probe2.py: 424 MiB per
+        # recording of the 200 k / 512^2 example, the 288 GB card full after ~875.)
+        self._pool = torch.cuda.graph_pool_handle()
+        # (the allocator drops a pool with its last graph and refuses to reopen it: a one-tensor graph that is never replayed
+        # keeps this one open between dropping a recording and making the next)
+        self._anchor = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._anchor, pool=self._pool):
+            self._anchor_out = torch.zeros(1, device="cuda")
+        self._warm_up(warmup)
+        self._capture()
+
+    def _warm_up(self, runs):
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
         with torch.cuda.stream(side):  # (torch.cuda.graph's own recipe: warm up on a side stream)
-            for _ in range(warmup):
-                fn()
+            for _ in range(runs):
+                self.fn()
         cur.wait_stream(side)
         rasterizer.clear_scratch(stream=side)  # (the warm-up stream is never used again: do not keep its entry-sort buffer)
+
+    def record_again(self, warmup=1):
+        """Records the step anew — after its inputs changed shape or address (a prune: new parameter tensors), which a replay
+        cannot follow. `warmup` eager runs first, as at construction (their counts size the new workspaces). Keeps this
+        step's memory pool: prefer it to constructing a new GraphedStep."""
+        if warmup < 1:
+            raise ValueError("GraphedStep needs at least one eager run before the capture")
+        torch.cuda.current_stream().synchronize()
+        self.graph = self.outputs = None  # (their memory serves the eager runs' successor: the new recording)
+        self.forwards = []
+        self._warm_up(warmup)
         self._capture()
 
     def _capture(self):
@@ -105,7 +130,7 @@ class GraphedStep:
         #                      counts they read are already merged into rasterizer._peak by fits())
         graph = torch.cuda.CUDAGraph()
         with rasterizer.record_captured(self._mirror) as forwards:
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, pool=self._pool):
                 out = self.fn()
         self.graph, self.outputs, self.forwards = graph, out, list(forwards)
 

@@ -93,6 +93,9 @@ def main(argv=None):
                     help="third render of the iteration: a random virtual camera at the view's size, resampled onto the view, "
                          "with the masked altitude / RGB consistency pair (train_pan.py:375-391, loss/main_loss.py:151-164)")
     ap.add_argument("--no-prune", action="store_true", help="keep every Gaussian (timing runs)")
+    ap.add_argument("--prune-every", type=int, default=50, metavar="N",
+                    help="iterations between prune points (the reference: 1, train_pan.py:673-678 — it asks the device "
+                         "`transparent_mask.any()` every iteration)")
     ap.add_argument("--defer-prune", type=int, default=0, metavar="K",
                     help="at the prune points retire the transparent Gaussians (opacity 0: eogs2_amd.optim.retire_rows) and "
                          "compact only at every K-th of them and at the end: same renders, same updates, but no shape changes, "
@@ -198,7 +201,7 @@ def main(argv=None):
         return loss.detach(), out.get("radii")
 
     first = last = None
-    step = None  # the recorded graph of fwd_bwd for the current set of Gaussians
+    step, stale = None, False  # the recorded graph of fwd_bwd; stale: recorded for parameter tensors that a prune replaced
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     t_steady = None  # (the clock of the last `timed` iterations: without the first ones, which allocate and record)
@@ -212,6 +215,9 @@ def main(argv=None):
                 from eogs2_amd.graph import GraphedStep
 
                 step = GraphedStep(fwd_bwd, warmup=1)  # (the eager warm-up run changes nothing: no optimizer step inside)
+            elif stale:
+                step.record_again()  # new parameter tensors, new shapes (fwd_bwd reads them from `model`); same memory pool
+            stale = False
             loss, radii = step()
         else:
             loss, radii = fwd_bwd()
@@ -220,25 +226,26 @@ def main(argv=None):
         with torch.no_grad():
             if radii is not None:  # train_pan.py:681-686 (densification statistics: only with require_radii)
                 model.max_radii2D = torch.maximum(model.max_radii2D, radii.float())
-            if it % 50 == 0 and not a.no_prune:  # train_pan.py:673-678
+            if it % a.prune_every == 0 and not a.no_prune:  # train_pan.py:673-678
                 keep = model._opacity.squeeze() >= math.log(0.005 / 0.995)
-                last_point = it + 50 > a.iters
-                if a.defer_prune and not last_point and (it // 50) % a.defer_prune:
+                last_point = it + a.prune_every > a.iters
+                if a.defer_prune and not last_point and (it // a.prune_every) % a.defer_prune:
                     retire_rows(model.optimizer, keep)
                 elif a.defer_prune:
                     alive = alive_rows(model.optimizer) & keep
                     if not bool(alive.all()):
                         model.prune(alive)
-                        step = None
+                        stale = True
                 elif not bool(keep.all()):
                     model.prune(keep)
-                    step = None  # new parameter tensors, new shapes: record again
+                    stale = True  # new parameter tensors, new shapes: record again
         if it == 1 or it % 25 == 0 or it == a.iters:
             v = float(loss)
             first = v if first is None else first
             last = v
             if not a.quiet:
-                print(f"iter {it:4d}  loss {v:.5f}  gaussians {model._xyz.shape[0]}")
+                print(f"iter {it:4d}  loss {v:.5f}  gaussians {model._xyz.shape[0]}  device memory in use "
+                      f"{(lambda f, t: (t - f) / 2**20)(*torch.cuda.mem_get_info()):.0f} MiB")
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     dt = t1 - t0

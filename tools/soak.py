@@ -23,8 +23,9 @@ def mem(tag):
 
     gc.collect()
     torch.cuda.empty_cache()
+    f, t = torch.cuda.mem_get_info()  # the device's own figure: what the HIP runtime holds besides the allocator's segments shows here only
     print(f"  [{tag}] allocated {torch.cuda.memory_allocated() / 2**20:8.1f} MiB   reserved {torch.cuda.memory_reserved() / 2**20:8.1f} MiB   "
-          f"peak allocated {torch.cuda.max_memory_allocated() / 2**20:8.1f} MiB", flush=True)
+          f"peak allocated {torch.cuda.max_memory_allocated() / 2**20:8.1f} MiB   device in use {(t - f) / 2**20:8.1f} MiB", flush=True)
     torch.cuda.reset_peak_memory_stats()
 
 
