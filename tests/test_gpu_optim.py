@@ -237,3 +237,54 @@ def test_densify_clone_and_split_match_reference_ops(dev, split):
         p.grad = torch.ones_like(p)
     opt.step()  # training goes on over the new rows
     assert all(int(opt.state[gr["params"][0]]["step"]) == 2 for gr in opt.param_groups)
+
+
+def test_retired_rows_render_nothing_and_stay_retired(dev):
+    """`retire_rows` (the deferred prune): a retired Gaussian is listed nowhere and gets zero gradients, the survivors' render and
+    gradients are those of the compacted model bit for bit, FusedAdam steps with momentum in the retired rows leave them retired,
+    and `prune_optimizer(alive_rows())` removes exactly them."""
+    from eogs2_amd.fused import rasterize_raw
+    from eogs2_amd.optim import RETIRED_LOGIT, FusedAdam, alive_rows, prune_optimizer, retire_rows
+    from eogs2_amd.synthetic import make_scene, settings_for
+
+    P, H, W = 20000, 160, 192
+    sc = make_scene(P, H, W, seed=5, opacity="trained", device=dev)
+    rs, alt = settings_for(sc, H, W), sc["viewmatrix"][:, 2].contiguous()
+    dL = torch.randn(5, H, W, device=dev) / (H * W)
+    names = ("xyz", "f_dc", "opacity", "scaling", "rotation")
+    init = dict(xyz=sc["means3D"], f_dc=torch.logit(sc["colors"][:, :3].clamp(0.01, 0.99)).reshape(P, 1, 3),
+                opacity=torch.logit(sc["opacities"].clamp(1e-4, 1 - 1e-4)), scaling=sc["scales"].log(), rotation=sc["rotations"])
+    opt = FusedAdam([{"params": [torch.nn.Parameter(init[n].clone())], "lr": 1e-2, "name": n} for n in names], lr=0.0, eps=1e-15)
+
+    def params():
+        return {g["name"]: g["params"][0] for g in opt.param_groups}
+
+    def fwd_bwd(p):
+        for t in p.values():
+            t.grad = None
+        m2 = torch.zeros_like(p["xyz"], requires_grad=True)
+        color, radii, _ = rasterize_raw(p["xyz"], m2, p["f_dc"], p["opacity"], p["scaling"], p["rotation"], alt, rs)
+        torch.autograd.backward([color], [dL])
+        return color.detach().clone()
+
+    fwd_bwd(params())
+    opt.step()  # every row now carries Adam momentum
+    keep = torch.rand(P, generator=torch.Generator().manual_seed(3)).to(dev) > 0.3
+    retire_rows(opt, keep)
+    p = params()
+    assert bool((p["opacity"].view(-1)[~keep] == RETIRED_LOGIT).all()) and bool(torch.equal(alive_rows(opt), keep))
+    color = fwd_bwd(p)
+    for n in names:
+        assert float(p[n].grad[~keep].abs().max()) == 0.0, n
+    # the compacted model: same image, same gradients in the surviving rows
+    compact = {n: torch.nn.Parameter(p[n].detach()[keep].clone()) for n in names}
+    color_c = fwd_bwd(compact)
+    assert torch.equal(color, color_c)
+    for n in names:
+        assert torch.equal(p[n].grad[keep], compact[n].grad), n
+    for _ in range(5):  # momentum from before the retirement, zero gradients since
+        opt.step()
+    assert bool(torch.equal(alive_rows(opt), keep))
+    new, _ = prune_optimizer(opt, alive_rows(opt))
+    assert new["xyz"].shape[0] == int(keep.sum())
+    assert torch.isfinite(new["opacity"]).all()
