@@ -88,12 +88,14 @@ class GraphedStep:
         # fits() polls them instead of waiting for the whole replay
         self._mirror = torch.empty((64 * (self.MAX_MIRRORED + 1),), dtype=torch.uint8, pin_memory=True)
         # Every recording of this step allocates from ONE private pool: what the previous recording held is reused by the next
-        # instead of going back to the device. (It also has to: with parallel branches in the graph, about half of what a
-        # released graph pool hands to hipFree stays with the runtime on this stack — tools/graph_leak_probe2.py: 424 MiB per
-        # recording of the 200 k / 512^2 example, the 288 GB card full after ~875.)
+        # instead of going back to the device. (It also had to: a step re-created per recording lost 424 MiB of device memory
+        # per recording of the 200 k / 512^2 example with parallel branches, the 288 GB card full after ~875 —
+        # tools/graph_leak_probe2.py)
         self._pool = torch.cuda.graph_pool_handle()
-        # (the allocator drops a pool with its last graph and refuses to reopen it: a one-tensor graph that is never replayed
-        # keeps this one open between dropping a recording and making the next)
+        # The allocator drops a pool with its last graph and refuses to reopen it: a one-tensor graph that is never replayed
+        # keeps this one open between dropping a recording and making the next. (Do not remove it as an optimisation: the
+        # control runs of the probe show that this small graph, captured first, is also what makes a DISCARDED step's memory
+        # return to the device in full on this stack.)
         self._anchor = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._anchor, pool=self._pool):
             self._anchor_out = torch.zeros(1, device="cuda")

@@ -22,6 +22,16 @@ def snap(tag):
           f"{torch.cuda.memory_allocated() / 2**20:7.0f} | segments {st.get('segment.all.current', 0)}", flush=True)
 
 
+if os.environ.get("PROBE_OLD_INIT"):  # GraphedStep as it was before it kept a pool: no pool argument, no anchor graph
+    def _old_init(self, fn, warmup=2, idempotent=True):
+        self.fn, self.idempotent = fn, idempotent
+        self.replays = self.recaptures = 0
+        self._mirror = torch.empty((64 * (self.MAX_MIRRORED + 1),), dtype=torch.uint8, pin_memory=True)
+        self._pool = None
+        self._warm_up(warmup)
+        self._capture()
+
+    G.GraphedStep.__init__ = _old_init
 orig = G.GraphedStep.__init__
 count = [0]
 
@@ -52,4 +62,20 @@ def patched_again(self, *a, **k):
 G.GraphedStep.record_again = patched_again
 base = ["--gaussians", "200000", "--size", "512", "--iters", "158", "--sun-altitude-only", "--random-camera", "--graph",
         "--prune-every", "1", "--quiet"]
-train_synthetic.main(base + sys.argv[1:])
+if os.environ.get("PROBE_NEW_STEP"):  # the behaviour before record_again: a new GraphedStep (a new pool) per recording
+    G.GraphedStep.record_again = lambda self, warmup=1: (_ for _ in ()).throw(RuntimeError("unused"))
+    src = open(train_synthetic.__file__).read().replace("elif stale:\n                step.record_again()", "elif stale:\n                step = None; step = GraphedStep(fwd_bwd, warmup=1)")
+    ns = {"__name__": "train_synthetic_new_step", "__file__": train_synthetic.__file__}
+    exec(compile(src, train_synthetic.__file__, "exec"), ns)
+    train_synthetic = type("M", (), {"main": staticmethod(ns["main"])})
+if os.environ.get("PROBE_NO_POOL"):  # every capture in a pool of its own, as before the step kept one (the anchor graph too)
+    _graph = torch.cuda.graph
+
+    class _NoPool(_graph):
+        def __init__(self, g, pool=None, **k):
+            super().__init__(g, **k)
+
+    torch.cuda.graph = _NoPool
+drop = [a[5:] for a in sys.argv[1:] if a.startswith("drop=")]
+base = [b for b in base if b not in drop]
+train_synthetic.main(base + [a for a in sys.argv[1:] if not a.startswith("drop=")])
