@@ -1066,10 +1066,10 @@ void launch_entry_sort(const GeomWS& g, const SortWS& w, int P, int H, int W, hi
 // =====================================================================================================================
 // Per block: depth order + split into the internal tiles' lists
 // =====================================================================================================================
-#define BL_T 1024                  // threads per workgroup (16 wave64)
-#define BL_NW (BL_T / 64)
+// threads per workgroup: 1024 (16 wave64), or — chosen per forward by launch_block_lists — 512 / 256 where blocks hold few entries
 
 namespace {
+template <int BL_NW>
 __device__ inline uint32_t bl_sum(uint32_t v, uint32_t* s_red) {  // sum over the workgroup (all threads call)
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -1097,11 +1097,16 @@ __device__ inline uint32_t bl_sum(uint32_t v, uint32_t* s_red) {  // sum over th
 // scratch ping-pong buffer ki (the entry buffer the block sort left free: 16 bytes per entry = two 8-byte pairs) with
 // running digit bases in LDS, the next digit's histogram taken while scattering; a block's data stays in its CU's L2.
 // Any n is handled (a block with a million entries only takes long).
-// Compiled for two workgroups per CU (64 VGPRs): the launch is one workgroup per block, all resident at once at 1024^2.
+// Compiled for 64 VGPRs (eight waves per SIMD): two 1024-thread workgroups per CU, the launch is one workgroup per block.
+// BL_T = 1024 threads where a block holds 1400 entries or more on average (1 M Gaussians at 1024^2: 1600 ... 2600), 512 / 256
+// below that (large images, small scenes: 4096 blocks of ~600 entries at 2048^2 — sixteen waves then wait at barriers for two
+// busy ones and the CU holds two such workgroups: 134 -> 72 us there; launch_block_lists, profiles/r04_experiments/ab_bl_threads.txt).
 // BL_ITEMS = 4 (LDS path up to 4096 entries, no spills) unless the average block holds 2800 ... 6000 entries: then 8
 // (8192 entries, a few spilled registers: 2 M Gaussians at trained opacities 218 -> 158 us; at 1700 entries per block the
 // 4-item build is faster, 59 against 77 us, and beyond 6000 the 8-item build loses to the 4-item streaming path).
-template <int MODE, int BL_ITEMS>
+#define BL_NARROW_256 750.0   // entries per block (average) up to which a block's workgroup has 256 threads ...
+#define BL_NARROW_512 1400.0  // ... 512 threads; above: 1024 (measured crossovers: profiles/r04_experiments/ab_bl_threads.txt)
+template <int MODE, int BL_ITEMS, int BL_T>
 __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __restrict__ ent, uint2* ki,
                                                               const uint32_t* __restrict__ bcount,
                                                               const uint32_t* __restrict__ bpairs,
@@ -1111,6 +1116,7 @@ __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __res
                                                               uint8_t* __restrict__ live, uint32_t cap_slots,
                                                               uint32_t cap_entries, const uint32_t* __restrict__ where,
                                                               uint4* __restrict__ desc, uint32_t lg16) {
+  constexpr int BL_NW = BL_T / 64;
   constexpr int BL_CH = BL_T * BL_ITEMS;  // entries per chunk of a pass = longest list the LDS path takes
   __shared__ uint16_t s_wcnt[BL_NW][256];
   __shared__ uint32_t s_base[256], s_cb[256], s_h[256], s_hn[256];
@@ -1156,8 +1162,8 @@ __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __res
       ve += bcount[i];
       if (MODE == 1) vp += bpairs[i];
     }
-    s0 = bl_sum(ve, s_red);
-    if (MODE == 1) pairs_before = bl_sum(vp, s_red);
+    s0 = bl_sum<BL_NW>(ve, s_red);
+    if (MODE == 1) pairs_before = bl_sum<BL_NW>(vp, s_red);
   }
   if (MODE != 1 && t == 0) ranges[b] = make_uint2(s0, s0 + n);
   if (MODE != 1 && t < 16)  // block lists: every tile of the block reads the block's list
@@ -1478,14 +1484,30 @@ void launch_block_lists(const GeomWS& g, const SortWS& w, const BinWS& b, const 
   uint2* ki = reinterpret_cast<uint2*>(inA ? w.entB : w.entA);
   const bool wide = nr_wide(R) != 0;  // 2800 ... 6000 entries per block on average (api.hip forward_counts)
   const uint32_t cap_slots = nr_slots(R), cap_entries = nr_entries(R) < w.cap ? nr_entries(R) : w.cap;
+  // Workgroup size by the entries a block holds on average (R carries the forward's entry count, or a capacity above it: then
+  // the larger workgroup is taken, which is only slower). A block's workgroup orders its entries in LDS up to 4 per thread; with a
+  // few hundred entries per block — large images: 4096 blocks at 2048^2 — sixteen waves mostly wait at barriers for one or two
+  // busy ones, and only two such workgroups fit a CU. Lists longer than 4 x the workgroup stream through global memory (any
+  // length is handled), so the thresholds leave room for the spread between blocks.
+  static const int forced = [] { const char* e = getenv("EOGS_BL_T"); return e ? atoi(e) : 0; }();  // tuning aid: 256 / 512 / 1024
+  const double per_block = (double)nr_entries(R) / (double)nblocks;
+  int T = wide ? 1024 : per_block <= BL_NARROW_256 ? 256 : per_block <= BL_NARROW_512 ? 512 : 1024;
+  if (!wide && (forced == 256 || forced == 512 || forced == 1024)) T = forced;
+  if (M > 1) (void)hipMemsetAsync(b.live, 0, (size_t)nr_slots(R), s);
+#define BL_LAUNCH(MODE_, ITEMS_, T_)                                                                                            \
+  hipLaunchKernelGGL((block_lists_kernel<MODE_, ITEMS_, T_>), dim3(nblocks), dim3(T_), 0, s, ent, ki, g.bcount, g.bpairs, g.misc, \
+                     gmx, gsx, gsy, b.point_list, b.sorted_keys, im.ranges, b.live, cap_slots, cap_entries, g.where, im.desc,    \
+                     16u * im.sched_lg)
   if (M > 1) {
-    (void)hipMemsetAsync(b.live, 0, (size_t)nr_slots(R), s);
-    auto* kern = wide ? block_lists_kernel<BLOCK_BIG, 8> : block_lists_kernel<BLOCK_BIG, 4>;
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(BL_T), 0, s, ent, ki, g.bcount, g.bpairs, g.misc, gmx, gsx, gsy, b.point_list,
-                       b.sorted_keys, im.ranges, b.live, cap_slots, cap_entries, g.where, im.desc, 16u * im.sched_lg);
+    if (wide) BL_LAUNCH(BLOCK_BIG, 8, 1024);
+    else if (T == 256) BL_LAUNCH(BLOCK_BIG, 4, 256);
+    else if (T == 512) BL_LAUNCH(BLOCK_BIG, 4, 512);
+    else BL_LAUNCH(BLOCK_BIG, 4, 1024);
   } else {
-    auto* kern = wide ? block_lists_kernel<1, 8> : block_lists_kernel<1, 4>;
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(BL_T), 0, s, ent, ki, g.bcount, g.bpairs, g.misc, gmx, gsx, gsy, b.point_list,
-                       b.sorted_keys, im.ranges, b.live, cap_slots, cap_entries, g.where, im.desc, 16u * im.sched_lg);
+    if (wide) BL_LAUNCH(1, 8, 1024);
+    else if (T == 256) BL_LAUNCH(1, 4, 256);
+    else if (T == 512) BL_LAUNCH(1, 4, 512);
+    else BL_LAUNCH(1, 4, 1024);
   }
+#undef BL_LAUNCH
 }

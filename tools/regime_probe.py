@@ -41,4 +41,8 @@ for rep in range(3):
     torch.cuda.synchronize()
     abi.profile_enable(0)
     prof = {k: round(v[0] / steps, 4) for k, v in abi.profile().items() if v[1]}
-    print(json.dumps({"rep": rep, "ms_per_step": round(ms, 4), "kernel_sum": round(sum(prof.values()), 4), "kernels": prof}), flush=True)
+    from eogs2_amd.rasterizer import last_exact_token
+    tok = int(last_exact_token(dev))
+    nblocks = ((S + 31) // 32) ** 2
+    print(json.dumps({"rep": rep, "ms_per_step": round(ms, 4), "kernel_sum": round(sum(prof.values()), 4),
+                      "entries_per_block": round(((tok >> 32) & 0x07FFFFFF) / nblocks, 1), "block_lists": (tok >> 62) & 1, "kernels": prof}), flush=True)
