@@ -23,6 +23,10 @@ level of threshold flips (examples/train_synthetic.py at 200 k / 512²: identica
 Gaussians) is frozen the same way, with a guard: a replay whose forward asks for it while the graph was
 recorded without it counts as not fitting (`CapturedForward.fits`) and is recorded again.
 
+When the tensors `fn` reads are REPLACED (a prune gives every parameter a new shape and address) the step has to be recorded
+again: `step.record_again()` does it inside the step's own memory pool — recording often then neither grows the process nor pays
+for allocations — and `eogs2_amd.optim.retire_rows` avoids the replacement altogether.
+
 `fn` follows the rules of torch.cuda.graph: it reads its inputs from tensors that exist before the capture, allocates
 everything else itself, and never waits for the device. Gradients: set them to None at the start of `fn`
 (`p.grad = None`), so the backward inside the capture writes fresh tensors instead of accumulating; a replay rewrites
@@ -114,8 +118,9 @@ class GraphedStep:
 
     def record_again(self, warmup=1):
         """Records the step anew — after its inputs changed shape or address (a prune: new parameter tensors), which a replay
-        cannot follow. `warmup` eager runs first, as at construction (their counts size the new workspaces). Keeps this
-        step's memory pool: prefer it to constructing a new GraphedStep."""
+        cannot follow. `warmup` eager runs first, as at construction (their counts size the new workspaces; like those they
+        really run `fn`: a step that updates its own inputs advances by them). Keeps this step's memory pool: prefer it to
+        constructing a new GraphedStep."""
         if warmup < 1:
             raise ValueError("GraphedStep needs at least one eager run before the capture")
         torch.cuda.current_stream().synchronize()
