@@ -671,7 +671,6 @@ __global__ __launch_bounds__(ES_T) void entry_colscan_kernel(uint32_t* __restric
 // Five workgroup scans, no atomics (8 k same-address LDS atomics made the first version 10 us), no 64-bit division (the
 // scatter launch that carries it is compiled for 64 VGPRs).
 #define SCHED_T 1024
-#define SCHED_ITEMS ((int)SCHED_MAX_BLOCKS / SCHED_T)
 #define SCHED_C0 10u     // fixed cost of a tile's wave, in list entries
 #ifndef SCHED_K
 #define SCHED_K 60.0f    // list entries x mean pair opacity after which a tile counts as saturated. Bracketed by measurement: at
@@ -680,6 +679,7 @@ __global__ __launch_bounds__(ES_T) void entry_colscan_kernel(uint32_t* __restric
 namespace {
 __device__ inline uint4 u4_add(const uint4& a, const uint4& b) { return make_uint4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 // exclusive prefix over the workgroup of four 32-bit sums per thread; totals returned through `total`. All threads call.
+template <int ST>
 __device__ inline uint4 sched_scan(uint4 v, uint4* s_w, uint4& total) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   uint4 inc = v;
@@ -694,7 +694,7 @@ __device__ inline uint4 sched_scan(uint4 v, uint4* s_w, uint4& total) {
   __syncthreads();
   uint4 base = make_uint4(0u, 0u, 0u, 0u), tot = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-  for (int k = 0; k < SCHED_T / 64; k++) {
+  for (int k = 0; k < ST / 64; k++) {
     const uint4 c = s_w[k];
     if (k < w) base = u4_add(base, c);
     tot = u4_add(tot, c);
@@ -711,10 +711,13 @@ __device__ inline uint32_t eighth_of(uint32_t a, uint32_t b) {
   return x;
 }
 
+// ST threads (the workgroup that runs it: 1024, or 512 inside the 12-bit scatter launch), SCHED_MAX_BLOCKS / ST blocks per thread
+template <int ST>
 __device__ __forceinline__ void tile_sched_body(const uint32_t* __restrict__ bpairs, const uint32_t* __restrict__ misc,
                                                 uint32_t nblocks, uint32_t lg, uint32_t flags, uint32_t* __restrict__ sched,
                                                 uint32_t* __restrict__ where) {
-  __shared__ uint4 s_w[SCHED_T / 64];
+  constexpr int SCHED_ITEMS = (int)SCHED_MAX_BLOCKS / ST;
+  __shared__ uint4 s_w[ST / 64];
   __shared__ uint32_t s_first[8], s_n0[8], s_nE[8], s_cnt[8], s_spill[8], s_free[9];
   const int t = threadIdx.x;
   // thread t holds blocks t * SCHED_ITEMS ... in block (row-major) order; the sums below fit 32 bits (pairs < 2^31, api.hip)
@@ -727,7 +730,7 @@ __device__ __forceinline__ void tile_sched_body(const uint32_t* __restrict__ bpa
     v.x += wk[i];
   }
   uint4 tot;
-  (void)sched_scan(v, s_w, tot);
+  (void)sched_scan<ST>(v, s_w, tot);
   const unsigned long long total_pairs = tot.x;
   // pairs of a block beyond which its tiles have saturated: 16 tiles x SCHED_K / (mean pair opacity), the mean pair opacity
   // being sum(round(64 opacity)) / (64 pairs) over the listed pairs (misc[MISC_OPW], written by the count scan)
@@ -743,7 +746,7 @@ __device__ __forceinline__ void tile_sched_body(const uint32_t* __restrict__ bpa
     wk[i] = wk[i] < cap ? wk[i] : cap;
     v.x += wk[i];
   }
-  (void)sched_scan(v, s_w, tot);
+  (void)sched_scan<ST>(v, s_w, tot);
   const unsigned long long total_work = tot.x;
   (void)total_pairs;
   // light: less than an eighth of the mean work (compared as products). By WORK, not pairs: where tiles saturate early a rim
@@ -756,7 +759,7 @@ __device__ __forceinline__ void tile_sched_body(const uint32_t* __restrict__ bpa
     light[i] = 8ull * wk[i] * nblocks < total_work;
     if (b < nblocks && !light[i]) { v.x += raw[i]; v.y++; }
   }
-  (void)sched_scan(v, s_w, tot);
+  (void)sched_scan<ST>(v, s_w, tot);
   // EDGE blocks (saturating regimes only: the mean block is beyond the cap): a block that lists clearly fewer pairs than its
   // peers — under three quarters of their mean — but more than the cap is a block the scene covers only partly: the pixels the
   // scene does not reach never saturate, its tiles walk their whole lists, and they are the launch's stragglers (wave traces
@@ -776,7 +779,7 @@ __device__ __forceinline__ void tile_sched_body(const uint32_t* __restrict__ bpa
       else { v.x += wk[i]; v.y++; }
     }
   }
-  uint4 run = sched_scan(v, s_w, tot);  // before this thread's blocks: {work, count} of the run blocks, edge blocks, light blocks
+  uint4 run = sched_scan<ST>(v, s_w, tot);  // before this thread's blocks: {work, count} of the run blocks, edge blocks, light blocks
   const uint32_t nE = tot.z, n1 = tot.w;
   uint32_t xcd[SCHED_ITEMS], crank[SCHED_ITEMS];
   uint4 c0x = make_uint4(0u, 0u, 0u, 0u);  // run blocks per XCD, 16 bits each: x = {xcd 0, 1}, y = {2, 3}, z = {4, 5}, w = {6, 7}
@@ -801,7 +804,7 @@ __device__ __forceinline__ void tile_sched_body(const uint32_t* __restrict__ bpa
     }
   }
   uint4 c0tot;
-  (void)sched_scan(c0x, s_w, c0tot);  // (at most 4096 blocks: a 16-bit field cannot overflow into its neighbour)
+  (void)sched_scan<ST>(c0x, s_w, c0tot);  // (at most 4096 blocks: a 16-bit field cannot overflow into its neighbour)
   if (t == 0) {
     uint32_t first0 = 0, a = 0, f = 0;
     for (uint32_t x = 0; x < 8; x++) {
@@ -872,9 +875,11 @@ __global__ __launch_bounds__(T_, (NBITS <= 10 && T_ == 1024 ? ES_WAVES : 1)) voi
                                                              uint32_t* __restrict__ where) {
   constexpr int ES_ITEMS_ = ES_TILE / T_, ES_NW_ = T_ / 64;
   constexpr uint32_t nb = 1u << NBITS, mask = nb - 1u;
-  if (T_ == SCHED_T && sched_blocks && blockIdx.x == gridDim.x - 1) {  // the launch's extra workgroup: the tile schedule
-    tile_sched_body(bpairs, misc, sched_blocks, sched_lg & 0xFFFFFFu, sched_lg >> 24, sched, where);
-    return;
+  if constexpr (T_ == 1024 || T_ == 512) {
+    if (sched_blocks && blockIdx.x == gridDim.x - 1) {  // the launch's extra workgroup: the tile schedule
+      tile_sched_body<T_>(bpairs, misc, sched_blocks, sched_lg & 0xFFFFFFu, sched_lg >> 24, sched, where);
+      return;
+    }
   }
   const uint32_t n = entries_on_device(misc, cap);
   const uint32_t tile0 = blockIdx.x * (uint32_t)ES_TILE;
@@ -1014,13 +1019,13 @@ struct SchedArgs {
 __global__ __launch_bounds__(SCHED_T) void tile_sched_kernel(const uint32_t* __restrict__ bpairs, const uint32_t* __restrict__ misc,
                                                              uint32_t nblocks, uint32_t lg, uint32_t* __restrict__ sched,
                                                              uint32_t* __restrict__ where) {
-  tile_sched_body(bpairs, misc, nblocks, lg & 0xFFFFFFu, lg >> 24, sched, where);
+  tile_sched_body<SCHED_T>(bpairs, misc, nblocks, lg & 0xFFFFFFu, lg >> 24, sched, where);
 }
 template <int NBITS>
 static void launch_entry_scatter_n(uint32_t nblk, hipStream_t s, const uint4* in, uint4* out, const uint32_t* misc, uint32_t cap,
                                    int shift, const uint32_t* hist, const uint32_t* dtotal, const SchedArgs& sa) {
   constexpr int T_ = NBITS <= 11 ? 1024 : 512;
-  const bool ride = sa.blocks != 0u && T_ == SCHED_T;
+  const bool ride = sa.blocks != 0u && (T_ == 1024 || T_ == 512);  // (every variant today: the stand-alone launch is the fallback)
   if (sa.blocks != 0u && !ride)
     hipLaunchKernelGGL(tile_sched_kernel, dim3(1), dim3(SCHED_T), 0, s, sa.bpairs, misc, sa.blocks, sa.lg, sa.sched, sa.where);
   hipLaunchKernelGGL((entry_scatter_kernel<NBITS, T_>), dim3(nblk + (ride ? 1u : 0u)), dim3(T_), 0, s, in, out, misc, cap, shift,
