@@ -290,8 +290,10 @@ def retire_rows(optimizer, keep, name="opacity"):
     for group in optimizer.param_groups:
         if group["name"] == name:
             p = group["params"][0]
+            if keep.numel() != p.numel():
+                raise ValueError(f"retire_rows: mask of {keep.numel()} rows for {p.numel()} Gaussians")
             with torch.no_grad():
-                p.view(-1).masked_fill_(~keep.view(-1), RETIRED_LOGIT)
+                p.view(-1).masked_fill_(~keep.reshape(-1).to(device=p.device, dtype=torch.bool), RETIRED_LOGIT)
             return
     raise KeyError(f"retire_rows: no parameter group named {name!r}")
 

@@ -49,3 +49,11 @@ def test_unknown_group_name_is_an_error():
         retire_rows(opt, torch.ones(4, dtype=torch.bool), name="opacities")
     with pytest.raises(KeyError):
         alive_rows(opt, name="opacities")
+
+
+def test_mask_of_another_dtype_or_length():
+    opt = _opt(6)
+    retire_rows(opt, torch.tensor([1, 0, 1, 1, 0, 1], dtype=torch.uint8))  # a 0/1 mask is a mask, not bits to invert
+    assert alive_rows(opt).tolist() == [True, False, True, True, False, True]
+    with pytest.raises(ValueError):
+        retire_rows(opt, torch.ones(5, dtype=torch.bool))
