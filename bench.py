@@ -484,10 +484,11 @@ def train_iteration(sc, P, H, W, dev, fused, iters=5, dist=None, view_seed=0, al
         if branches is not None:
             # the largest render (the 2H x 2W sun camera) is queued first: its long kernels start at once and the two small
             # renders fill in beside them, instead of the sun camera finishing alone (2.73-2.76 -> 2.58-2.63 ms with the
-            # altitude-only sun render; tools/branch_order_probe.py). Gradients accumulate in the order queued.
+            # altitude-only sun render; tools/branch_order_probe.py). The shared parameters' gradients are summed after the join,
+            # in the order queued (eogs2_amd.graph.Branches).
             order = [int(x) for x in os.environ["EOGS_BRANCH_ORDER"].split(",")] if "EOGS_BRANCH_ORDER" in os.environ else \
                 sorted(range(len(views)), key=lambda vi: -(views[vi][3].shape[-1] * views[vi][3].shape[-2]))
-            branches.run([lambda vi=vi: one_view(vi) for vi in order])
+            branches.run([lambda vi=vi: one_view(vi) for vi in order], shared=list(params.values()))
         else:
             for vi in range(len(views)):
                 one_view(vi)

@@ -288,7 +288,8 @@ int token_from_counts(const uint32_t* m, int P, int H, int W, bool have_scratch,
   const bool btf = !alt && P > 0 && btf_switch > 0.0 && (double)total >= btf_switch * (double)P * ntiles8;
   const int block = (btf || alt) ? 1 : ((by_footprint || by_depth) ? BLOCK_BIG : 1);
   if (m[MISC_ERR] & 1u) return fail(EOGS_ERR_ALTITUDE, "Point is too high: altitude > 200");
-  if (total >= ((uint64_t)1 << 31) || entries >= ((uint64_t)1 << 27)) return fail(EOGS_ERR_OVERFLOW, "num_rendered overflows 31 bits");
+  if (total >= ((uint64_t)1 << 31) || entries >= ((uint64_t)1 << 27)) return fail(EOGS_ERR_OVERFLOW, "the forward lists more than the token holds: 2^31 record slots (tile, Gaussian) or 2^27 list "
+                                                                                                   "entries (32-px block, Gaussian)");
   // block_lists_kernel's 8-item build pays when the average block holds 2800 ... 6000 entries (csrc/binning.hip)
   const double per_block = (double)entries / ((double)macro_grid_x(W, BLOCK_BIG) * (double)macro_grid_y(H, BLOCK_BIG));
   // (nothing listed: the token is 0, as include/eogs_rast.h says — callers test it whole, every R > 0 shortcut applies)

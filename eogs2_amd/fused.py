@@ -50,7 +50,7 @@ class _RasterizeRaw(torch.autograd.Function):
             return (z(xyz), z(xyz), z(f_dc), z(opacity_logit), z(log_scaling), z(raw_rotation),
                     torch.zeros_like(rs.viewmatrix) if want_vm else None, None, None, None)
         d_means2D, d_fdc, d_logit, d_xyz, _cov, d_logscale, d_rawrot, grad_viewmatrix = _run_backward(
-            rs, ctx.num_rendered, grad_out_color, None if ctx.altitude_only else grad_out_depth, xyz, None, opacity_logit,
+            rs, ctx.num_rendered, grad_out_color, grad_out_depth, xyz, None, opacity_logit,
             log_scaling, raw_rotation, None, radii, geom, binning, img, color, invdepths, want_vm, alt_affine=alt_affine, raw=True,
             alt_only=ctx.altitude_only,
         )
@@ -62,7 +62,8 @@ def rasterize_raw(xyz, means2D, f_dc, opacity_logit, log_scaling, raw_rotation, 
     """(color[5,H,W], radii[P], invdepths[1,H,W]) from raw parameters.
 
     `altitude_only=True` (EOGS_FLAG_ALT_ONLY, include/eogs_rast.h): only the altitude feature is rendered — `color` is then
-    [1,H,W], equal to channel 3 of the full render, `invdepths` is left unwritten — for renders that are consumed through
+    [1,H,W], equal to channel 3 of the full render, and the third result is None (there is no inverse-depth image to read
+    or to differentiate) — for renders that are consumed through
     their altitude alone: the reference's 2H x 2W sun-camera render before `iterstart_L_sun_resample` (train_pan.py:305-324,
     gs_config/train.yaml:123). Forward and backward then blend one channel instead of five.
 

@@ -44,30 +44,63 @@ class Branches:
     the current stream. Recorded inside `GraphedStep` they become parallel branches of the HIP graph: one render's
     launch-floor kernels (count scan, histogram, column scan: a workgroup or sixteen) and the tail of its blend kernels
     (profiles/r04_wave_trace.txt: a fifth of a render launch runs at half occupancy) run beside another render's large
-    ones. Results are those of the serial order bit for bit: every piece does the same arithmetic, and gradients of shared
-    parameters accumulate in the order the pieces were queued (autograd accumulates on the stream the parameter was first
-    used on; each `backward()` call has queued its accumulation before it returns).
+    ones.
+
+    Gradients of parameters the pieces SHARE. A piece that calls `backward()` itself leaves its gradient in `p.grad` on the
+    piece's own stream, and the next piece's `p.grad += g` runs on ANOTHER stream with nothing ordering the two: autograd
+    binds a leaf's accumulation to the stream that was current when the leaf entered the piece's autograd graph, and that
+    graph — and the binding with it — is gone when the piece returns (in a replayed graph with truly parallel
+    branches a small render's `+=` can run before the large render has stored the buffer it adds to). `run` therefore takes
+    the shared parameters explicitly: every piece starts from `p.grad = None`, so its backward only ever WRITES a gradient
+    tensor of its own, and after the join the pieces' gradients are summed on the current stream in the order the pieces
+    were queued — `g_0`, `+= g_1`, `+= g_2`, onto whatever `p.grad` held before: the arithmetic and the order of the serial
+    loop, bit for bit, with every dependency an edge of the graph. Pieces that only run forwards (one `backward()` after
+    the join: autograd orders that itself) pass `shared=()`.
 
         br = Branches(3)
         def fn():
-            br.run([lambda v=v: render_and_backward(v) for v in views])
+            br.run([lambda v=v: render_and_backward(v) for v in views], shared=model_parameters)
     """
 
     def __init__(self, n, device=None):
         self.streams = [torch.cuda.Stream(device=device) for _ in range(n)]
 
-    def run(self, fns):
+    def run(self, fns, *, shared):
+        """fns: callables, one per branch, queued in this order. shared: the leaf tensors more than one piece differentiates
+        (an empty sequence when no piece calls backward). Returns the pieces' results."""
         fns = list(fns)
+        shared = list(shared)
         if len(fns) > len(self.streams):
             raise ValueError(f"Branches({len(self.streams)}) asked to run {len(fns)} pieces")
         cur = torch.cuda.current_stream()
-        outs = []
-        for s, fn in zip(self.streams, fns):
-            s.wait_stream(cur)  # fork: the piece sees everything queued so far
-            with torch.cuda.stream(s):
-                outs.append(fn())
-        for s in self.streams[:len(fns)]:
-            cur.wait_stream(s)  # join
+        before = [p.grad for p in shared]
+        outs, parts = [], []
+        try:
+            for s, fn in zip(self.streams, fns):
+                s.wait_stream(cur)  # fork: the piece sees everything queued so far
+                for p in shared:
+                    p.grad = None  # the piece's backward writes a tensor of its own, it never adds into another piece's
+                with torch.cuda.stream(s):
+                    outs.append(fn())
+                parts.append([p.grad for p in shared])
+        finally:
+            for s in self.streams[:len(fns)]:
+                cur.wait_stream(s)  # join
+            # The sum, after the join, in queue order. (Allocator note: a piece's gradient was allocated on the piece's stream
+            # and is read here and by the optimizer on `cur`; its block can only be reused by a later allocation on that same
+            # piece stream, and everything queued there comes after a fork that waits for `cur` — so no record_stream.)
+            with torch.no_grad():
+                for k, p in enumerate(shared):
+                    acc = before[k]
+                    for part in parts:
+                        g = part[k]
+                        if g is None:
+                            continue
+                        if acc is None:
+                            acc = g
+                        else:
+                            acc.add_(g)
+                    p.grad = acc
         return outs
 
 

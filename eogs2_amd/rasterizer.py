@@ -283,7 +283,7 @@ def _run_forward(rs, viewmat, means3D, colors, opacities, scales, rotations, cov
 
     Returns (num_rendered, color, radii, invdepths, geom, binning, img). With `raw` the per-Gaussian tensors are the
     model's raw parameters (EOGS_FLAG_RAW_PARAMS, include/eogs_rast.h) and `colors` is f_dc [P,3]. With `alt_only`
-    (EOGS_FLAG_ALT_ONLY) only feature channel 3 is rendered: `color` is [1, H, W] and `invdepths` is not written.
+    (EOGS_FLAG_ALT_ONLY) only feature channel 3 is rendered: `color` is [1, H, W] and `invdepths` is None.
     """
     abi = _backend()
     # DGR/rasterize_points.cu:58-60
@@ -298,14 +298,15 @@ def _run_forward(rs, viewmat, means3D, colors, opacities, scales, rotations, cov
     with _Ctx(abi, dev) as cx:
         # outputs as DGR/rasterize_points.cu:69-76 (zero images when P == 0: forward is skipped)
         color = torch.empty((1 if alt_only else NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
-        invdepths = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+        invdepths = None if alt_only else torch.empty((1, H, W), dtype=torch.float32, device=dev)  # (alt_only: no such output)
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
         empty_u8 = torch.empty((0,), dtype=torch.uint8, device=dev)
         geom = binning = img = empty_u8
         num_rendered = 0
         if P == 0:
             color.zero_()
-            invdepths.zero_()
+            if invdepths is not None:
+                invdepths.zero_()
         else:
             # DGR/cuda_rasterizer/rasterizer_impl.cu:244-247
             if colors is None or colors.numel() == 0:

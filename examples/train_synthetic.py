@@ -132,7 +132,8 @@ def main(argv=None):
             sun_img, out, rnd_img = branches.run([
                 lambda: render(sun, m, pipe, bg, altitude_only=a.sun_altitude_only)["render"],
                 lambda: render(cam, m, pipe, bg),
-                lambda: render(rnd, m, pipe, bg)["render"] if a.random_camera else None])
+                lambda: render(rnd, m, pipe, bg)["render"] if a.random_camera else None],
+                shared=())  # forwards only: the iteration's one backward() follows the join
             img, altitude = out["render"][:3], out["render"][3]
             uva = torch.stack((U, V, altitude / 350.0), dim=-1)
             if a.sun_altitude_only:

@@ -47,7 +47,9 @@ extern "C" {
 #define EOGS_ERR_DEVICE (-2)      /* a HIP call or kernel failed                        */
 #define EOGS_ERR_WORKSPACE (-3)   /* workspace smaller than the *_bytes query           */
 #define EOGS_ERR_ALTITUDE (-4)    /* a Gaussian's altitude > 200 (DGR/cuda_rasterizer/forward.cu:267-272 traps) */
-#define EOGS_ERR_OVERFLOW (-5)    /* num_rendered does not fit 31 bits                  */
+#define EOGS_ERR_OVERFLOW (-5)    /* a forward lists more than the token holds: 2^31 (tile, Gaussian) record slots or, since ABI 7,
+                                   * 2^27 (32-px block, Gaussian) list entries (ABI 6: 2^28) — about 22 M Gaussians of EOGS footprint;
+                                   * the reference's own limit is 2^31 (tile, Gaussian) pairs (int num_rendered) */
 #define EOGS_ERR_NO_COLORS (-6)   /* colors_precomp missing (DGR/cuda_rasterizer/rasterizer_impl.cu:244-247 throws) */
 
 /* flags */
@@ -120,8 +122,8 @@ int eogs_rast_scratch_bytes(int P, int H, int W, size_t* bytes);
  *   untouched, must then be handed to forward_render. Without it (or when a forward has more entries than the buffer
  *   holds: six per Gaussian) forward_render does that work inside a correspondingly larger binning workspace.
  * Writes radii[P] and *num_rendered (host). num_rendered is an opaque token for the three calls below (it packs this
- * library's pair counts, list granularity and where the entries were sorted, see csrc/common.h nr_pack); 0 means
- * nothing is listed. */
+ * library's pair counts, list granularity and where the entries were sorted, see csrc/common.h nr_pack: record slots in
+ * bits 0..30, list entries in bits 32..58, flags above); 0 means nothing is listed. */
 int eogs_rast_forward_prepare(
     int P, int H, int W,
     const float* means3D, const float* scales, const float* rotations,

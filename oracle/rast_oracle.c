@@ -424,8 +424,10 @@ int eogs_rast_forward_render(
     void* geom, size_t geom_bytes, void* binning, size_t binning_bytes,
     void* image, size_t image_bytes, void* scratch, size_t scratch_bytes,
     float* out_color, float* out_invdepth, void* stream) {
-  (void)flags; (void)stream; (void)scratch; (void)scratch_bytes;
+  (void)stream; (void)scratch; (void)scratch_bytes;
   g_err[0] = 0;
+  if (flags & EOGS_FLAG_ALT_ONLY)
+    return fail(EOGS_ERR_INVALID_ARG, "forward_render: EOGS_FLAG_ALT_ONLY is not restated by the CPU oracle");
   if (P < 0 || H <= 0 || W <= 0 || R < 0 || !out_color || !bg || !image)
     return fail(EOGS_ERR_INVALID_ARG, "forward_render: bad argument");
   if (image_bytes < image_layout(NULL, H, W, NULL)) return fail(EOGS_ERR_WORKSPACE, "forward_render: image workspace too small");
@@ -906,6 +908,10 @@ int eogs_rast_forward_prepare(
     int64_t* num_rendered, void* stream) {
   (void)scratch; (void)scratch_bytes;
   g_deferred_token = -1;
+  /* The restatement follows the reference, which has no one-channel render: a caller that asked for one would hand over
+   * [1,H,W] images and this code would write five planes into them. */
+  if (flags & EOGS_FLAG_ALT_ONLY)
+    return fail(EOGS_ERR_INVALID_ARG, "forward_prepare: EOGS_FLAG_ALT_ONLY is not restated by the CPU oracle (compare channel 3 of a full render)");
   const int rc = forward_prepare_now(P, H, W, means3D, scales, rotations, cov3D_precomp, opacities, colors, scale_modifier,
                                      viewmatrix, projmatrix, alt_affine, flags, radii, geom, geom_bytes, num_rendered, stream);
   g_last_token = rc == EOGS_OK ? *num_rendered : -1;

@@ -162,3 +162,24 @@ def test_gradbucket_zero_keeps_the_gradients_inside_the_exchange_buffer():
     bucket.zero_()  # the next step: same tensors, cleared
     assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(params, views)) and float(bucket.flat.abs().sum()) == 0.0
     bucket.close()
+
+
+def test_oracle_refuses_the_altitude_only_render(oracle_backend):
+    """the restatement follows the reference, which has no one-channel render. Over the oracle library
+    `rasterize_raw(..., altitude_only=True)` must fail with its error, not write five planes into a [1,H,W] image."""
+    from eogs2_amd import RastError
+    from eogs2_amd.fused import rasterize_raw
+    from eogs2_amd.synthetic import settings_for
+
+    H, W, P = 32, 24, 50
+    scene = make_scene(P, H, W, seed=4, opacity="trained")
+    raw, alt = raw_params_from_scene(scene)
+    rs = settings_for(scene, H, W)
+    m2 = torch.zeros(P, 3)
+    with pytest.raises(RastError, match="ALT_ONLY"):
+        rasterize_raw(raw["xyz"], m2, raw["f_dc"], raw["opacity_logit"], raw["log_scaling"], raw["raw_rotation"], alt, rs,
+                      altitude_only=True)
+    # the full render of the same inputs goes through
+    color, radii, invd = rasterize_raw(raw["xyz"], m2, raw["f_dc"], raw["opacity_logit"], raw["log_scaling"],
+                                       raw["raw_rotation"], alt, rs)
+    assert tuple(color.shape) == (5, H, W) and tuple(invd.shape) == (1, H, W)

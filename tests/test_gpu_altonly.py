@@ -121,8 +121,9 @@ def test_nothing_visible_and_errors(dev):
     rs = settings_for(scene, H, W)
     leaves = {k: v.clone().requires_grad_(True) for k, v in raw.items()}
     m2 = torch.zeros(P, 3, device=dev, requires_grad=True)
-    color, radii, _ = rasterize_raw(leaves["xyz"], m2, leaves["f_dc"], leaves["opacity_logit"], leaves["log_scaling"],
-                                    leaves["raw_rotation"], alt, rs, altitude_only=True)
+    color, radii, invd = rasterize_raw(leaves["xyz"], m2, leaves["f_dc"], leaves["opacity_logit"], leaves["log_scaling"],
+                                       leaves["raw_rotation"], alt, rs, altitude_only=True)
+    assert invd is None  # (no inverse-depth image exists for such a render: nothing uninitialised to read)
     assert torch.equal(color, scene["bg"][3].expand(1, H, W))  # the background's altitude everywhere
     color.sum().backward()
     assert all(float(v.grad.abs().max()) == 0.0 for v in leaves.values())

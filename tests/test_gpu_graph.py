@@ -218,7 +218,7 @@ def test_three_renders_as_parallel_branches_equal_the_serial_graph(dev):
             v.grad = None
         for _, _, m2, _ in views:
             m2.grad = None
-        cols = br.run([lambda vi=vi: one(vi) for vi in range(3)]) if parallel else [one(vi) for vi in range(3)]
+        cols = br.run([lambda vi=vi: one(vi) for vi in range(3)], shared=list(leaves.values())) if parallel else [one(vi) for vi in range(3)]
         return tuple(cols) + tuple(v.grad for v in leaves.values()) + tuple(m2.grad for _, _, m2, _ in views)
 
     eager = [t.clone() for t in fn(False)]
@@ -234,6 +234,57 @@ def test_three_renders_as_parallel_branches_equal_the_serial_graph(dev):
     _same([t.clone() for t in par()], want)
     _same([t.clone() for t in serial()], want)
     _same([t.clone() for t in fn(True)], want)  # the eager iteration on three streams as well
+
+
+def test_parallel_branches_large_scene_sun_camera_first(dev):
+    """the bench queues the 2H x 2W sun camera FIRST; at a size where the branches really overlap a small render's
+    gradient must still be added to the large one's only after that one has been stored. `Branches.run(shared=...)` sums the
+    pieces' own gradient tensors after the join, in queue order: the replayed graph equals the serial eager loop in that
+    order bit for bit, replay after replay with the parameters moving in between (a lost or early update would show: the
+    buffers hold the previous replay's values), and a gradient that was there before the step is added to, not replaced."""
+    from eogs2_amd.fused import rasterize_raw
+    from eogs2_amd.graph import Branches, GraphedStep
+    from eogs2_amd.synthetic import make_camera, make_scene, settings_for
+
+    P, H, W = 400000, 512, 512
+    sc = make_scene(P, H, W, seed=29, opacity=0.05, device=dev)
+    leaves = dict(xyz=sc["means3D"].clone(), f_dc=torch.logit(sc["colors"][:, :3].clamp(0.01, 0.99)),
+                  opl=torch.logit(sc["opacities"].clamp(1e-4, 1 - 1e-4)), lsc=sc["scales"].log(), rot=sc["rotations"].clone())
+    for v in leaves.values():
+        v.requires_grad_(True)
+    views = []
+    for seed, (h, w) in ((1, (H, W)), (2, (2 * H, 2 * W)), (3, (H, W))):
+        vm = make_camera(h, w, seed=seed, device=dev)
+        views.append((settings_for(dict(sc, viewmatrix=vm), h, w), vm[:, 2].contiguous(), torch.randn(5, h, w, device=dev) / (h * w)))
+    order = (1, 0, 2)  # the sun camera first, as bench.py queues them
+    carry = {k: torch.randn_like(v) * 1e-6 for k, v in leaves.items()}  # a gradient already there when the step starts
+
+    def one(vi):
+        rs, alt, dL = views[vi]
+        m2 = torch.zeros_like(leaves["xyz"], requires_grad=True)
+        color, _, _ = rasterize_raw(leaves["xyz"], m2, leaves["f_dc"], leaves["opl"], leaves["lsc"], leaves["rot"], alt, rs)
+        torch.autograd.backward([color], [dL])
+
+    br = Branches(3, device=dev)
+
+    def fn(parallel):
+        for k, v in leaves.items():
+            v.grad = carry[k].clone()
+        if parallel:
+            br.run([lambda vi=vi: one(vi) for vi in order], shared=list(leaves.values()))
+        else:
+            for vi in order:
+                one(vi)
+        return tuple(v.grad for v in leaves.values())
+
+    par = GraphedStep(lambda: fn(True), warmup=1)
+    for rep in range(4):
+        with torch.no_grad():
+            leaves["xyz"].add_(0.002 * (rep + 1))
+            leaves["opl"].add_(0.3 if rep % 2 else -0.3)
+        got = [t.clone() for t in par()]
+        _same(got, [t.clone() for t in fn(False)])
+    _same([t.clone() for t in fn(True)], [t.clone() for t in fn(False)])  # eager on three streams
 
 
 def test_record_again_after_the_parameters_were_replaced_keeps_the_memory(dev):
@@ -271,7 +322,7 @@ def test_record_again_after_the_parameters_were_replaced_keeps_the_memory(dev):
     def fn(parallel=True):
         for v in leaves.values():
             v.grad = None
-        cols = br.run([lambda vi=vi: one(vi) for vi in range(3)]) if parallel else [one(vi) for vi in range(3)]
+        cols = br.run([lambda vi=vi: one(vi) for vi in range(3)], shared=list(leaves.values())) if parallel else [one(vi) for vi in range(3)]
         return tuple(cols) + tuple(v.grad for v in leaves.values())
 
     def in_use():

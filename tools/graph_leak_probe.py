@@ -90,7 +90,7 @@ def step_leg(branches):
     def fn():
         for p in (xyz, f_dc, logit, lsc, rot):
             p.grad = None
-        losses = br.run([one, one, one]) if br is not None else [one(), one(), one()]
+        losses = br.run([one, one, one], shared=()) if br is not None else [one(), one(), one()]
         loss = losses[0] + losses[1] + losses[2]
         loss.backward()
         return loss.detach()
