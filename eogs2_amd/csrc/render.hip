@@ -35,6 +35,7 @@
 //     Gaussian's live records in fixed order (bitwise reproducible gradients).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #pragma clang fp contract(fast)
 
@@ -73,6 +74,26 @@ __device__ inline uint32_t wave_max_u32(uint32_t v) {
   }
   return v;
 }
+// wave-uniform sum on the DPP path: four rotations inside each row of 16 lanes, the row totals handed on by row_bcast15 /
+// row_bcast31, lane 63 read back — seven VALU instructions and no LDS round trip (__shfl_xor is a ds_bpermute_b32: six
+// dependent ones cost the quad forward 4 % when this sum sat in its chunk loop, profiles/r05_ab_plain_trips.txt)
+__device__ inline float wave_sum_f32(float v) {
+  auto dpp = [](float x, auto ctrl, auto rows) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, decltype(rows)::value, 0xF, true));
+  };
+  v += dpp(v, std::integral_constant<int, 0x121>{}, std::integral_constant<int, 0xF>{});  // row_ror:1
+  v += dpp(v, std::integral_constant<int, 0x122>{}, std::integral_constant<int, 0xF>{});  // row_ror:2
+  v += dpp(v, std::integral_constant<int, 0x124>{}, std::integral_constant<int, 0xF>{});  // row_ror:4
+  v += dpp(v, std::integral_constant<int, 0x128>{}, std::integral_constant<int, 0xF>{});  // row_ror:8: every lane holds its row's sum
+  v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});  // row_bcast15 into rows 1 and 3
+  v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});  // row_bcast31 into rows 2 and 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// The quad forward's plain chunks (render_fwd_quad_kernel): while the bound on T — the product of (1 - opacity) over everything
+// a tile has listed so far — stays above 2^-13 = 1.22e-4 no pixel can reach the reference's stop test T (1 - alpha) < 1e-4
+// (forward.cu:378-382): 22 % of margin against the rounding of a product of a few thousand fp32 factors (relative error
+// < 1e-3) and of the bound's own fp32 sum.
+#define PLAIN_LOG2_T (-13.0f)
 // LDS produced and consumed by the SAME wave: the hardware executes a wave's LDS instructions in order, so only
 // the compiler must be kept from reordering them.
 __device__ inline void wave_lds_sync() {
@@ -212,7 +233,7 @@ __global__ __launch_bounds__(RBLK) void render_fwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx, const uint4* __restrict__ desc, const uint32_t* __restrict__ sched, int lg16,
     const float4* __restrict__ packed, const float* __restrict__ bg,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-    float* __restrict__ out_invdepth) {
+    float* __restrict__ out_invdepth, int opts) {
   __shared__ __attribute__((aligned(16))) float s_slab[RBLK / 64][FWD_CAP * ENT];
   const int lane = threadIdx.x & 63;
   uint2 range = make_uint2(0u, 0u);
@@ -367,7 +388,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_FW, E
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx, const uint4* __restrict__ desc, const uint32_t* __restrict__ sched, int lg16,
     const float4* __restrict__ packed, const float* __restrict__ bg,
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
-    float* __restrict__ out_invdepth) {
+    float* __restrict__ out_invdepth, int opts) {
   static_assert(MACRO == 1, "quad sub-lists run on per-tile lists: every chunk of 64 list entries is processed at once");
   // slab position FQ_CAP holds a DUMMY entry (opacity 0: alpha = 0 fails the 1/255 test at every pixel); sub-lists
   // shorter than the longest one are padded with it, so the hot loop needs no "is my quad still active" test
@@ -406,102 +427,136 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_FW, E
   uint32_t jbase = 0;  // entries of THIS tile processed so far: list positions are counted over the tile's own entries
   Cand nxt = gather_cand<1>(peek_cand<1>(range.x + lane, range.y, keys, point_list), 0u, packed);
   Peek pk = peek_cand<1>(range.x + 64 + lane, range.y, keys, point_list);
-  for (uint32_t c0 = range.x; c0 < range.y; c0 += 64) {
-    wave_lds_sync();  // previous chunk's reads are done
-    int nq[4] = {0, 0, 0, 0};
-    {
-      // per-tile lists: the in-range entries are lanes 0..fill-1, parked at their own lane index
-      const uint32_t qm = nxt.hit ? quad_mask(nxt, bx0, by0) : 0u;
-      quad_append(sidx, lane, nxt.hit, lane, qm, nq);
-    }
-    const int fill = park(slab, nullptr, lane, nxt, 0);
-    nxt = gather_cand<1>(pk, 0u, packed);                           // chunk c0+64: in flight during this chunk
-    pk = peek_cand<1>(c0 + 128 + lane, range.y, keys, point_list);  // chunk c0+128
-    wave_lds_sync();
-    if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;  // every pixel of the tile has terminated
-    const int nmax = max(max(nq[0], nq[1]), max(nq[2], nq[3]));
-    // pad the shorter sub-lists up to nmax (+2 for the pipelined over-read) with the dummy entry
+  uint32_t c0 = range.x;
+  float lsum = 0.f;  // log2 of the bound on every pixel's T behind the chunks taken so far (wave-uniform)
+  // The chunk loop exists twice, one after the other. PLAIN: the tile's first chunks, as long as no pixel of the tile can reach
+  // the stop test inside the chunk (`lsum`) and no entry of it has o > 0.99 (then o 2^p <= o: the clamp never binds). The stop
+  // test, the clamp and the `done` mask are no-ops there and are left out: three instructions of the 4-cycle class (v_min,
+  // v_cmp, v_cndmask) and three mask operations of a trip's 22; what is computed is computed by the same expressions as in the
+  // general form, bit for bit. The first chunk that does not qualify, and every chunk after it, takes the general loop.
+  // (Two loops in sequence, not two trip loops inside one chunk loop: that form kept both variants' registers alive together
+  // and spilled 72 bytes per lane; profiles/r05_ab_plain_trips_first.txt.)
+  auto chunks = [&](auto plainc) {
+    constexpr bool PLAIN = decltype(plainc)::value;
+    for (; c0 < range.y; c0 += 64) {
+      if constexpr (PLAIN) {
+        // alpha <= o for every pixel: T >= prod (1 - min(o, 0.99)) over everything listed up to and including this chunk
+        const float l = lsum + wave_sum_f32(nxt.hit ? __builtin_amdgcn_logf(1.f - fminf(nxt.q1.y, 0.99f)) : 0.f);
+        if (!(l > PLAIN_LOG2_T) || __builtin_amdgcn_ballot_w64(nxt.hit && nxt.q1.y > 0.99f) != 0ull) return;
+        lsum = l;
+      }
+      wave_lds_sync();  // previous chunk's reads are done
+      int nq[4] = {0, 0, 0, 0};
+      {
+        // per-tile lists: the in-range entries are lanes 0..fill-1, parked at their own lane index
+        const uint32_t qm = nxt.hit ? quad_mask(nxt, bx0, by0) : 0u;
+        quad_append(sidx, lane, nxt.hit, lane, qm, nq);
+      }
+      const int fill = park(slab, nullptr, lane, nxt, 0);
+      nxt = gather_cand<1>(pk, 0u, packed);                           // chunk c0+64: in flight during this chunk
+      pk = peek_cand<1>(c0 + 128 + lane, range.y, keys, point_list);  // chunk c0+128
+      wave_lds_sync();
+      if (!PLAIN && __builtin_amdgcn_ballot_w64(!done) == 0ull) {  // every pixel of the tile has terminated
+        c0 = range.y;
+        return;
+      }
+      const int nmax = max(max(nq[0], nq[1]), max(nq[2], nq[3]));
+      // pad the shorter sub-lists up to nmax (+2 for the pipelined over-read) with the dummy entry
 #pragma unroll
-    for (int q = 0; q < 4; q++)
-      if (lane <= nmax + 1 - nq[q]) sidx[q * QCAP + nq[q] + lane] = (uint32_t)(FQ_CAP * 4 * ENT);
-    wave_lds_sync();
-    // one entry of this lane's quad sub-list against the lane's pixel
-    // Every trip evaluates four different entries, each picked because it reaches its quad: a trip in which no pixel of
-    // the wave blends is rare, so there is no wave-uniform early-out here (the ballot it needs costs two VALU
-    // instructions per trip). test_T >= 0 and finite, so its bits order like the value: ONE integer compare serves both
-    // `term` and `!term` (the float compare is emitted twice, once per polarity, for NaN's sake).
-    uint32_t last_off = 0xFFFFFFFFu;  // slab byte offset of this pixel's last blended entry in this chunk
-    auto fetch_off = [&](uint32_t off) {
-      const float4* e4 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(slab) + off);
-      Ent e;
-      e.q0 = e4[0];
-      if (ALT) {  // C, opacity and the altitude feature: 12 of the other 32 bytes
-        const float2 co = *reinterpret_cast<const float2*>(e4 + 1);
-        e.q1 = make_float4(co.x, co.y, 0.f, 0.f);
-        e.q2 = make_float4(0.f, reinterpret_cast<const float*>(e4 + 2)[1], 0.f, 0.f);
-      } else {
-        e.q1 = e4[1]; e.q2 = e4[2];
-      }
-      return e;
-    };
-    auto blend = [&](const Ent& e, uint32_t off) {
-      const float dx = e.q0.x - pxf, dy = e.q0.y - pyf;
-      const float p = power_of(e, dx, dy);
-      const float alpha = fminf(e.q1.y * __builtin_amdgcn_exp2f(p), 0.99f);
-      bool valid = !done && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);
-      const float test_T = T * (1.f - alpha);
-      const bool stop = valid && __float_as_uint(test_T) < __float_as_uint(0.0001f);
-      done = done || stop;    // this Gaussian is NOT blended; the pixel is finished
-      valid = valid != stop;  // (stop implies valid: one mask xor instead of a second compare)
-      const float wgt = valid ? alpha * T : 0.f;
-      if (ALT) {
-        C[3] += e.q2.y * wgt;
-      } else {
-        C[0] += e.q1.z * wgt; C[1] += e.q1.w * wgt;
-        C[2] += e.q2.x * wgt; C[3] += e.q2.y * wgt; C[4] += e.q2.z * wgt;
-        invd += e.q2.w * wgt;
-      }
-      T = valid ? test_T : T;
-      last_off = valid ? off : last_off;
-    };
-    // software pipeline: sub-list elements two trips ahead, entry reads one trip ahead, two register sets; groups of eight
-    // trips are unrolled so that the sub-list reads sit at immediate offsets (four elements per ds_read2_b64)
-    uint32_t o0 = myidx[0], o1 = myidx[1];
-    Ent ea = fetch_off(o0);
-    const int ngrp = nmax >> 3;
-    for (int gi = 0; gi < ngrp; gi++) {
-      const uint32_t* ip = myidx + 8 * gi;
+      for (int q = 0; q < 4; q++)
+        if (lane <= nmax + 1 - nq[q]) sidx[q * QCAP + nq[q] + lane] = (uint32_t)(FQ_CAP * 4 * ENT);
+      wave_lds_sync();
+      // one entry of this lane's quad sub-list against the lane's pixel
+      // Every trip evaluates four different entries, each picked because it reaches its quad: a trip in which no pixel of
+      // the wave blends is rare, so there is no wave-uniform early-out here (the ballot it needs costs two VALU
+      // instructions per trip). test_T >= 0 and finite, so its bits order like the value: ONE integer compare serves both
+      // `term` and `!term` (the float compare is emitted twice, once per polarity, for NaN's sake).
+      uint32_t last_off = 0xFFFFFFFFu;  // slab byte offset of this pixel's last blended entry in this chunk
+      auto fetch_off = [&](uint32_t off) {
+        const float4* e4 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(slab) + off);
+        Ent e;
+        e.q0 = e4[0];
+        if (ALT) {  // C, opacity and the altitude feature: 12 of the other 32 bytes
+          const float2 co = *reinterpret_cast<const float2*>(e4 + 1);
+          e.q1 = make_float4(co.x, co.y, 0.f, 0.f);
+          e.q2 = make_float4(0.f, reinterpret_cast<const float*>(e4 + 2)[1], 0.f, 0.f);
+        } else {
+          e.q1 = e4[1]; e.q2 = e4[2];
+        }
+        return e;
+      };
+      auto blend = [&](const Ent& e, uint32_t off) {
+        const float dx = e.q0.x - pxf, dy = e.q0.y - pyf;
+        const float p = power_of(e, dx, dy);
+        float wgt;
+        bool valid;
+        if constexpr (PLAIN) {
+          const float alpha = e.q1.y * __builtin_amdgcn_exp2f(p);
+          valid = !(p > 0.0f) && !(alpha < 1.0f / 255.0f);
+          const float a_eff = valid ? alpha : 0.f;
+          wgt = a_eff * T;
+          T = T * (1.f - a_eff);
+        } else {
+          const float alpha = fminf(e.q1.y * __builtin_amdgcn_exp2f(p), 0.99f);
+          valid = !done && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);
+          const float test_T = T * (1.f - alpha);
+          const bool stop = valid && __float_as_uint(test_T) < __float_as_uint(0.0001f);
+          done = done || stop;    // this Gaussian is NOT blended; the pixel is finished
+          valid = valid != stop;  // (stop implies valid: one mask xor instead of a second compare)
+          wgt = valid ? alpha * T : 0.f;
+          T = valid ? test_T : T;
+        }
+        if (ALT) {
+          C[3] += e.q2.y * wgt;
+        } else {
+          C[0] += e.q1.z * wgt; C[1] += e.q1.w * wgt;
+          C[2] += e.q2.x * wgt; C[3] += e.q2.y * wgt; C[4] += e.q2.z * wgt;
+          invd += e.q2.w * wgt;
+        }
+        last_off = valid ? off : last_off;
+      };
+      // software pipeline: sub-list elements two trips ahead, entry reads one trip ahead, two register sets; groups of eight
+      // trips are unrolled so that the sub-list reads sit at immediate offsets (four elements per ds_read2_b64)
+      uint32_t o0 = myidx[0], o1 = myidx[1];
+      Ent ea = fetch_off(o0);
+      const int ngrp = nmax >> 3;
+      for (int gi = 0; gi < ngrp; gi++) {
+        const uint32_t* ip = myidx + 8 * gi;
 #pragma unroll
-      for (int t = 0; t < 8; t += 2) {
-        const Ent eb = fetch_off(o1);
-        const uint32_t o2 = ip[t + 2];
-        blend(ea, o0);
-        ea = fetch_off(o2);
-        const uint32_t o3 = ip[t + 3];
-        blend(eb, o1);
-        o0 = o2;
-        o1 = o3;
+        for (int t = 0; t < 8; t += 2) {
+          const Ent eb = fetch_off(o1);
+          const uint32_t o2 = ip[t + 2];
+          blend(ea, o0);
+          ea = fetch_off(o2);
+          const uint32_t o3 = ip[t + 3];
+          blend(eb, o1);
+          o0 = o2;
+          o1 = o3;
+        }
       }
-    }
-    {
-      const int rem = nmax & 7;
-      const uint32_t* ip = myidx + 8 * ngrp;
-      int t = 0;
-      for (; t + 1 < rem; t += 2) {
-        const Ent eb = fetch_off(o1);
-        const uint32_t o2 = ip[t + 2];
-        blend(ea, o0);
-        ea = fetch_off(o2);
-        const uint32_t o3 = ip[t + 3];
-        blend(eb, o1);
-        o0 = o2;
-        o1 = o3;
+      {
+        const int rem = nmax & 7;
+        const uint32_t* ip = myidx + 8 * ngrp;
+        int t = 0;
+        for (; t + 1 < rem; t += 2) {
+          const Ent eb = fetch_off(o1);
+          const uint32_t o2 = ip[t + 2];
+          blend(ea, o0);
+          ea = fetch_off(o2);
+          const uint32_t o3 = ip[t + 3];
+          blend(eb, o1);
+          o0 = o2;
+          o1 = o3;
+        }
+        if (t < rem) blend(ea, o0);
       }
-      if (t < rem) blend(ea, o0);
+      if (last_off != 0xFFFFFFFFu) last_contributor = jbase + last_off / (uint32_t)(4 * ENT) + 1u;
+      jbase += (uint32_t)fill;
     }
-    if (last_off != 0xFFFFFFFFu) last_contributor = jbase + last_off / (uint32_t)(4 * ENT) + 1u;
-    jbase += (uint32_t)fill;
-  }
+  };
+  // (a tile that hangs over the image's edge keeps the general loop: its outside pixels are `done` from the start)
+  if ((opts & 1) != 0 && __builtin_amdgcn_ballot_w64(!inside) == 0ull) chunks(std::true_type{});
+  chunks(std::false_type{});
   if (inside) {
     const size_t HW = (size_t)H * W;
     final_T[pix_id] = T;
@@ -522,6 +577,14 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_FW, E
 // measured ahead of the one-list-per-tile kernels at every footprint tried (fwd -20 % / bwd -18 % at 4.0 listed tiles per
 // Gaussian, -9 % / -4 % at 10.8, -10 % / -6 % at 12 - 14, level at 31). EOGS_QUAD_SWITCH=<listed tiles per Gaussian>
 // overrides the crossover (0 disables the quad kernel).
+// `opts` of the forward kernels: bit 0 = the quad kernel may take its plain chunks (PLAIN_LOG2_T above; EOGS_PLAIN_TRIPS=0: never)
+static int render_opts() {
+  static const int v = [] {
+    const char* e = getenv("EOGS_PLAIN_TRIPS");
+    return (e && atoi(e) == 0) ? 0 : 1;
+  }();
+  return v;
+}
 #define EOGS_QUAD_SWITCH_DEFAULT 1.0e9
 static double quad_switch() {
   static const double v = [] {
@@ -553,7 +616,7 @@ void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, 
   auto* kern = variant == 1 ? render_fwd_kernel<BLOCK_BIG> : (variant == 2 ? (nr_alt(R) ? render_fwd_quad_kernel<1, true> : render_fwd_quad_kernel<1, false>) : render_fwd_kernel<1>);
   hipLaunchKernelGGL(kern, dim3(render_grid(ntiles, im, R)), dim3(RBLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H, gsx,
                      ntiles, (int)macro_grid_x(W, b.block), render_desc(im, R), g.sched, (int)(16u * im.sched_lg), g.packed, bg, im.final_T, im.n_contrib,
-                     out_color, out_invdepth);
+                     out_color, out_invdepth, render_opts());
 }
 
 // ------------------------------------------------------------------------------------------------------
