@@ -56,14 +56,22 @@ namespace {
 #define FWD_CAP 96   // slab entries, forward: up to FWD_MIN-1 waiting + 64 appended
 #define FWD_MIN 32   // forward processes the slab once it holds this many entries (or the list is exhausted)
 #define KSURV 8  // survivors per transposition round (backward)
-// u/v matrices [survivor k][pixel p] in LDS, laid out as two half-matrices (pixels 0..31 / 32..63) with row stride 33 and
-// 268 floats between the halves: bank(k,p) = 12*(p>>5) + k + (p&31) mod 32. The pixel-parallel writes (lane = p, fixed k)
-// hit 32 consecutive banks per half-wave, and the transposed reads (lane = 8k + o reads pixel 8o + i) hit
-// {k + 8(o&3) + 12(o>>2) + i}: 32 different banks for the 32 (k,o) pairs of a half-wave.
+// u/v matrices [survivor k][pixel p] in LDS, laid out as two half-matrices (pixels 0..31 / 32..63) with row stride UV_ROW = 32
+// and 268 floats between the halves. The pixel-parallel writes (lane = p, fixed k) hit 32 consecutive banks per half-wave.
+// The transposed reads (lane = 8k + o reads pixels 8o .. 8o + 7 of row k) are two ds_read_b128 per matrix: a b128 read is
+// served in four groups of 16 lanes over 64 banks (MI355X_MICROARCH.md, LDS table), and with this stride and half distance
+// the 16 lanes of every group fall into 16 different 16-byte slots — 4 LDS cycles per instruction, 16 per round for u and v
+// where rounds 1-4 (row stride 33, four ds_read2_b32 per matrix) took 32 (the render backward keeps the LDS array busy for
+// 80 % of its cycles: every cycle less there counts).
+#define UV_ROW 32
 #define UV_HALF 268
 #define UV_SIZE (2 * UV_HALF)
 #define UV_PITCH 576  // >= UV_SIZE, multiple of 64 dwords
-__device__ inline int uv_index(int k, int p) { return (p >> 5) * UV_HALF + k * 33 + (p & 31); }
+__device__ inline int uv_index(int k, int p) { return (p >> 5) * UV_HALF + k * UV_ROW + (p & 31); }
+__device__ inline void uv_row8(const float* row, float (&x)[8]) {  // eight consecutive pixels of a row (16-byte aligned)
+  const float4 a = *reinterpret_cast<const float4*>(row), b = *reinterpret_cast<const float4*>(row + 4);
+  x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+}
 
 // ---- wave64 helpers ----
 __device__ inline uint32_t wave_max_u32(uint32_t v) {
@@ -686,9 +694,12 @@ __device__ inline void transpose_round(int nsurv, int lane, const float* rb, con
   const float* urow = s_u + uv_index(k, 8 * o);  // a pixel row (8 pixels) never straddles the two halves
   const float* vrow = s_v + uv_index(k, 8 * o);
   const float* prow = s_pix + (8 * o) * 8 + 4 * o;  // 8 floats per pixel, +4 floats per pixel row against bank conflicts
+  float u8[8], v8[8];
+  uv_row8(urow, u8);
+  uv_row8(vrow, v8);
 #pragma unroll
   for (int i = 0; i < 8; i++) {
-    const float u = urow[i], v = vrow[i];
+    const float u = u8[i], v = v8[i];
     const float4 ga = *reinterpret_cast<const float4*>(prow + i * 8);
     const float gb = prow[i * 8 + 4];
     const float dx = gxr - (float)i;
@@ -816,6 +827,7 @@ __global__ __launch_bounds__(RBLK) void render_bwd_kernel(
 
       float gc = g[0] * e.q1.z + g[1] * e.q1.w + g[2] * e.q2.x + g[3] * e.q2.y + g[4] * e.q2.z;
       if (have_inv) gc += ginv * e.q2.w;
+      else asm volatile("" :: "v"(e.q2.w));  // (keeps the entry's third read a ds_read_b128: see render_bwd_quad_kernel's grad)
       // pixels that skip this Gaussian behave as alpha = 0, G = 0 (selects, not multiplications: exp2 may have
       // overflowed there): wgt = 0, T unchanged, v = 0. No zeroing when alpha was clamped (backward.cu:624).
       const float a_eff = valid ? alpha : 0.f;
@@ -825,7 +837,7 @@ __global__ __launch_bounds__(RBLK) void render_bwd_kernel(
       const float one_m = 1.f - a_eff;
       const float dLda = T * gc - (Dfinal - Dacc) * __builtin_amdgcn_rcpf(one_m);
       T = T * one_m;
-      float* const uv = uvlane + k * 33;  // = su + uv_index(k, lane); k is wave-uniform
+      float* const uv = uvlane + k * UV_ROW;  // = su + uv_index(k, lane); k is wave-uniform
       uv[0] = wgt;
       uv[UV_PITCH] = G_eff * dLda;  // v = G dL/dalpha
       kj |= (unsigned long long)j << (8 * k);
@@ -975,7 +987,7 @@ __global__ __launch_bounds__(RBLK) void render_bwd_btf_kernel(
       dLda *= Tn;
       dLda += (-Tfin / one_m) * bgdot;  // backward.cu:617-620
       // pixels that skip this Gaussian: weight 0, v = 0, state unchanged (selects: exp2 may have overflowed there)
-      float* const uv = uvlane + k * 33;
+      float* const uv = uvlane + k * UV_ROW;
       uv[0] = valid ? alpha * Tn : 0.f;
       uv[UV_PITCH] = valid ? G * dLda : 0.f;
       T = valid ? Tn : T;
@@ -1022,7 +1034,7 @@ namespace {
 #define QB 68     // entries per quad sub-list in backward (64 + pipelined over-read); an entry is the BYTE OFFSET of its slab
                   // entry (position * 48) as a full dword: the hot loop's ds_read needs no address arithmetic or extraction
 #define PIXB 296  // pixel gradients for the VALU transposition: channels 0..3 as one float4 per pixel (+1 float4 per 8 pixels
-                  // against bank conflicts) in floats [0, 288), channel 4 at PIXB + pixel + (pixel >> 3)
+                  // against bank conflicts) in floats [0, 288), channel 4 at PIXB + pixel (read eight at a time: two ds_read_b128)
 #define STG 12    // floats per staged (trip, quad) partial: 11 used
 
 // Transposition of one round of `nk` trips (trips 8 r .. 8 r + nk - 1 of the chunk). ALT (altitude-only render): the one
@@ -1040,20 +1052,29 @@ __device__ inline void transpose_round_quad(int nk, int r, int lane, const uint3
   const float* urow = s_u + uv_index(k, 8 * o);
   const float* vrow = s_v + uv_index(k, 8 * o);
   const float* pa = s_pix + (8 * o) * 4 + 4 * o;
-  const float* pb = s_pix + PIXB + 8 * o + o;
+  // four pixels (one row of the quad) at a time: one ds_read_b128 each for u, v and the fifth channel's gradients (the same
+  // address in all eight lanes of an o: a broadcast); the second row's reads stay behind the first row's arithmetic
+  // (all eight pixels' operands in flight at once cost the kernel 52 bytes of scratch per lane)
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    const float u = urow[i], v = vrow[i];
-    const float gb = pb[i];
-    const float dx = gxr - (float)(i & 3);
-    const float t1 = v * dx;
-    if (i < 4) { S0a += v; Sxa += t1; Sxxa += t1 * dx; }
-    else { S0b += v; Sxb += t1; Sxxb += t1 * dx; }
-    if (!ALT) {
-      const float4 ga = *reinterpret_cast<const float4*>(pa + i * 4);
-      c0 += u * ga.x; c1 += u * ga.y; c2 += u * ga.z; c3 += u * ga.w;
+  for (int hrow = 0; hrow < 2; hrow++) {
+    const float4 u4 = *reinterpret_cast<const float4*>(urow + 4 * hrow), v4 = *reinterpret_cast<const float4*>(vrow + 4 * hrow);
+    const float4 gb4 = *reinterpret_cast<const float4*>(s_pix + PIXB + 8 * o + 4 * hrow);
+    const float uu[4] = {u4.x, u4.y, u4.z, u4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w}, gg[4] = {gb4.x, gb4.y, gb4.z, gb4.w};
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+      const int i = 4 * hrow + x;
+      const float u = uu[x], v = vv[x];
+      const float dx = gxr - (float)x;
+      const float t1 = v * dx;
+      if (hrow == 0) { S0a += v; Sxa += t1; Sxxa += t1 * dx; }
+      else { S0b += v; Sxb += t1; Sxxb += t1 * dx; }
+      if (!ALT) {
+        const float4 ga = *reinterpret_cast<const float4*>(pa + i * 4);
+        c0 += u * ga.x; c1 += u * ga.y; c2 += u * ga.z; c3 += u * ga.w;
+      }
+      c4 += u * gg[x];
     }
-    c4 += u * gb;
+    if (hrow == 0) __builtin_amdgcn_sched_barrier(0);
   }
   if (ALT) {
     float c[7] = {S0a + S0b, Sxa + Sxb, dy0 * S0a + dy1 * S0b, Sxxa + Sxxb, dy0 * Sxa + dy1 * Sxb,
@@ -1241,10 +1262,10 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
       fyv[h] = ey == 0 ? 1.f : (ey == 1 ? y : y * y);
     }
   } else if (ALT) {  // the one plane the altitude-only transposition reads
-    spix[PIXB + lane + (lane >> 3)] = g[3];
+    spix[PIXB + lane] = g[3];
   } else {  // pixel gradients for the transposition rounds (pixel index = lane): see PIXB
     *reinterpret_cast<float4*>(spix + lane * 4 + 4 * (lane >> 3)) = make_float4(g[0], g[1], g[2], g[3]);
-    spix[PIXB + lane + (lane >> 3)] = g[4];
+    spix[PIXB + lane] = g[4];
   }
   for (int t = lane; t < 4 * QB; t += 64) sidx[t] = 0u;  // over-read entries: valid offsets
   if (lane < ENT) slab[64 * ENT + lane] = 0.f;
@@ -1253,7 +1274,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
   const float bx0 = (float)tx0, by0 = (float)ty0;
   float T = 1.0f, Dacc = 0.f;
   float* const uvlane = RED ? su + lane : su + uv_index(0, lane);
-  constexpr int ROWF = RED ? URS : 33;  // floats between the u/v rows of consecutive trips of a round
+  constexpr int ROWF = RED ? URS : UV_ROW;  // floats between the u/v rows of consecutive trips of a round
   float* const vlane = uvlane + UV_PITCH;
 
   PHASE_DECL;
@@ -1318,11 +1339,12 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
           const float4 a0 = st[0], a1 = st[1];
           acc[0] += a0.x; acc[1] += a0.y; acc[2] += a0.z; acc[3] += a0.w;
           acc[4] += a1.x; acc[5] += a1.y; acc[6] += a1.z;
+          if (ALT) asm volatile("" :: "v"(a1.w));  // (ds_read_b128, not ds_read_b96: see grad)
           if (!ALT) {
-            float4 a2 = st[2];
-            asm volatile("" : "+v"(a2.w));  // (a ds_read_b128, not the 8-cycle ds_read_b96 the unused fourth float would make of it)
+            const float4 a2 = st[2];
             acc[7] += a1.w;
             acc[8] += a2.x; acc[9] += a2.y; acc[10] += a2.z;
+            asm volatile("" :: "v"(a2.w));  // (a ds_read_b128, not the 8-cycle ds_read_b96 the unused fourth float would make of it)
           }
         }
       }
@@ -1339,10 +1361,6 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
         e.q2 = make_float4(0.f, reinterpret_cast<const float*>(e4 + 2)[1], 0.f, 0.f);
       } else {
         e.q1 = e4[1]; e.q2 = e4[2];
-        // keep the third read a ds_read_b128 (4 LDS cycles) although 1/depth may go unused: the compiler narrows it to
-        // ds_read_b96, which the LDS serves in 8 (MI355X_MICROARCH.md, LDS table) — and this kernel keeps the LDS array busy
-        // for 80 % of its cycles (profiles/r02_v23_lds: SQ_LDS_IDX_ACTIVE)
-        if (!HAVE_INV) asm volatile("" : "+v"(e.q2.w));
       }
       return e;
     };
@@ -1353,6 +1371,11 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
       const float G = __builtin_amdgcn_exp2f(p);
       const float alpha = fminf(e.q1.y * G, 0.99f);
       const bool valid = (off < nc_off) && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);  // (the dummy: alpha = 0)
+      // Keep the entry's third read a ds_read_b128 (4 LDS cycles) although 1/depth goes unused here: the compiler narrows it to
+      // a ds_read_b96, which the LDS serves in 8 (MI355X_MICROARCH.md, LDS table), and this kernel keeps the LDS array busy for
+      // 80 % of its cycles (profiles/r02_v23_lds: SQ_LDS_IDX_ACTIVE). An empty use HERE, where the other three floats of the
+      // quarter are consumed — at the read itself it made the wave wait for the data it had just asked for.
+      if (!ALT && !HAVE_INV) asm volatile("" :: "v"(e.q2.w));
       float gc = ALT ? g[3] * e.q2.y : g[0] * e.q1.z + g[1] * e.q1.w + g[2] * e.q2.x + g[3] * e.q2.y + g[4] * e.q2.z;
       if (HAVE_INV) gc += ginv * e.q2.w;
       const float a_eff = valid ? alpha : 0.f;
