@@ -524,7 +524,7 @@ int eogs_rast_backward_range(int P, int H, int W, int64_t R, const float* bg, co
                  viewmatrix, projmatrix, radii, scale_modifier, (flags & EOGS_FLAG_ANTIALIASING) != 0,
                  dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, have_sr ? dL_dscales : nullptr,
                  have_sr ? dL_drotations : nullptr, dL_dT_sum, dL_dvm_mean, raw, alt_affine, dL_dcolors_lead,
-                 dL_dcolors_lead ? lead_cols : 0, nr_alt(R) != 0};
+                 dL_dcolors_lead ? lead_cols : 0, nr_alt(R) != 0, R > 0 ? render_bwd_noflag_ok(b.block, R, P) : 0};
   { ProfScope ps(PS_GAUSS_BWD, s); launch_gaussian_bwd(a, g, b, p_begin, p_end, s); }
   LAUNCH_TRY(s, debug, "gaussian_bwd");
   return EOGS_OK;

@@ -56,6 +56,19 @@ __host__ __device__ inline size_t rec_q(size_t slot, int q, size_t plane, int qu
 #define MISC_MACRO_HI 7
 #define MISC_OPW_LO 8    // sum over listed (tile, Gaussian) pairs of round(64 opacity) (u64, lo/hi): mean pair opacity
 #define MISC_OPW_HI 9
+// Flag-free records (quad backward on per-tile lists only). Where no tile comes near saturation every listed pair is walked
+// by the backward, so render_bwd_quad_kernel writes the record of EVERY pair (zeros where nothing contributed), walks every
+// chunk of a list whatever its pixels' last contributors are, and nobody writes or reads the one-byte live flags — 4.2 M
+// scattered byte stores at the headline, each dirtying a 64-byte line of its own (3 % of the dominant kernel). Correct for
+// any scene (a saturated tile only costs the walk over its dead entries); chosen where the mean over tiles of the listed
+// pairs' summed opacity stays below NOFLAG_K (saturation needs ~9 along ONE pixel, which sees a third of its tile's list).
+// Both kernels evaluate this same expression on the same words of `misc` (written by pblock_scan_kernel).
+#define NOFLAG_K 8.0f
+__host__ __device__ inline bool noflag_scene(uint32_t opw_lo, uint32_t opw_hi, int W, int H) {
+  const float opw = (float)opw_lo + 4294967296.0f * (float)opw_hi;  // sum over listed pairs of round(64 opacity)
+  const float ntiles8 = (float)((W + 7) / 8) * (float)((H + 7) / 8);
+  return opw <= 64.0f * NOFLAG_K * ntiles8;
+}
 #define MISC_READBACK 10 // words copied to the host by forward_prepare
 #define MISC_DEPTH_PASSES 10  // 8-bit digits that cover the varying bits of the listed Gaussians' depth keys (0..4)
 #define MISC_WORDS 64
@@ -147,12 +160,14 @@ __device__ inline void row_span(const SpanParams& p, int sy, int sx0, int sx1, i
 // b_c = b/c and b_a = b/a are per-Gaussian constants (the unclamped minimiser on an edge).
 __device__ inline bool block_hit(float gx, float gy, float a, float b, float c, float b_c, float b_a, float tau_m,
                                  float x0, float y0, float x1, float y1) {
-  const float cx = fminf(fmaxf(gx, x0), x1), cy = fminf(fmaxf(gy, y0), y1);
+  // clamps as v_med3_f32 (x0 <= x1, y0 <= y1): one instruction each instead of v_max + v_min, and no canonicalised copies of
+  // the box corners for the compiler to keep in registers (a NaN operand leaves the smaller bound, as fminf(fmaxf()) did)
+  const float cx = __builtin_amdgcn_fmed3f(gx, x0, x1), cy = __builtin_amdgcn_fmed3f(gy, y0, y1);
   const float dxe = gx - cx, dye = gy - cy;
-  const float py = fminf(fmaxf(gy + b_c * dxe, y0), y1);  // edge x = cx, free y
+  const float py = __builtin_amdgcn_fmed3f(gy + b_c * dxe, y0, y1);  // edge x = cx, free y
   const float dy1 = gy - py;
   const float q1 = a * dxe * dxe + 2.f * b * dxe * dy1 + c * dy1 * dy1;
-  const float pxs = fminf(fmaxf(gx + b_a * dye, x0), x1);  // edge y = cy, free x
+  const float pxs = __builtin_amdgcn_fmed3f(gx + b_a * dye, x0, x1);  // edge y = cy, free x
   const float dx2 = gx - pxs;
   const float q2 = a * dx2 * dx2 + 2.f * b * dx2 * dye + c * dye * dye;
   return !(fminf(q1, q2) > tau_m);
@@ -460,6 +475,7 @@ void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, 
 // which render kernel a forward / backward runs: 0 = one list per tile, 1 = block lists, 2 = quad sub-lists (render.hip)
 int render_fwd_variant(int block, int64_t R, int P);
 int render_bwd_variant(int block, int64_t R, int P);  // 0 tile, 1 block, 2 quad, 3 / 4 MFMA experiments, 5 back to front
+int render_bwd_noflag_ok(int block, int64_t R, int P);  // that backward writes flag-free records: 0 no, 1 where noflag_scene() holds, 3 always
 struct GaussBwdArgs {
   int P, H, W;
   const float *means3D, *scales, *rotations, *cov3D_precomp, *opacities, *viewmatrix, *projmatrix;
@@ -473,6 +489,7 @@ struct GaussBwdArgs {
   float* dL_dcolors_lead;  // second destination of the colour gradient's first lead_cols columns (or NULL)
   int lead_cols;
   bool alt_only;           // the records are those of an altitude-only render (REC_ALT)
+  int noflag_ok;           // render_bwd_noflag_ok(): the records are flag-free (bit 0) where the scene allows / always (bit 1)
 };
 // per-Gaussian backward over rows [p_begin, p_end) (p_begin a multiple of BLK); the camera sums are finished by the call
 // whose p_end == P

@@ -396,7 +396,7 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
     float* __restrict__ dL_dmeans3D, float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscales,
     float* __restrict__ dL_drotations, bool want_T, bool want_vm, float* __restrict__ vmpart, uint32_t blk0,
     float* __restrict__ dL_dcolors_lead, int lead_cols, const uint32_t* __restrict__ misc, uint32_t cap_slots,
-    uint32_t cap_entries) {
+    uint32_t cap_entries, int noflag_ok) {
   __shared__ float s_m[3 * BLK];
   __shared__ float s_s[3 * BLK];
   __shared__ float s_red[BLK / 64][18];
@@ -414,6 +414,8 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
   const float opw = (float)misc[MISC_OPW_LO] + 4294967296.0f * (float)misc[MISC_OPW_HI];
   const float ntiles8 = (float)((W + SUBX - 1) / SUBX) * (float)((H + SUBY - 1) / SUBY);
   const uint32_t dlim = opw > 64.0f * 60.0f * ntiles8 ? 1u : GB_DIRECT;
+  // flag-free records (common.h noflag_scene): every listed pair's record was written, the flags were not
+  const bool noflag = (noflag_ok & 1) != 0 && ((noflag_ok & 2) != 0 || noflag_scene(misc[MISC_OPW_LO], misc[MISC_OPW_HI], W, H));
   const int t = threadIdx.x;
   const uint32_t blk = blk0 + blockIdx.x;  // workgroup index over ALL Gaussians (the launch may cover a range of them)
   const size_t row0 = (size_t)blk * BLK;
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
           const uint32_t qq = u < n ? u : 0u;  // (n == 0: slot s0 itself may lie past the arrays — never dereferenced)
           lv[u] = false;
           if (u < n) {
-            lv[u] = live[s0 + qq] != 0;
+            lv[u] = noflag || live[s0 + qq] != 0;
             ra[u] = r4[rec_q(s0 + qq, 0, cap_slots, RQ)];
             rb[u] = r4[rec_q(s0 + qq, 1, cap_slots, RQ)];
             if (!ALT) rc[u] = reinterpret_cast<const float3*>(r4 + rec_q(s0 + qq, 2, cap_slots, RQ))[0];
@@ -490,8 +492,10 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
       for (uint32_t q0 = q_first; q0 < n; q0 += 32) {
         const uint32_t m_n = n - q0 < 32u ? n - q0 : 32u;
         uint32_t m = 0;
+        if (noflag) m = m_n >= 32u ? 0xFFFFFFFFu : (1u << m_n) - 1u;
+        else
 #pragma unroll 4
-        for (uint32_t q = 0; q < m_n; q++) m |= (uint32_t)(live[s0 + q0 + q] != 0) << q;
+          for (uint32_t q = 0; q < m_n; q++) m |= (uint32_t)(live[s0 + q0 + q] != 0) << q;
         while (m) {  // up to four live records per trip: twelve independent loads in flight, summed in list order
           uint32_t q[4];
           bool have[4];
@@ -753,7 +757,7 @@ void launch_gaussian_bwd(const GaussBwdArgs& a, const GeomWS& g, const BinWS& b,
                        a.cov3D_precomp, a.opacities, a.viewmatrix, a.projmatrix, a.alt_affine, a.radii, a.scale_modifier,
                        (int)a.antialiasing, g.binfo, g.pblock, b.records, b.live, a.dL_dmeans2D, a.dL_dcolors, a.dL_dopacity,
                        a.dL_dmeans3D, a.dL_dcov3D, a.dL_dscales, a.dL_drotations, want_T, want_vm, g.vmpart, blk0,
-                       a.dL_dcolors_lead, a.lead_cols, g.misc, b.cap_slots, b.cap_entries);
+                       a.dL_dcolors_lead, a.lead_cols, g.misc, b.cap_slots, b.cap_entries, a.noflag_ok);
   if ((want_T || want_vm) && p_end == a.P)
     hipLaunchKernelGGL(camera_sum_kernel, dim3(1), dim3(BLK), 0, s, g.vmpart, nblk_all, a.dL_dT_sum, a.dL_dvm_mean);
 }

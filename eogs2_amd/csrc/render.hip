@@ -1186,7 +1186,8 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx, const uint4* __restrict__ desc, const uint32_t* __restrict__ sched, int lg16,
     const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ out_color, const float* __restrict__ out_invdepth, const float* __restrict__ dL_dpix,
-    const float* __restrict__ dL_dinv, float* __restrict__ records, uint8_t* __restrict__ live_flag, uint32_t rec_plane) {
+    const float* __restrict__ dL_dinv, float* __restrict__ records, uint8_t* __restrict__ live_flag, uint32_t rec_plane,
+    const uint32_t* __restrict__ misc, int opts) {
   // slab position 64 holds a DUMMY entry (opacity 0 -> alpha = 0 -> never valid): shorter sub-lists are padded with it
   __shared__ __attribute__((aligned(16))) float s_slab[RBLK / 64][65 * ENT];
   __shared__ __attribute__((aligned(16))) float s_uv[RBLK / 64][RED ? 2 * UV_PITCH : UV_PITCH + UV_SIZE];
@@ -1269,8 +1270,10 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
   }
   for (int t = lane; t < 4 * QB; t += 64) sidx[t] = 0u;  // over-read entries: valid offsets
   if (lane < ENT) slab[64 * ENT + lane] = 0.f;
-  const uint32_t tile_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(ncontrib));
-  const float kx = LN2 * 0.5f * W, ky = LN2 * 0.5f * H;
+  // flag-free records (common.h noflag_scene; opts bit 0: the caller's gaussian_bwd reads them that way): every chunk of the
+  // list is walked and every entry's record written, whatever the pixels' last contributors are; no live flags
+  const bool noflag = (opts & 1) != 0 && ((opts & 2) != 0 || noflag_scene(misc[MISC_OPW_LO], misc[MISC_OPW_HI], W, H));
+  const uint32_t tile_last = noflag ? 0xFFFFFFFFu : (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(ncontrib));
   const float bx0 = (float)tx0, by0 = (float)ty0;
   float T = 1.0f, Dacc = 0.f;
   float* const uvlane = RED ? su + lane : su + uv_index(0, lane);
@@ -1286,7 +1289,11 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
     int nq[4];
     uint32_t myranks = 0xFFFFFFFFu;  // byte q: the trip in which quad q evaluates this lane's entry (0xFF: never)
     {
-      const uint32_t qm = nxt.hit ? quad_mask(nxt, bx0, by0) : 0u;
+      // (the tile origin through an opaque copy: the four quads' box corners are then computed here, per chunk, instead of being
+      // hoisted out of the chunk loop into eight VGPRs this kernel does not have — it spilled them)
+      float bxq = bx0, byq = by0;
+      asm volatile("" : "+v"(bxq), "+v"(byq));
+      const uint32_t qm = nxt.hit ? quad_mask(nxt, bxq, byq) : 0u;
       // per-tile lists: the in-range entries are lanes 0..jn-1, parked at their own lane index
       const bool listed = nxt.hit && jbase + (uint32_t)lane < tile_last;  // entries behind the last contributor are dead
 #pragma unroll
@@ -1389,7 +1396,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
       vlane[slot * ROWF] = G_eff * dLda;  // v = G dL/dalpha
     };
     PHASE(0);
-    if (nmax > 0) {
+    if (nmax > 0 || noflag) {  // (flag-free: an entry that reaches no quad still gets its record of zeros)
       // trips are never skipped: trip j is slot j & 7 of round j >> 3. Full rounds are unrolled (slots, sub-list reads and u/v
       // rows at immediate offsets); the entry of trip j + 1 and the sub-list element of trip j + 2 are in flight during trip j
       uint32_t o0 = myidx[0], o1 = myidx[1];
@@ -1431,7 +1438,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
       bool any = false;
 #pragma unroll
       for (int t = 0; t < NACC; t++) any = any || acc[t] != 0.f;
-      if (lane < jn && any) {
+      if (lane < jn && (any || noflag)) {
         const float4 q0 = *reinterpret_cast<const float4*>(slab + lane * ENT);
         const float2 q1 = *reinterpret_cast<const float2*>(slab + lane * ENT + 4);
         const float A = q0.z, B = q0.w, Cq = q1.x, op = q1.y;
@@ -1445,8 +1452,10 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
           acc[4] = gxr * Sdy - gyr * Sx + Sxy;
           acc[5] = gyr * (Sdy - Sy) + Syy;
         }
-        const float m2x = op * kx * (2.f * A * acc[1] - B * acc[2]);
-        const float m2y = op * ky * (2.f * Cq * acc[2] - B * acc[1]);
+        float opq = op;
+        asm volatile("" : "+v"(opq));  // (kx, ky formed here, once per chunk, not kept in registers across the trips)
+        const float m2x = opq * (LN2 * 0.5f * W) * (2.f * A * acc[1] - B * acc[2]);
+        const float m2y = opq * (LN2 * 0.5f * H) * (2.f * Cq * acc[2] - B * acc[1]);
         const float ho = -0.5f * op;
         constexpr int RQ = (ALT ? REC_ALT : REC) / 4;  // layout: common.h REC / REC_ALT, rec_q
         float4* r4 = reinterpret_cast<float4*>(records);
@@ -1457,7 +1466,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
           r4[rec_q(cur_slot, 1, rec_plane, RQ)] = make_float4(ho * acc[4], ho * acc[5], acc[6], acc[7]);
           reinterpret_cast<float3*>(r4 + rec_q(cur_slot, 2, rec_plane, RQ))[0] = make_float3(acc[8], acc[9], acc[10]);
         }
-        live_flag[cur_slot] = 1;
+        if (!noflag) live_flag[cur_slot] = 1;
       }
     }
     jbase += (uint32_t)jn;
@@ -1740,6 +1749,18 @@ int render_bwd_variant(int block, int64_t R, int P) {
   return bwd_mfma_on() == 1 ? 3 : (bwd_mfma_on() == 2 ? 4 : 2);
 }
 
+// Does the backward that (block, R, P) selects write flag-free records (common.h noflag_scene)? 0 = no, 1 = where the scene
+// allows, 3 = whatever the scene (EOGS_NOFLAG=2). The quad backward only. gaussian_bwd_kernel is told the same answer (api.hip).
+int render_bwd_noflag_ok(int block, int64_t R, int P) {
+  static const int mode = [] {  // EOGS_NOFLAG: 0 = never, 1 = where the scene allows (default), 2 = always (tests: correct for any scene)
+    const char* e = getenv("EOGS_NOFLAG");
+    return e ? atoi(e) : 1;
+  }();
+  const int v = render_bwd_variant(block, R, P);
+  if (mode <= 0 || !(v == 2 || v == 4 || v == 6)) return 0;
+  return mode >= 2 ? 3 : 1;
+}
+
 void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, const float* colors,
                        const float* out_color, const float* out_invdepth, const float* dL_dcolor,
                        const float* dL_dinvdepth, const float* bg, hipStream_t s) {
@@ -1753,10 +1774,16 @@ void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, 
   }
   auto* kern = variant == 1 ? (dL_dinvdepth ? render_bwd_kernel<BLOCK_BIG, true> : render_bwd_kernel<BLOCK_BIG, false>)
                             : (dL_dinvdepth ? render_bwd_kernel<1, true> : render_bwd_kernel<1, false>);
-  if (variant == 2) kern = dL_dinvdepth ? render_bwd_quad_kernel<true, 0, false> : render_bwd_quad_kernel<false, 0, false>;
-  if (variant == 6) kern = render_bwd_quad_kernel<false, 0, true>;  // altitude-only (no inverse-depth gradient: api.hip checks)
+  if (variant == 2 || variant == 4 || variant == 6) {  // the quad backward (variant 6: altitude-only, no inverse-depth gradient: api.hip checks)
+    auto* kq = dL_dinvdepth ? render_bwd_quad_kernel<true, 0, false> : render_bwd_quad_kernel<false, 0, false>;
+    if (variant == 6) kq = render_bwd_quad_kernel<false, 0, true>;
+    if (variant == 4) kq = dL_dinvdepth ? render_bwd_quad_kernel<true, 1, false> : render_bwd_quad_kernel<false, 1, false>;
+    hipLaunchKernelGGL(kq, dim3(render_grid(ntiles, im, R)), dim3(RBLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H, gsx,
+                       ntiles, (int)macro_grid_x(W, b.block), render_desc(im, R), g.sched, (int)(16u * im.sched_lg), g.packed, im.n_contrib, out_color,
+                       out_invdepth, dL_dcolor, dL_dinvdepth, b.records, b.live, b.cap_slots, g.misc, render_bwd_noflag_ok(b.block, R, P));
+    return;
+  }
   if (variant == 3) kern = dL_dinvdepth ? render_bwd_mfma_kernel<true> : render_bwd_mfma_kernel<false>;
-  if (variant == 4) kern = dL_dinvdepth ? render_bwd_quad_kernel<true, 1, false> : render_bwd_quad_kernel<false, 1, false>;
   hipLaunchKernelGGL(kern, dim3(render_grid(ntiles, im, R)), dim3(RBLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H, gsx,
                      ntiles, (int)macro_grid_x(W, b.block), render_desc(im, R), g.sched, (int)(16u * im.sched_lg), g.packed, im.n_contrib, out_color,
                      out_invdepth, dL_dcolor, dL_dinvdepth, b.records, b.live, b.cap_slots);

@@ -341,5 +341,8 @@ def test_record_again_after_the_parameters_were_replaced_keeps_the_memory(dev):
         if i in (1, 12):
             _same(got, [t.clone() for t in fn(False)])
         marks.append(in_use())
-    # (measured: flat to 2 MiB; a new pool per recording grew by ~100 MiB each at this size)
-    assert marks[-1] - marks[1] < 48, marks
+    # (measured: flat to 2 MiB; a new pool per recording grew by ~100 MiB each at this size, 1 GiB over these recordings. The
+    # first and the last mark follow an EAGER comparison run, whose blocks the ordinary allocator keeps cached — 60 MiB once,
+    # depending on what the process ran before: they are held to a looser bound, the recordings in between to the tight one)
+    assert marks[-2] - marks[1] < 48, marks
+    assert marks[-1] - marks[1] < 200, marks
