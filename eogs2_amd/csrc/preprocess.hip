@@ -460,12 +460,18 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
         float4 ra[GB_DIRECT], rb[GB_DIRECT];
         float3 rc[GB_DIRECT];
         bool lv[GB_DIRECT];
+        // the (up to four) flags of this Gaussian's consecutive slots in ONE unaligned 4-byte load (bytes past its n-th flag
+        // are other Gaussians' or the 256 bytes of slack behind the array, common.h bin_layout: read, never used): the four
+        // byte loads cost this kernel 10 % (profiles/r05_ab_noflag.txt: it runs 0.085 instead of 0.0955 ms without them)
+        static_assert(GB_DIRECT == 4u, "one dword of flags");
+        uint32_t fl4 = 0x01010101u;
+        if (!noflag && n) __builtin_memcpy(&fl4, live + s0, 4);
 #pragma unroll
         for (uint32_t u = 0; u < GB_DIRECT; u++) {
           const uint32_t qq = u < n ? u : 0u;  // (n == 0: slot s0 itself may lie past the arrays — never dereferenced)
           lv[u] = false;
           if (u < n) {
-            lv[u] = noflag || live[s0 + qq] != 0;
+            lv[u] = ((fl4 >> (8u * u)) & 0xFFu) != 0u;
             ra[u] = r4[rec_q(s0 + qq, 0, cap_slots, RQ)];
             rb[u] = r4[rec_q(s0 + qq, 1, cap_slots, RQ)];
             if (!ALT) rc[u] = reinterpret_cast<const float3*>(r4 + rec_q(s0 + qq, 2, cap_slots, RQ))[0];
@@ -492,10 +498,18 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
       for (uint32_t q0 = q_first; q0 < n; q0 += 32) {
         const uint32_t m_n = n - q0 < 32u ? n - q0 : 32u;
         uint32_t m = 0;
-        if (noflag) m = m_n >= 32u ? 0xFFFFFFFFu : (1u << m_n) - 1u;
-        else
-#pragma unroll 4
-          for (uint32_t q = 0; q < m_n; q++) m |= (uint32_t)(live[s0 + q0 + q] != 0) << q;
+        const uint32_t all = m_n >= 32u ? 0xFFFFFFFFu : (1u << m_n) - 1u;
+        if (noflag) {
+          m = all;
+        } else {  // four flags (bytes that are 0 or 1) per unaligned 4-byte load; what lies past the m_n-th is masked away
+#pragma unroll 2
+          for (uint32_t q = 0; q < m_n; q += 4) {
+            uint32_t f;
+            __builtin_memcpy(&f, live + s0 + q0 + q, 4);
+            m |= ((f & 1u) | ((f >> 7) & 2u) | ((f >> 14) & 4u) | ((f >> 21) & 8u)) << q;
+          }
+          m &= all;
+        }
         while (m) {  // up to four live records per trip: twelve independent loads in flight, summed in list order
           uint32_t q[4];
           bool have[4];
