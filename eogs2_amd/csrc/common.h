@@ -61,9 +61,12 @@ __host__ __device__ inline size_t rec_q(size_t slot, int q, size_t plane, int qu
 // chunk of a list whatever its pixels' last contributors are, and nobody writes or reads the one-byte live flags — 4.2 M
 // scattered byte stores at the headline, each dirtying a 64-byte line of its own (3 % of the dominant kernel). Correct for
 // any scene (a saturated tile only costs the walk over its dead entries); chosen where the mean over tiles of the listed
-// pairs' summed opacity stays below NOFLAG_K (saturation needs ~9 along ONE pixel, which sees a third of its tile's list).
+// pairs' summed opacity stays below NOFLAG_K (saturation needs ~9 along ONE pixel, which sees a third of its tile's list at
+// a fraction of its opacity). Forced on, it still pays at a mean of 53 (1 M Gaussians at opacity 0.1: render_bwd -1.5 %,
+// gaussian_bwd -1.4 %; opacity 0.05, mean 23: -3 % / -3 %) and costs +75 % at 121 (opacity 0.2, where tiles saturate):
+// profiles/r05_ab_noflag.txt. 24 keeps a factor of two to where the gain ends.
 // Both kernels evaluate this same expression on the same words of `misc` (written by pblock_scan_kernel).
-#define NOFLAG_K 8.0f
+#define NOFLAG_K 24.0f
 __host__ __device__ inline bool noflag_scene(uint32_t opw_lo, uint32_t opw_hi, int W, int H) {
   const float opw = (float)opw_lo + 4294967296.0f * (float)opw_hi;  // sum over listed pairs of round(64 opacity)
   const float ntiles8 = (float)((W + 7) / 8) * (float)((H + 7) / 8);
