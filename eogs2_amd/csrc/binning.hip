@@ -32,16 +32,6 @@
 
 namespace {
 
-__device__ inline uint32_t wave_incl_scan_u32(uint32_t v) {
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    uint32_t n = __shfl_up(v, o, 64);
-    if (lane >= o) v += n;
-  }
-  return v;
-}
-
 // Exclusive scan across the 256 threads of a workgroup; `total` = sum over the workgroup. s_w: 4 words of LDS.
 __device__ inline uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, uint32_t& total) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -91,12 +81,7 @@ __device__ inline uint32_t entries_on_device(const uint32_t* __restrict__ misc, 
 namespace {
 __device__ inline unsigned long long wg_excl_scan_u64(unsigned long long v, unsigned long long* s_w, unsigned long long& total) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  unsigned long long inc = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const unsigned long long nb = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += nb;
-  }
+  const unsigned long long inc = wave_incl_scan_u64(v);  // (DPP path, common.h: this one-workgroup kernel is all latency)
   if (lane == 63) s_w[w] = inc;
   __syncthreads();
   unsigned long long pre = 0ull;
@@ -152,14 +137,11 @@ __global__ __launch_bounds__(PS_T) void pblock_scan_kernel(uint32_t* __restrict_
     carry_t += tot_t;
     carry_e += tot_e;
   }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    const uint32_t a = __shfl_xor(kmax, o, 64), b = __shfl_xor(knmin, o, 64);
-    kmax = a > kmax ? a : kmax;
-    knmin = b > knmin ? b : knmin;
-    opw += __shfl_xor(opw, o, 64);
-    err |= __shfl_xor(err, o, 64);
-  }
+  kmax = wave_max_u32_dpp(kmax);
+  knmin = wave_max_u32_dpp(knmin);
+  // (a lane's opw < 2^33: the low 24 bits and the rest summed apart, each exact in 32 bits)
+  opw = (unsigned long long)wave_sum_u32_dpp((uint32_t)(opw & 0xFFFFFFull)) + ((unsigned long long)wave_sum_u32_dpp((uint32_t)(opw >> 24)) << 24);
+  err = wave_or_u32_dpp(err);
   __shared__ unsigned long long s_o[PS_T / 64];
   __shared__ uint32_t s_err[PS_T / 64];
   if (lane == 0) { s_k[0][w] = kmax; s_k[1][w] = knmin; s_o[w] = opw; s_err[w] = err; }
@@ -682,13 +664,7 @@ __device__ inline uint4 u4_add(const uint4& a, const uint4& b) { return make_uin
 template <int ST>
 __device__ inline uint4 sched_scan(uint4 v, uint4* s_w, uint4& total) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  uint4 inc = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint4 n = make_uint4((uint32_t)__shfl_up((int)inc.x, d, 64), (uint32_t)__shfl_up((int)inc.y, d, 64),
-                               (uint32_t)__shfl_up((int)inc.z, d, 64), (uint32_t)__shfl_up((int)inc.w, d, 64));
-    if (lane >= d) inc = u4_add(inc, n);
-  }
+  const uint4 inc = make_uint4(wave_incl_scan_u32(v.x), wave_incl_scan_u32(v.y), wave_incl_scan_u32(v.z), wave_incl_scan_u32(v.w));
   __syncthreads();
   if (lane == 63) s_w[w] = inc;
   __syncthreads();

@@ -44,6 +44,42 @@ __host__ __device__ inline size_t rec_q(size_t slot, int q, size_t plane, int qu
 }
 
 // ---- misc[] slots (u32) in the geometry workspace ----
+// Inclusive prefix sum over the 64 lanes of a wave on the DPP path: row_shr 1, 2, 4, 8 inside each row of 16 lanes, then the
+// rows' totals handed on with row_bcast15 / row_bcast31 — six VALU instructions. The __shfl_up form is six DEPENDENT
+// ds_bpermute_b32 (an LDS round trip each, ~100 cycles of latency): in kernels that scan between workgroup barriers
+// (pblock_scan, expand, the entry scatter, block_lists) that latency is on the critical path of every wave.
+__device__ inline uint32_t wave_incl_scan_u32(uint32_t v) {
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);  // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);  // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);  // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);  // row_shr:8: inclusive inside each row
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);  // row_bcast15 -> rows 1 and 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);  // row_bcast31 -> rows 2 and 3
+  return (uint32_t)x;
+}
+// Wave-wide reductions on the same path (identity 0: unsigned max, sum, or): rotations inside the rows, row_bcast15 / 31 across
+// them, the total read from lane 63 into an SGPR — every lane gets it.
+template <class Op>
+__device__ inline uint32_t wave_reduce_u32(uint32_t v, Op op) {
+  int x = (int)v;
+  x = (int)op((uint32_t)x, (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x121, 0xF, 0xF, false));  // row_ror:1
+  x = (int)op((uint32_t)x, (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x122, 0xF, 0xF, false));  // row_ror:2
+  x = (int)op((uint32_t)x, (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x124, 0xF, 0xF, false));  // row_ror:4
+  x = (int)op((uint32_t)x, (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x128, 0xF, 0xF, false));  // row_ror:8: every lane = its row
+  x = (int)op((uint32_t)x, (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false));  // row_bcast15 -> rows 1, 3
+  x = (int)op((uint32_t)x, (uint32_t)__builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false));  // row_bcast31 -> rows 2, 3
+  return (uint32_t)__builtin_amdgcn_readlane(x, 63);
+}
+__device__ inline uint32_t wave_max_u32_dpp(uint32_t v) { return wave_reduce_u32(v, [](uint32_t a, uint32_t b) { return a > b ? a : b; }); }
+__device__ inline uint32_t wave_sum_u32_dpp(uint32_t v) { return wave_reduce_u32(v, [](uint32_t a, uint32_t b) { return a + b; }); }
+__device__ inline uint32_t wave_or_u32_dpp(uint32_t v) { return wave_reduce_u32(v, [](uint32_t a, uint32_t b) { return a | b; }); }
+__device__ inline unsigned long long wave_incl_scan_u64(unsigned long long v) {
+  // four 16-bit pieces, each scanned exactly in 32 bits (64 lanes x 65535 < 2^32), recombined with 64-bit adds
+  const uint32_t a = wave_incl_scan_u32((uint32_t)(v & 0xFFFFu)), b = wave_incl_scan_u32((uint32_t)((v >> 16) & 0xFFFFu));
+  const uint32_t c = wave_incl_scan_u32((uint32_t)((v >> 32) & 0xFFFFu)), d = wave_incl_scan_u32((uint32_t)(v >> 48));
+  return (unsigned long long)a + ((unsigned long long)b << 16) + ((unsigned long long)c << 32) + ((unsigned long long)d << 48);
+}
 #define MISC_TOTAL_LO 0  // sum of tiles_touched (u64, lo/hi)
 #define MISC_TOTAL_HI 1
 #define MISC_ERR 2       // bit0: altitude > 200

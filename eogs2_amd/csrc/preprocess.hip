@@ -314,13 +314,8 @@ __global__ __launch_bounds__(BLK) PP_ATTR void preprocess_fwd_kernel(
   }
   // exclusive prefix of the tile counts inside the workgroup (record slots in Gaussian-id order) and the
   // workgroup total
-  uint32_t inc = my_tiles;
+  const uint32_t inc = wave_incl_scan_u32(my_tiles);
   const int lane = t & 63;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t nb = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += nb;
-  }
   if (lane == 63) s_cnt[t >> 6] = inc;
   __syncthreads();
   const uint32_t w0 = s_cnt[0], w1 = s_cnt[1], w2 = s_cnt[2], w3 = s_cnt[3];
@@ -339,15 +334,11 @@ __global__ __launch_bounds__(BLK) PP_ATTR void preprocess_fwd_kernel(
   // bit 31 of the stored word is the error flag (the sum only feeds the list-granularity heuristic)
   const unsigned long long o64 = (unsigned long long)my_tiles * op64;
   uint32_t osum = o64 > 0x7FFFFFull ? 0x7FFFFFu : (uint32_t)o64;
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    const uint32_t a = __shfl_xor(kmax, o, 64), b = __shfl_xor(knmin, o, 64);
-    kmax = a > kmax ? a : kmax;
-    knmin = b > knmin ? b : knmin;
-    esum += __shfl_xor(esum, o, 64);
-    osum += __shfl_xor(osum, o, 64);
-    my_err |= __shfl_xor(my_err, o, 64);
-  }
+  kmax = wave_max_u32_dpp(kmax);
+  knmin = wave_max_u32_dpp(knmin);
+  esum = wave_sum_u32_dpp(esum);
+  osum = wave_sum_u32_dpp(osum);
+  my_err = wave_or_u32_dpp(my_err);
   if (lane == 0) { s_k[0][w] = kmax; s_k[1][w] = knmin; s_k[2][w] = esum; s_k[3][w] = osum; s_k[4][w] = my_err; }
   __syncthreads();
   if (t == 0) {
