@@ -74,14 +74,7 @@ __device__ inline void uv_row8(const float* row, float (&x)[8]) {  // eight cons
 }
 
 // ---- wave64 helpers ----
-__device__ inline uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    uint32_t n = __shfl_xor(v, o, 64);
-    v = n > v ? n : v;
-  }
-  return v;
-}
+__device__ inline uint32_t wave_max_u32(uint32_t v) { return wave_max_u32_dpp(v); }  // (common.h: DPP path, no LDS round trips)
 // wave-uniform sum on the DPP path: four rotations inside each row of 16 lanes, the row totals handed on by row_bcast15 /
 // row_bcast31, lane 63 read back — seven VALU instructions and no LDS round trip (__shfl_xor is a ds_bpermute_b32: six
 // dependent ones cost the quad forward 4 % when this sum sat in its chunk loop, profiles/r05_ab_plain_trips.txt)
