@@ -373,9 +373,10 @@ def _profile_is_current(pmc_json):
     return meta.get("kernel_source_sha256") == source_hash() and not meta.get("bench_args", "").strip()
 
 
-def measured_valu(kernel, a):
+def measured_valu(kernel, a, counter=None):
     """VALU wave-instructions per launch of `kernel` from the same committed PMC passes (SQ_INSTS_VALU), for the
-    instruction-issue bound the render kernels actually sit at."""
+    instruction-issue bound the render kernels actually sit at; `counter`: another counter of that kernel
+    from the same passes (None when the profile does not hold it)."""
     import glob
     import re
 
@@ -395,6 +396,8 @@ def measured_valu(kernel, a):
             continue
         for name, c in pm.items():
             if name.startswith((kernel + "_kernel", kernel + "_quad_kernel", kernel + "_mfma_kernel")) and "SQ_INSTS_VALU" in c:
+                if counter is not None:
+                    return float(c[counter]) if counter in c else None
                 return float(c["SQ_INSTS_VALU"])
     return None
 
@@ -1245,6 +1248,16 @@ def main():
                 floor_cyc = 105.0 / 32.0
                 roof["valu"] = {"bound": "valu", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
                                 "issue_floor_simd_cycles_per_inst": floor_cyc, "frac_of_issue_floor": floor_cyc / cyc}
+                # the second pipe this kernel keeps busy: the LDS array (one per CU, 256 B per clock). SQ_LDS_IDX_ACTIVE = its
+                # active cycles summed over the CUs; against 256 CUs x the launch's duration at the nominal 2.4 GHz (the
+                # clock under this load is lower, DESIGN.md 2.8: the true share is higher). Round 5 found the backward at
+                # 0.65 of that (0.8 of its real clock) beside a VALU that never idles: its ds_read_b96 and ds_read2_b32 forms
+                # were costing twice their bytes.
+                lds_active, lds_conf = measured_valu(dom, a, "SQ_LDS_IDX_ACTIVE"), measured_valu(dom, a, "SQ_LDS_BANK_CONFLICT")
+                if lds_active:
+                    cu_cycles = 256 * kern[dom] * 1e-3 * 2.4e9
+                    roof["lds"] = {"lds_array_active_cycles": lds_active, "cu_cycles_at_2.4GHz": cu_cycles,
+                                   "frac_of_cu_cycles": lds_active / cu_cycles, "bank_conflict_cycles": lds_conf}
         # every kernel group against the HBM roofline (the render kernels are VALU-issue-bound: DESIGN.md §4)
         per_kernel = {}
         for k, ms in kern.items():
