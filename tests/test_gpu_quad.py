@@ -44,3 +44,25 @@ def test_quad_kernels_agree_with_tile_kernels(tmp_path, P, H, W, opacity, invdep
     for k in plain:
         if k.startswith("g_"):
             assert_close(torch.from_numpy(quad[k]), torch.from_numpy(plain[k]), k, rtol=2e-5)
+
+
+@pytest.mark.parametrize("P,H,W,opacity,invdepth", [(150_000, 344, 392, "init", 0), (80_000, 256, 250, "0.04", 1),
+                                                    (60_000, 200, 264, "trained", 0)])
+def test_round5_fast_paths_change_no_bit(tmp_path, P, H, W, opacity, invdepth):
+    """Round 5: the forward's plain chunks leave out operations that are no-ops where they are left out,
+    and the backward's flag-free records add exact zeros: with both switched off, on (the default picks per scene and per
+    chunk) or forced, every output and every gradient is the same BITS (-0.0 and +0.0 count as equal: a zero record added to
+    a zero sum). The image is partly off the 8-px grid (344 x 392, 256 x 250): edge tiles keep the general loop beside
+    interior tiles' plain chunks; the 'trained' scene saturates, so its forced flag-free backward walks dead entries."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    args = (P, H, W, opacity, invdepth)
+    quad = {"EOGS_BLOCK_SWITCH": "1000", "EOGS_QUAD_SWITCH": "1000", "EOGS_QUAD_BWD_SWITCH": "1000", "EOGS_BTF_SWITCH": "0"}
+    off = _render(tmp_path, "off", dict(quad, EOGS_PLAIN_TRIPS="0", EOGS_NOFLAG="0"), args)
+    auto = _render(tmp_path, "auto", dict(quad), args)
+    forced = _render(tmp_path, "forced", dict(quad, EOGS_NOFLAG="2"), args)
+    assert float(np.abs(off["out_color"]).max()) > 0.1 and float(np.abs(off["g_means3D"]).max()) > 0
+    for name, got in (("default", auto), ("forced flag-free", forced)):
+        for k in off:
+            d = off[k] != got[k]  # (numpy: -0.0 == 0.0; a NaN would differ from itself and fail here as it should)
+            assert not d.any(), f"{name}: {k} differs in {int(d.sum())} of {d.size} elements from the run with the fast paths off"
