@@ -1032,14 +1032,27 @@ namespace {
 
 // Transposition of one round of `nk` trips (trips 8 r .. 8 r + nk - 1 of the chunk). ALT (altitude-only render): the one
 // colour sum of channel 3, whose pixel gradients sit in the single plane at s_pix + PIXB; 7 partials per (trip, quad).
-template <bool ALT>
+// ORG (round 5, EOGS_ORIGIN_MOMENTS): the six moments of v are taken in TILE-LOCAL pixel coordinates {1, X, Y, X^2, XY, Y^2}
+// instead of about the Gaussian's centre: a row of four pixels costs three sums with constant weights (v1 + 2 v2 + 3 v3,
+// v1 + 4 v2 + 9 v3) instead of a subtraction, a product and two multiply-adds per pixel, the lane needs neither the entry's
+// centre nor its sub-list element (two LDS reads per round), and the four quads' partials add up in the owner as they are; the
+// owner shifts the sums to the centre once per entry and chunk (sum v (g - X) = g S0 - SX, ...), as the MFMA variant always did.
+#ifndef EOGS_ORIGIN_MOMENTS
+#define EOGS_ORIGIN_MOMENTS 1
+#endif
+template <bool ALT, bool ORG>
 __device__ inline void transpose_round_quad(int nk, int r, int lane, const uint32_t* sidx, const float* slab, float* s_u,
                                             const float* s_v, const float* s_pix, float bx0, float by0) {
   const int k = lane >> 3, o = lane & 7, q = o >> 1, h = o & 1;
-  const uint32_t off = sidx[q * QB + 8 * r + k];  // the entry quad q evaluated in trip k (any staged value is a valid offset)
-  const float2 gxy = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(slab) + off);
-  const float gxr = gxy.x - (bx0 + (float)(4 * (q & 1)));  // centre relative to the quad's first column
-  const float dy0 = gxy.y - (by0 + (float)(4 * (q >> 1) + 2 * h)), dy1 = dy0 - 1.f;
+  float gxr = 0.f, dy0 = 0.f, dy1 = 0.f;
+  if (!ORG) {
+    const uint32_t off = sidx[q * QB + 8 * r + k];  // the entry quad q evaluated in trip k (any staged value is a valid offset)
+    const float2 gxy = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(slab) + off);
+    gxr = gxy.x - (bx0 + (float)(4 * (q & 1)));  // centre relative to the quad's first column
+    dy0 = gxy.y - (by0 + (float)(4 * (q >> 1) + 2 * h));
+    dy1 = dy0 - 1.f;
+  }
+  // !ORG: S0 / Sx / Sxx = sum v {1, dx, dx^2} of a row (dx = centre - pixel); ORG: s0 / s1 / s2 = sum v {1, x, x^2}, x = 0..3
   float S0a = 0.f, Sxa = 0.f, Sxxa = 0.f, S0b = 0.f, Sxb = 0.f, Sxxb = 0.f;
   float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f, c4 = 0.f;
   const float* urow = s_u + uv_index(k, 8 * o);
@@ -1053,14 +1066,23 @@ __device__ inline void transpose_round_quad(int nk, int r, int lane, const uint3
     const float4 u4 = *reinterpret_cast<const float4*>(urow + 4 * hrow), v4 = *reinterpret_cast<const float4*>(vrow + 4 * hrow);
     const float4 gb4 = *reinterpret_cast<const float4*>(s_pix + PIXB + 8 * o + 4 * hrow);
     const float uu[4] = {u4.x, u4.y, u4.z, u4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w}, gg[4] = {gb4.x, gb4.y, gb4.z, gb4.w};
+    if (ORG) {
+      const float s0 = (vv[0] + vv[1]) + (vv[2] + vv[3]);
+      const float s1 = __builtin_fmaf(3.f, vv[3], __builtin_fmaf(2.f, vv[2], vv[1]));
+      const float s2 = __builtin_fmaf(9.f, vv[3], __builtin_fmaf(4.f, vv[2], vv[1]));
+      if (hrow == 0) { S0a = s0; Sxa = s1; Sxxa = s2; }
+      else { S0b = s0; Sxb = s1; Sxxb = s2; }
+    }
 #pragma unroll
     for (int x = 0; x < 4; x++) {
       const int i = 4 * hrow + x;
       const float u = uu[x], v = vv[x];
-      const float dx = gxr - (float)x;
-      const float t1 = v * dx;
-      if (hrow == 0) { S0a += v; Sxa += t1; Sxxa += t1 * dx; }
-      else { S0b += v; Sxb += t1; Sxxb += t1 * dx; }
+      if (!ORG) {
+        const float dx = gxr - (float)x;
+        const float t1 = v * dx;
+        if (hrow == 0) { S0a += v; Sxa += t1; Sxxa += t1 * dx; }
+        else { S0b += v; Sxb += t1; Sxxb += t1 * dx; }
+      }
       if (!ALT) {
         const float4 ga = *reinterpret_cast<const float4*>(pa + i * 4);
         c0 += u * ga.x; c1 += u * ga.y; c2 += u * ga.z; c3 += u * ga.w;
@@ -1069,9 +1091,23 @@ __device__ inline void transpose_round_quad(int nk, int r, int lane, const uint3
     }
     if (hrow == 0) __builtin_amdgcn_sched_barrier(0);
   }
+  float m[6];
+  if (ORG) {  // rows Ya, Ya + 1 and columns X0 .. X0 + 3 of the tile: X = X0 + x
+    const float X0 = (float)(4 * (q & 1)), Ya = (float)(4 * (q >> 1) + 2 * h), Yb = Ya + 1.f;
+    const float s1 = Sxa + Sxb;
+    const float xa = __builtin_fmaf(X0, S0a, Sxa), xb = __builtin_fmaf(X0, S0b, Sxb);  // sum v X of each row
+    m[0] = S0a + S0b;
+    m[1] = xa + xb;
+    m[2] = __builtin_fmaf(Ya, S0a, Yb * S0b);
+    m[3] = __builtin_fmaf(X0, m[1] + s1, Sxxa + Sxxb);  // sum v X^2 = s2 + 2 X0 s1 + X0^2 s0 = s2 + X0 (s1 + (s1 + X0 s0))
+    m[4] = __builtin_fmaf(Ya, xa, Yb * xb);
+    m[5] = __builtin_fmaf(Ya * Ya, S0a, (Yb * Yb) * S0b);
+  } else {
+    m[0] = S0a + S0b; m[1] = Sxa + Sxb; m[2] = dy0 * S0a + dy1 * S0b; m[3] = Sxxa + Sxxb; m[4] = dy0 * Sxa + dy1 * Sxb;
+    m[5] = dy0 * dy0 * S0a + dy1 * dy1 * S0b;
+  }
   if (ALT) {
-    float c[7] = {S0a + S0b, Sxa + Sxb, dy0 * S0a + dy1 * S0b, Sxxa + Sxxb, dy0 * Sxa + dy1 * Sxb,
-                  dy0 * dy0 * S0a + dy1 * dy1 * S0b, c4};
+    float c[7] = {m[0], m[1], m[2], m[3], m[4], m[5], c4};
     DPP_STEP7("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1");  // lane h = 1 += lane h = 0
     if (h == 1 && k < nk) {
       float4* st = reinterpret_cast<float4*>(s_u + (k * 4 + q) * STG);
@@ -1080,8 +1116,7 @@ __device__ inline void transpose_round_quad(int nk, int r, int lane, const uint3
     }
     return;
   }
-  float c[11] = {S0a + S0b, Sxa + Sxb, dy0 * S0a + dy1 * S0b, Sxxa + Sxxb, dy0 * Sxa + dy1 * Sxb,
-                 dy0 * dy0 * S0a + dy1 * dy1 * S0b, c0, c1, c2, c3, c4};
+  float c[11] = {m[0], m[1], m[2], m[3], m[4], m[5], c0, c1, c2, c3, c4};
   DPP_STEP11("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1");  // lane h = 1 += lane h = 0
   // every lane has read its u/v above (LDS instructions of a wave execute in order): the u matrix becomes the staging area
   if (h == 1 && k < nk) {
@@ -1217,6 +1252,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
   float ginv = 0.f, Dfinal = 0.f;
   uint32_t ncontrib = 0;
   static_assert(!ALT || (RED == 0 && !HAVE_INV), "the altitude-only variant exists for the VALU transposition without inverse depth");
+  constexpr bool ORG = RED == 0 && EOGS_ORIGIN_MOMENTS != 0;  // tile-local moments in the VALU transposition (transpose_round_quad)
   if (inside) {
     ncontrib = n_contrib[pix_id];
     if (ALT) {  // single planes: the altitude image and its gradient
@@ -1328,7 +1364,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
       PHASE(1);
       wave_lds_sync();
       if (RED) mfma_round_quad(nk, lane, su, fxv, fyv, au_row);
-      else transpose_round_quad<ALT>(nk, r, lane, sidx, slab, su, sv, spix, bx0, by0);
+      else transpose_round_quad<ALT, ORG>(nk, r, lane, sidx, slab, su, sv, spix, bx0, by0);
       wave_lds_sync();
       PHASE(2);
 #pragma unroll
@@ -1435,7 +1471,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
         const float4 q0 = *reinterpret_cast<const float4*>(slab + lane * ENT);
         const float2 q1 = *reinterpret_cast<const float2*>(slab + lane * ENT + 4);
         const float A = q0.z, B = q0.w, Cq = q1.x, op = q1.y;
-        if (RED) {  // moments about the tile origin -> about the Gaussian centre: sum v (gx - x) = gx S0 - Sx, ...
+        if (RED || ORG) {  // moments about the tile origin -> about the Gaussian centre: sum v (gx - x) = gx S0 - Sx, ...
           const float gxr = q0.x - bx0, gyr = q0.y - by0;
           const float S0 = acc[0], Sx = acc[1], Sy = acc[2], Sxx = acc[3], Sxy = acc[4], Syy = acc[5];
           const float Sdx = gxr * S0 - Sx, Sdy = gyr * S0 - Sy;
