@@ -1313,7 +1313,21 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
   uint32_t jbase = 0;
   Cand nxt = gather_cand<1>(peek_cand<1>(range.x + lane, range.y, keys, point_list), 0u, packed);
   Peek pk = peek_cand<1>(range.x + 64 + lane, range.y, keys, point_list);
-  for (uint32_t c0 = range.x; c0 < range.y && jbase < tile_last; c0 += 64) {
+  uint32_t c0 = range.x;
+  // The chunk loop exists twice, one after the other (the forward's construction, render_fwd_quad_kernel). PLAIN: the tile's
+  // first chunks, while every pixel of the tile contributes past the chunk's last entry (`off < nc_off` then holds for every
+  // entry of it) and no entry of the chunk has o > 0.99 (the clamp never binds): one v_cmp, one v_min and one mask operation
+  // less per trip, every value the same bits. Measured at -0.7 % while the LDS array was this kernel's other bound; after the
+  // LDS cuts of DESIGN.md 2.10 the instruction count is what is left. The first chunk that does not qualify, and every
+  // chunk after it, takes the general loop.
+  const uint32_t nc_min = ~(uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(inside ? ~ncontrib : 0u));  // earliest last contributor
+  auto chunks = [&](auto plainc) {
+  constexpr bool PLAIN = decltype(plainc)::value;
+  for (; c0 < range.y && jbase < tile_last; c0 += 64) {
+    if constexpr (PLAIN) {
+      const unsigned long long hm = __builtin_amdgcn_ballot_w64(nxt.hit);
+      if (nc_min < jbase + (uint32_t)__popcll(hm) || __builtin_amdgcn_ballot_w64(nxt.hit && nxt.q1.y > 0.99f) != 0ull) return;
+    }
     wave_lds_sync();
     int nq[4];
     uint32_t myranks = 0xFFFFFFFFu;  // byte q: the trip in which quad q evaluates this lane's entry (0xFF: never)
@@ -1405,8 +1419,8 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
       const float dx = e.q0.x - pxf, dy = e.q0.y - pyf;
       const float p = power_of(e, dx, dy);
       const float G = __builtin_amdgcn_exp2f(p);
-      const float alpha = fminf(e.q1.y * G, 0.99f);
-      const bool valid = (off < nc_off) && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);  // (the dummy: alpha = 0)
+      const float alpha = PLAIN ? e.q1.y * G : fminf(e.q1.y * G, 0.99f);
+      const bool valid = (PLAIN || off < nc_off) && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);  // (the dummy: alpha = 0)
       // Keep the entry's third read a ds_read_b128 (4 LDS cycles) although 1/depth goes unused here: the compiler narrows it to
       // a ds_read_b96, which the LDS serves in 8 (MI355X_MICROARCH.md, LDS table), and this kernel keeps the LDS array busy for
       // 80 % of its cycles (profiles/r02_v23_lds: SQ_LDS_IDX_ACTIVE). An empty use HERE, where the other three floats of the
@@ -1501,6 +1515,9 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
     jbase += (uint32_t)jn;
     PHASE(4);
   }
+  };
+  if ((opts & 4) != 0) chunks(std::true_type{});
+  chunks(std::false_type{});
   PHASE_FLUSH;
   WTRACE_END(1, tile);
 }
@@ -1789,6 +1806,8 @@ int render_bwd_noflag_ok(int block, int64_t R, int P) {
   if (mode <= 0 || !(v == 2 || v == 4 || v == 6)) return 0;
   return mode >= 2 ? 3 : 1;
 }
+// `opts` of render_bwd_quad_kernel: bits 0, 1 = render_bwd_noflag_ok(), bit 2 = plain chunks allowed (EOGS_PLAIN_TRIPS=0: never)
+static int render_bwd_opts(int block, int64_t R, int P) { return render_bwd_noflag_ok(block, R, P) | ((render_opts() & 1) ? 4 : 0); }
 
 void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, const float* colors,
                        const float* out_color, const float* out_invdepth, const float* dL_dcolor,
@@ -1809,7 +1828,7 @@ void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, 
     if (variant == 4) kq = dL_dinvdepth ? render_bwd_quad_kernel<true, 1, false> : render_bwd_quad_kernel<false, 1, false>;
     hipLaunchKernelGGL(kq, dim3(render_grid(ntiles, im, R)), dim3(RBLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H, gsx,
                        ntiles, (int)macro_grid_x(W, b.block), render_desc(im, R), g.sched, (int)(16u * im.sched_lg), g.packed, im.n_contrib, out_color,
-                       out_invdepth, dL_dcolor, dL_dinvdepth, b.records, b.live, b.cap_slots, g.misc, render_bwd_noflag_ok(b.block, R, P));
+                       out_invdepth, dL_dcolor, dL_dinvdepth, b.records, b.live, b.cap_slots, g.misc, render_bwd_opts(b.block, R, P));
     return;
   }
   if (variant == 3) kern = dL_dinvdepth ? render_bwd_mfma_kernel<true> : render_bwd_mfma_kernel<false>;
