@@ -448,7 +448,8 @@ static inline BinWS bin_layout(char* base, int H, int W, int64_t R) {
 struct ImgWS {
   uint2* ranges;       // per block (M x M internal tiles, M chosen per forward) [start,end) into point_list
   float* final_T;      // transmittance after the last blended Gaussian
-  uint32_t* n_contrib; // 1 + list index of the last blended Gaussian
+  uint32_t* n_contrib; // list entries at positions >= this take no part at the pixel: 1 + the index of its last blended entry
+                       // (tile / block forward kernels) or the index of its stop entry, 0xFFFFFFFF if it never stopped (quad forward)
   uint4* desc;         // one descriptor per dispatched render workgroup (nullptr without a tile schedule): XCD x's i-th workgroup
                        // reads desc[x * 16 sched_lg + i] = {tile tx | ty << 16 (0xFFFFFFFF: outside the image), list begin, list end, -},
                        // written by block_lists_kernel at its block's place in the schedule (GeomWS::where)

@@ -420,7 +420,13 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_FW, E
   static_assert(QCAP >= FQ_CAP + 3, "sub-list sizing");
 
   float T = 1.0f;
-  uint32_t last_contributor = 0;
+  // What this kernel leaves in n_contrib: the number of list entries BEFORE the entry at which the pixel stopped (that entry
+  // is not blended: forward.cu:378-382), or 0xFFFFFFFF when it never stopped. The backward kernels read it as "entries at
+  // positions >= n_contrib take no part"; everything between a pixel's last blended entry (the reference's n_contrib - 1 and
+  // what the one-list-per-tile forward kernels store) and its stop entry fails the alpha test on its own, so any value in that
+  // range gives the same gradients bit for bit — and this one needs no select per trip in the plain chunks, and tells the
+  // backward's plain chunks that a pixel which never stopped contributes down to the end of the list.
+  uint32_t stop_at = 0xFFFFFFFFu;
   float C[NCH] = {0.f, 0.f, 0.f, 0.f, 0.f};
   float invd = 0.f;
   bool done = !inside;
@@ -472,7 +478,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_FW, E
       // the wave blends is rare, so there is no wave-uniform early-out here (the ballot it needs costs two VALU
       // instructions per trip). test_T >= 0 and finite, so its bits order like the value: ONE integer compare serves both
       // `term` and `!term` (the float compare is emitted twice, once per polarity, for NaN's sake).
-      uint32_t last_off = 0xFFFFFFFFu;  // slab byte offset of this pixel's last blended entry in this chunk
+      uint32_t stop_off = 0xFFFFFFFFu;  // slab byte offset of the entry at which this pixel stopped, if in this chunk
       auto fetch_off = [&](uint32_t off) {
         const float4* e4 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(slab) + off);
         Ent e;
@@ -506,6 +512,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_FW, E
           valid = valid != stop;  // (stop implies valid: one mask xor instead of a second compare)
           wgt = valid ? alpha * T : 0.f;
           T = valid ? test_T : T;
+          stop_off = stop ? off : stop_off;
         }
         if (ALT) {
           C[3] += e.q2.y * wgt;
@@ -514,7 +521,6 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_FW, E
           C[2] += e.q2.x * wgt; C[3] += e.q2.y * wgt; C[4] += e.q2.z * wgt;
           invd += e.q2.w * wgt;
         }
-        last_off = valid ? off : last_off;
       };
       // software pipeline: sub-list elements two trips ahead, entry reads one trip ahead, two register sets; groups of eight
       // trips are unrolled so that the sub-list reads sit at immediate offsets (four elements per ds_read2_b64)
@@ -551,7 +557,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_FW, E
         }
         if (t < rem) blend(ea, o0);
       }
-      if (last_off != 0xFFFFFFFFu) last_contributor = jbase + last_off / (uint32_t)(4 * ENT) + 1u;
+      if (!PLAIN && stop_off != 0xFFFFFFFFu) stop_at = jbase + stop_off / (uint32_t)(4 * ENT);
       jbase += (uint32_t)fill;
     }
   };
@@ -561,7 +567,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_FW, E
   if (inside) {
     const size_t HW = (size_t)H * W;
     final_T[pix_id] = T;
-    n_contrib[pix_id] = last_contributor;
+    n_contrib[pix_id] = stop_at;
     if (ALT) {
       out_color[pix_id] = C[3] + T * bg[3];
     } else {
