@@ -517,7 +517,7 @@ int eogs_rast_backward_range(int P, int H, int W, int64_t R, const float* bg, co
     return fail(EOGS_ERR_WORKSPACE, "backward: workspace too small");
 
   if (R > 0 && p_begin == 0) {  // the per-pixel pass covers the whole image: once, with the first range
-    { ProfScope ps(PS_RENDER_BWD, s); launch_render_bwd(g, b, im, P, H, W, R, colors, out_color, out_invdepth, dL_dout_color, dL_dout_invdepth, bg, s); }
+    { ProfScope ps(PS_RENDER_BWD, s); launch_render_bwd(g, b, im, P, H, W, R, colors, out_color, out_invdepth, dL_dout_color, dL_dout_invdepth, bg, raw, s); }
     LAUNCH_TRY(s, debug, "render_bwd");
   }
   GaussBwdArgs a{P, H, W, means3D, have_sr ? scales : nullptr, have_sr ? rotations : nullptr, cov3D_precomp, opacities,

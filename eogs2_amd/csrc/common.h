@@ -511,7 +511,7 @@ void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, 
                        const float* bg, float* out_color, float* out_invdepth, hipStream_t s);
 void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, const float* colors,
                        const float* out_color, const float* out_invdepth, const float* dL_dcolor,
-                       const float* dL_dinvdepth, const float* bg, hipStream_t s);
+                       const float* dL_dinvdepth, const float* bg, bool raw, hipStream_t s);
 // which render kernel a forward / backward runs: 0 = one list per tile, 1 = block lists, 2 = quad sub-lists (render.hip)
 int render_fwd_variant(int block, int64_t R, int P);
 int render_bwd_variant(int block, int64_t R, int P);  // 0 tile, 1 block, 2 quad, 3 / 4 MFMA experiments, 5 back to front

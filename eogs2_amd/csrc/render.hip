@@ -652,6 +652,20 @@ namespace {
                "v_add_f32_dpp %10, %10, %10 " CTRL                                                                \
                : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), \
                  "+v"(c[8]), "+v"(c[9]), "+v"(c[10]))
+#define DPP_STEP10(CTRL)                                                                                         \
+  asm volatile("s_nop 1\n\t"                                                                                     \
+               "v_add_f32_dpp %0, %0, %0 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %1, %1, %1 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %2, %2, %2 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %3, %3, %3 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %4, %4, %4 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %5, %5, %5 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %6, %6, %6 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %7, %7, %7 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %8, %8, %8 " CTRL "\n\t"                                                            \
+               "v_add_f32_dpp %9, %9, %9 " CTRL                                                                   \
+               : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), \
+                 "+v"(c[8]), "+v"(c[9]))
 #define DPP_STEP7(CTRL)                                                                                          \
   asm volatile("s_nop 1\n\t"                                                                                     \
                "v_add_f32_dpp %0, %0, %0 " CTRL "\n\t"                                                            \
@@ -1046,7 +1060,9 @@ namespace {
 #ifndef EOGS_ORIGIN_MOMENTS
 #define EOGS_ORIGIN_MOMENTS 1
 #endif
-template <bool ALT, bool ORG>
+// NOC4 (raw-parameter renders, EOGS_FLAG_RAW_PARAMS): the fifth feature is the constant 1 (renderer.py:88-95), so nobody consumes its
+// gradient: ten sums instead of eleven, no reads of the fifth channel's pixel gradients.
+template <bool ALT, bool ORG, bool NOC4>
 __device__ inline void transpose_round_quad(int nk, int r, int lane, const uint32_t* sidx, const float* slab, float* s_u,
                                             const float* s_v, const float* s_pix, float bx0, float by0) {
   const int k = lane >> 3, o = lane & 7, q = o >> 1, h = o & 1;
@@ -1070,7 +1086,8 @@ __device__ inline void transpose_round_quad(int nk, int r, int lane, const uint3
 #pragma unroll
   for (int hrow = 0; hrow < 2; hrow++) {
     const float4 u4 = *reinterpret_cast<const float4*>(urow + 4 * hrow), v4 = *reinterpret_cast<const float4*>(vrow + 4 * hrow);
-    const float4 gb4 = *reinterpret_cast<const float4*>(s_pix + PIXB + 8 * o + 4 * hrow);
+    float4 gb4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!NOC4) gb4 = *reinterpret_cast<const float4*>(s_pix + PIXB + 8 * o + 4 * hrow);
     const float uu[4] = {u4.x, u4.y, u4.z, u4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w}, gg[4] = {gb4.x, gb4.y, gb4.z, gb4.w};
     if (ORG) {
       const float s0 = (vv[0] + vv[1]) + (vv[2] + vv[3]);
@@ -1093,7 +1110,7 @@ __device__ inline void transpose_round_quad(int nk, int r, int lane, const uint3
         const float4 ga = *reinterpret_cast<const float4*>(pa + i * 4);
         c0 += u * ga.x; c1 += u * ga.y; c2 += u * ga.z; c3 += u * ga.w;
       }
-      c4 += u * gg[x];
+      if (!NOC4) c4 += u * gg[x];
     }
     if (hrow == 0) __builtin_amdgcn_sched_barrier(0);
   }
@@ -1123,13 +1140,15 @@ __device__ inline void transpose_round_quad(int nk, int r, int lane, const uint3
     return;
   }
   float c[11] = {m[0], m[1], m[2], m[3], m[4], m[5], c0, c1, c2, c3, c4};
-  DPP_STEP11("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1");  // lane h = 1 += lane h = 0
+  if (NOC4) DPP_STEP10("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1");
+  else DPP_STEP11("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1");  // lane h = 1 += lane h = 0
   // every lane has read its u/v above (LDS instructions of a wave execute in order): the u matrix becomes the staging area
   if (h == 1 && k < nk) {
     float4* st = reinterpret_cast<float4*>(s_u + (k * 4 + q) * STG);
     st[0] = make_float4(c[0], c[1], c[2], c[3]);
     st[1] = make_float4(c[4], c[5], c[6], c[7]);
-    st[2] = make_float4(c[8], c[9], c[10], 0.f);
+    if (NOC4) *reinterpret_cast<float2*>(st + 2) = make_float2(c[8], c[9]);  // (ds_write_b64: 6 LDS cycles where the b128 takes 13)
+    else st[2] = make_float4(c[8], c[9], c[10], 0.f);
   }
 }
 
@@ -1215,7 +1234,7 @@ __device__ unsigned long long g_bwd_phase[PHASE_TILES][6];  // per tile (wave): 
 #ifndef EOGS_BW
 #define EOGS_BW 4  // waves per SIMD the quad backward is compiled for (10 KB of LDS per wave: four fit)
 #endif
-template <bool HAVE_INV, int RED, bool ALT>
+template <bool HAVE_INV, int RED, bool ALT, bool NOC4 = false>
 __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, EOGS_BW))) void render_bwd_quad_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx, const uint4* __restrict__ desc, const uint32_t* __restrict__ sched, int lg16,
     const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib,
@@ -1258,6 +1277,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
   float ginv = 0.f, Dfinal = 0.f;
   uint32_t ncontrib = 0;
   static_assert(!ALT || (RED == 0 && !HAVE_INV), "the altitude-only variant exists for the VALU transposition without inverse depth");
+  static_assert(!NOC4 || (RED == 0 && !ALT), "ten sums: the VALU transposition of a five-channel render");
   constexpr bool ORG = RED == 0 && EOGS_ORIGIN_MOMENTS != 0;  // tile-local moments in the VALU transposition (transpose_round_quad)
   if (inside) {
     ncontrib = n_contrib[pix_id];
@@ -1384,7 +1404,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
       PHASE(1);
       wave_lds_sync();
       if (RED) mfma_round_quad(nk, lane, su, fxv, fyv, au_row);
-      else transpose_round_quad<ALT, ORG>(nk, r, lane, sidx, slab, su, sv, spix, bx0, by0);
+      else transpose_round_quad<ALT, ORG, NOC4>(nk, r, lane, sidx, slab, su, sv, spix, bx0, by0);
       wave_lds_sync();
       PHASE(2);
 #pragma unroll
@@ -1396,7 +1416,11 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
           acc[0] += a0.x; acc[1] += a0.y; acc[2] += a0.z; acc[3] += a0.w;
           acc[4] += a1.x; acc[5] += a1.y; acc[6] += a1.z;
           if (ALT) asm volatile("" :: "v"(a1.w));  // (ds_read_b128, not ds_read_b96: see grad)
-          if (!ALT) {
+          if (!ALT && NOC4) {
+            const float2 a2 = *reinterpret_cast<const float2*>(st + 2);
+            acc[7] += a1.w;
+            acc[8] += a2.x; acc[9] += a2.y;
+          } else if (!ALT) {
             const float4 a2 = st[2];
             acc[7] += a1.w;
             acc[8] += a2.x; acc[9] += a2.y; acc[10] += a2.z;
@@ -1817,7 +1841,7 @@ static int render_bwd_opts(int block, int64_t R, int P) { return render_bwd_nofl
 
 void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, const float* colors,
                        const float* out_color, const float* out_invdepth, const float* dL_dcolor,
-                       const float* dL_dinvdepth, const float* bg, hipStream_t s) {
+                       const float* dL_dinvdepth, const float* bg, bool raw, hipStream_t s) {
   const int gsx = (W + SUBX - 1) / SUBX, gsy = (H + SUBY - 1) / SUBY, ntiles = gsx * gsy;
   const int variant = render_bwd_variant(b.block, R, P);
   if (variant == 5) {
@@ -1830,6 +1854,7 @@ void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, 
                             : (dL_dinvdepth ? render_bwd_kernel<1, true> : render_bwd_kernel<1, false>);
   if (variant == 2 || variant == 4 || variant == 6) {  // the quad backward (variant 6: altitude-only, no inverse-depth gradient: api.hip checks)
     auto* kq = dL_dinvdepth ? render_bwd_quad_kernel<true, 0, false> : render_bwd_quad_kernel<false, 0, false>;
+    if (variant == 2 && raw) kq = dL_dinvdepth ? render_bwd_quad_kernel<true, 0, false, true> : render_bwd_quad_kernel<false, 0, false, true>;
     if (variant == 6) kq = render_bwd_quad_kernel<false, 0, true>;
     if (variant == 4) kq = dL_dinvdepth ? render_bwd_quad_kernel<true, 1, false> : render_bwd_quad_kernel<false, 1, false>;
     hipLaunchKernelGGL(kq, dim3(render_grid(ntiles, im, R)), dim3(RBLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H, gsx,
