@@ -157,13 +157,17 @@ struct SpanParams {
   float boa, boc;  // b/a, b/c
   float ta, da;  // tau_m/a, det/a^2:  u(v) = -(b/a) v +- sqrt(ta - da v^2)
 };
+// (v_rcp_f32 / v_sqrt_f32 instead of IEEE divisions and square roots — ten instructions each —: what these constants decide is
+// which tiles a Gaussian LISTS, behind margins of 1e-3 relative + 1e-2 px (row_span), five orders above the 1-ulp error of the fast
+// forms; preprocess counts and expand emits with this same code on the same bits, so count and emission cannot disagree.)
 __device__ inline SpanParams span_params(float gx, float gy, float a, float b, float c, float tau_m) {
   const float det = a * c - b * b;
+  const float ra = __builtin_amdgcn_rcpf(a), rc = __builtin_amdgcn_rcpf(c), rdet = __builtin_amdgcn_rcpf(det);
   SpanParams p;
   p.gx = gx; p.gy = gy;
-  p.ex = sqrtf(tau_m * c / det); p.ey = sqrtf(tau_m * a / det);
-  p.boa = b / a; p.boc = b / c;
-  p.ta = tau_m / a; p.da = det / (a * a);
+  p.ex = __builtin_amdgcn_sqrtf(tau_m * c * rdet); p.ey = __builtin_amdgcn_sqrtf(tau_m * a * rdet);
+  p.boa = b * ra; p.boc = b * rc;
+  p.ta = tau_m * ra; p.da = det * (ra * ra);
   return p;
 }
 // Internal tiles of row sy (pixel centres y in [SUBY sy, SUBY sy + SUBY-1]) whose continuous block intersects the
@@ -177,8 +181,8 @@ __device__ inline void row_span(const SpanParams& p, int sy, int sx0, int sx1, i
   const float w0 = fmaxf(v0, -p.ey), w1 = fminf(v0 + (float)(SUBY - 1), p.ey);
   if (!(w0 <= w1)) return;  // the band misses the ellipse
   const float vr = fminf(fmaxf(-p.boc * p.ex, w0), w1), vl = fminf(fmaxf(p.boc * p.ex, w0), w1);
-  const float ur = -p.boa * vr + sqrtf(fmaxf(p.ta - p.da * vr * vr, 0.f));
-  const float ul = -p.boa * vl - sqrtf(fmaxf(p.ta - p.da * vl * vl, 0.f));
+  const float ur = -p.boa * vr + __builtin_amdgcn_sqrtf(fmaxf(p.ta - p.da * vr * vr, 0.f));
+  const float ul = -p.boa * vl - __builtin_amdgcn_sqrtf(fmaxf(p.ta - p.da * vl * vl, 0.f));
   const float xr = p.gx + ur + (1e-3f * fabsf(ur) + 1e-2f), xl = p.gx + ul - (1e-3f * fabsf(ul) + 1e-2f);
   // internal tile j covers [SUBX j, SUBX j + SUBX-1]
   const float j0 = fmaxf(ceilf((xl - (float)(SUBX - 1)) * (1.f / SUBX)), (float)sx0);

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(BLK) PP_ATTR void preprocess_fwd_kernel(
         if (op < 1.f / 255.f) {
           any = false;  // alpha = op * G <= op < 1/255 at every pixel (G <= 1): never blended
         } else if (tau_m >= 0.f && tau_m < 3.0e38f) {
-          const float ex = sqrtf(tau_m * cx) * 1.001f + 1e-2f, ey = sqrtf(tau_m * cz) * 1.001f + 1e-2f;
+          const float ex = __builtin_amdgcn_sqrtf(tau_m * cx) * 1.001f + 1e-2f, ey = __builtin_amdgcn_sqrtf(tau_m * cz) * 1.001f + 1e-2f;
           // pixel centres are the integers: hit pixels lie in [ceil(px - ex), floor(px + ex)]
           const float fx0 = floorf((px - ex) * (1.f / SUBX)), fx1 = floorf((px + ex) * (1.f / SUBX)) + 1.f;
           const float fy0 = floorf((py - ey) * (1.f / SUBY)), fy1 = floorf((py + ey) * (1.f / SUBY)) + 1.f;
