@@ -385,6 +385,8 @@ struct BinWS {
   uint32_t* sorted_keys; // BLOCK_BIG only: per entry {block id | sub-mask << 16}
   float* records;   // backward scratch: REC floats per record slot (Gaussian-id order, see GeomWS::pblock)
   uint8_t* live;    // backward scratch: 1 = the pair's record was written (dead pairs are never touched)
+  uint8_t* qmask;   // block 1 only: per list entry the 4-bit mask of the tile's 4 x 4-px quads the Gaussian can reach, written by
+                    // the quad forward for the chunks it walked and read by the quad backward instead of being computed again
   SortWS sort;      // entry sort of a forward whose entries did not fit the caller's scratch (nr_sorted(R) == 0)
   int block;
   uint32_t cap_slots, cap_entries;  // what the token sized these arrays for (a forward that needs more has built no lists)
@@ -438,6 +440,7 @@ static inline BinWS bin_layout(char* base, int H, int W, int64_t R) {
   o = ws_carve(base, o, b.sorted_keys, b.block > 1 ? ne : (size_t)0);
   o = ws_carve(base, o, b.records, nslots * REC);
   o = ws_carve(base, o, b.live, nslots);
+  o = ws_carve(base, o, b.qmask, b.block > 1 ? (size_t)0 : nslots);
   b.sort = sort_layout(nullptr, 0);
   if (!nr_sorted(R) && ne) {
     o = ws_align(o);

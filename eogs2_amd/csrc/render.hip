@@ -154,6 +154,7 @@ struct Cand {
   float4 q1;  // C op f0 f1
   float4 q2;  // f2 f3 f4 1/depth
   uint32_t slot;
+  uint32_t qm;  // (quad backward only) the forward's quad mask of the entry, see peek_cand_q
   bool hit;  // the entry lists this wave's internal tile
 };
 
@@ -179,11 +180,25 @@ __device__ inline Peek peek_cand(uint32_t k, uint32_t end, const uint32_t* __res
   }
   return p;
 }
+// The quad backward's peek on per-tile lists: the entry's in-range flag (bit 4) and, where the quad FORWARD walked the chunk, the 4-bit
+// quad mask it left in `qmask` (BinWS::qmask) — the backward's chunk set-up then needs no quad_mask() of its own (four block_hit
+// tests, a v_log and two v_rcp per entry: half of the set-up's instructions).
+__device__ inline Peek peek_cand_q(uint32_t k, uint32_t end, const uint8_t* __restrict__ qmask, const uint2* __restrict__ point_list) {
+  Peek p;
+  p.key = 0u;
+  p.e = make_uint2(0u, 0u);
+  if (k < end) {
+    p.key = 0x10u | (qmask ? (uint32_t)qmask[k] : 0u);
+    p.e = point_list[k];
+  }
+  return p;
+}
 template <int MACRO>
 __device__ inline Cand gather_cand(const Peek& p, uint32_t sub, const float4* __restrict__ packed) {
   Cand c;
   c.q0 = c.q1 = c.q2 = make_float4(0.f, 0.f, 0.f, 0.f);
   c.slot = 0;
+  c.qm = MACRO > 1 ? 0u : (p.key & 0xFu);
   const uint32_t mask = MACRO > 1 ? p.key >> MACRO_KEY_BITS : p.key;  // block size 1: peek_cand's in-range flag
   c.hit = MACRO > 1 ? ((mask >> sub) & 1u) != 0u : mask != 0u;
   if (c.hit) {
@@ -457,6 +472,9 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_FW, E
       {
         // per-tile lists: the in-range entries are lanes 0..fill-1, parked at their own lane index
         const uint32_t qm = nxt.hit ? quad_mask(nxt, bx0, by0) : 0u;
+        // (`keys` is unused on per-tile lists: this launch receives BinWS::qmask through it — one byte per list entry, written
+        // coalesced, for the quad backward's chunk set-up: peek_cand_q)
+        if (nxt.hit && keys != nullptr) const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(keys))[c0 + (uint32_t)lane] = (uint8_t)qm;
         quad_append(sidx, lane, nxt.hit, lane, qm, nq);
       }
       const int fill = park(slab, nullptr, lane, nxt, 0);
@@ -621,7 +639,9 @@ void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, 
   const int gsx = (W + SUBX - 1) / SUBX, gsy = (H + SUBY - 1) / SUBY, ntiles = gsx * gsy;
   const int variant = render_fwd_variant(b.block, R, P);
   auto* kern = variant == 1 ? render_fwd_kernel<BLOCK_BIG> : (variant == 2 ? (nr_alt(R) ? render_fwd_quad_kernel<1, true> : render_fwd_quad_kernel<1, false>) : render_fwd_kernel<1>);
-  hipLaunchKernelGGL(kern, dim3(render_grid(ntiles, im, R)), dim3(RBLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H, gsx,
+  // (the quad forward leaves its quad masks for the backward in BinWS::qmask, handed over in place of the keys it does not read)
+  const uint32_t* keys = variant == 2 ? reinterpret_cast<const uint32_t*>(b.qmask) : b.sorted_keys;
+  hipLaunchKernelGGL(kern, dim3(render_grid(ntiles, im, R)), dim3(RBLK), 0, s, im.ranges, keys, b.point_list, W, H, gsx,
                      ntiles, (int)macro_grid_x(W, b.block), render_desc(im, R), g.sched, (int)(16u * im.sched_lg), g.packed, bg, im.final_T, im.n_contrib,
                      out_color, out_invdepth, render_opts());
 }
@@ -1337,8 +1357,12 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
 
   PHASE_DECL;
   uint32_t jbase = 0;
-  Cand nxt = gather_cand<1>(peek_cand<1>(range.x + lane, range.y, keys, point_list), 0u, packed);
-  Peek pk = peek_cand<1>(range.x + 64 + lane, range.y, keys, point_list);
+  // opts bit 3: the quad forward walked these lists and left its quad masks in BinWS::qmask, which this launch receives in place of
+  // the keys it does not read on per-tile lists (peek_cand_q); without it the masks are computed here (quad_mask)
+  const bool fwd_masks = (opts & 8) != 0 && keys != nullptr;
+  const uint8_t* const qmask = fwd_masks ? reinterpret_cast<const uint8_t*>(keys) : nullptr;
+  Cand nxt = gather_cand<1>(peek_cand_q(range.x + lane, range.y, qmask, point_list), 0u, packed);
+  Peek pk = peek_cand_q(range.x + 64 + lane, range.y, qmask, point_list);
   uint32_t c0 = range.x;
   // The chunk loop exists twice, one after the other (the forward's construction, render_fwd_quad_kernel). PLAIN: the tile's
   // first chunks, while every pixel of the tile contributes past the chunk's last entry (`off < nc_off` then holds for every
@@ -1362,7 +1386,9 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
       // hoisted out of the chunk loop into eight VGPRs this kernel does not have — it spilled them)
       float bxq = bx0, byq = by0;
       asm volatile("" : "+v"(bxq), "+v"(byq));
-      const uint32_t qm = nxt.hit ? quad_mask(nxt, bxq, byq) : 0u;
+      // (the forward's masks where it left them — of the chunks it walked: the others lie behind every pixel's stop entry, where
+      // no evaluation is valid whatever the sub-lists hold)
+      const uint32_t qm = fwd_masks ? nxt.qm : (nxt.hit ? quad_mask(nxt, bxq, byq) : 0u);
       // per-tile lists: the in-range entries are lanes 0..jn-1, parked at their own lane index
       const bool listed = nxt.hit && jbase + (uint32_t)lane < tile_last;  // entries behind the last contributor are dead
 #pragma unroll
@@ -1380,7 +1406,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
     const uint32_t cur_slot = nxt.slot;
     const int jn = park(slab, nullptr, lane, nxt, 0);
     nxt = gather_cand<1>(pk, 0u, packed);
-    pk = peek_cand<1>(c0 + 128 + lane, range.y, keys, point_list);
+    pk = peek_cand_q(c0 + 128 + lane, range.y, qmask, point_list);
     wave_lds_sync();
     const int nmax = max(max(nq[0], nq[1]), max(nq[2], nq[3]));
     // pad the shorter sub-lists up to the next multiple of 8 trips with the dummy entry (transposition rounds read the
@@ -1836,7 +1862,15 @@ int render_bwd_noflag_ok(int block, int64_t R, int P) {
   if (mode <= 0 || !(v == 2 || v == 4 || v == 6)) return 0;
   return mode >= 2 ? 3 : 1;
 }
-// `opts` of render_bwd_quad_kernel: bits 0, 1 = render_bwd_noflag_ok(), bit 2 = plain chunks allowed (EOGS_PLAIN_TRIPS=0: never)
+static bool fwd_masks_on() {  // EOGS_FWD_MASKS=0: the quad backward computes its quad masks itself (A/B)
+  static const bool v = [] {
+    const char* e = getenv("EOGS_FWD_MASKS");
+    return !(e && atoi(e) == 0);
+  }();
+  return v;
+}
+// `opts` of render_bwd_quad_kernel: bits 0, 1 = render_bwd_noflag_ok(), bit 2 = plain chunks allowed (EOGS_PLAIN_TRIPS=0: never),
+// bit 3 = the forward's quad masks are in BinWS::qmask
 static int render_bwd_opts(int block, int64_t R, int P) { return render_bwd_noflag_ok(block, R, P) | ((render_opts() & 1) ? 4 : 0); }
 
 void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, const float* colors,
@@ -1857,9 +1891,10 @@ void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, 
     if (variant == 2 && raw) kq = dL_dinvdepth ? render_bwd_quad_kernel<true, 0, false, true> : render_bwd_quad_kernel<false, 0, false, true>;
     if (variant == 6) kq = render_bwd_quad_kernel<false, 0, true>;
     if (variant == 4) kq = dL_dinvdepth ? render_bwd_quad_kernel<true, 1, false> : render_bwd_quad_kernel<false, 1, false>;
-    hipLaunchKernelGGL(kq, dim3(render_grid(ntiles, im, R)), dim3(RBLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H, gsx,
+    const bool fwd_quad = render_fwd_variant(b.block, R, P) == 2 && b.qmask != nullptr && fwd_masks_on();
+    hipLaunchKernelGGL(kq, dim3(render_grid(ntiles, im, R)), dim3(RBLK), 0, s, im.ranges, reinterpret_cast<const uint32_t*>(b.qmask), b.point_list, W, H, gsx,
                        ntiles, (int)macro_grid_x(W, b.block), render_desc(im, R), g.sched, (int)(16u * im.sched_lg), g.packed, im.n_contrib, out_color,
-                       out_invdepth, dL_dcolor, dL_dinvdepth, b.records, b.live, b.cap_slots, g.misc, render_bwd_opts(b.block, R, P));
+                       out_invdepth, dL_dcolor, dL_dinvdepth, b.records, b.live, b.cap_slots, g.misc, render_bwd_opts(b.block, R, P) | (fwd_quad ? 8 : 0));
     return;
   }
   if (variant == 3) kern = dL_dinvdepth ? render_bwd_mfma_kernel<true> : render_bwd_mfma_kernel<false>;

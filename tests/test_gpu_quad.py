@@ -50,15 +50,16 @@ def test_quad_kernels_agree_with_tile_kernels(tmp_path, P, H, W, opacity, invdep
                                                     (60_000, 200, 264, "trained", 0)])
 def test_round5_fast_paths_change_no_bit(tmp_path, P, H, W, opacity, invdepth):
     """Round 5: the forward's plain chunks leave out operations that are no-ops where they are left out,
-    and the backward's flag-free records add exact zeros: with both switched off, on (the default picks per scene and per
-    chunk) or forced, every output and every gradient is the same BITS (-0.0 and +0.0 count as equal: a zero record added to
+    the backward's flag-free records add exact zeros, and the quad masks the backward takes over from the forward are the
+    ones it would compute itself: with all of it switched off, on (the default picks per scene and per chunk) or forced, every
+    output and every gradient is the same BITS (-0.0 and +0.0 count as equal: a zero record added to
     a zero sum). The image is partly off the 8-px grid (344 x 392, 256 x 250): edge tiles keep the general loop beside
     interior tiles' plain chunks; the 'trained' scene saturates, so its forced flag-free backward walks dead entries."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     args = (P, H, W, opacity, invdepth)
     quad = {"EOGS_BLOCK_SWITCH": "1000", "EOGS_QUAD_SWITCH": "1000", "EOGS_QUAD_BWD_SWITCH": "1000", "EOGS_BTF_SWITCH": "0"}
-    off = _render(tmp_path, "off", dict(quad, EOGS_PLAIN_TRIPS="0", EOGS_NOFLAG="0"), args)
+    off = _render(tmp_path, "off", dict(quad, EOGS_PLAIN_TRIPS="0", EOGS_NOFLAG="0", EOGS_FWD_MASKS="0"), args)
     auto = _render(tmp_path, "auto", dict(quad), args)
     forced = _render(tmp_path, "forced", dict(quad, EOGS_NOFLAG="2"), args)
     assert float(np.abs(off["out_color"]).max()) > 0.1 and float(np.abs(off["g_means3D"]).max()) > 0
