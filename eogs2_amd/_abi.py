@@ -96,6 +96,7 @@ SIGNATURES = {
     "eogs_loss_backward": (_i, [_i, _i, _i, _p, _p, _u, _f, _f, _p, _p, _p, _z, _p, _p]),
     # include/eogs_optim.h
     "eogs_adam_step": (_i, [_i, _p, C.c_double, C.c_double, C.c_double, _i64, _p]),
+    "eogs_sum_into": (_i, [_i, _p, _i, _p]),
     "eogs_pack_columns": (_i, [_i64, _i, _p, _p, _i, _i, _p]),
     "eogs_compact_bytes": (_i, [_i64, C.POINTER(_z)]),
     "eogs_compact_plan": (_i, [_i64, _p, _p, _z, C.POINTER(_i64), _p]),
@@ -119,7 +120,7 @@ SIGNATURES = {
     "eogs_tsdf_integrate": (_i, [_i, _i, _i, _p, _p, _p, _p, _f, _f, _i, _i, _p, _p, _p, _p, _p]),
 }
 # symbols only the HIP library exports (the CPU oracle of the loss is oracle/loss_oracle.py, not a C-ABI twin)
-HIP_ONLY = ("eogs_pack_columns", "eogs_loss_bytes", "eogs_loss_forward", "eogs_loss_backward", "eogs_adam_step", "eogs_compact_bytes",
+HIP_ONLY = ("eogs_sum_into", "eogs_pack_columns", "eogs_loss_bytes", "eogs_loss_forward", "eogs_loss_backward", "eogs_adam_step", "eogs_compact_bytes",
             "eogs_compact_plan", "eogs_compact_apply", "eogs_resample_forward", "eogs_resample_bytes", "eogs_resample_backward", "eogs_knn_bytes",
             "eogs_knn_mean_dist2", "eogs_shade_bytes", "eogs_shade_forward", "eogs_shade_backward", "eogs_mloss_forward",
             "eogs_mloss_backward", "eogs_tshadow_forward", "eogs_tshadow_backward", "eogs_tsdf_integrate")
@@ -129,6 +130,12 @@ class PackTensor(C.Structure):
     """eogs_pack_tensor (include/eogs_optim.h)"""
 
     _fields_ = [("data", _p), ("width", _i), ("col0", _i), ("ncols", _i)]
+
+
+class SumTensor(C.Structure):
+    """eogs_sum_tensor (include/eogs_optim.h)"""
+
+    _fields_ = [("dst", _p), ("src", _p * 4), ("numel", _i64)]
 
 
 class AdamTensor(C.Structure):
@@ -169,7 +176,7 @@ class RastABI:
             raise RastError(code, self.cdll.eogs_rast_last_error().decode())
 
     def __getattr__(self, name):
-        short = name.startswith(("loss_", "adam_", "pack_", "compact_", "resample_", "knn_", "shade_", "mloss_", "tshadow_", "tsdf_"))
+        short = name.startswith(("loss_", "adam_", "sum_", "pack_", "compact_", "resample_", "knn_", "shade_", "mloss_", "tshadow_", "tsdf_"))
         return getattr(self.cdll, ("eogs_" if short else "eogs_rast_") + name)
 
     def path_info(self, P, num_rendered):

@@ -669,6 +669,21 @@ int eogs_adam_step(int n, const eogs_adam_tensor* tensors, double beta1, double 
   return EOGS_OK;
 }
 
+int eogs_sum_into(int n, const eogs_sum_tensor* tensors, int nsrc, void* stream) {
+  g_err[0] = 0;
+  if (n < 0 || n > EOGS_SUM_MAX_TENSORS || nsrc < 0 || nsrc > EOGS_SUM_MAX_SOURCES || (n > 0 && !tensors))
+    return fail(EOGS_ERR_INVALID_ARG, "sum_into: bad argument (at most 8 tensors with at most 4 sources each)");
+  for (int i = 0; i < n; i++) {
+    if (tensors[i].numel < 0 || (tensors[i].numel > 0 && !tensors[i].dst)) return fail(EOGS_ERR_INVALID_ARG, "sum_into: NULL tensor");
+    for (int k = 0; k < nsrc; k++)
+      if (tensors[i].numel > 0 && !tensors[i].src[k]) return fail(EOGS_ERR_INVALID_ARG, "sum_into: NULL source");
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (launch_sum_into(n, tensors, nsrc, s)) return fail(EOGS_ERR_OVERFLOW, "sum_into: too many elements for one launch");
+  LAUNCH_TRY(s, false, "sum_into");
+  return EOGS_OK;
+}
+
 int eogs_pack_columns(int64_t rows, int n, const eogs_pack_tensor* tensors, float* packed, int packed_cols, int unpack,
                       void* stream) {
   g_err[0] = 0;

@@ -572,6 +572,7 @@ struct CompactWS {
 };
 CompactWS compact_layout(char* base, int64_t n_rows);
 int launch_adam(int n, const eogs_adam_tensor* tensors, double beta1, double beta2, double eps, int64_t step, hipStream_t s);
+int launch_sum_into(int n, const eogs_sum_tensor* tensors, int nsrc, hipStream_t s);
 void launch_pack_columns(int64_t rows, int n, const eogs_pack_tensor* tensors, float* packed, int packed_cols, int unpack,
                          hipStream_t s);
 void launch_compact_plan(const CompactWS& w, int64_t n_rows, const uint8_t* keep, hipStream_t s);

@@ -63,6 +63,38 @@ __global__ __launch_bounds__(BLK) void adam_kernel(AdamTable tab, float w1, floa
   }
 }
 
+// ---- dst += src0 (+ src1 ...) for several tensors in one launch (include/eogs_optim.h eogs_sum_into) ----
+struct SumTable {
+  eogs_sum_tensor t[EOGS_SUM_MAX_TENSORS];
+  uint32_t first_block[EOGS_SUM_MAX_TENSORS + 1];
+  int n, nsrc;
+};
+
+__global__ __launch_bounds__(BLK) void sum_into_kernel(SumTable tab) {
+  int ti = 0;
+  while (ti + 1 < tab.n && blockIdx.x >= tab.first_block[ti + 1]) ti++;
+  const eogs_sum_tensor T = tab.t[ti];
+  const int64_t i0 = ((int64_t)(blockIdx.x - tab.first_block[ti]) * BLK + threadIdx.x) * ADAM_VEC;
+  if (i0 >= T.numel) return;
+  uintptr_t al = (uintptr_t)T.dst;
+  for (int s = 0; s < tab.nsrc; s++) al |= (uintptr_t)T.src[s];
+  if (i0 + ADAM_VEC <= T.numel && (al & 15u) == 0) {
+    float4 a = *reinterpret_cast<const float4*>(T.dst + i0);
+    for (int s = 0; s < tab.nsrc; s++) {  // (in order: the sum autograd would have made source by source)
+      const float4 b = *reinterpret_cast<const float4*>(T.src[s] + i0);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    *reinterpret_cast<float4*>(T.dst + i0) = a;
+  } else {
+    for (int k = 0; k < ADAM_VEC; k++)
+      if (i0 + k < T.numel) {
+        float a = T.dst[i0 + k];
+        for (int s = 0; s < tab.nsrc; s++) a += T.src[s][i0 + k];
+        T.dst[i0 + k] = a;
+      }
+  }
+}
+
 // ---- compaction ----
 constexpr int COMPACT_ROWS = BLK;  // rows per workgroup
 
@@ -212,6 +244,25 @@ int launch_adam(int n, const eogs_adam_tensor* tensors, double beta1, double bet
   const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
   hipLaunchKernelGGL(adam_kernel, dim3((uint32_t)blocks), dim3(BLK), 0, s, tab, (float)(1.0 - beta1), (float)beta2,
                      (float)(1.0 - beta2), (float)eps, (float)(1.0 / bc1), (float)sqrt(bc2));
+  return 0;
+}
+
+int launch_sum_into(int n, const eogs_sum_tensor* tensors, int nsrc, hipStream_t s) {
+  SumTable tab;
+  tab.n = 0;
+  tab.nsrc = nsrc;
+  uint64_t blocks = 0;
+  for (int i = 0; i < n; i++) {
+    if (tensors[i].numel <= 0) continue;
+    tab.t[tab.n] = tensors[i];
+    tab.first_block[tab.n] = (uint32_t)blocks;
+    blocks += (uint64_t)((tensors[i].numel + ADAM_CHUNK - 1) / ADAM_CHUNK);
+    tab.n++;
+  }
+  tab.first_block[tab.n] = (uint32_t)blocks;
+  if (tab.n == 0 || nsrc == 0) return 0;
+  if (blocks > 0x7FFFFFFFull) return -1;
+  hipLaunchKernelGGL(sum_into_kernel, dim3((uint32_t)blocks), dim3(BLK), 0, s, tab);
   return 0;
 }
 

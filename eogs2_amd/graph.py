@@ -65,6 +65,31 @@ class Branches:
     def __init__(self, n, device=None):
         self.streams = [torch.cuda.Stream(device=device) for _ in range(n)]
 
+    @staticmethod
+    def _sum_fused(shared, before, parts):
+        """The sum after the join as ONE launch for all parameters (eogs2_amd.optim.sum_into_: the same additions in the same
+        order) when every piece left a dense fp32 gradient for every shared parameter; False -> the caller adds tensor by tensor."""
+        if not shared or not parts or any(g is None for part in parts for g in part):
+            return False
+        every = [g for part in parts for g in part] + [b for b in before if b is not None]
+        if any(not (g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and not g.is_sparse) for g in every):
+            return False
+        if any((b is None) != (before[0] is None) for b in before):
+            return False
+        from .optim import sum_into_
+
+        if before[0] is None:
+            dsts, srcs = parts[0], parts[1:]
+        else:
+            dsts, srcs = before, parts
+        if any(d.numel() != s[k].numel() for s in srcs for k, d in enumerate(dsts)):
+            return False
+        if srcs:
+            sum_into_(dsts, srcs)
+        for p, d in zip(shared, dsts):
+            p.grad = d
+        return True
+
     def run(self, fns, *, shared):
         """fns: callables, one per branch, queued in this order. shared: the leaf tensors more than one piece differentiates
         (an empty sequence when no piece calls backward). Returns the pieces' results."""
@@ -90,7 +115,10 @@ class Branches:
             # and is read here and by the optimizer on `cur`; its block can only be reused by a later allocation on that same
             # piece stream, and everything queued there comes after a fork that waits for `cur` — so no record_stream.)
             with torch.no_grad():
+                fused = self._sum_fused(shared, before, parts)
                 for k, p in enumerate(shared):
+                    if fused:
+                        break
                     acc = before[k]
                     for part in parts:
                         g = part[k]

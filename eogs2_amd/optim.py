@@ -22,10 +22,39 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from ._abi import AdamTensor
+from ._abi import AdamTensor, SumTensor
 from .rasterizer import _Ctx, _ptr
 
 MAX_TENSORS = 16  # EOGS_ADAM_MAX_TENSORS
+SUM_MAX_TENSORS, SUM_MAX_SOURCES = 8, 4  # EOGS_SUM_MAX_TENSORS / _SOURCES
+
+
+def sum_into_(dsts, sources):
+    """dsts[k] += sources[0][k]; dsts[k] += sources[1][k]; ... for every k, in that order, in ONE launch (eogs_sum_into,
+    include/eogs_optim.h): the gradient accumulation of an iteration's renders (autograd's `p.grad += g`, render by render:
+    train_pan.py:278-469) without one add kernel per parameter and render. fp32 contiguous tensors on one GPU."""
+    dsts, sources = list(dsts), [list(s) for s in sources]
+    if not dsts or not sources:
+        return
+    if any(len(s) != len(dsts) for s in sources):
+        raise ValueError("sum_into_: every source list needs one tensor per destination")
+    dev = dsts[0].device
+    for k, d in enumerate(dsts):
+        for t in [d] + [s[k] for s in sources]:
+            if t.device != dev or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != d.numel():
+                raise RuntimeError("sum_into_: contiguous fp32 tensors of equal size on one device")
+    abi = _lib.get()
+    with _Ctx(abi, dev) as cx, torch.no_grad():
+        for s0 in range(0, len(sources), SUM_MAX_SOURCES):
+            srcs = sources[s0:s0 + SUM_MAX_SOURCES]
+            for k0 in range(0, len(dsts), SUM_MAX_TENSORS):
+                chunk = range(k0, min(k0 + SUM_MAX_TENSORS, len(dsts)))
+                arr = (SumTensor * len(chunk))()
+                for a, k in zip(arr, chunk):
+                    a.dst, a.numel = dsts[k].data_ptr(), dsts[k].numel()
+                    for j, s in enumerate(srcs):
+                        a.src[j] = s[k].data_ptr()
+                abi.check(abi.sum_into(len(chunk), ctypes.cast(arr, ctypes.c_void_p), len(srcs), cx.stream))
 
 
 class FusedAdam(torch.optim.Adam):

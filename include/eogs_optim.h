@@ -10,6 +10,7 @@
  *        Arithmetic = torch.optim.Adam (amsgrad off, no weight decay, maximize off), fp32:
  *            m <- b1 m + (1-b1) g;  v <- b2 v + (1-b2) g^2
  *            p <- p - (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+ *  - eogs_sum_into: the gradient accumulation of an iteration's renders, every parameter tensor in one launch.
  *  - eogs_pack_columns: gathers column ranges of several row-major [P, k] gradient tensors side by side into ONE
  *        row-major [P, K] bucket (or scatters it back) in one launch: the pack step of the view-sharded data-parallel
  *        all-reduce (xyz 3 + f_dc 3 + opacity 1 + scaling 3 + rotation 4 = 14 floats = 56 B/Gaussian).
@@ -46,6 +47,20 @@ typedef struct {
  * Tensors with numel == 0 are skipped. Asynchronous on `stream`. */
 int eogs_adam_step(int n, const eogs_adam_tensor* tensors, double beta1, double beta2, double eps, int64_t step,
                    void* stream);
+
+/* Gradient accumulation over the renders of one iteration, all parameter tensors in ONE launch:
+ *     dst[i] = ((dst[i] + src[0][i]) + src[1][i]) + ...      (fp32, this order: what autograd's `p.grad += g` does render by render,
+ *     train_pan.py:278-469: the reference accumulates the view's, the sun camera's and the random camera's backward into p.grad).
+ * `tensors` is a HOST array of n <= EOGS_SUM_MAX_TENSORS descriptors with nsrc <= EOGS_SUM_MAX_SOURCES sources each (all non-NULL,
+ * none overlapping its dst). Tensors with numel == 0 are skipped. Asynchronous on `stream`. */
+#define EOGS_SUM_MAX_TENSORS 8
+#define EOGS_SUM_MAX_SOURCES 4
+typedef struct {
+  float* dst;
+  const float* src[EOGS_SUM_MAX_SOURCES];
+  int64_t numel;
+} eogs_sum_tensor;
+int eogs_sum_into(int n, const eogs_sum_tensor* tensors, int nsrc, void* stream);
 
 /* One tensor of a pack: `data` holds rows x width fp32 values; columns [col0, col0 + ncols) take part. */
 #define EOGS_PACK_MAX_TENSORS 8

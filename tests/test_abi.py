@@ -15,7 +15,7 @@ def header_symbols(headers=("eogs_rast.h", "eogs_loss.h", "eogs_optim.h", "eogs_
     for h in headers:
         src = open(os.path.join(ROOT, "include", h)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-        out |= set(re.findall(r"\b(eogs_(?:rast|loss|adam|pack|compact|resample|knn|shade|mloss|tshadow|tsdf)_[a-z_0-9]+)\s*\(", src))
+        out |= set(re.findall(r"\b(eogs_(?:rast|loss|adam|sum|pack|compact|resample|knn|shade|mloss|tshadow|tsdf)_[a-z_0-9]+)\s*\(", src))
     return sorted(out)
 
 

@@ -288,3 +288,30 @@ def test_retired_rows_render_nothing_and_stay_retired(dev):
     new, _ = prune_optimizer(opt, alive_rows(opt))
     assert new["xyz"].shape[0] == int(keep.sum())
     assert torch.isfinite(new["opacity"]).all()
+
+
+def test_sum_into_equals_the_sequence_of_adds(dev):
+    """eogs_sum_into (include/eogs_optim.h): dst += s0; dst += s1; ... for several tensors in one launch — the additions autograd
+    makes render by render, bit for bit, odd sizes and unaligned views included; `Branches.run(shared=...)` sums its pieces with it."""
+    from eogs2_amd.optim import sum_into_
+
+    g = torch.Generator(device="cpu").manual_seed(3)
+    shapes = [(1000, 3), (1000, 1, 3), (1000, 1), (777, 4), (5,), (0, 3)]
+    base = [torch.randn(s, generator=g).to(dev) for s in shapes]
+    srcs = [[torch.randn(s, generator=g).to(dev) * (10.0 ** j) for s in shapes] for j in range(3)]
+    # an unaligned destination / source (a view one float into a larger buffer): the scalar path
+    big = torch.randn(4001, generator=g).to(dev)
+    base.append(big[1:])
+    for j in range(3):
+        srcs[j].append(torch.randn(4003, generator=g).to(dev)[3:])
+    want = [b.clone() for b in base]
+    for s in srcs:
+        for w, x in zip(want, s):
+            w.add_(x)
+    got = [b.clone() for b in base[:-1]] + [big.clone()[1:]]
+    sum_into_(got, srcs)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    with pytest.raises(RuntimeError):
+        sum_into_([base[0]], [[base[3]]])  # sizes differ
+    sum_into_([], [])  # nothing to do
