@@ -20,6 +20,29 @@ thread_local PendingCounts g_pending_counts = {false, 0, 0, 0, false, 0u, nullpt
 // the side stream of a count copy into g_pinned that nobody has waited for yet (a deferred forward whose counts were never
 // asked for): the next forward_prepare drains it before it arms g_pinned again, or the old copy would land as the new counts
 thread_local hipStream_t g_copy_in_flight = nullptr;
+// What the host knew about a forward when it built the token from the forward's counts, and what the token has no bit left
+// for: how deep its lists are in opacity (list depth x mean pair opacity, token_from_counts — beyond ~60 a tile's pixels
+// saturate before its list ends). The backward of that token picks its per-Gaussian kernel by it (gaussian_bwd_wide: occupancy
+// against loads in flight; every choice computes the same bits). Process-wide, not per thread: autograd runs the backward on a
+// thread of its own. A backward whose token is not here launches the kernel that does not need to know; a capacity token
+// inherits the hint of the forward it was counted on.
+struct FwdHint { int64_t token; int P; float list_depth; };
+std::mutex g_hint_mu;
+FwdHint g_hints[16];
+unsigned g_hint_next = 0;
+void hint_put(int64_t token, int P, float list_depth) {
+  if (token == 0) return;
+  std::lock_guard<std::mutex> lk(g_hint_mu);
+  for (auto& h : g_hints)
+    if (h.token == token && h.P == P) { h.list_depth = list_depth; return; }
+  g_hints[g_hint_next++ % 16u] = FwdHint{token, P, list_depth};
+}
+float hint_list_depth(int64_t token, int P) {  // < 0: unknown
+  std::lock_guard<std::mutex> lk(g_hint_mu);
+  for (const auto& h : g_hints)
+    if (h.token == token && h.P == P) return h.list_depth;
+  return -1.f;
+}
 #define MIRROR_PENDING 0xFFFFFFFFu  // sentinel of a count word that has not arrived (never a legitimate high word of a count below 2^31)
 
 // per calling thread and device: a non-blocking side stream + event for the num_rendered readback
@@ -296,6 +319,7 @@ int token_from_counts(const uint32_t* m, int P, int H, int W, bool have_scratch,
   // (... except for an altitude-only forward, whose token must still say so: the render launches pick their variant by it)
   *num_rendered = (total == 0 && entries == 0 && !alt) ? 0 : nr_pack((uint32_t)total, (uint32_t)entries, block, have_scratch && entries <= (uint64_t)sort_cap,
                           per_block > 2800.0 && per_block <= 6000.0, btf, alt);
+  hint_put(*num_rendered, P, (float)list_depth);
   return EOGS_OK;
 }
 
@@ -403,6 +427,10 @@ int eogs_rast_capacity_token(int P, int64_t num_rendered, double slack, int have
   const int alt = (have_scratch & 2) != 0 || nr_alt(num_rendered);  // (an altitude-only forward: per-tile lists, never back to front)
   *capacity = nr_pack((uint32_t)slots, (uint32_t)ents, alt ? 1 : nr_block(num_rendered), sorted, nr_wide(num_rendered),
                       alt ? 0 : nr_btf(num_rendered), alt);
+  {  // (... and that forward's list-depth hint, for the backward's choice of per-Gaussian kernel: speed only)
+    const float depth = hint_list_depth(num_rendered, P);
+    if (depth >= 0.f) hint_put(*capacity, P, depth);
+  }
   // A capacity token carries the list granularity, the 8-item build and the back-to-front choice of the EARLIER forward. The
   // first two are speed only. The third is not quite: a forward of image-sized opaque Gaussians needs the back-to-front
   // backward to hold 1e-4, so a forward that asks for it does not "fit" a token counted on one that did not
@@ -524,7 +552,8 @@ int eogs_rast_backward_range(int P, int H, int W, int64_t R, const float* bg, co
                  viewmatrix, projmatrix, radii, scale_modifier, (flags & EOGS_FLAG_ANTIALIASING) != 0,
                  dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, have_sr ? dL_dscales : nullptr,
                  have_sr ? dL_drotations : nullptr, dL_dT_sum, dL_dvm_mean, raw, alt_affine, dL_dcolors_lead,
-                 dL_dcolors_lead ? lead_cols : 0, nr_alt(R) != 0, R > 0 ? render_bwd_noflag_ok(b.block, R, P) : 0};
+                 dL_dcolors_lead ? lead_cols : 0, nr_alt(R) != 0, R > 0 ? render_bwd_noflag_ok(b.block, R, P) : 0,
+                 R > 0 ? gaussian_bwd_wide(R, P, hint_list_depth(R, P)) : 0};
   { ProfScope ps(PS_GAUSS_BWD, s); launch_gaussian_bwd(a, g, b, p_begin, p_end, s); }
   LAUNCH_TRY(s, debug, "gaussian_bwd");
   return EOGS_OK;

@@ -537,7 +537,11 @@ struct GaussBwdArgs {
   int lead_cols;
   bool alt_only;           // the records are those of an altitude-only render (REC_ALT)
   int noflag_ok;           // render_bwd_noflag_ok(): the records are flag-free (bit 0) where the scene allows / always (bit 1)
+  int wide;                // records in flight per lane: gaussian_bwd_kernel's WIDE (0, 1, 2), gaussian_bwd_wide()
 };
+// Which gaussian_bwd_kernel variant a backward of (R, P) launches. list_depth: the forward's mean list length x mean pair
+// opacity (token_from_counts), < 0 = not known on the host (a token that was not built from counts). EOGS_GB_WIDE=0|1|2 forces one.
+int gaussian_bwd_wide(int64_t R, int P, float list_depth);
 // per-Gaussian backward over rows [p_begin, p_end) (p_begin a multiple of BLK); the camera sums are finished by the call
 // whose p_end == P
 void launch_gaussian_bwd(const GaussBwdArgs& a, const GeomWS& g, const BinWS& b, int p_begin, int p_end, hipStream_t s);

@@ -16,6 +16,7 @@
 // through LDS so that their global loads are contiguous dwords per lane. Records are read in Gaussian-id order
 // (a workgroup's 256 Gaussians own one contiguous region), flags first, then two records per trip.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -371,11 +372,16 @@ void launch_preprocess_fwd(const FwdPrepArgs& a, const GeomWS& g, hipStream_t s)
 // ------------------------------------------------------------------------------------------------------
 // Backward, per Gaussian.
 // ------------------------------------------------------------------------------------------------------
-#ifndef GB_DIRECT
-#define GB_DIRECT 4u  // listed tiles up to which a Gaussian's flags and records are read in one trip (see the kernel)
-#endif
+// WIDE: how many of a Gaussian's records are in flight at once, chosen per launch (launch_gaussian_bwd; every variant adds the same
+// records in the same order: the same bits). 0: four (70 VGPRs, seven waves per SIMD). 1: eight per trip of the long-list loop
+// while any lane of the wave has more than four to go (122 VGPRs, four waves). 2: as 1, and a Gaussian with up to EIGHT listed
+// tiles reads its flags and records in one trip. Measured (profiles/r05_ab_gaussian_bwd_wide.txt), ms at 0 / 1 / 2:
+// 1 M at 1024^2 opacity 0.01 (4.05 tiles per Gaussian) 0.0894 / 0.0854 / 0.0922; opacity 0.1 (8.7) 0.1757 / 0.1534 / 0.1456;
+// 2048^2 (9.5) 0.1823 / 0.1544 / 0.1455; 2 M at opacity 0.1 (6.6) 0.2134 / 0.1912 / 0.1887; trained opacities (10.8 listed, most
+// of them dead: flags first, few records) 0.0787 / 0.0827 / 0.0826 — there the seven waves hide the flags -> records chain better
+// than more loads per lane do.
 // ALT: the records of an altitude-only render (32 bytes, common.h REC_ALT): only colour 3 has a gradient.
-template <bool RAW, bool ALT>
+template <bool RAW, bool ALT, int WIDE>
 __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
     int P, int H, int W,
     const float* __restrict__ means3D, const float* __restrict__ scales, const float* __restrict__ rotations,
@@ -394,6 +400,8 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
   // A forward queued on a capacity token (EOGS_FLAG_DEFER_COUNTS) that needed more than its workspaces hold has built no
   // lists (binning.hip block_lists_kernel) and wrote no record: its slots would lie beyond `records` / `live`. The same
   // comparison here: such a backward reads none of them and returns zero gradients (the host repeats the forward).
+  constexpr uint32_t GB_DIRECT = WIDE == 2 ? 8u : 4u;  // listed tiles up to which flags and records are read in one trip
+  constexpr bool GB_WIDE = WIDE != 0;
   const bool fits = misc[MISC_TOTAL_HI] == 0u && misc[MISC_MACRO_HI] == 0u && misc[MISC_TOTAL_LO] <= cap_slots &&
                     misc[MISC_MACRO_LO] <= cap_entries;
   // Where tiles saturate (trained opacities: a tile's pixels stop after a tenth of its list) most listed pairs are DEAD — behind
@@ -451,18 +459,18 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
         float4 ra[GB_DIRECT], rb[GB_DIRECT];
         float3 rc[GB_DIRECT];
         bool lv[GB_DIRECT];
-        // the (up to four) flags of this Gaussian's consecutive slots in ONE unaligned 4-byte load (bytes past its n-th flag
+        // the (up to four; WIDE = 2: eight) flags of this Gaussian's consecutive slots in ONE unaligned 4- or 8-byte load (bytes past its n-th flag
         // are other Gaussians' or the 256 bytes of slack behind the array, common.h bin_layout: read, never used): the four
         // byte loads cost this kernel 10 % (profiles/r05_ab_noflag.txt: it runs 0.085 instead of 0.0955 ms without them)
-        static_assert(GB_DIRECT == 4u, "one dword of flags");
-        uint32_t fl4 = 0x01010101u;
-        if (!noflag && n) __builtin_memcpy(&fl4, live + s0, 4);
+        static_assert(GB_DIRECT == 4u || GB_DIRECT == 8u, "one or two dwords of flags");
+        unsigned long long fl4 = 0x0101010101010101ull;
+        if (!noflag && n) __builtin_memcpy(&fl4, live + s0, GB_DIRECT);
 #pragma unroll
         for (uint32_t u = 0; u < GB_DIRECT; u++) {
           const uint32_t qq = u < n ? u : 0u;  // (n == 0: slot s0 itself may lie past the arrays — never dereferenced)
           lv[u] = false;
           if (u < n) {
-            lv[u] = ((fl4 >> (8u * u)) & 0xFFu) != 0u;
+            lv[u] = ((uint32_t)(fl4 >> (8u * u)) & 0xFFu) != 0u;
             ra[u] = r4[rec_q(s0 + qq, 0, cap_slots, RQ)];
             rb[u] = r4[rec_q(s0 + qq, 1, cap_slots, RQ)];
             if (!ALT) rc[u] = reinterpret_cast<const float3*>(r4 + rec_q(s0 + qq, 2, cap_slots, RQ))[0];
@@ -501,26 +509,37 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
           }
           m &= all;
         }
-        while (m) {  // up to four live records per trip: twelve independent loads in flight, summed in list order
-          uint32_t q[4];
-          bool have[4];
+        // up to four live records per trip: twelve independent loads in flight, summed in list order; EIGHT per trip while any
+        // lane of the wave still has more than four to go (ballot: the lanes inside this loop)
+        auto trip = [&](auto widthc) {
+          constexpr int NW = decltype(widthc)::value;
+          uint32_t q[NW];
+          bool have[NW];
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
+          for (int u = 0; u < NW; u++) {
             have[u] = m != 0u;
             q[u] = have[u] ? q0 + (uint32_t)__builtin_ctz(m) : q0;
             m &= m - 1u;  // (0 & anything stays 0)
           }
-          float4 ra[4], rb[4];
-          float3 rc[4];
+          float4 ra[NW], rb[NW];
+          float3 rc[NW];
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
+          for (int u = 0; u < NW; u++) {
+            if (NW > 4 && u >= 4) {  // the wide trip's second half: only the lanes that have that many
+              if (have[u]) {
+                ra[u] = r4[rec_q(s0 + q[u], 0, cap_slots, RQ)];
+                rb[u] = r4[rec_q(s0 + q[u], 1, cap_slots, RQ)];
+                if (!ALT) rc[u] = reinterpret_cast<const float3*>(r4 + rec_q(s0 + q[u], 2, cap_slots, RQ))[0];
+              }
+              continue;
+            }
             const uint32_t qq = have[u] ? q[u] : q[0];  // a valid address either way
             ra[u] = r4[rec_q(s0 + qq, 0, cap_slots, RQ)];
             rb[u] = r4[rec_q(s0 + qq, 1, cap_slots, RQ)];
             if (!ALT) rc[u] = reinterpret_cast<const float3*>(r4 + rec_q(s0 + qq, 2, cap_slots, RQ))[0];
           }
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
+          for (int u = 0; u < NW; u++) {
             if (have[u]) {  // record (common.h REC) -> acc: 0,1 mean2D  2,3,4 conic  5 opacity  6..10 colour
               acc[0] += ra[u].x; acc[1] += ra[u].y; acc[2] += ra[u].z; acc[5] += ra[u].w;
               acc[3] += rb[u].x; acc[4] += rb[u].y;
@@ -532,6 +551,10 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
               }
             }
           }
+        };
+        while (m) {
+          if (GB_WIDE && __builtin_amdgcn_ballot_w64(__popc(m) > 4) != 0ull) trip(std::integral_constant<int, 8>{});
+          else trip(std::integral_constant<int, 4>{});
         }
       }
     }
@@ -751,12 +774,32 @@ __global__ __launch_bounds__(BLK) void camera_sum_kernel(const float* __restrict
   }
 }
 
+// Four waves per SIMD with eight records in flight per lane beat seven waves with four while most listed pairs are live; where
+// tiles saturate early, few records follow the flags and the waves are what hides the flags -> records chain. The crossover
+// (1 M / 2 M Gaussians at 1024^2, gaussian_bwd ms narrow / wide by list depth x mean pair opacity): 80: 0.212 / 0.188,
+// 120: 0.118 / 0.101, 195: 0.093 / 0.086, 350: 0.078 / 0.080, trained 1 M: 0.075 / 0.078, trained 2 M: 0.105 / 0.120
+// (profiles/r05_ab_gaussian_bwd_wide.txt). A host that does not know the depth keeps the narrow kernel.
+#define GB_WIDE_DEPTH 256.0f
+int gaussian_bwd_wide(int64_t R, int P, float list_depth) {
+  static const int forced = [] {
+    const char* e = getenv("EOGS_GB_WIDE");
+    return e ? atoi(e) : -1;
+  }();
+  if (forced >= 0) return forced > 2 ? 2 : forced;
+  if (list_depth < 0.f || list_depth > GB_WIDE_DEPTH || P <= 0) return 0;
+  return (double)nr_slots(R) >= 6.0 * (double)P ? 2 : 1;
+}
+
 void launch_gaussian_bwd(const GaussBwdArgs& a, const GeomWS& g, const BinWS& b, int p_begin, int p_end, hipStream_t s) {
   const uint32_t nblk_all = ceil_div_u32((uint64_t)a.P, BLK);
   const uint32_t blk0 = (uint32_t)p_begin / BLK, nblk = ceil_div_u32((uint64_t)(p_end - p_begin), BLK);
   const bool want_T = a.dL_dT_sum != nullptr, want_vm = a.dL_dvm_mean != nullptr;
-  auto* kern = a.raw ? gaussian_bwd_kernel<true, false> : gaussian_bwd_kernel<false, false>;
-  if (a.alt_only) kern = a.raw ? gaussian_bwd_kernel<true, true> : gaussian_bwd_kernel<false, true>;
+  using Kern = decltype(&gaussian_bwd_kernel<false, false, 0>);
+  static Kern const table[3][2][2] = {
+      {{gaussian_bwd_kernel<false, false, 0>, gaussian_bwd_kernel<false, true, 0>}, {gaussian_bwd_kernel<true, false, 0>, gaussian_bwd_kernel<true, true, 0>}},
+      {{gaussian_bwd_kernel<false, false, 1>, gaussian_bwd_kernel<false, true, 1>}, {gaussian_bwd_kernel<true, false, 1>, gaussian_bwd_kernel<true, true, 1>}},
+      {{gaussian_bwd_kernel<false, false, 2>, gaussian_bwd_kernel<false, true, 2>}, {gaussian_bwd_kernel<true, false, 2>, gaussian_bwd_kernel<true, true, 2>}}};
+  Kern kern = table[a.wide < 0 ? 0 : (a.wide > 2 ? 2 : a.wide)][a.raw ? 1 : 0][a.alt_only ? 1 : 0];
   if (nblk)
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(BLK), 0, s, a.P, a.H, a.W, a.means3D, a.scales, a.rotations,
                        a.cov3D_precomp, a.opacities, a.viewmatrix, a.projmatrix, a.alt_affine, a.radii, a.scale_modifier,

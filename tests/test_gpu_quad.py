@@ -59,11 +59,14 @@ def test_round5_fast_paths_change_no_bit(tmp_path, P, H, W, opacity, invdepth):
         pytest.skip("needs a GPU")
     args = (P, H, W, opacity, invdepth)
     quad = {"EOGS_BLOCK_SWITCH": "1000", "EOGS_QUAD_SWITCH": "1000", "EOGS_QUAD_BWD_SWITCH": "1000", "EOGS_BTF_SWITCH": "0"}
-    off = _render(tmp_path, "off", dict(quad, EOGS_PLAIN_TRIPS="0", EOGS_NOFLAG="0", EOGS_FWD_MASKS="0"), args)
+    off = _render(tmp_path, "off", dict(quad, EOGS_PLAIN_TRIPS="0", EOGS_NOFLAG="0", EOGS_FWD_MASKS="0", EOGS_GB_WIDE="0"), args)
     auto = _render(tmp_path, "auto", dict(quad), args)
-    forced = _render(tmp_path, "forced", dict(quad, EOGS_NOFLAG="2"), args)
+    # (EOGS_GB_WIDE: the per-Gaussian backward with four / eight records in flight per lane, csrc/preprocess.hip gaussian_bwd_wide:
+    # the same sums in the same order)
+    forced = _render(tmp_path, "forced", dict(quad, EOGS_NOFLAG="2", EOGS_GB_WIDE="2"), args)
+    wide1 = _render(tmp_path, "wide1", dict(quad, EOGS_GB_WIDE="1"), args)
     assert float(np.abs(off["out_color"]).max()) > 0.1 and float(np.abs(off["g_means3D"]).max()) > 0
-    for name, got in (("default", auto), ("forced flag-free", forced)):
+    for name, got in (("default", auto), ("forced flag-free, eight records per trip", forced), ("eight records per long-list trip", wide1)):
         for k in off:
             d = off[k] != got[k]  # (numpy: -0.0 == 0.0; a NaN would differ from itself and fail here as it should)
             assert not d.any(), f"{name}: {k} differs in {int(d.sum())} of {d.size} elements from the run with the fast paths off"
