@@ -689,7 +689,8 @@ __device__ inline uint32_t eighth_of(uint32_t a, uint32_t b) {
 
 // ST threads (the workgroup that runs it: 1024, or 512 inside the 12-bit scatter launch), SCHED_MAX_BLOCKS / ST blocks per thread
 template <int ST>
-__device__ __forceinline__ void tile_sched_body(const uint32_t* __restrict__ bpairs, const uint32_t* __restrict__ misc,
+__device__ __forceinline__ void tile_sched_body(const uint32_t* __restrict__ bpairs, const uint32_t* __restrict__ bcount,
+                                                const uint32_t* __restrict__ misc,
                                                 uint32_t nblocks, uint32_t lg, uint32_t flags, uint32_t* __restrict__ sched,
                                                 uint32_t* __restrict__ where) {
   constexpr int SCHED_ITEMS = (int)SCHED_MAX_BLOCKS / ST;
@@ -699,11 +700,30 @@ __device__ __forceinline__ void tile_sched_body(const uint32_t* __restrict__ bpa
   // thread t holds blocks t * SCHED_ITEMS ... in block (row-major) order; the sums below fit 32 bits (pairs < 2^31, api.hip)
   uint32_t wk[SCHED_ITEMS];
   uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  {
+    uint32_t ne[SCHED_ITEMS];
 #pragma unroll
-  for (int i = 0; i < SCHED_ITEMS; i++) {
-    const uint32_t b = (uint32_t)t * SCHED_ITEMS + i;
-    wk[i] = b < nblocks ? bpairs[b] : 0u;
-    v.x += wk[i];
+    for (int i = 0; i < SCHED_ITEMS; i++) {
+      const uint32_t b = (uint32_t)t * SCHED_ITEMS + i;
+      wk[i] = b < nblocks ? bpairs[b] : 0u;
+      ne[i] = b < nblocks ? bcount[b] : 0u;
+      v.x += wk[i];
+      v.y += ne[i];
+    }
+    // Where every block's entries and pairs start (exclusive prefixes of the per-block counts, in the second and third third of
+    // `where`): block_lists_kernel's 1024 ... 4096 workgroups each summed the counts of all the blocks before their own —
+    // a global round trip and two workgroup reductions at the head of a chain of dependent steps (tools/bl_phases.py: 8 % of a
+    // workgroup's time at 1024 blocks, 18 % at 4096) — for what this scan has as a by-product.
+    uint4 tot0;
+    uint4 pre = sched_scan<ST>(v, s_w, tot0);
+#pragma unroll
+    for (int i = 0; i < SCHED_ITEMS; i++) {
+      const uint32_t b = (uint32_t)t * SCHED_ITEMS + i;
+      if (b < nblocks) *reinterpret_cast<uint2*>(where + SCHED_MAX_BLOCKS + 2u * b) = make_uint2(pre.y, pre.x);  // {entries, pairs} before b
+      pre.x += wk[i];
+      pre.y += ne[i];
+    }
+    v.y = 0u;
   }
   uint4 tot;
   (void)sched_scan<ST>(v, s_w, tot);
@@ -853,7 +873,7 @@ __global__ __launch_bounds__(T_, (NBITS <= 10 && T_ == 1024 ? ES_WAVES : 1)) voi
   constexpr uint32_t nb = 1u << NBITS, mask = nb - 1u;
   if constexpr (T_ == 1024 || T_ == 512) {
     if (sched_blocks && blockIdx.x == gridDim.x - 1) {  // the launch's extra workgroup: the tile schedule
-      tile_sched_body<T_>(bpairs, misc, sched_blocks, sched_lg & 0xFFFFFFu, sched_lg >> 24, sched, where);
+      tile_sched_body<T_>(bpairs, dtotal, misc, sched_blocks, sched_lg & 0xFFFFFFu, sched_lg >> 24, sched, where);  // (one pass: dtotal IS the per-block entry count)
       return;
     }
   }
@@ -992,10 +1012,11 @@ struct SchedArgs {
   uint32_t* sched;
   uint32_t* where;
 };
-__global__ __launch_bounds__(SCHED_T) void tile_sched_kernel(const uint32_t* __restrict__ bpairs, const uint32_t* __restrict__ misc,
+__global__ __launch_bounds__(SCHED_T) void tile_sched_kernel(const uint32_t* __restrict__ bpairs, const uint32_t* __restrict__ bcount,
+                                                             const uint32_t* __restrict__ misc,
                                                              uint32_t nblocks, uint32_t lg, uint32_t* __restrict__ sched,
                                                              uint32_t* __restrict__ where) {
-  tile_sched_body<SCHED_T>(bpairs, misc, nblocks, lg & 0xFFFFFFu, lg >> 24, sched, where);
+  tile_sched_body<SCHED_T>(bpairs, bcount, misc, nblocks, lg & 0xFFFFFFu, lg >> 24, sched, where);
 }
 template <int NBITS>
 static void launch_entry_scatter_n(uint32_t nblk, hipStream_t s, const uint4* in, uint4* out, const uint32_t* misc, uint32_t cap,
@@ -1003,7 +1024,7 @@ static void launch_entry_scatter_n(uint32_t nblk, hipStream_t s, const uint4* in
   constexpr int T_ = NBITS <= 11 ? 1024 : 512;
   const bool ride = sa.blocks != 0u && (T_ == 1024 || T_ == 512);  // (every variant today: the stand-alone launch is the fallback)
   if (sa.blocks != 0u && !ride)
-    hipLaunchKernelGGL(tile_sched_kernel, dim3(1), dim3(SCHED_T), 0, s, sa.bpairs, misc, sa.blocks, sa.lg, sa.sched, sa.where);
+    hipLaunchKernelGGL(tile_sched_kernel, dim3(1), dim3(SCHED_T), 0, s, sa.bpairs, dtotal, misc, sa.blocks, sa.lg, sa.sched, sa.where);
   hipLaunchKernelGGL((entry_scatter_kernel<NBITS, T_>), dim3(nblk + (ride ? 1u : 0u)), dim3(T_), 0, s, in, out, misc, cap, shift,
                      hist, dtotal, sa.bpairs, ride ? sa.blocks : 0u, sa.lg, sa.sched, sa.where);
 }
@@ -1087,6 +1108,16 @@ __device__ inline uint32_t bl_sum(uint32_t v, uint32_t* s_red) {  // sum over th
 // 4-item build is faster, 59 against 77 us, and beyond 6000 the 8-item build loses to the 4-item streaming path).
 #define BL_NARROW_256 750.0   // entries per block (average) up to which a block's workgroup has 256 threads ...
 #define BL_NARROW_512 1400.0  // ... 512 threads; above: 1024 (measured crossovers: profiles/r04_experiments/ab_bl_threads.txt)
+// -DEOGS_BL_PHASES: where a block's workgroup spends its time (wave 0's clock at the phase boundaries, summed over the workgroups
+// into g_bl_phase[]; read with eogs_debug_bl_phases, tools/bl_phases.py). Diagnostics only.
+#ifdef EOGS_BL_PHASES
+__device__ unsigned long long g_bl_phase[8];
+#define BLP_DECL unsigned long long blp_t = __builtin_readcyclecounter()
+#define BLP(i) do { const unsigned long long blp_n = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_bl_phase[i], blp_n - blp_t); blp_t = blp_n; } while (0)
+#else
+#define BLP_DECL
+#define BLP(i)
+#endif
 template <int MODE, int BL_ITEMS, int BL_T>
 __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __restrict__ ent, uint2* ki,
                                                               const uint32_t* __restrict__ bcount,
@@ -1104,9 +1135,17 @@ __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __res
   __shared__ uint32_t s_red[BL_NW];
   __shared__ uint32_t s_tc[16], s_tb[16], s_cw[BL_NW][16];
   __shared__ uint2 s_stage[BL_CH];
+  // {Gaussian id, first record slot} of the block's entries by their position in the entry buffer, kept from the one coalesced
+  // load of the entries: the split into tile lists then finds them in LDS instead of gathering 16 bytes per ordered entry from
+  // global memory — a dependent round trip of ~5 us per workgroup under the launch's own load (tools/bl_phases.py: the split was
+  // 40 % of a workgroup's 32 us). Per-tile lists with four items per thread only: with eight the two arrays would leave one
+  // workgroup per CU.
+  constexpr bool IDS = MODE == 1 && BL_ITEMS == 4;
+  __shared__ uint2 s_ids[IDS ? BL_CH : 1];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const uint32_t b = blockIdx.x;
   const int npass = (int)misc[MISC_DEPTH_PASSES];
+  BLP_DECL;
   // The render workgroup that takes internal tile `sub` of this block finds tile and list in ONE 16-byte descriptor at the
   // block's place in the tile schedule (tile_sched_body): XCD x's sequence starts at desc[x * lg16], 16 descriptors per block.
   auto put_desc = [&](uint32_t sub, uint32_t tx, uint32_t ty, uint32_t begin, uint32_t end) {
@@ -1133,11 +1172,15 @@ __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __res
     }
   }
 
-  // where this block's entries and pairs start: sums of the counts of the blocks before it (a few loads per thread at the
-  // usual 1024 ... 4096 blocks)
+  // where this block's entries and pairs start: read from the prefixes the tile schedule's workgroup left behind `where`
+  // (tile_sched_body; desc != nullptr <=> that workgroup ran), else sums of the counts of the blocks before it
   uint32_t s0, pairs_before = 0;
   const uint32_t n = bcount[b];
-  {
+  if (desc != nullptr) {
+    const uint2 pf = *reinterpret_cast<const uint2*>(where + SCHED_MAX_BLOCKS + 2u * b);
+    s0 = pf.x;
+    pairs_before = pf.y;
+  } else {
     uint32_t ve = 0, vp = 0;
     for (uint32_t i = t; i < b; i += BL_T) {
       ve += bcount[i];
@@ -1152,6 +1195,7 @@ __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __res
   if (t < 256) s_h[t] = 0;
   if (t < 16) s_tc[t] = 0;
   __syncthreads();
+  BLP(0);  // prologue: counts fit, where the block's entries and pairs start
 
   const bool fast = n <= (uint32_t)BL_CH;
   uint2* src = ki + 2 * (size_t)s0;
@@ -1169,10 +1213,17 @@ __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __res
       dk[i] = 0xFFFFFFFFu; px[i] = 0;
       const uint32_t k = wb0 + i * 64 + lane;
       if ((uint32_t)i < per0 && k < n) {
-        const uint2 kd = *reinterpret_cast<const uint2*>(ent + s0 + k);  // {key, depth key}
-        dk[i] = kd.y; px[i] = (kd.x & 0xFFFF0000u) | k;
+        if (IDS) {
+          const uint4 e = ent[s0 + k];  // {key, depth key, Gaussian id, first slot}
+          dk[i] = e.y; px[i] = (e.x & 0xFFFF0000u) | k;
+          s_ids[k] = make_uint2(e.z, e.w);
+        } else {
+          const uint2 kd = *reinterpret_cast<const uint2*>(ent + s0 + k);  // {key, depth key}
+          dk[i] = kd.y; px[i] = (kd.x & 0xFFFF0000u) | k;
+        }
       }
     }
+    BLP(1);  // entries loaded (issued)
     for (int p = 0; p < npass; p++) {
       const int sh = 8 * p;
       for (int k = t; k < BL_NW * 128; k += BL_T) reinterpret_cast<uint32_t*>(&s_wcnt[0][0])[k] = 0u;
@@ -1336,6 +1387,7 @@ __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __res
     }
   }
   __syncthreads();  // the ordered pairs (s_stage / src) and s_tc are visible
+  BLP(2);  // radix passes
 
   if (MODE != 1) {
     for (uint32_t i = t; i < n; i += BL_T) {
@@ -1388,6 +1440,7 @@ __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __res
     if (tx < gsx && ty < gsy) ranges[ty * gsx + tx] = make_uint2(pre, pre + s_tc[t]);
     put_desc((uint32_t)t, tx, ty, pre, pre + s_tc[t]);
   }
+  BLP(3);  // per-tile counts, ranges, descriptors
   {
     // live flags of this block's pairs: which records get written depends only on forward state (lists and n_contrib),
     // so one clear per forward serves every backward over this workspace
@@ -1405,6 +1458,7 @@ __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __res
     }
   }
   __syncthreads();
+  BLP(4);  // live flags cleared
   for (uint32_t c0 = 0; c0 < n; c0 += BL_CH) {
     const uint32_t cend = n - c0 < (uint32_t)BL_CH ? n : c0 + (uint32_t)BL_CH;
     const uint32_t per = ((cend - c0 + 63u) / 64u + BL_NW - 1u) / BL_NW;
@@ -1433,8 +1487,14 @@ __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __res
       const uint32_t k = wb + i * 64 + lane;
       uint32_t sub = 0, id = 0, sl = 0;
       if (k < cend) {
-        const uint4 e = ent[s0 + (fast ? (s_stage[k].y & 0xFFFFu) : src[k].y)];
-        sub = e.x >> MACRO_KEY_BITS; id = e.z; sl = e.w;
+        if (IDS && fast) {
+          const uint32_t sv = s_stage[k].y;  // sub-mask << 16 | position in the entry buffer
+          const uint2 is = s_ids[sv & 0xFFFFu];
+          sub = sv >> 16; id = is.x; sl = is.y;
+        } else {
+          const uint4 e = ent[s0 + (fast ? (s_stage[k].y & 0xFFFFu) : src[k].y)];
+          sub = e.x >> MACRO_KEY_BITS; id = e.z; sl = e.w;
+        }
       }
 #pragma unroll
       for (int j = 0; j < 16; j++) {
@@ -1448,6 +1508,10 @@ __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __res
     }
     __syncthreads();  // s_cw is rewritten by the next chunk
   }
+  BLP(5);  // split into the tiles' lists
+#ifdef EOGS_BL_PHASES
+  if (threadIdx.x == 0) atomicAdd(&g_bl_phase[7], 1ull);
+#endif
 }
 
 void launch_block_lists(const GeomWS& g, const SortWS& w, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R,
@@ -1492,3 +1556,15 @@ void launch_block_lists(const GeomWS& g, const SortWS& w, const BinWS& b, const 
   }
 #undef BL_LAUNCH
 }
+
+#ifdef EOGS_BL_PHASES
+extern "C" int eogs_debug_bl_phases(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_bl_phase), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) {
+    void* dptr = nullptr;
+    if (hipGetSymbolAddress(&dptr, HIP_SYMBOL(g_bl_phase)) != hipSuccess) return -1;
+    if (hipMemset(dptr, 0, 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif

@@ -319,7 +319,8 @@ struct GeomWS {
                         // block b's entries start in the block-sorted entry array)
   uint32_t* bpairs;     // [MAX_BLOCKS] per block: listed (internal tile, Gaussian) pairs
   uint32_t* sched;      // [16] tile schedule of the render launches (binning.hip tile_sched_body): [0..8) blocks in XCD x's sequence
-  uint32_t* where;      // [SCHED_MAX_BLOCKS] block b's place in that schedule: XCD << 24 | position in the XCD's sequence
+  uint32_t* where;      // [3 x SCHED_MAX_BLOCKS] block b's place in that schedule: XCD << 24 | position in the XCD's sequence;
+                        // behind them {list entries, pairs} of the blocks before b (two words per block: block_lists_kernel's start)
   uint32_t* misc;       // MISC_WORDS
   float* vmpart;        // backward: per-workgroup partials of the 18 camera-gradient sums [ceil(P/256)][18]
   uint32_t nblkE;
@@ -339,7 +340,7 @@ static inline GeomWS geom_layout(char* base, int P) {
   o = ws_carve(base, o, g.bcount, (size_t)MAX_BLOCKS);
   o = ws_carve(base, o, g.bpairs, (size_t)MAX_BLOCKS);
   o = ws_carve(base, o, g.sched, (size_t)16);
-  o = ws_carve(base, o, g.where, (size_t)SCHED_MAX_BLOCKS);
+  o = ws_carve(base, o, g.where, (size_t)3 * SCHED_MAX_BLOCKS);
   o = ws_carve(base, o, g.misc, MISC_WORDS);
   o = ws_carve(base, o, g.vmpart, (size_t)g.nblkE * 18);
   g.bytes = ws_align(o) + 256;  // slack so a base that is only 1-aligned still fits after rounding
