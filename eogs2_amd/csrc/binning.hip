@@ -1139,8 +1139,9 @@ __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __res
   // load of the entries: the split into tile lists then finds them in LDS instead of gathering 16 bytes per ordered entry from
   // global memory — a dependent round trip of ~5 us per workgroup under the launch's own load (tools/bl_phases.py: the split was
   // 40 % of a workgroup's 32 us). Per-tile lists with four items per thread only: with eight the two arrays would leave one
-  // workgroup per CU.
-  constexpr bool IDS = MODE == 1 && BL_ITEMS == 4;
+  // workgroup per CU; and 1024-thread workgroups only: the smaller ones (few entries per block) measured no gain and would
+  // lose a resident workgroup to the extra LDS.
+  constexpr bool IDS = MODE == 1 && BL_ITEMS == 4 && BL_T == 1024;
   __shared__ uint2 s_ids[IDS ? BL_CH : 1];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const uint32_t b = blockIdx.x;
