@@ -86,6 +86,26 @@ __device__ inline void stage_rows3(const float* __restrict__ src, size_t row0, i
   }
 }
 
+// The same in two halves — the loads into registers, the LDS stores later — for kernels that have other loads to request
+// before anything waits for these (gaussian_bwd_kernel).
+__device__ inline void stage_rows3_load(const float* __restrict__ src, size_t row0, int rows, float (&r)[3]) {
+  const int t = threadIdx.x, n = rows * 3;
+  const float* p = src + row0 * 3;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const int e = i * BLK + t;
+    r[i] = e < n ? p[e] : 0.f;
+  }
+}
+__device__ inline void stage_rows3_store(int rows, const float (&r)[3], float* s_dst) {
+  const int t = threadIdx.x, n = rows * 3;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const int e = i * BLK + t;
+    if (e < n) s_dst[e] = r[i];
+  }
+}
+
 constexpr float SH_C0 = 0.28209479177387814f;  // utils/sh_utils.py:25
 
 __device__ inline float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
@@ -419,21 +439,26 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
   const uint32_t blk = blk0 + blockIdx.x;  // workgroup index over ALL Gaussians (the launch may cover a range of them)
   const size_t row0 = (size_t)blk * BLK;
   const int rows = (int)(((size_t)P - row0) < (size_t)BLK ? ((size_t)P - row0) : (size_t)BLK);
-  stage_rows3(means3D, row0, rows, s_m);
-  if (scales) stage_rows3(scales, row0, rows, s_s);
-  __syncthreads();
-
   const size_t idx = row0 + t;
   float vmsum[18];
 #pragma unroll
   for (int k = 0; k < 18; k++) vmsum[k] = 0.f;
+  // (Summing the records in double was measured: 0.109 -> 0.130 ms, and no accuracy gained — the residual error of
+  // extreme footprints comes from the per-pixel pass)
+  float acc[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) acc[k] = 0.f;
+  bool visible = false;
+  float4 rot_in = make_float4(1.f, 0.f, 0.f, 0.f);
+  float op_raw = 0.f;
+  // The rows of means3D / scales that the math below reads through LDS are REQUESTED here and parked in LDS only after the record
+  // sum: the workgroup barrier that publishes them used to stand at the kernel's head, in front of every other load — one more
+  // dependent round trip (rows -> barrier -> radii / binning record -> records) of a kernel that is nothing but round trips.
+  float st_m[3], st_s[3] = {0.f, 0.f, 0.f};
+  stage_rows3_load(means3D, row0, rows, st_m);
+  if (scales) stage_rows3_load(scales, row0, rows, st_s);
 
   if (t < rows) {
-    // (Summing the records in double was measured: 0.109 -> 0.130 ms, and no accuracy gained — the residual error of
-    // extreme footprints comes from the per-pixel pass)
-    float acc[12];
-#pragma unroll
-    for (int k = 0; k < 12; k++) acc[k] = 0.f;
     // Round 4: everything that does not depend on another load is requested up front (the kernel waited 45 % of its wave
     // time, profiles/r03_v30: radii -> binfo -> flags -> records -> rotation / opacity was a chain of five dependent round
     // trips per workgroup): radii, the binning record, the workgroup's first slot and the per-Gaussian inputs of the math
@@ -443,11 +468,9 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
     const int radius_in = radii[idx];
     const uint4 bi1 = binfo[(size_t)P + idx];  // (its own plane: this kernel reads 16 of a Gaussian's 32 bytes, and fetched all 32 while they shared a line)
     const uint32_t pb = pblock[blk];
-    float4 rot_in = make_float4(1.f, 0.f, 0.f, 0.f);
-    float op_raw = 0.f;
     if (!cov3D_precomp) rot_in = reinterpret_cast<const float4*>(rotations)[idx];
     if (RAW || antialiasing) op_raw = opacities[idx];
-    const bool visible = radius_in > 0;
+    visible = radius_in > 0;
     if (visible) {
       // fixed-order sum of this Gaussian's (tile,Gaussian) records: deterministic, no atomics
       const uint32_t n = fits ? bi1.x : 0u;
@@ -558,6 +581,11 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
         }
       }
     }
+  }
+  stage_rows3_store(rows, st_m, s_m);
+  if (scales) stage_rows3_store(rows, st_s, s_s);
+  __syncthreads();
+  if (t < rows) {
     // record layout: 0,1 = dL/dmean2D (NDC units)  2,3,4 = dL/dconic (a,b,c)  5 = dL/dopacity  6..10 = dL/dcolor
     const float gxn = acc[0], gyn = acc[1];
     float dop = acc[5];
