@@ -433,6 +433,7 @@ __global__ __launch_bounds__(BLK, 4) void expand_entries_kernel(const uint4* __r
                                                                 const uint32_t* __restrict__ pblockE,
                                                                 const uint32_t* __restrict__ misc, uint32_t cap, uint32_t P,
                                                                 uint32_t gmx, uint4* __restrict__ ent) {
+  if (entries_on_device(misc, cap) == 0u) return;  // nothing listed, or more entries than this buffer holds
   __shared__ uint32_t s_w[4];
   const int lane = threadIdx.x & 63;
   const uint32_t k = blockIdx.x * BLK + threadIdx.x;
@@ -440,22 +441,18 @@ __global__ __launch_bounds__(BLK, 4) void expand_entries_kernel(const uint4* __r
   it.id = k; it.c = 0; it.m = 0ull; it.sx0 = it.sy0 = it.sx1 = it.sy1 = 0; it.rbase = 0; it.kind = BK_RECT; it.depth = 0;
   float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0;  // SpanParams of a BK_SPANS Gaussian
   uint4 ia = make_uint4(0u, 0u, 0u, 0u), ib = ia;
-  // (the binning records and the workgroup's prefixes are requested before the count check below looks at misc: one round trip,
-  // not two — the addresses are valid whatever the counts say)
   if (k < P) {
     ia = binfo[(size_t)k];              // (two planes of P records: common.h GeomWS::binfo)
     ib = binfo[(size_t)P + (size_t)k];
+    it.c = ib.x ? (ib.w >> 2) : 0u;
   }
-  const uint32_t pbE = pblockE[blockIdx.x], pbT = pblock[blockIdx.x];
-  if (entries_on_device(misc, cap) == 0u) return;  // nothing listed, or more entries than this buffer holds
-  if (k < P) it.c = ib.x ? (ib.w >> 2) : 0u;
   uint32_t tot;
-  it.pos0 = pbE + block_excl_scan(it.c, s_w, tot);
+  it.pos0 = pblockE[blockIdx.x] + block_excl_scan(it.c, s_w, tot);
   if (it.c) {
     it.m = ((unsigned long long)ia.w << 32) | ia.z;
     it.sx0 = ia.x & 0xFFFFu; it.sy0 = ia.y & 0xFFFFu;  // internal-tile rect, already clipped (preprocess_fwd_kernel)
     it.sx1 = ia.x >> 16; it.sy1 = ia.y >> 16;
-    it.rbase = pbT + ib.y;
+    it.rbase = pblock[blockIdx.x] + ib.y;
     it.depth = ib.z;
     it.kind = ib.w & 3u;
     if (it.kind == BK_SPANS) {
@@ -889,10 +886,6 @@ __global__ __launch_bounds__(T_, (NBITS <= 10 && T_ == 1024 ? ES_WAVES : 1)) voi
   __shared__ uint32_t s_w[ES_NW_], s_w2[ES_NW_];
   __shared__ uint4 s_win[ES_WIN];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  // the first digits' global totals and this workgroup's column offsets: requested with the entries, not behind the ranking's
-  // barrier (a second dependent round trip of every workgroup)
-  const uint32_t v_first = (uint32_t)t < nb ? dtotal[t] : 0u;
-  const uint32_t h_first = (uint32_t)t < nb ? hist[(size_t)blockIdx.x * nb + (uint32_t)t] : 0u;
   for (uint32_t k = t; k < (uint32_t)ES_NW_ * (nb < 2u ? 2u : nb) / 2u; k += T_) reinterpret_cast<uint32_t*>(&s_wcnt[0][0])[k] = 0u;
   __syncthreads();
   const uint32_t base = tile0 + (uint32_t)w * (64 * ES_ITEMS_);
@@ -926,7 +919,7 @@ __global__ __launch_bounds__(T_, (NBITS <= 10 && T_ == 1024 ? ES_WAVES : 1)) voi
   uint32_t carry = 0, carry2 = 0;
   for (uint32_t d0 = 0; d0 < nb; d0 += T_) {
     const uint32_t d = d0 + t;
-    const uint32_t v = d0 == 0u ? v_first : (d < nb ? dtotal[d] : 0u);
+    const uint32_t v = d < nb ? dtotal[d] : 0u;
     uint32_t run = 0;
     if (d < nb) {
 #pragma unroll
@@ -947,7 +940,7 @@ __global__ __launch_bounds__(T_, (NBITS <= 10 && T_ == 1024 ? ES_WAVES : 1)) voi
       tot2 += s_w2[k];
     }
     if (d < nb) {
-      s_gbase[d] = carry + pre + inc - v + (d0 == 0u ? h_first : hist[(size_t)blockIdx.x * nb + d]);
+      s_gbase[d] = carry + pre + inc - v + hist[(size_t)blockIdx.x * nb + d];
       s_dstart[d] = carry2 + pre2 + inc2 - run;
     }
     carry += tot;
