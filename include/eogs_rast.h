@@ -123,7 +123,10 @@ int eogs_rast_scratch_bytes(int P, int H, int W, size_t* bytes);
  *   holds: six per Gaussian) forward_render does that work inside a correspondingly larger binning workspace.
  * Writes radii[P] and *num_rendered (host). num_rendered is an opaque token for the three calls below (it packs this
  * library's pair counts, list granularity and where the entries were sorted, see csrc/common.h nr_pack: record slots in
- * bits 0..30, list entries in bits 32..58, flags above); 0 means nothing is listed. */
+ * bits 0..30, list entries in bits 32..58, flags above); 0 means nothing is listed.
+ * Beside the token the library keeps, per process, the mean list depth x mean pair opacity of the last 16 tokens it built from
+ * counts (the token has no bit left for it; a capacity token inherits it): eogs_rast_backward picks between two builds of its
+ * per-Gaussian kernel by it. A hint only: both builds compute the same bits, and a token the table no longer holds gets the default. */
 int eogs_rast_forward_prepare(
     int P, int H, int W,
     const float* means3D, const float* scales, const float* rotations,
