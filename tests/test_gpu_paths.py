@@ -24,8 +24,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # EOGS_BTF_SWITCH: fraction of the image's tiles a Gaussian lists on average from which a forward takes per-tile lists and the
 # back-to-front backward (0 = never; the default 0.1 would take the image-sized sweep cases out of the other forced paths).
 FORCED = {  # (the default switches run in-process: tests/test_gpu_parity.py, same cases, same comparison)
+    # (EOGS_TILE_SCHED=0 here: the band mapping of rounds 1-3 instead of the tile schedule — no descriptors, and block_lists_kernel
+    # finds its block's start by summing the counts of the blocks before it instead of reading the schedule workgroup's prefixes)
     "tile": {"EOGS_BLOCK_SWITCH": "1000", "EOGS_DEPTH_SWITCH": "0", "EOGS_QUAD_SWITCH": "0", "EOGS_QUAD_BWD_SWITCH": "0",
-             "EOGS_BTF_SWITCH": "0"},
+             "EOGS_BTF_SWITCH": "0", "EOGS_TILE_SCHED": "0"},
     "block": {"EOGS_BLOCK_SWITCH": "0.5", "EOGS_DEPTH_SWITCH": "0.001", "EOGS_BTF_SWITCH": "0"},
     # (EOGS_NOFLAG=0: the quad backward with live flags on every case; the next entry forces its flag-free records on every case —
     # correct for any scene, chosen by default only where no tile comes near saturation: csrc/common.h noflag_scene)
