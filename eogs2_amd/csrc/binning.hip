@@ -1497,6 +1497,11 @@ __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __res
           sub = e.x >> MACRO_KEY_BITS; id = e.z; sl = e.w;
         }
       }
+      // The values are made "arrived" HERE, once, for every lane: each of the sixteen conditional stores below otherwise got its
+      // own s_waitcnt vmcnt(0) from the compiler (the first use of id / sl sits in a block that does not dominate the next one),
+      // and vmcnt(0) also waits for every STORE before it — sixteen serialised store round trips per group of 64 entries, 9 of a
+      // workgroup's 27 us (tools/bl_phases.py with a timer around this loop).
+      asm volatile("" : "+v"(sub), "+v"(id), "+v"(sl));
 #pragma unroll
       for (int j = 0; j < 16; j++) {
         const bool has = (sub >> j) & 1u;
