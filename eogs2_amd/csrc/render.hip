@@ -166,6 +166,7 @@ struct Cand {
 //          listed tiles before this one.
 struct Peek {
   uint32_t key;
+  uint32_t qraw;  // peek_cand_q: the byte loaded from BinWS::qmask, untouched (see there)
   uint2 e;
 };
 template <int MACRO>
@@ -173,6 +174,7 @@ __device__ inline Peek peek_cand(uint32_t k, uint32_t end, const uint32_t* __res
                                  const uint2* __restrict__ point_list) {
   Peek p;
   p.key = 0u;  // empty sub-mask: never a hit
+  p.qraw = 0u;
   p.e = make_uint2(0u, 0u);
   if (k < end) {
     p.key = MACRO > 1 ? keys[k] : 1u;  // block size 1: every entry of the tile's own list is a hit
@@ -184,11 +186,18 @@ __device__ inline Peek peek_cand(uint32_t k, uint32_t end, const uint32_t* __res
 // quad mask it left in `qmask` (BinWS::qmask) — the backward's chunk set-up then needs no quad_mask() of its own (four block_hit
 // tests, a v_log and two v_rcp per entry: half of the set-up's instructions).
 __device__ inline Peek peek_cand_q(uint32_t k, uint32_t end, const uint8_t* __restrict__ qmask, const uint2* __restrict__ point_list) {
+  // (The loaded byte is NOT combined with the flag here: `0x10 | qmask[k]` is a use, and the compiler waits for the load on the
+  // spot — s_waitcnt vmcnt(0), which also waits for the three record loads of the next chunk's gather issued just before it: one
+  // full memory round trip per chunk in the middle of the chunk set-up, found in the ISA (render_bwd -2.9 % without it). The
+  // byte is first looked at a chunk later, in gather_cand. Taking "in range" as an argument of the gather instead of carrying
+  // the flag — no scratch, 8 bytes with it — measured 1 % slower at the headline and 1 % faster at trained opacities.)
   Peek p;
   p.key = 0u;
+  p.qraw = 0u;
   p.e = make_uint2(0u, 0u);
   if (k < end) {
-    p.key = 0x10u | (qmask ? (uint32_t)qmask[k] : 0u);
+    p.key = 0x10u;
+    if (qmask) p.qraw = (uint32_t)qmask[k];
     p.e = point_list[k];
   }
   return p;
@@ -198,7 +207,7 @@ __device__ inline Cand gather_cand(const Peek& p, uint32_t sub, const float4* __
   Cand c;
   c.q0 = c.q1 = c.q2 = make_float4(0.f, 0.f, 0.f, 0.f);
   c.slot = 0;
-  c.qm = MACRO > 1 ? 0u : (p.key & 0xFu);
+  c.qm = MACRO > 1 ? 0u : ((p.key | p.qraw) & 0xFu);
   const uint32_t mask = MACRO > 1 ? p.key >> MACRO_KEY_BITS : p.key;  // block size 1: peek_cand's in-range flag
   c.hit = MACRO > 1 ? ((mask >> sub) & 1u) != 0u : mask != 0u;
   if (c.hit) {
@@ -1533,6 +1542,12 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
         if (t < rem) grad(ea, o0, t);
         round(nfull, rem);
       }
+      // The prefetches that travel into the next chunk (its gathered entry, the peek behind it) are made "arrived" HERE, in front
+      // of the record stores: loads and stores share one in-order counter, the loop's back edge copies the prefetched registers,
+      // and a wait placed there has to wait for the stores issued just before it too — a store round trip at the end of every
+      // chunk (found in the ISA: s_waitcnt vmcnt(0) behind the record stores). The loads have been in flight for the whole
+      // chunk; the wait here costs nothing.
+      asm volatile("" : "+v"(nxt.q0.x), "+v"(nxt.q1.x), "+v"(nxt.q2.x), "+v"(pk.e.x), "+v"(pk.e.y), "+v"(pk.qraw));
       // entry `lane`: accumulated moments -> record (backward.cu:624-640, as in transpose_round)
       bool any = false;
 #pragma unroll
