@@ -564,11 +564,19 @@ __global__ __launch_bounds__(ES_T) void entry_hist_kernel(const uint4* __restric
   __shared__ uint32_t h[1 << ES_MAXBITS], hp[1 << ES_MAXBITS];
   for (uint32_t d = t; d < nb; d += ES_T) { h[d] = 0; hp[d] = 0; }
   __syncthreads();
+  // (all of a thread's keys are requested before the first is used: with load and LDS atomic in one bounds check the compiler
+  // waits for each load before it issues the next — ES_ITEMS serialised round trips in a kernel that is little else)
+  uint32_t keyv[ES_ITEMS];
+#pragma unroll
+  for (int i = 0; i < ES_ITEMS; i++) {
+    const uint32_t k = base + i * ES_T + t;
+    keyv[i] = k < n ? ent[k].x : 0u;
+  }
 #pragma unroll
   for (int i = 0; i < ES_ITEMS; i++) {
     const uint32_t k = base + i * ES_T + t;
     if (k < n) {
-      const uint32_t key = ent[k].x, d = (key >> shift) & mask;
+      const uint32_t key = keyv[i], d = (key >> shift) & mask;
       atomicAdd(&h[d], 1u);
       if (histp) atomicAdd(&hp[d], (uint32_t)__popc(key >> MACRO_KEY_BITS));
     }
@@ -592,11 +600,19 @@ __global__ __launch_bounds__(ES_T) void entry_colscan_kernel(uint32_t* __restric
   __shared__ uint32_t s_part[ES_NW][64], s_pp[ES_NW][64];
   const uint32_t slab = (nlive + ES_NW - 1u) / ES_NW;
   const uint32_t r0 = (uint32_t)w * slab, r1 = r0 + slab < nlive ? r0 + slab : nlive;
+  // (rows eight at a time, all eight loads requested before the first is added: a loop of load-and-add waits for every row)
+  constexpr uint32_t CS_CH = 8;
   uint32_t sum = 0, psum = 0;
   if (d < nb)
-    for (uint32_t r = r0; r < r1; r++) {
-      sum += hist[(size_t)r * nb + d];
-      if (histp) psum += histp[(size_t)r * nb + d];
+    for (uint32_t r = r0; r < r1; r += CS_CH) {
+      uint32_t c[CS_CH], pc[CS_CH];
+#pragma unroll
+      for (uint32_t j = 0; j < CS_CH; j++) {
+        c[j] = r + j < r1 ? hist[(size_t)(r + j) * nb + d] : 0u;
+        pc[j] = (histp && r + j < r1) ? histp[(size_t)(r + j) * nb + d] : 0u;
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < CS_CH; j++) { sum += c[j]; psum += pc[j]; }
     }
   s_part[w][lane] = sum;
   s_pp[w][lane] = psum;
@@ -610,10 +626,15 @@ __global__ __launch_bounds__(ES_T) void entry_colscan_kernel(uint32_t* __restric
     ptot += s_pp[k][lane];
   }
   if (d < nb) {
-    for (uint32_t r = r0; r < r1; r++) {
-      const uint32_t c = hist[(size_t)r * nb + d];
-      hist[(size_t)r * nb + d] = run;
-      run += c;
+    for (uint32_t r = r0; r < r1; r += CS_CH) {
+      uint32_t c[CS_CH];
+#pragma unroll
+      for (uint32_t j = 0; j < CS_CH; j++) c[j] = r + j < r1 ? hist[(size_t)(r + j) * nb + d] : 0u;
+#pragma unroll
+      for (uint32_t j = 0; j < CS_CH; j++) {
+        if (r + j < r1) hist[(size_t)(r + j) * nb + d] = run;
+        run += c[j];
+      }
     }
     if (w == 0) {
       dtotal[d] = tot;

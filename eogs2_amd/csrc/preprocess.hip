@@ -75,19 +75,10 @@ __device__ inline void cov2d(const float T[2][3], const float c6[6], float& cxx,
 
 __device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// Cooperative load of `rows` consecutive 3-float rows (12 B, AoS) into LDS with dword-contiguous lanes.
-__device__ inline void stage_rows3(const float* __restrict__ src, size_t row0, int rows, float* s_dst) {
-  const int t = threadIdx.x, n = rows * 3;
-  const float* p = src + row0 * 3;
-#pragma unroll
-  for (int i = 0; i < 3; i++) {
-    int e = i * BLK + t;
-    if (e < n) s_dst[e] = p[e];
-  }
-}
-
-// The same in two halves — the loads into registers, the LDS stores later — for kernels that have other loads to request
-// before anything waits for these (gaussian_bwd_kernel).
+// Cooperative load of `rows` consecutive 3-float rows (12 B, AoS) into LDS with dword-contiguous lanes, in two halves — the
+// loads into registers, the LDS stores later: a kernel requests ALL its rows (and whatever else it can) before anything waits.
+// (One function that loaded and stored element by element was what rounds 1-5 used: the compiler waits for each load inside its
+// bounds check before it issues the next — five to eight serialised round trips at the head of every preprocess workgroup.)
 __device__ inline void stage_rows3_load(const float* __restrict__ src, size_t row0, int rows, float (&r)[3]) {
   const int t = threadIdx.x, n = rows * 3;
   const float* p = src + row0 * 3;
@@ -154,9 +145,24 @@ __global__ __launch_bounds__(BLK) PP_ATTR void preprocess_fwd_kernel(
   const int t = threadIdx.x;
   const size_t row0 = (size_t)blockIdx.x * BLK;
   const int rows = (int)(((size_t)P - row0) < (size_t)BLK ? ((size_t)P - row0) : (size_t)BLK);
-  stage_rows3(means3D, row0, rows, s_m);
-  if (scales) stage_rows3(scales, row0, rows, s_s);
-  if (RAW) stage_rows3(colors, row0, rows, s_c);
+  float4 q_pre = make_float4(1.f, 0.f, 0.f, 0.f);
+  float op_pre = 0.f;
+  {
+    // all the rows' loads first, then their LDS stores (see stage_rows3_load)
+    float st_m[3], st_s[3] = {0.f, 0.f, 0.f}, st_c[3] = {0.f, 0.f, 0.f};
+    stage_rows3_load(means3D, row0, rows, st_m);
+    if (scales) stage_rows3_load(scales, row0, rows, st_s);
+    if (RAW) stage_rows3_load(colors, row0, rows, st_c);
+    // (... and the Gaussian's rotation and opacity with them, not behind the barrier / inside `area != 0`: two more dependent
+    // round trips otherwise)
+    if (t < rows) {
+      if (!cov3D_precomp) q_pre = reinterpret_cast<const float4*>(rotations)[row0 + t];
+      op_pre = opacities[row0 + t];
+    }
+    stage_rows3_store(rows, st_m, s_m);
+    if (scales) stage_rows3_store(rows, st_s, s_s);
+    if (RAW) stage_rows3_store(rows, st_c, s_c);
+  }
   __syncthreads();
 
   const size_t idx = row0 + t;
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(BLK) PP_ATTR void preprocess_fwd_kernel(
       float2 a = c2[0], b = c2[1], c = c2[2];
       c6[0] = a.x; c6[1] = a.y; c6[2] = b.x; c6[3] = b.y; c6[4] = c.x; c6[5] = c.y;
     } else {
-      const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
+      const float4 q = q_pre;
       float s[3] = {s_s[3 * t], s_s[3 * t + 1], s_s[3 * t + 2]};
       float qq[4] = {q.x, q.y, q.z, q.w};
       if (RAW) raw_activate(s, qq);
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(BLK) PP_ATTR void preprocess_fwd_kernel(
         radius = r;
         const float d = (float)(200.0 - (double)pv[2]);  // forward.cu:267
         if (d < 0) my_err = 0x80000000u;  // altitude > 200: reported through the workgroup's partials (no zero-initialised word)
-        const float op_in = RAW ? sigmoidf(opacities[idx]) : opacities[idx];
+        const float op_in = RAW ? sigmoidf(op_pre) : op_pre;
         const float ca = cz * det_inv, cb = -cy * det_inv, cc = cx * det_inv, op = op_in * hcs;
         op64 = (uint32_t)(fminf(fmaxf(op, 0.f), 1.f) * 64.f + 0.5f);  // (NaN -> 0)
         // Internal SUBX x SUBY tiles: the reference's 16-px tile rect clipped to the image, intersected with the
