@@ -178,7 +178,14 @@ __device__ inline Peek peek_cand(uint32_t k, uint32_t end, const uint32_t* __res
   p.e = make_uint2(0u, 0u);
   if (k < end) {
     p.key = MACRO > 1 ? keys[k] : 1u;  // block size 1: every entry of the tile's own list is a hit
-    p.e = point_list[k];
+    // (two 4-byte loads, not one 8-byte load: the gather extends e.x to a 64-bit offset in the register PAIR the 8-byte load
+    // wrote, so the compiler moved e.y out of that pair right behind the load — a use, hence an s_waitcnt there, which with the
+    // in-order counter also waits for the next chunk's three gather loads issued just before: a memory round trip per chunk in
+    // the block-list kernels, found in the ISA)
+    const uint32_t* pl = reinterpret_cast<const uint32_t*>(point_list + k);
+    p.e.x = pl[0];
+    asm volatile("" ::: "memory");  // (keeps the two loads apart: merged again they are the 8-byte load)
+    p.e.y = pl[1];
   }
   return p;
 }
