@@ -84,6 +84,7 @@ SIGNATURES = {
     ),
     "eogs_rast_mark_visible": (_i, [_i, _p, _p, _p, _p, _p]),
     "eogs_rast_path_info": (_i, [_i, _i64, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    "eogs_rast_backward_info": (_i, [_i, _i64, C.POINTER(_i)]),
     "eogs_rast_profile_enable": (_i, [_i]),
     "eogs_rast_profile_select": (_i, [_u]),
     "eogs_rast_profile_reset": (_i, []),
@@ -184,6 +185,12 @@ class RastABI:
         b, f, w = _i(), _i(), _i()
         self.check(self.cdll.eogs_rast_path_info(int(P), int(num_rendered), C.byref(b), C.byref(f), C.byref(w)))
         return b.value, f.value, w.value
+
+    def backward_info(self, P, num_rendered):
+        """Which build of the per-Gaussian backward kernel a backward of this token would launch now (include/eogs_rast.h)."""
+        w = _i()
+        self.check(self.cdll.eogs_rast_backward_info(int(P), int(num_rendered), C.byref(w)))
+        return w.value
 
     def profile_slot_names(self):
         names = []

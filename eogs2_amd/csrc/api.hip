@@ -585,6 +585,12 @@ int eogs_rast_path_info(int P, int64_t R, int* list_block_px, int* fwd_kernel, i
   return EOGS_OK;
 }
 
+int eogs_rast_backward_info(int P, int64_t R, int* gaussian_bwd_wide_out) {
+  if (P < 0 || R < 0 || !gaussian_bwd_wide_out) return fail(EOGS_ERR_INVALID_ARG, "backward_info: bad argument");
+  *gaussian_bwd_wide_out = R > 0 ? gaussian_bwd_wide(R, P, hint_list_depth(R, P)) : 0;
+  return EOGS_OK;
+}
+
 // checkFrustum's predicate has its culling commented out (DGR/cuda_rasterizer/auxiliary.h:151-176): all visible.
 int eogs_rast_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                            uint8_t* present, void* stream) {

@@ -266,6 +266,11 @@ int eogs_rast_profile_get(int slot, double* total_ms, int64_t* launches, const c
  *                              (DGR/cuda_rasterizer/backward.cu:536-643), chosen for image-sized Gaussians
  * The oracle reports 16 / -1 / -1 (the reference's 16-px tiles, no kernel variants). */
 int eogs_rast_path_info(int P, int64_t num_rendered, int* list_block_px, int* fwd_kernel, int* bwd_kernel);
+/* Which build of the per-Gaussian backward kernel eogs_rast_backward would launch for this token right now: 0 = four records
+ * in flight per lane (seven waves per SIMD), 1 / 2 = eight (four waves; 2: up to eight listed tiles in one trip). It depends on
+ * the token AND on the per-process hint kept beside it (the forward's list depth x mean pair opacity, see forward_prepare):
+ * unknown or deep in opacity -> 0. All three compute the same bits; tests use this to see the hint travel. The oracle reports -1. */
+int eogs_rast_backward_info(int P, int64_t num_rendered, int* gaussian_bwd_wide);
 /* Runs the library's wave64 primitive self-test (DPP reduction, readlane broadcast) on `stream` and returns,
  * after synchronising, a bit mask of failing primitives in *failed (0 = all good). scratch: >= 4 device bytes. */
 int eogs_rast_selftest(void* scratch, unsigned* failed, void* stream);

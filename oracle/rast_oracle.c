@@ -1128,6 +1128,13 @@ int eogs_rast_path_info(int P, int64_t num_rendered, int* list_block_px, int* fw
   return EOGS_OK;
 }
 
+int eogs_rast_backward_info(int P, int64_t num_rendered, int* gaussian_bwd_wide) {  /* (no kernel builds here: -1) */
+  (void)P; (void)num_rendered;
+  if (!gaussian_bwd_wide) return fail(EOGS_ERR_INVALID_ARG, "backward_info: bad argument");
+  *gaussian_bwd_wide = -1;
+  return EOGS_OK;
+}
+
 /* checkFrustum (rasterizer_impl.cu:54-66): in_frustum's culling is commented out and the function
  * falls off its end (auxiliary.h:151-176); the intended value is "visible". */
 int eogs_rast_mark_visible(int P, const float* means3D, const float* viewmatrix,

@@ -70,3 +70,44 @@ def test_round5_fast_paths_change_no_bit(tmp_path, P, H, W, opacity, invdepth):
         for k in off:
             d = off[k] != got[k]  # (numpy: -0.0 == 0.0; a NaN would differ from itself and fail here as it should)
             assert not d.any(), f"{name}: {k} differs in {int(d.sum())} of {d.size} elements from the run with the fast paths off"
+
+
+def test_backward_kernel_hint_travels_with_the_token():
+    """The per-Gaussian backward has a narrow and two wide builds (csrc/preprocess.hip gaussian_bwd_wide); which one a backward
+    launches depends on the forward's list depth x mean pair opacity, which the host learns with the counts and keeps PER TOKEN
+    beside the token (include/eogs_rast.h, forward_prepare). Shallow scene -> a wide build; saturating scene -> the narrow
+    one; a capacity token counted on a forward inherits that forward's hint; a token the library never built -> narrow."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import ctypes
+
+    from eogs2_amd import GaussianRasterizer, _lib
+    from eogs2_amd.rasterizer import last_exact_token
+    from eogs2_amd.synthetic import make_camera, make_scene, settings_for
+
+    if os.environ.get("EOGS_GB_WIDE") is not None:
+        pytest.skip("EOGS_GB_WIDE forces one build")
+    abi = _lib.get()
+    dev = torch.device("cuda:0")
+    P, H, W = 200_000, 256, 256  # (trained opacities: ~2000 listed pairs per tile x a mean opacity of ~0.5, far beyond the switch at 256)
+
+    def token_of(opacity):
+        sc = make_scene(P, H, W, seed=3, opacity=opacity, device=dev)
+        sc["viewmatrix"] = make_camera(H, W, seed=3, device=dev)
+        rast = GaussianRasterizer(settings_for(sc, H, W))
+        with torch.no_grad():
+            rast(sc["means3D"], torch.zeros(P, 3, device=dev), sc["opacities"], colors_precomp=sc["colors"], scales=sc["scales"],
+                 rotations=sc["rotations"])
+        torch.cuda.synchronize()
+        return int(last_exact_token(dev))
+
+    shallow, deep = token_of("init"), token_of("trained")
+    assert shallow > 0 and deep > 0
+    assert abi.backward_info(P, shallow) in (1, 2)
+    assert abi.backward_info(P, deep) == 0
+    cap = ctypes.c_int64()
+    abi.check(abi.capacity_token(P, shallow, 0.25, 1, shallow, ctypes.byref(cap), None))
+    assert cap.value != shallow and abi.backward_info(P, cap.value) == abi.backward_info(P, shallow)
+    abi.check(abi.capacity_token(P, deep, 0.25, 1, deep, ctypes.byref(cap), None))
+    assert abi.backward_info(P, cap.value) == 0
+    assert abi.backward_info(P, shallow + 12345) == 0  # not a token the library built: no hint, the narrow build
