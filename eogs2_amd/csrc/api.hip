@@ -298,14 +298,15 @@ int token_from_counts(const uint32_t* m, int P, int H, int W, bool have_scratch,
   const double list_depth = (double)opw / 64.0 / ntiles8;  // = L * mean pair opacity
   const bool by_footprint = (double)total > block_switch * (double)P;
   const bool by_depth = depth_switch > 0.0 && list_depth > depth_switch && total >= 2 * entries;  // blocks must merge entries
-  // Gaussians that list a tenth of the image's tiles each (sigma of hundreds of pixels on a small image: outside the reference's
-  // operating range — the bench's regimes sit at 0.0002 ... 0.0014 — inside the parity sweeps'): lists hundreds deep under a
-  // few opaque front Gaussians. There the front-to-back form
+  // Gaussians that list 2 % or more of the image's tiles each (sigma of tens to hundreds of pixels on a small image: outside the
+  // reference's operating range — the bench's regimes sit at 0.0002 ... 0.0014 — inside the parity sweeps'): lists hundreds
+  // deep under a few opaque front Gaussians. (Rounds 3-5 switched at a tenth; a fifth sweep range found two cases at 0.026 and
+  // 0.089 that only the back-to-front form holds: profiles/r05_sweeps.txt.) There the front-to-back form
   // of dL/dalpha (render.hip) loses what the reference's back-to-front recursion keeps; such forwards take
   // per-tile lists and the back-to-front backward, which is the reference's arithmetic (bit 60 of the token).
   static const double btf_switch = [] {  // EOGS_BTF_SWITCH=<fraction of the image's tiles a Gaussian lists on average>; 0 = never
     const char* e = getenv("EOGS_BTF_SWITCH");
-    return e ? atof(e) : 0.1;
+    return e ? atof(e) : 0.02;
   }();
   // (an altitude-only forward — EOGS_FLAG_ALT_ONLY — runs the quad kernels' one-channel variants: per-tile lists, front to back)
   const bool btf = !alt && P > 0 && btf_switch > 0.0 && (double)total >= btf_switch * (double)P * ntiles8;

@@ -406,7 +406,7 @@ static inline int ceil_log2_u32(uint32_t n) {  // smallest b with (1<<b) >= n
 // entries were sorted in the caller's scratch by forward_prepare, bit 62 = the render kernels read block lists
 // (BLOCK_BIG) instead of per-tile lists, bit 31 = a block holds 2800 ... 6000 entries on average (block_lists_kernel's
 // 8-item build; a property of the forward the token was counted on, carried over into capacity tokens), bit 60 = the
-// Gaussians list a tenth of the image's tiles each on average: per-tile lists and the back-to-front backward
+// Gaussians list 2 % of the image's tiles or more each on average: per-tile lists and the back-to-front backward
 // (render_bwd_btf_kernel).
 static inline uint32_t nr_slots(int64_t R) { return (uint32_t)((uint64_t)R & 0x7FFFFFFFull); }
 static inline uint32_t nr_entries(int64_t R) { return (uint32_t)(((uint64_t)R >> 32) & 0x07FFFFFFull); }
