@@ -6,7 +6,7 @@ exports the same symbols over host pointers.
 """
 import ctypes as C
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 EOGS_OK = 0
 ERR_NAMES = {

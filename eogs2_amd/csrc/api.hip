@@ -20,29 +20,6 @@ thread_local PendingCounts g_pending_counts = {false, 0, 0, 0, false, 0u, nullpt
 // the side stream of a count copy into g_pinned that nobody has waited for yet (a deferred forward whose counts were never
 // asked for): the next forward_prepare drains it before it arms g_pinned again, or the old copy would land as the new counts
 thread_local hipStream_t g_copy_in_flight = nullptr;
-// What the host knew about a forward when it built the token from the forward's counts, and what the token has no bit left
-// for: how deep its lists are in opacity (list depth x mean pair opacity, token_from_counts — beyond ~60 a tile's pixels
-// saturate before its list ends). The backward of that token picks its per-Gaussian kernel by it (gaussian_bwd_wide: occupancy
-// against loads in flight; every choice computes the same bits). Process-wide, not per thread: autograd runs the backward on a
-// thread of its own. A backward whose token is not here launches the kernel that does not need to know; a capacity token
-// inherits the hint of the forward it was counted on.
-struct FwdHint { int64_t token; int P; float list_depth; };
-std::mutex g_hint_mu;
-FwdHint g_hints[16];
-unsigned g_hint_next = 0;
-void hint_put(int64_t token, int P, float list_depth) {
-  if (token == 0) return;
-  std::lock_guard<std::mutex> lk(g_hint_mu);
-  for (auto& h : g_hints)
-    if (h.token == token && h.P == P) { h.list_depth = list_depth; return; }
-  g_hints[g_hint_next++ % 16u] = FwdHint{token, P, list_depth};
-}
-float hint_list_depth(int64_t token, int P) {  // < 0: unknown
-  std::lock_guard<std::mutex> lk(g_hint_mu);
-  for (const auto& h : g_hints)
-    if (h.token == token && h.P == P) return h.list_depth;
-  return -1.f;
-}
 #define MIRROR_PENDING 0xFFFFFFFFu  // sentinel of a count word that has not arrived (never a legitimate high word of a count below 2^31)
 
 // per calling thread and device: a non-blocking side stream + event for the num_rendered readback
@@ -298,19 +275,8 @@ int token_from_counts(const uint32_t* m, int P, int H, int W, bool have_scratch,
   const double list_depth = (double)opw / 64.0 / ntiles8;  // = L * mean pair opacity
   const bool by_footprint = (double)total > block_switch * (double)P;
   const bool by_depth = depth_switch > 0.0 && list_depth > depth_switch && total >= 2 * entries;  // blocks must merge entries
-  // Gaussians that list 2 % or more of the image's tiles each (sigma of tens to hundreds of pixels on a small image: outside the
-  // reference's operating range — the bench's regimes sit at 0.0002 ... 0.0014 — inside the parity sweeps'): lists hundreds
-  // deep under a few opaque front Gaussians. (Rounds 3-5 switched at a tenth; a fifth sweep range found two cases at 0.026 and
-  // 0.089 that only the back-to-front form holds: profiles/r05_sweeps.txt.) There the front-to-back form
-  // of dL/dalpha (render.hip) loses what the reference's back-to-front recursion keeps; such forwards take
-  // per-tile lists and the back-to-front backward, which is the reference's arithmetic (bit 60 of the token).
-  static const double btf_switch = [] {  // EOGS_BTF_SWITCH=<fraction of the image's tiles a Gaussian lists on average>; 0 = never
-    const char* e = getenv("EOGS_BTF_SWITCH");
-    return e ? atof(e) : 0.02;
-  }();
-  // (an altitude-only forward — EOGS_FLAG_ALT_ONLY — runs the quad kernels' one-channel variants: per-tile lists, front to back)
-  const bool btf = !alt && P > 0 && btf_switch > 0.0 && (double)total >= btf_switch * (double)P * ntiles8;
-  const int block = (btf || alt) ? 1 : ((by_footprint || by_depth) ? BLOCK_BIG : 1);
+  // (an altitude-only forward — EOGS_FLAG_ALT_ONLY — runs the quad kernels' one-channel variants: per-tile lists)
+  const int block = alt ? 1 : ((by_footprint || by_depth) ? BLOCK_BIG : 1);
   if (m[MISC_ERR] & 1u) return fail(EOGS_ERR_ALTITUDE, "Point is too high: altitude > 200");
   if (total >= ((uint64_t)1 << 31) || entries >= ((uint64_t)1 << 27)) return fail(EOGS_ERR_OVERFLOW, "the forward lists more than the token holds: 2^31 record slots (tile, Gaussian) or 2^27 list "
                                                                                                    "entries (32-px block, Gaussian)");
@@ -319,8 +285,7 @@ int token_from_counts(const uint32_t* m, int P, int H, int W, bool have_scratch,
   // (nothing listed: the token is 0, as include/eogs_rast.h says — callers test it whole, every R > 0 shortcut applies)
   // (... except for an altitude-only forward, whose token must still say so: the render launches pick their variant by it)
   *num_rendered = (total == 0 && entries == 0 && !alt) ? 0 : nr_pack((uint32_t)total, (uint32_t)entries, block, have_scratch && entries <= (uint64_t)sort_cap,
-                          per_block > 2800.0 && per_block <= 6000.0, btf, alt);
-  hint_put(*num_rendered, P, (float)list_depth);
+                          per_block > 2800.0 && per_block <= 6000.0, list_depth <= (double)GB_WIDE_DEPTH, alt);
   return EOGS_OK;
 }
 
@@ -425,18 +390,12 @@ int eogs_rast_capacity_token(int P, int64_t num_rendered, double slack, int have
   if (ents > 0x07FFFFFFull) ents = 0x07FFFFFFull;
   // "sorted in scratch" only if every forward that fits this capacity also fits the scratch (then forward_prepare did sort)
   const int sorted = (have_scratch & 1) && ents <= (uint64_t)ent_cap(P);
-  const int alt = (have_scratch & 2) != 0 || nr_alt(num_rendered);  // (an altitude-only forward: per-tile lists, never back to front)
+  const int alt = (have_scratch & 2) != 0 || nr_alt(num_rendered);  // (an altitude-only forward: per-tile lists)
   *capacity = nr_pack((uint32_t)slots, (uint32_t)ents, alt ? 1 : nr_block(num_rendered), sorted, nr_wide(num_rendered),
-                      alt ? 0 : nr_btf(num_rendered), alt);
-  {  // (... and that forward's list-depth hint, for the backward's choice of per-Gaussian kernel: speed only)
-    const float depth = hint_list_depth(num_rendered, P);
-    if (depth >= 0.f) hint_put(*capacity, P, depth);
-  }
-  // A capacity token carries the list granularity, the 8-item build and the back-to-front choice of the EARLIER forward. The
-  // first two are speed only. The third is not quite: a forward of image-sized opaque Gaussians needs the back-to-front
-  // backward to hold 1e-4, so a forward that asks for it does not "fit" a token counted on one that did not
-  //  and is redone / recorded again with its own flags; the converse is harmless (that kernel is always right).
-  if (fits) *fits = exact >= 0 && nr_slots(exact) <= slots && nr_entries(exact) <= ents && !(nr_btf(exact) && !nr_btf(num_rendered));
+                      nr_shallow(num_rendered), alt);
+  // A capacity token carries the list granularity and the 8-item build of the EARLIER forward: speed only, every choice computes
+  // the same values (ABI 3-7 also carried a choice of backward formulation that did matter for parity; gone with ABI 8).
+  if (fits) *fits = exact >= 0 && nr_slots(exact) <= slots && nr_entries(exact) <= ents;
   return EOGS_OK;
 }
 
@@ -451,7 +410,7 @@ int eogs_rast_forward_render(int P, int H, int W, int64_t R, const float* bg, un
   if (((flags & EOGS_FLAG_ALT_ONLY) != 0) != (nr_alt(R) != 0))
     return fail(EOGS_ERR_INVALID_ARG, "forward_render: EOGS_FLAG_ALT_ONLY and the token disagree (the flag goes to forward_prepare too; "
                                       "tokens built without flags take it as have_scratch | 2)");
-  if (nr_alt(R) && (nr_block(R) > 1 || nr_btf(R))) return fail(EOGS_ERR_INVALID_ARG, "forward_render: malformed altitude-only token");
+  if (nr_alt(R) && nr_block(R) > 1) return fail(EOGS_ERR_INVALID_ARG, "forward_render: malformed altitude-only token");
   hipStream_t s = (hipStream_t)stream;
   const bool debug = flags & EOGS_FLAG_DEBUG;
   char* ibase = ws_base(image);
@@ -513,21 +472,21 @@ int eogs_rast_backward_range(int P, int H, int W, int64_t R, const float* bg, co
     return EOGS_OK;
   }
   const bool raw = (flags & EOGS_FLAG_RAW_PARAMS) != 0;
-  if (!means3D || !radii || !opacities || !viewmatrix || !projmatrix || !dL_dout_color || !out_color || !geom ||
+  if (!means3D || !radii || !opacities || !viewmatrix || !projmatrix || !dL_dout_color || !geom ||
       !image || !dL_dmeans2D || !dL_dcolors || !dL_dopacity || !dL_dmeans3D || (!raw && !colors) ||
       (cov3D_precomp && !dL_dcov3D))
     return fail(EOGS_ERR_INVALID_ARG, "backward: NULL argument");
-  if (dL_dout_invdepth && !out_invdepth) return fail(EOGS_ERR_INVALID_ARG, "backward: out_invdepth required with dL_dout_invdepth");
+  (void)out_color; (void)out_invdepth;  // (ABI <= 7 read the rendered images back; the back-to-front walk starts from final_T in the image workspace)
   const bool have_sr = scales && rotations;
   if (have_sr == (cov3D_precomp != nullptr)) return fail(EOGS_ERR_INVALID_ARG, "backward: scale/rotation xor cov3D_precomp");
   if (have_sr && (!dL_dscales || !dL_drotations)) return fail(EOGS_ERR_INVALID_ARG, "backward: NULL scale/rotation gradient");
   if (raw && (!have_sr || !alt_affine))
     return fail(EOGS_ERR_INVALID_ARG, "backward: EOGS_FLAG_RAW_PARAMS needs scales, rotations and alt_affine");
   if (R > 0 && !binning) return fail(EOGS_ERR_INVALID_ARG, "backward: NULL binning workspace");
-  if (R > 0 && nr_btf(R) && !bg) return fail(EOGS_ERR_INVALID_ARG, "backward: bg is required (back-to-front backward)");
+  if (R > 0 && !bg) return fail(EOGS_ERR_INVALID_ARG, "backward: bg is required");
   if (R > 0 && nr_alt(R) && dL_dout_invdepth)
     return fail(EOGS_ERR_INVALID_ARG, "backward: an altitude-only render (EOGS_FLAG_ALT_ONLY) has no inverse-depth output");
-  if (R > 0 && nr_alt(R) && (nr_block(R) > 1 || nr_btf(R)))
+  if (R > 0 && nr_alt(R) && nr_block(R) > 1)
     return fail(EOGS_ERR_INVALID_ARG, "backward: malformed altitude-only token");
   if (dL_dcolors_lead && (lead_cols <= 0 || lead_cols > (raw ? 3 : NCH))) return fail(EOGS_ERR_INVALID_ARG, "backward: bad lead_cols");
 
@@ -546,7 +505,7 @@ int eogs_rast_backward_range(int P, int H, int W, int64_t R, const float* bg, co
     return fail(EOGS_ERR_WORKSPACE, "backward: workspace too small");
 
   if (R > 0 && p_begin == 0) {  // the per-pixel pass covers the whole image: once, with the first range
-    { ProfScope ps(PS_RENDER_BWD, s); launch_render_bwd(g, b, im, P, H, W, R, colors, out_color, out_invdepth, dL_dout_color, dL_dout_invdepth, bg, raw, s); }
+    { ProfScope ps(PS_RENDER_BWD, s); launch_render_bwd(g, b, im, P, H, W, R, dL_dout_color, dL_dout_invdepth, bg, raw, s); }
     LAUNCH_TRY(s, debug, "render_bwd");
   }
   GaussBwdArgs a{P, H, W, means3D, have_sr ? scales : nullptr, have_sr ? rotations : nullptr, cov3D_precomp, opacities,
@@ -554,7 +513,7 @@ int eogs_rast_backward_range(int P, int H, int W, int64_t R, const float* bg, co
                  dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, have_sr ? dL_dscales : nullptr,
                  have_sr ? dL_drotations : nullptr, dL_dT_sum, dL_dvm_mean, raw, alt_affine, dL_dcolors_lead,
                  dL_dcolors_lead ? lead_cols : 0, nr_alt(R) != 0, R > 0 ? render_bwd_noflag_ok(b.block, R, P) : 0,
-                 R > 0 ? gaussian_bwd_wide(R, P, hint_list_depth(R, P)) : 0};
+                 R > 0 ? gaussian_bwd_wide(R, P) : 0};
   { ProfScope ps(PS_GAUSS_BWD, s); launch_gaussian_bwd(a, g, b, p_begin, p_end, s); }
   LAUNCH_TRY(s, debug, "gaussian_bwd");
   return EOGS_OK;
@@ -588,7 +547,7 @@ int eogs_rast_path_info(int P, int64_t R, int* list_block_px, int* fwd_kernel, i
 
 int eogs_rast_backward_info(int P, int64_t R, int* gaussian_bwd_wide_out) {
   if (P < 0 || R < 0 || !gaussian_bwd_wide_out) return fail(EOGS_ERR_INVALID_ARG, "backward_info: bad argument");
-  *gaussian_bwd_wide_out = R > 0 ? gaussian_bwd_wide(R, P, hint_list_depth(R, P)) : 0;
+  *gaussian_bwd_wide_out = R > 0 ? gaussian_bwd_wide(R, P) : 0;
   return EOGS_OK;
 }
 

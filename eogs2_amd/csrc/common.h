@@ -405,18 +405,20 @@ static inline int ceil_log2_u32(uint32_t n) {  // smallest b with (1<<b) >= n
 // forward (EOGS_FLAG_ALT_ONLY: per-tile lists, the quad kernels' one-channel variants, 32-byte gradient records), bit 61 = the
 // entries were sorted in the caller's scratch by forward_prepare, bit 62 = the render kernels read block lists
 // (BLOCK_BIG) instead of per-tile lists, bit 31 = a block holds 2800 ... 6000 entries on average (block_lists_kernel's
-// 8-item build; a property of the forward the token was counted on, carried over into capacity tokens), bit 60 = the
-// Gaussians list 2 % of the image's tiles or more each on average: per-tile lists and the back-to-front backward
-// (render_bwd_btf_kernel).
+// 8-item build; a property of the forward the token was counted on, carried over into capacity tokens), bit 60 = the forward's
+// lists are shallow in opacity (mean list length x mean pair opacity <= GB_WIDE_DEPTH: most listed pairs are live, and the
+// backward launches the build of its per-Gaussian kernel that keeps eight records in flight per lane — speed only, every build
+// computes the same bits; carried over into capacity tokens. ABI 3-7 used the bit for "the back-to-front backward": every
+// backward walks back to front since ABI 8, and the hint lived in a per-process table beside the token).
 static inline uint32_t nr_slots(int64_t R) { return (uint32_t)((uint64_t)R & 0x7FFFFFFFull); }
 static inline uint32_t nr_entries(int64_t R) { return (uint32_t)(((uint64_t)R >> 32) & 0x07FFFFFFull); }
 static inline int nr_alt(int64_t R) { return (int)(((uint64_t)R >> 59) & 1ull); }  // altitude-only forward (EOGS_FLAG_ALT_ONLY)
-static inline int nr_btf(int64_t R) { return (int)(((uint64_t)R >> 60) & 1ull); }
+static inline int nr_shallow(int64_t R) { return (int)(((uint64_t)R >> 60) & 1ull); }
 static inline int nr_sorted(int64_t R) { return (int)(((uint64_t)R >> 61) & 1ull); }
 static inline int nr_block(int64_t R) { return (((uint64_t)R >> 62) & 1ull) ? BLOCK_BIG : 1; }
 static inline int nr_wide(int64_t R) { return (int)(((uint64_t)R >> 31) & 1ull); }
-static inline int64_t nr_pack(uint32_t slots, uint32_t entries, int block, int sorted, int wide, int btf, int alt = 0) {
-  return (int64_t)(((uint64_t)(block > 1) << 62) | ((uint64_t)(sorted != 0) << 61) | ((uint64_t)(btf != 0) << 60) |
+static inline int64_t nr_pack(uint32_t slots, uint32_t entries, int block, int sorted, int wide, int shallow, int alt = 0) {
+  return (int64_t)(((uint64_t)(block > 1) << 62) | ((uint64_t)(sorted != 0) << 61) | ((uint64_t)(shallow != 0) << 60) |
                    ((uint64_t)(alt != 0) << 59) | ((uint64_t)(entries & 0x07FFFFFFu) << 32) | ((uint64_t)(wide != 0) << 31) | slots);
 }
 static inline uint32_t macro_grid_x(int W, int M) { return (uint32_t)(((W + SUBX - 1) / SUBX + M - 1) / M); }
@@ -456,8 +458,9 @@ static inline BinWS bin_layout(char* base, int H, int W, int64_t R) {
 struct ImgWS {
   uint2* ranges;       // per block (M x M internal tiles, M chosen per forward) [start,end) into point_list
   float* final_T;      // transmittance after the last blended Gaussian
-  uint32_t* n_contrib; // list entries at positions >= this take no part at the pixel: 1 + the index of its last blended entry
-                       // (tile / block forward kernels) or the index of its stop entry, 0xFFFFFFFF if it never stopped (quad forward)
+  uint32_t* n_contrib; // entries at positions >= this — positions in the list the render wave walks: the tile's, or its block's —
+                       // take no part at the pixel: 1 + the position of its last blended entry (tile / block forward kernels)
+                       // or the position of its stop entry, 0xFFFFFFFF if it never stopped (quad forward)
   uint4* desc;         // one descriptor per dispatched render workgroup (nullptr without a tile schedule): XCD x's i-th workgroup
                        // reads desc[x * 16 sched_lg + i] = {tile tx | ty << 16 (0xFFFFFFFF: outside the image), list begin, list end, -},
                        // written by block_lists_kernel at its block's place in the schedule (GeomWS::where)
@@ -517,12 +520,11 @@ void launch_block_lists(const GeomWS& g, const SortWS& w, const BinWS& b, const 
                         hipStream_t s);
 void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R,
                        const float* bg, float* out_color, float* out_invdepth, hipStream_t s);
-void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, const float* colors,
-                       const float* out_color, const float* out_invdepth, const float* dL_dcolor,
-                       const float* dL_dinvdepth, const float* bg, bool raw, hipStream_t s);
+void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R,
+                       const float* dL_dcolor, const float* dL_dinvdepth, const float* bg, bool raw, hipStream_t s);
 // which render kernel a forward / backward runs: 0 = one list per tile, 1 = block lists, 2 = quad sub-lists (render.hip)
 int render_fwd_variant(int block, int64_t R, int P);
-int render_bwd_variant(int block, int64_t R, int P);  // 0 tile, 1 block, 2 quad, 3 / 4 MFMA experiments, 5 back to front
+int render_bwd_variant(int block, int64_t R, int P);  // 0 tile, 1 block, 2 quad, 6 quad of an altitude-only render
 int render_bwd_noflag_ok(int block, int64_t R, int P);  // that backward writes flag-free records: 0 no, 1 where noflag_scene() holds, 3 always
 struct GaussBwdArgs {
   int P, H, W;
@@ -540,9 +542,10 @@ struct GaussBwdArgs {
   int noflag_ok;           // render_bwd_noflag_ok(): the records are flag-free (bit 0) where the scene allows / always (bit 1)
   int wide;                // records in flight per lane: gaussian_bwd_kernel's WIDE (0, 1, 2), gaussian_bwd_wide()
 };
-// Which gaussian_bwd_kernel variant a backward of (R, P) launches. list_depth: the forward's mean list length x mean pair
-// opacity (token_from_counts), < 0 = not known on the host (a token that was not built from counts). EOGS_GB_WIDE=0|1|2 forces one.
-int gaussian_bwd_wide(int64_t R, int P, float list_depth);
+// Which gaussian_bwd_kernel variant a backward of (R, P) launches (token bit 60: the forward's lists are shallow in opacity).
+// EOGS_GB_WIDE=0|1|2 forces one.
+#define GB_WIDE_DEPTH 256.0f
+int gaussian_bwd_wide(int64_t R, int P);
 // per-Gaussian backward over rows [p_begin, p_end) (p_begin a multiple of BLK); the camera sums are finished by the call
 // whose p_end == P
 void launch_gaussian_bwd(const GaussBwdArgs& a, const GeomWS& g, const BinWS& b, int p_begin, int p_end, hipStream_t s);

@@ -813,14 +813,13 @@ __global__ __launch_bounds__(BLK) void camera_sum_kernel(const float* __restrict
 // (1 M / 2 M Gaussians at 1024^2, gaussian_bwd ms narrow / wide by list depth x mean pair opacity): 80: 0.212 / 0.188,
 // 120: 0.118 / 0.101, 195: 0.093 / 0.086, 350: 0.078 / 0.080, trained 1 M: 0.075 / 0.078, trained 2 M: 0.105 / 0.120
 // (profiles/r05_ab_gaussian_bwd_wide.txt). A host that does not know the depth keeps the narrow kernel.
-#define GB_WIDE_DEPTH 256.0f
-int gaussian_bwd_wide(int64_t R, int P, float list_depth) {
+int gaussian_bwd_wide(int64_t R, int P) {
   static const int forced = [] {
     const char* e = getenv("EOGS_GB_WIDE");
     return e ? atoi(e) : -1;
   }();
   if (forced >= 0) return forced > 2 ? 2 : forced;
-  if (list_depth < 0.f || list_depth > GB_WIDE_DEPTH || P <= 0) return 0;
+  if (!nr_shallow(R) || P <= 0) return 0;
   return (double)nr_slots(R) >= 6.0 * (double)P ? 2 : 1;
 }
 

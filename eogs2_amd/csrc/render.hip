@@ -19,12 +19,16 @@
 //
 // Forward semantics: DGR/cuda_rasterizer/forward.cu:288-411.
 // Backward semantics: DGR/cuda_rasterizer/backward.cu:457-643, restructured:
-//   * traversal is FRONT-TO-BACK like the forward (no T /= (1-alpha) division chain). With
-//       D_final = sum_ch g_ch * out_ch (+ g_inv * out_invdepth)   [contains the T_final * bg.g term]
-//       D_j     = sum_{k<=j} (g . c_k) alpha_k T_k
-//     the reference's dL/dalpha_j = T_j (g.c_j - g.accum_rec_j) - T_final/(1-alpha_j) bg.g   (:586-620)
-//     equals  T_j (g.c_j) - (D_final - D_j) / (1 - alpha_j): one dot product per pair instead of a
-//     5-channel recurrence.
+//   * traversal is BACK TO FRONT like the reference's (:536-643): last contributor first, T recovered from the forward's final
+//     transmittance by T_j = T_{j+1} / (1 - alpha_j) (:573), the background term from T_final (:617-620). The colour behind a
+//     Gaussian — the reference's five-channel accum_rec recursion (:586-599) — is carried as ONE number per pixel, its projection
+//     on the pixel's upstream gradient g (a constant of the pixel):
+//       a_j = g . accum_rec_j,   a_j = a_{j+1} + alpha_{j+1} (g.c_{j+1} - a_{j+1}),   a_last = 0
+//       dL/dalpha_j = T_j (g.c_j - a_j) - T_final / (1 - alpha_j) (bg . g)
+//     — the same recursion, term for term, at one dot product, one reciprocal and six multiply-adds per pair. (Rounds 1-5 walked
+//     front to back and took the sum behind a Gaussian as "rendered total minus running prefix": the same instruction count, but
+//     an absolute error of an ulp of the TOTAL in a quantity that, deep under opaque Gaussians, is orders of magnitude smaller;
+//     forwards of image-sized Gaussians had to be switched to a second, slower kernel by a tuned threshold. DESIGN.md 5.)
 //   * the 12 atomicAdd per contributing (pixel,Gaussian) of the reference (:598-640) are replaced by a
 //     transposition through LDS: the pixel-parallel pass only produces two numbers per (pixel, Gaussian),
 //     u = alpha T and v = G dL/dalpha; every 8 surviving Gaussians the wave switches to lanes = (Gaussian,
@@ -192,7 +196,7 @@ __device__ inline Peek peek_cand(uint32_t k, uint32_t end, const uint32_t* __res
 // The quad backward's peek on per-tile lists: the entry's in-range flag (bit 4) and, where the quad FORWARD walked the chunk, the 4-bit
 // quad mask it left in `qmask` (BinWS::qmask) — the backward's chunk set-up then needs no quad_mask() of its own (four block_hit
 // tests, a v_log and two v_rcp per entry: half of the set-up's instructions).
-__device__ inline Peek peek_cand_q(uint32_t k, uint32_t end, const uint8_t* __restrict__ qmask, const uint2* __restrict__ point_list) {
+__device__ inline Peek peek_cand_q(uint32_t k, uint32_t begin, uint32_t end, const uint8_t* __restrict__ qmask, const uint2* __restrict__ point_list) {
   // (The loaded byte is NOT combined with the flag here: `0x10 | qmask[k]` is a use, and the compiler waits for the load on the
   // spot — s_waitcnt vmcnt(0), which also waits for the three record loads of the next chunk's gather issued just before it: one
   // full memory round trip per chunk in the middle of the chunk set-up, found in the ISA (render_bwd -2.9 % without it). The
@@ -202,7 +206,7 @@ __device__ inline Peek peek_cand_q(uint32_t k, uint32_t end, const uint8_t* __re
   p.key = 0u;
   p.qraw = 0u;
   p.e = make_uint2(0u, 0u);
-  if (k < end) {
+  if (k >= begin && k < end) {  // (the backward walks from the list's end: an index may also fall in front of the list)
     p.key = 0x10u;
     if (qmask) p.qraw = (uint32_t)qmask[k];
     p.e = point_list[k];
@@ -267,11 +271,13 @@ __global__ __launch_bounds__(RBLK) void render_fwd_kernel(
     float* __restrict__ final_T, uint32_t* __restrict__ n_contrib, float* __restrict__ out_color,
     float* __restrict__ out_invdepth, int opts) {
   __shared__ __attribute__((aligned(16))) float s_slab[RBLK / 64][FWD_CAP * ENT];
+  __shared__ uint32_t s_pos[RBLK / 64][FWD_CAP];  // list position of every slab entry (what n_contrib counts)
   const int lane = threadIdx.x & 63;
   uint2 range = make_uint2(0u, 0u);
   const int tile = tile_of_wave(desc, sched, lg16, gsx, range);
   if (tile >= ntiles) return;  // wave-uniform; waves never synchronise with each other
   float* slab = s_slab[RBLK == 64 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+  uint32_t* spos = s_pos[RBLK == 64 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
   const int px = (tile % gsx) * SUBX + (lane & 7), py = (tile / gsx) * SUBY + (lane >> 3);
   const bool inside = px < W && py < H;
   const uint32_t pix_id = (uint32_t)py * (uint32_t)W + (uint32_t)px;
@@ -286,13 +292,16 @@ __global__ __launch_bounds__(RBLK) void render_fwd_kernel(
   float invd = 0.f;
   bool done = !inside;
 
-  uint32_t jbase = 0;  // entries of THIS tile processed so far: list positions are counted over the tile's own entries
+  // What this kernel leaves in n_contrib: 1 + the position, IN THE LIST THE WAVE WALKS (the tile's own list, or its block's list
+  // with the other tiles' entries in between), of the pixel's last blended entry; 0 = none. The backward of the same list
+  // granularity reads it as "entries at positions >= n_contrib take no part" and starts its back-to-front walk there.
   int fill = 0;        // entries waiting in the slab
   Cand nxt = gather_cand<MACRO>(peek_cand<MACRO>(range.x + lane, range.y, keys, point_list), sub, packed);
   Peek pk = peek_cand<MACRO>(range.x + 64 + lane, range.y, keys, point_list);
   for (uint32_t c0 = range.x; c0 < range.y; c0 += 64) {
     wave_lds_sync();  // previous chunk's reads are done
-    fill += park(slab, nullptr, lane, nxt, fill);
+    nxt.slot = c0 - range.x + (uint32_t)lane;  // (the forward has no use for the record slot: the entry's list position travels in its place)
+    fill += park(slab, spos, lane, nxt, fill);
     nxt = gather_cand<MACRO>(pk, sub, packed);                                  // chunk c0+64: in flight during this chunk
     pk = peek_cand<MACRO>(c0 + 128 + lane, range.y, keys, point_list);  // chunk c0+128
     wave_lds_sync();
@@ -334,8 +343,7 @@ __global__ __launch_bounds__(RBLK) void render_fwd_kernel(
       blend(eb, j + 1);
     }
     if (j < n) blend(ea, j);
-    if (last_pos >= 0) last_contributor = jbase + (uint32_t)last_pos + 1u;
-    jbase += (uint32_t)n;
+    if (last_pos >= 0) last_contributor = spos[last_pos] + 1u;
   }
   if (inside) {
     const size_t HW = (size_t)H * W;
@@ -774,14 +782,25 @@ __device__ inline void transpose_round(int nsurv, int lane, const float* rb, con
 
 }  // namespace
 
+// A peek for the back-to-front walks: chunks are taken from the list's end, so an index may also fall in front of the list.
+template <int MACRO>
+__device__ inline Peek peek_cand_r(uint32_t k, uint32_t begin, uint32_t end, const uint32_t* __restrict__ keys,
+                                   const uint2* __restrict__ point_list) {
+  return peek_cand<MACRO>(k >= begin ? k : 0xFFFFFFFFu, end, keys, point_list);
+}
+
 // HAVE_INV: an upstream gradient of the inverse-depth image exists (the reference always materialises a zero one,
 // renderer.py:101 never consumes invdepths; here the common case compiles the term away).
+// One list per tile (MACRO = 1) or per 32 x 32-px block (MACRO = BLOCK_BIG: the wave keeps the entries whose sub-mask lists its
+// tile). Back to front (file header): the walk starts at the chunk that holds the tile's last contributor — n_contrib counts
+// positions of the list the wave walks, render_fwd_kernel — and every eight surviving entries are transposed (transpose_round);
+// a round may span chunks.
 template <int MACRO, bool HAVE_INV>
 __global__ __launch_bounds__(RBLK) void render_bwd_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx, const uint4* __restrict__ desc, const uint32_t* __restrict__ sched, int lg16,
-    const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib,
-    const float* __restrict__ out_color, const float* __restrict__ out_invdepth, const float* __restrict__ dL_dpix,
-    const float* __restrict__ dL_dinv, float* __restrict__ records, uint8_t* __restrict__ live_flag, uint32_t rec_plane) {
+    const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib, const float* __restrict__ final_T,
+    const float* __restrict__ bg, const float* __restrict__ dL_dpix, const float* __restrict__ dL_dinv,
+    float* __restrict__ records, uint8_t* __restrict__ live_flag, uint32_t rec_plane) {
   __shared__ __attribute__((aligned(16))) float s_slab[RBLK / 64][64 * ENT];
   __shared__ __attribute__((aligned(16))) float s_round[RBLK / 64][KSURV * 8];
   // u and v matrices of a wave sit UV_PITCH floats (a multiple of 64 dwords) apart: one ds_write2st64_b32 stores both
@@ -808,162 +827,6 @@ __global__ __launch_bounds__(RBLK) void render_bwd_kernel(
   if (desc == nullptr) range = ranges[(fty / MACRO) * gmx + ftx / MACRO];  // the macro block's list
   const uint32_t sub = (uint32_t)((fty % MACRO) * MACRO + ftx % MACRO);
   const size_t HW = (size_t)H * W;
-  constexpr bool have_inv = HAVE_INV;
-
-  float g[NCH] = {0.f, 0.f, 0.f, 0.f, 0.f};
-  float ginv = 0.f, Dfinal = 0.f;
-  uint32_t ncontrib = 0;
-  if (inside) {
-    ncontrib = n_contrib[pix_id];
-#pragma unroll
-    for (int ch = 0; ch < NCH; ch++) {
-      g[ch] = dL_dpix[ch * HW + pix_id];
-      Dfinal += g[ch] * out_color[ch * HW + pix_id];
-    }
-    if (have_inv) {
-      ginv = dL_dinv[pix_id];
-      Dfinal += ginv * out_invdepth[pix_id];
-    }
-  }
-  {  // pixel gradients for the transposition rounds: 8 floats per pixel, each pixel row offset by 4 more floats
-    float* d = spix + lane * 8 + 4 * (lane >> 3);
-    *reinterpret_cast<float4*>(d) = make_float4(g[0], g[1], g[2], g[3]);
-    d[4] = g[4];
-  }
-  // list entries past the last contributor of every pixel of the tile receive no gradient
-  const uint32_t tile_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(ncontrib));
-  const float kx = LN2 * 0.5f * W, ky = LN2 * 0.5f * H;  // d(pixel)/d(ndc) times the ln2 of the log2-domain conic
-  const float bx0 = (float)tx0, by0 = (float)ty0;
-  float T = 1.0f, Dacc = 0.f;
-  float* const uvlane = su + uv_index(0, lane);
-
-  // the block's list is only walked until this tile's last contributor has been seen: entries behind it are dead
-  // (never gathered, never written). Positions count the tile's own entries, exactly as in the forward kernel.
-  uint32_t jbase = 0;  // entries of this tile already processed
-  int k = 0, kstashed = 0;      // survivors waiting in the current transposition round (rounds span chunks), and how many
-                                // of them already have their geometry in the round buffer
-  unsigned long long kj = 0ull;  // slab positions of the survivors not yet stashed, 8 bits each
-  Cand nxt = gather_cand<MACRO>(peek_cand<MACRO>(range.x + lane, range.y, keys, point_list), sub, packed);
-  Peek pk = peek_cand<MACRO>(range.x + 64 + lane, range.y, keys, point_list);
-  for (uint32_t c0 = range.x; c0 < range.y && jbase < tile_last; c0 += 64) {
-    wave_lds_sync();
-    const int jn = park(slab, sslot, lane, nxt, 0);
-    nxt = gather_cand<MACRO>(pk, sub, packed);
-    pk = peek_cand<MACRO>(c0 + 128 + lane, range.y, keys, point_list);
-    wave_lds_sync();
-    if (jn == 0) continue;
-    // survivors [from, to) of the current round live in this chunk's slab: lane i copies survivor i's geometry and
-    // record slot into the round buffer (the slab is overwritten by the next chunk, the round may outlive it)
-    auto stash = [&](int from, int to) {
-      if (lane >= from && lane < to) {
-        const uint32_t jk = (uint32_t)(kj >> (8 * lane)) & 63u;
-        const float4 a = *reinterpret_cast<const float4*>(slab + jk * ENT);
-        const float2 b = *reinterpret_cast<const float2*>(slab + jk * ENT + 4);
-        *reinterpret_cast<float4*>(rb + lane * 8) = a;
-        *reinterpret_cast<float4*>(rb + lane * 8 + 4) = make_float4(b.x, b.y, __uint_as_float(sslot[jk]), 0.f);
-      }
-    };
-    const int nc_rel = (int)min(ncontrib - min(ncontrib, jbase), 64u);  // contributing list positions, chunk-relative
-    auto grad = [&](const Ent& e, int j) {
-      const float dx = e.q0.x - pxf, dy = e.q0.y - pyf;
-      const float p = power_of(e, dx, dy);
-      const float G = __builtin_amdgcn_exp2f(p);
-      const float alpha = fminf(e.q1.y * G, 0.99f);
-      const bool valid = (j < nc_rel) && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);
-      // wave-uniform skip: this entry reaches no pixel of the tile (`valid` is an AND of three compare masks: its ballot is
-      // that mask, no v_cndmask + v_cmp as for a general boolean)
-      if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;
-
-      float gc = g[0] * e.q1.z + g[1] * e.q1.w + g[2] * e.q2.x + g[3] * e.q2.y + g[4] * e.q2.z;
-      if (have_inv) gc += ginv * e.q2.w;
-      else asm volatile("" :: "v"(e.q2.w));  // (keeps the entry's third read a ds_read_b128: see render_bwd_quad_kernel's grad)
-      // pixels that skip this Gaussian behave as alpha = 0, G = 0 (selects, not multiplications: exp2 may have
-      // overflowed there): wgt = 0, T unchanged, v = 0. No zeroing when alpha was clamped (backward.cu:624).
-      const float a_eff = valid ? alpha : 0.f;
-      const float G_eff = valid ? G : 0.f;
-      const float wgt = a_eff * T;
-      Dacc += gc * wgt;
-      const float one_m = 1.f - a_eff;
-      const float dLda = T * gc - (Dfinal - Dacc) * __builtin_amdgcn_rcpf(one_m);
-      T = T * one_m;
-      float* const uv = uvlane + k * UV_ROW;  // = su + uv_index(k, lane); k is wave-uniform
-      uv[0] = wgt;
-      uv[UV_PITCH] = G_eff * dLda;  // v = G dL/dalpha
-      kj |= (unsigned long long)j << (8 * k);
-      if (++k == KSURV) {
-        stash(kstashed, KSURV);
-        wave_lds_sync();
-        transpose_round(KSURV, lane, rb, su, sv, spix, bx0, by0, kx, ky, records, live_flag, rec_plane);
-        wave_lds_sync();
-        k = 0;
-        kstashed = 0;
-        kj = 0ull;
-      }
-    };
-    Ent ea = fetch(slab, 0);
-    int j = 0;
-    for (; j + 1 < jn; j += 2) {
-      const Ent eb = fetch(slab, j + 1);
-      grad(ea, j);
-      ea = fetch(slab, j + 2 < jn ? j + 2 : j + 1);
-      grad(eb, j + 1);
-    }
-    if (j < jn) grad(ea, j);
-    jbase += (uint32_t)jn;
-    if (k > kstashed) {  // survivors waiting for the next chunk: keep what the round needs of them
-      stash(kstashed, k);
-      kstashed = k;
-    }
-  }
-  if (k) {  // the last, partial round
-    wave_lds_sync();
-    transpose_round(k, lane, rb, su, sv, spix, bx0, by0, kx, ky, records, live_flag, rec_plane);
-  }
-}
-
-
-
-// ------------------------------------------------------------------------------------------------------
-// Backward, back to front: the reference's own recursion (DGR/cuda_rasterizer/backward.cu:536-643), per-tile lists
-// ------------------------------------------------------------------------------------------------------
-// render_bwd_kernel / render_bwd_quad_kernel walk the list front to back and take the sum behind a Gaussian as "rendered total
-// minus running prefix": one dot product per pair, no division chain — and an absolute error of an ulp of the TOTAL in a
-// quantity that, hundreds of entries deep under opaque Gaussians, is orders of magnitude smaller. When the
-// Gaussians list a tenth of the image each (token bit 60) the lists are exactly that deep, and this kernel runs instead: last
-// contributor first, T recovered by T /= (1 - alpha) from the forward's final transmittance, the colour behind a Gaussian
-// carried as the reference's accum_rec recursion per channel, the background term from T_final. Same records, same
-// transposition rounds (the order of the entries inside a round does not enter any sum). It costs a division and ten more
-// multiply-adds per pair and is never chosen for footprints of a few tiles.
-template <bool HAVE_INV>
-__global__ __launch_bounds__(RBLK) void render_bwd_btf_kernel(
-    const uint2* __restrict__ ranges, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles,
-    const uint4* __restrict__ desc, const uint32_t* __restrict__ sched, int lg16,
-    const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib, const float* __restrict__ final_T,
-    const float* __restrict__ bg, const float* __restrict__ dL_dpix, const float* __restrict__ dL_dinv,
-    float* __restrict__ records, uint8_t* __restrict__ live_flag, uint32_t rec_plane) {
-  __shared__ __attribute__((aligned(16))) float s_slab[RBLK / 64][64 * ENT];
-  __shared__ __attribute__((aligned(16))) float s_round[RBLK / 64][KSURV * 8];
-  __shared__ __attribute__((aligned(16))) float s_uv[RBLK / 64][UV_PITCH + UV_SIZE];
-  __shared__ __attribute__((aligned(16))) float s_pix[RBLK / 64][64 * 8 + 32];
-  __shared__ uint32_t s_slot[RBLK / 64][64];
-  const int lane = threadIdx.x & 63;
-  uint2 range = make_uint2(0u, 0u);
-  const int tile = tile_of_wave(desc, sched, lg16, gsx, range);
-  if (tile >= ntiles) return;
-  const int w = RBLK == 64 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  float* slab = s_slab[w];
-  float* su = s_uv[w];
-  float* sv = s_uv[w] + UV_PITCH;
-  float* spix = s_pix[w];
-  uint32_t* sslot = s_slot[w];
-  float* rb = s_round[w];
-  const int tx0 = (tile % gsx) * SUBX, ty0 = (tile / gsx) * SUBY;
-  const int px = tx0 + (lane & 7), py = ty0 + (lane >> 3);
-  const bool inside = px < W && py < H;
-  const uint32_t pix_id = (uint32_t)py * (uint32_t)W + (uint32_t)px;
-  const float pxf = (float)px, pyf = (float)py;
-  if (desc == nullptr) range = ranges[tile];  // the tile's own list
-  const size_t HW = (size_t)H * W;
 
   float g[NCH] = {0.f, 0.f, 0.f, 0.f, 0.f};
   float ginv = 0.f, Tfin = 1.f, bgdot = 0.f;
@@ -978,69 +841,83 @@ __global__ __launch_bounds__(RBLK) void render_bwd_btf_kernel(
     }
     if (HAVE_INV) ginv = dL_dinv[pix_id];
   }
-  {
+  {  // pixel gradients for the transposition rounds: 8 floats per pixel, each pixel row offset by 4 more floats
     float* d = spix + lane * 8 + 4 * (lane >> 3);
     *reinterpret_cast<float4*>(d) = make_float4(g[0], g[1], g[2], g[3]);
     d[4] = g[4];
   }
+  // list entries past the last contributor of every pixel of the tile receive no gradient: never gathered, never written
   const uint32_t tile_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(ncontrib));
-  const uint32_t n = min(range.y - range.x, tile_last);  // entries behind every pixel's last contributor are dead
+  const uint32_t n = min(range.y - range.x, tile_last);
   if (n == 0u) return;
-  const float kx = LN2 * 0.5f * W, ky = LN2 * 0.5f * H;
+  const uint32_t lend = range.x + n;
+  const float kx = LN2 * 0.5f * W, ky = LN2 * 0.5f * H;  // d(pixel)/d(ndc) times the ln2 of the log2-domain conic
   const float bx0 = (float)tx0, by0 = (float)ty0;
-  float T = Tfin, last_alpha = 0.f, arec_inv = 0.f, last_inv = 0.f;
-  float arec[NCH] = {0.f, 0.f, 0.f, 0.f, 0.f}, lastc[NCH] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  const float bgT = -Tfin * bgdot;  // backward.cu:617-620: dL/dalpha += (-T_final / (1 - alpha)) (bg . g)
+  float T = Tfin, a = 0.f;          // transmittance behind the entry at hand; g . (colour behind it, normalised): file header
   float* const uvlane = su + uv_index(0, lane);
-  int k = 0, kstashed = 0;
-  unsigned long long kj = 0ull;
-  for (int c = (int)((n - 1u) / 64u) * 64; c >= 0; c -= 64) {  // chunks of 64 list entries, the last one first
+
+  int k = 0, kstashed = 0;       // survivors waiting in the current transposition round (rounds span chunks), and how many
+                                 // of them already have their geometry in the round buffer
+  unsigned long long kj = 0ull;  // slab positions of the survivors not yet stashed, 8 bits each
+  int c = (int)((n - 1u) / 64u) * 64;  // chunks of 64 list entries, the last one first
+  Cand nxt = gather_cand<MACRO>(peek_cand_r<MACRO>(range.x + (uint32_t)c + lane, range.x, lend, keys, point_list), sub, packed);
+  Peek pk = peek_cand_r<MACRO>(range.x + (uint32_t)(c - 64) + lane, range.x, lend, keys, point_list);
+  for (; c >= 0; c -= 64) {
     wave_lds_sync();
-    const Cand cur = gather_cand<1>(peek_cand<1>(range.x + (uint32_t)c + lane, range.x + n, nullptr, point_list), 0u, packed);
-    const int jn = park(slab, sslot, lane, cur, 0);
+    unsigned long long hm = __builtin_amdgcn_ballot_w64(nxt.hit);  // which of the chunk's entries list this tile
+    const int jn = park(slab, sslot, lane, nxt, 0);
+    nxt = gather_cand<MACRO>(pk, sub, packed);                                                        // chunk c-64: in flight during this chunk
+    pk = peek_cand_r<MACRO>(range.x + (uint32_t)(c - 128) + lane, range.x, lend, keys, point_list);  // chunk c-128
     wave_lds_sync();
+    if (jn == 0) continue;
+    // survivors [from, to) of the current round live in this chunk's slab: lane i copies survivor i's geometry and
+    // record slot into the round buffer (the slab is overwritten by the next chunk, the round may outlive it)
     auto stash = [&](int from, int to) {
       if (lane >= from && lane < to) {
         const uint32_t jk = (uint32_t)(kj >> (8 * lane)) & 63u;
-        const float4 a = *reinterpret_cast<const float4*>(slab + jk * ENT);
-        const float2 b = *reinterpret_cast<const float2*>(slab + jk * ENT + 4);
-        *reinterpret_cast<float4*>(rb + lane * 8) = a;
-        *reinterpret_cast<float4*>(rb + lane * 8 + 4) = make_float4(b.x, b.y, __uint_as_float(sslot[jk]), 0.f);
+        const float4 qa = *reinterpret_cast<const float4*>(slab + jk * ENT);
+        const float2 qb = *reinterpret_cast<const float2*>(slab + jk * ENT + 4);
+        *reinterpret_cast<float4*>(rb + lane * 8) = qa;
+        *reinterpret_cast<float4*>(rb + lane * 8 + 4) = make_float4(qb.x, qb.y, __uint_as_float(sslot[jk]), 0.f);
       }
     };
-    for (int j = jn - 1; j >= 0; j--) {
-      const Ent e = fetch(slab, j);
+    auto grad = [&](const Ent& e, int j) {
+      // list position of slab entry j: the chunk's hit entries were parked in list order, so walking the slab backwards walks
+      // the set bits of the hit mask from the top (wave-uniform: scalar instructions)
+      uint32_t pos;
+      if (MACRO > 1) {
+        const int top = 63 - (int)__builtin_clzll(hm);
+        hm &= ~(1ull << top);
+        pos = (uint32_t)(c + top);
+      } else {
+        pos = (uint32_t)(c + j);
+      }
       const float dx = e.q0.x - pxf, dy = e.q0.y - pyf;
       const float p = power_of(e, dx, dy);
       const float G = __builtin_amdgcn_exp2f(p);
       const float alpha = fminf(e.q1.y * G, 0.99f);
       // (contributor >= last_contributor: skip, backward.cu:561-563; then the forward's own two tests)
-      const bool valid = ((uint32_t)(c + j) < ncontrib) && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);
-      if (__builtin_amdgcn_ballot_w64(valid) == 0ull) continue;
-      const float one_m = 1.f - alpha;
-      const float Tn = T / one_m;  // backward.cu:573
-      const float cc[NCH] = {e.q1.z, e.q1.w, e.q2.x, e.q2.y, e.q2.z};
-      float dLda = 0.f;
-#pragma unroll
-      for (int ch = 0; ch < NCH; ch++) {  // backward.cu:586-599
-        const float ar = last_alpha * lastc[ch] + (1.f - last_alpha) * arec[ch];
-        dLda += (cc[ch] - ar) * g[ch];
-        arec[ch] = valid ? ar : arec[ch];
-        lastc[ch] = valid ? cc[ch] : lastc[ch];
-      }
-      if (HAVE_INV) {  // backward.cu:602-609
-        const float ar = last_alpha * last_inv + (1.f - last_alpha) * arec_inv;
-        dLda += (e.q2.w - ar) * ginv;
-        arec_inv = valid ? ar : arec_inv;
-        last_inv = valid ? e.q2.w : last_inv;
-      }
-      dLda *= Tn;
-      dLda += (-Tfin / one_m) * bgdot;  // backward.cu:617-620
-      // pixels that skip this Gaussian: weight 0, v = 0, state unchanged (selects: exp2 may have overflowed there)
-      float* const uv = uvlane + k * UV_ROW;
-      uv[0] = valid ? alpha * Tn : 0.f;
-      uv[UV_PITCH] = valid ? G * dLda : 0.f;
-      T = valid ? Tn : T;
-      last_alpha = valid ? alpha : last_alpha;
+      const bool valid = (pos < ncontrib) && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);
+      // wave-uniform skip: this entry reaches no pixel of the tile (`valid` is an AND of three compare masks: its ballot is
+      // that mask, no v_cndmask + v_cmp as for a general boolean)
+      if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;
+
+      float gc = g[0] * e.q1.z + g[1] * e.q1.w + g[2] * e.q2.x + g[3] * e.q2.y + g[4] * e.q2.z;
+      if (HAVE_INV) gc += ginv * e.q2.w;
+      else asm volatile("" :: "v"(e.q2.w));  // (keeps the entry's third read a ds_read_b128: see render_bwd_quad_kernel's grad)
+      // pixels that skip this Gaussian behave as alpha = 0, G = 0 (selects, not multiplications: exp2 may have
+      // overflowed there): weight 0, v = 0, T and a unchanged. No zeroing when alpha was clamped (backward.cu:624).
+      const float a_eff = valid ? alpha : 0.f;
+      const float G_eff = valid ? G : 0.f;
+      const float rinv = __builtin_amdgcn_rcpf(1.f - a_eff);
+      T = T * rinv;                 // backward.cu:573
+      const float d = gc - a;       // (c_j - accum_rec_j) . g, backward.cu:586-609
+      const float dLda = __builtin_fmaf(d, T, bgT * rinv);
+      a = __builtin_fmaf(a_eff, d, a);
+      float* const uv = uvlane + k * UV_ROW;  // = su + uv_index(k, lane); k is wave-uniform
+      uv[0] = a_eff * T;
+      uv[UV_PITCH] = G_eff * dLda;  // v = G dL/dalpha
       kj |= (unsigned long long)j << (8 * k);
       if (++k == KSURV) {
         stash(kstashed, KSURV);
@@ -1051,13 +928,22 @@ __global__ __launch_bounds__(RBLK) void render_bwd_btf_kernel(
         kstashed = 0;
         kj = 0ull;
       }
+    };
+    Ent ea = fetch(slab, jn - 1);
+    int j = jn - 1;
+    for (; j >= 1; j -= 2) {
+      const Ent eb = fetch(slab, j - 1);
+      grad(ea, j);
+      ea = fetch(slab, j >= 2 ? j - 2 : 0);
+      grad(eb, j - 1);
     }
-    if (k > kstashed) {
+    if (j == 0) grad(ea, 0);
+    if (k > kstashed) {  // survivors waiting for the next chunk: keep what the round needs of them
       stash(kstashed, k);
       kstashed = k;
     }
   }
-  if (k) {
+  if (k) {  // the last, partial round
     wave_lds_sync();
     transpose_round(k, lane, rb, su, sv, spix, bx0, by0, kx, ky, records, live_flag, rec_plane);
   }
@@ -1080,8 +966,9 @@ __global__ __launch_bounds__(RBLK) void render_bwd_btf_kernel(
 // chunk by the owner exactly as transpose_round writes it.
 namespace {
 
-#define QB 68     // entries per quad sub-list in backward (64 + pipelined over-read); an entry is the BYTE OFFSET of its slab
+#define QB 68     // dwords per quad sub-list in backward (QLEAD + 64 + 2 spare); an entry is the BYTE OFFSET of its slab
                   // entry (position * 48) as a full dword: the hot loop's ds_read needs no address arithmetic or extraction
+#define QLEAD 2   // ... of which the first two lie in front of the list: the backward walk's pipelined over-read
 #define PIXB 296  // pixel gradients for the VALU transposition: channels 0..3 as one float4 per pixel (+1 float4 per 8 pixels
                   // against bank conflicts) in floats [0, 288), channel 4 at PIXB + pixel (read eight at a time: two ds_read_b128)
 #define STG 12    // floats per staged (trip, quad) partial: 11 used
@@ -1188,65 +1075,6 @@ __device__ inline void transpose_round_quad(int nk, int r, int lane, const uint3
   }
 }
 
-// ---- transposition of a round on the matrix pipe (RED = 1) ----
-// The u / v matrices keep their trip-indexed rows (8 trips per round, row stride URS floats, v behind u at UV_PITCH), but
-// the sums over a quad's 16 pixels are taken by v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate: a k-ordered fmaf chain):
-// D_q[m][n] = sum_p A[m][p] B_q[p][n], n = trip, p = the quad's pixels, A rows {1, x, y, x^2, x y, y^2} in TILE-LOCAL pixel
-// coordinates for the v-part and the pixel's five upstream colour gradients for the u-part (constant per lane, in
-// registers). Lane (n, g) then holds rows 4g..4g+3 of trip n for each quad and parks them in the staging area exactly where
-// the VALU transposition puts its partials; the owner pull is unchanged. Moments arrive relative to the tile origin and
-// are shifted to the Gaussian centre once per entry, when the owner forms the record.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-#define URS 72  // row stride (18 x 16 B): the b128 operand reads of 8 rows x 2 k-slices of a lane group hit 16 different
-                // 16-byte bank slots, and the pixel-parallel stores (lane = pixel) 32 consecutive banks per half-wave
-static_assert(8 * URS <= UV_PITCH, "u rows fit below the v matrix");
-
-__device__ inline void mfma_round_quad(int nk, int lane, float* s_u, const float (&fxv)[8], const float (&fyv)[2],
-                                       const float* au_row) {
-  const int n = lane & 15, kk = lane >> 4;
-  const float* op = s_u + (n & 7) * URS + 4 * kk;  // (columns 8..15 duplicate trips 0..7: harmless, never stored)
-  // two quads at a time (register pressure: the kernel must stay at 128 VGPRs for 4 waves/SIMD); their two accumulator
-  // chains are issued alternately: dependent-accumulator latency 40 cycles, issue interval 32
-  f32x4 res[4];
-#pragma unroll
-  for (int qp = 0; qp < 4; qp += 2) {
-    float4 bv[2], bu[2], au4[2];
-#pragma unroll
-    for (int d = 0; d < 2; d++) {
-      bv[d] = *reinterpret_cast<const float4*>(op + UV_PITCH + 16 * (qp + d));
-      bu[d] = *reinterpret_cast<const float4*>(op + 16 * (qp + d));
-      au4[d] = *reinterpret_cast<const float4*>(au_row + 16 * (qp + d));  // u-part A operands: re-read per round
-    }
-    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-      for (int d = 0; d < 2; d++) {
-        const float b = i == 0 ? bv[d].x : (i == 1 ? bv[d].y : (i == 2 ? bv[d].z : bv[d].w));
-        // v-part A operand of k-step (quad qp + d, column i): fx(x) fy(y), x = 4 ((qp + d) & 1) + i, y = 4 ((qp + d) >> 1) + kk
-        const float a = fxv[4 * ((qp + d) & 1) + i] * fyv[(qp + d) >> 1];
-        acc[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[d], 0, 0, 0);
-      }
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-      for (int d = 0; d < 2; d++) {
-        const float b = i == 0 ? bu[d].x : (i == 1 ? bu[d].y : (i == 2 ? bu[d].z : bu[d].w));
-        const float a = i == 0 ? au4[d].x : (i == 1 ? au4[d].y : (i == 2 ? au4[d].z : au4[d].w));
-        acc[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[d], 0, 0, 0);
-      }
-    res[qp] = acc[0];
-    res[qp + 1] = acc[1];
-  }
-  // rows 0..3 {S0 Sx Sy Sxx} | 4..7 {Sxy Syy c0 c1} | 8..11 {c2 c3 c4 -}: the staging record of (trip n, quad q).
-  // (All operand reads above were issued before these stores: the staging area aliases the u rows.)
-  if (n < nk && kk < 3) {
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-      *reinterpret_cast<float4*>(s_u + (n * 4 + q) * STG + 4 * kk) = make_float4(res[q][0], res[q][1], res[q][2], res[q][3]);
-  }
-}
-
 }  // namespace
 
 // -DEOGS_BWD_PHASES: where a wave of render_bwd_quad_kernel spends its residency (s_memtime at the phase boundaries, summed
@@ -1263,29 +1091,31 @@ __device__ unsigned long long g_bwd_phase[PHASE_TILES][6];  // per tile (wave): 
 #define PHASE(i)
 #define PHASE_FLUSH
 #endif
-// ALT (with RED = 0, HAVE_INV = false): the backward of an altitude-only render (EOGS_FLAG_ALT_ONLY). out_color and dL_dpix are
-// single planes (channel 3); one product instead of a five-term dot per pair, one colour sum instead of five in the
+// ALT (HAVE_INV = false): the backward of an altitude-only render (EOGS_FLAG_ALT_ONLY). dL_dpix is a single plane
+// (channel 3); one product instead of a five-term dot per pair, one colour sum instead of five in the
 // transposition, 7 instead of 11 values through the DPP merge, the staging area and the owner pull, and a 32-byte record
 // {mean2D.x, .y, conic.a, opacity | conic.b, conic.c, colour3, -} (REC_ALT) that gaussian_bwd_kernel<., true> reads.
 #ifndef EOGS_BW
 #define EOGS_BW 4  // waves per SIMD the quad backward is compiled for (10 KB of LDS per wave: four fit)
 #endif
-template <bool HAVE_INV, int RED, bool ALT, bool NOC4 = false>
+// Back to front (file header): the tile's chunks are taken from the one that holds its last contributor down to the list's
+// head, and inside a chunk every quad walks its sub-list from the end. Trip j of a chunk is still slot j & 7 of round j >> 3, so
+// the transposition, the staging area and the owner pull do not know the direction; the chunk's partial round comes first.
+template <bool HAVE_INV, bool ALT, bool NOC4 = false>
 __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, EOGS_BW))) void render_bwd_quad_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx, const uint4* __restrict__ desc, const uint32_t* __restrict__ sched, int lg16,
-    const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib,
-    const float* __restrict__ out_color, const float* __restrict__ out_invdepth, const float* __restrict__ dL_dpix,
+    const uint2* __restrict__ ranges, const uint8_t* __restrict__ qmask, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, const uint4* __restrict__ desc, const uint32_t* __restrict__ sched, int lg16,
+    const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib, const float* __restrict__ final_T,
+    const float* __restrict__ bg, const float* __restrict__ dL_dpix,
     const float* __restrict__ dL_dinv, float* __restrict__ records, uint8_t* __restrict__ live_flag, uint32_t rec_plane,
     const uint32_t* __restrict__ misc, int opts) {
   // slab position 64 holds a DUMMY entry (opacity 0 -> alpha = 0 -> never valid): shorter sub-lists are padded with it
   __shared__ __attribute__((aligned(16))) float s_slab[RBLK / 64][65 * ENT];
-  __shared__ __attribute__((aligned(16))) float s_uv[RBLK / 64][RED ? 2 * UV_PITCH : UV_PITCH + UV_SIZE];
-  // RED = 0: 8 floats per pixel (+ padding) for the VALU transposition; RED = 1: [channel 0..4 | zero row][pixel], the
-  // u-part A operands of the MFMA transposition
+  __shared__ __attribute__((aligned(16))) float s_uv[RBLK / 64][UV_PITCH + UV_SIZE];
+  // 8 floats per pixel (+ padding) for the transposition
   __shared__ __attribute__((aligned(16))) float s_pix[RBLK / 64][6 * 64];
   __shared__ __attribute__((aligned(16))) uint32_t s_idx[RBLK / 64][4 * QB];
   static_assert(PIXB + 72 <= 6 * 64, "both pixel-gradient planes fit");
-  static_assert(32 * STG <= UV_SIZE && 32 * STG <= 8 * URS, "the staging area lives inside the u matrix");
+  static_assert(32 * STG <= UV_SIZE, "the staging area lives inside the u matrix");
   const int lane = threadIdx.x & 63;
   uint2 range = make_uint2(0u, 0u);
   const int tile = tile_of_wave(desc, sched, lg16, gsx, range);
@@ -1307,53 +1137,32 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
   if (desc == nullptr) range = ranges[tile];
   const size_t HW = (size_t)H * W;
   const int myq = lane >> 4;
-  const uint32_t* myidx = sidx + myq * QB;
+  // A quad's sub-list starts two dwords into its QB: the pipelined walk reads two elements past the one it evaluates, and walking
+  // backwards those lie IN FRONT of the list (kept valid slab offsets: the zeros of the initialisation below)
+  const uint32_t* myidx = sidx + myq * QB + QLEAD;
 
   float g[NCH] = {0.f, 0.f, 0.f, 0.f, 0.f};
-  float ginv = 0.f, Dfinal = 0.f;
+  float ginv = 0.f, Tfin = 1.f, bgdot = 0.f;
   uint32_t ncontrib = 0;
-  static_assert(!ALT || (RED == 0 && !HAVE_INV), "the altitude-only variant exists for the VALU transposition without inverse depth");
-  static_assert(!NOC4 || (RED == 0 && !ALT), "ten sums: the VALU transposition of a five-channel render");
-  constexpr bool ORG = RED == 0 && EOGS_ORIGIN_MOMENTS != 0;  // tile-local moments in the VALU transposition (transpose_round_quad)
+  static_assert(!ALT || !HAVE_INV, "the altitude-only variant has no inverse-depth output");
+  static_assert(!NOC4 || !ALT, "ten sums: a five-channel render");
+  constexpr bool ORG = EOGS_ORIGIN_MOMENTS != 0;  // tile-local moments in the transposition (transpose_round_quad)
   if (inside) {
     ncontrib = n_contrib[pix_id];
-    if (ALT) {  // single planes: the altitude image and its gradient
+    Tfin = final_T[pix_id];
+    if (ALT) {  // a single plane: the altitude image's gradient
       g[3] = dL_dpix[pix_id];
-      Dfinal = g[3] * out_color[pix_id];
+      bgdot = bg[3] * g[3];
     } else {
 #pragma unroll
       for (int ch = 0; ch < NCH; ch++) {
         g[ch] = dL_dpix[ch * HW + pix_id];
-        Dfinal += g[ch] * out_color[ch * HW + pix_id];
+        bgdot += bg[ch] * g[ch];  // backward.cu:527-529
       }
     }
-    if (HAVE_INV) {
-      ginv = dL_dinv[pix_id];
-      Dfinal += ginv * out_invdepth[pix_id];
-    }
+    if (HAVE_INV) ginv = dL_dinv[pix_id];
   }
-  // RED = 1: this lane's v-part A operands, factored: A = fx(x) fy(y) (x: 8 tile columns; y: 2 rows for this lane's kk)
-  float fxv[8], fyv[2];
-  const float* au_row = spix;
-  if (RED) {
-    // MFMA lane (m = lane & 15, kk = lane >> 4), k-step (q, i): pixel = lane 16 q + 4 kk + i of the pixel pass, i.e.
-    // tile-local (x, y) = (4 (q & 1) + i, 4 (q >> 1) + kk). Rows 0..5: v-part {1, x, y, x^2, x y, y^2}; rows 6..10:
-    // u-part, the pixel's upstream gradient of colour channel 0..4 (kept in LDS, [channel | zero row][pixel]); 11..15: zero.
-    const int mrow = lane & 15, kk = lane >> 4;
-#pragma unroll
-    for (int ch = 0; ch < NCH; ch++) spix[ch * 64 + lane] = g[ch];
-    spix[NCH * 64 + lane] = 0.f;
-    au_row = spix + ((mrow >= 6 && mrow <= 10) ? mrow - 6 : NCH) * 64 + 4 * kk;
-    const int ex = (mrow == 1 || mrow == 4) ? 1 : (mrow == 3 ? 2 : 0);
-    const int ey = (mrow == 2 || mrow == 4) ? 1 : (mrow == 5 ? 2 : 0);
-#pragma unroll
-    for (int x = 0; x < 8; x++) fxv[x] = mrow < 6 ? (ex == 0 ? 1.f : (ex == 1 ? (float)x : (float)(x * x))) : 0.f;
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const float y = (float)(4 * h + kk);
-      fyv[h] = ey == 0 ? 1.f : (ey == 1 ? y : y * y);
-    }
-  } else if (ALT) {  // the one plane the altitude-only transposition reads
+  if (ALT) {  // the one plane the altitude-only transposition reads
     spix[PIXB + lane] = g[3];
   } else {  // pixel gradients for the transposition rounds (pixel index = lane): see PIXB
     *reinterpret_cast<float4*>(spix + lane * 4 + 4 * (lane >> 3)) = make_float4(g[0], g[1], g[2], g[3]);
@@ -1365,34 +1174,41 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
   // list is walked and every entry's record written, whatever the pixels' last contributors are; no live flags
   const bool noflag = (opts & 1) != 0 && ((opts & 2) != 0 || noflag_scene(misc[MISC_OPW_LO], misc[MISC_OPW_HI], W, H));
   const uint32_t tile_last = noflag ? 0xFFFFFFFFu : (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(ncontrib));
+  // entries behind the last contributor of every pixel are dead: never gathered, never written (flags), or zero records (flag-free)
+  const uint32_t n = min(range.y - range.x, tile_last);
+  if (n == 0u) {
+    WTRACE_END(1, tile);
+    return;
+  }
+  const uint32_t lend = range.x + n;
   const float bx0 = (float)tx0, by0 = (float)ty0;
-  float T = 1.0f, Dacc = 0.f;
-  float* const uvlane = RED ? su + lane : su + uv_index(0, lane);
-  constexpr int ROWF = RED ? URS : UV_ROW;  // floats between the u/v rows of consecutive trips of a round
+  const float bgT = -Tfin * bgdot;  // backward.cu:617-620: dL/dalpha += (-T_final / (1 - alpha)) (bg . g)
+  float T = Tfin, a = 0.f;          // transmittance behind the entry at hand; g . (colour behind it, normalised): file header
+  float* const uvlane = su + uv_index(0, lane);
+  constexpr int ROWF = UV_ROW;  // floats between the u/v rows of consecutive trips of a round
   float* const vlane = uvlane + UV_PITCH;
 
   PHASE_DECL;
-  uint32_t jbase = 0;
-  // opts bit 3: the quad forward walked these lists and left its quad masks in BinWS::qmask, which this launch receives in place of
-  // the keys it does not read on per-tile lists (peek_cand_q); without it the masks are computed here (quad_mask)
-  const bool fwd_masks = (opts & 8) != 0 && keys != nullptr;
-  const uint8_t* const qmask = fwd_masks ? reinterpret_cast<const uint8_t*>(keys) : nullptr;
-  Cand nxt = gather_cand<1>(peek_cand_q(range.x + lane, range.y, qmask, point_list), 0u, packed);
-  Peek pk = peek_cand_q(range.x + 64 + lane, range.y, qmask, point_list);
-  uint32_t c0 = range.x;
-  // The chunk loop exists twice, one after the other (the forward's construction, render_fwd_quad_kernel). PLAIN: the tile's
-  // first chunks, while every pixel of the tile contributes past the chunk's last entry (`off < nc_off` then holds for every
-  // entry of it) and no entry of the chunk has o > 0.99 (the clamp never binds): one v_cmp, one v_min and one mask operation
-  // less per trip, every value the same bits. Measured at -0.7 % while the LDS array was this kernel's other bound; after the
-  // LDS cuts of DESIGN.md 2.10 the instruction count is what is left. The first chunk that does not qualify, and every
-  // chunk after it, takes the general loop.
-  const uint32_t nc_min = ~(uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(inside ? ~ncontrib : 0u));  // earliest last contributor
+  // opts bit 3: the quad forward walked these lists and left its quad masks in BinWS::qmask (peek_cand_q); without it the masks
+  // are computed here (quad_mask)
+  const bool fwd_masks = (opts & 8) != 0 && qmask != nullptr;
+  const uint8_t* const qm_bytes = fwd_masks ? qmask : nullptr;
+  int c = (int)((n - 1u) / 64u) * 64;  // list position of the chunk at hand: the last one first
+  Cand nxt = gather_cand<1>(peek_cand_q(range.x + (uint32_t)c + lane, range.x, lend, qm_bytes, point_list), 0u, packed);
+  Peek pk = peek_cand_q(range.x + (uint32_t)(c - 64) + lane, range.x, lend, qm_bytes, point_list);
+  // The chunk loop exists twice, one after the other (the forward's construction, render_fwd_quad_kernel). The walk begins in the
+  // general loop; PLAIN: once every pixel of the tile contributes past the END of the chunk at hand — then `off < nc_off` holds
+  // for every entry of it and of every chunk in front of it — the remaining chunks leave that test out: one v_cmp and one mask
+  // operation less per trip, every value the same bits. (A tile that hangs over the image's edge keeps the general loop: its
+  // outside pixels must never count as contributing — their T would be divided up without bound.)
+  const uint32_t nc_min = __builtin_amdgcn_ballot_w64(!inside) != 0ull
+                              ? 0u
+                              : ~(uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(~ncontrib));  // earliest last contributor
   auto chunks = [&](auto plainc) {
   constexpr bool PLAIN = decltype(plainc)::value;
-  for (; c0 < range.y && jbase < tile_last; c0 += 64) {
-    if constexpr (PLAIN) {
-      const unsigned long long hm = __builtin_amdgcn_ballot_w64(nxt.hit);
-      if (nc_min < jbase + (uint32_t)__popcll(hm) || __builtin_amdgcn_ballot_w64(nxt.hit && nxt.q1.y > 0.99f) != 0ull) return;
+  for (; c >= 0; c -= 64) {
+    if constexpr (!PLAIN) {
+      if ((opts & 4) != 0 && (uint32_t)c + 64u <= nc_min) return;  // the plain loop takes over
     }
     wave_lds_sync();
     int nq[4];
@@ -1405,15 +1221,14 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
       // (the forward's masks where it left them — of the chunks it walked: the others lie behind every pixel's stop entry, where
       // no evaluation is valid whatever the sub-lists hold)
       const uint32_t qm = fwd_masks ? nxt.qm : (nxt.hit ? quad_mask(nxt, bxq, byq) : 0u);
-      // per-tile lists: the in-range entries are lanes 0..jn-1, parked at their own lane index
-      const bool listed = nxt.hit && jbase + (uint32_t)lane < tile_last;  // entries behind the last contributor are dead
+      // per-tile lists: the in-range entries (list positions < n) are lanes 0..jn-1, parked at their own lane index
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const bool in = listed && ((qm >> q) & 1u);
+        const bool in = nxt.hit && ((qm >> q) & 1u);
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(in);
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
         if (in) {
-          sidx[q * QB + (int)rank] = (uint32_t)(lane * (4 * ENT));
+          sidx[q * QB + QLEAD + (int)rank] = (uint32_t)(lane * (4 * ENT));
           myranks = (myranks & ~(0xFFu << (8 * q))) | (rank << (8 * q));
         }
         nq[q] = (int)__popcll(bal);
@@ -1421,8 +1236,8 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
     }
     const uint32_t cur_slot = nxt.slot;
     const int jn = park(slab, nullptr, lane, nxt, 0);
-    nxt = gather_cand<1>(pk, 0u, packed);
-    pk = peek_cand_q(c0 + 128 + lane, range.y, qmask, point_list);
+    nxt = gather_cand<1>(pk, 0u, packed);                                                             // chunk c-64: in flight during this chunk
+    pk = peek_cand_q(range.x + (uint32_t)(c - 128) + lane, range.x, lend, qm_bytes, point_list);  // chunk c-128
     wave_lds_sync();
     const int nmax = max(max(nq[0], nq[1]), max(nq[2], nq[3]));
     // pad the shorter sub-lists up to the next multiple of 8 trips with the dummy entry (transposition rounds read the
@@ -1431,11 +1246,11 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
       const int npad = (nmax + 7) & ~7;
 #pragma unroll
       for (int q = 0; q < 4; q++)
-        if (lane < npad + 2 - nq[q]) sidx[q * QB + nq[q] + lane] = (uint32_t)(64 * 4 * ENT);
+        if (lane < npad - nq[q]) sidx[q * QB + QLEAD + nq[q] + lane] = (uint32_t)(64 * 4 * ENT);
       wave_lds_sync();
     }
     // contributing list positions of this pixel, relative to the chunk, as a slab byte offset
-    const uint32_t nc_off = min(ncontrib - min(ncontrib, jbase), 64u) * (uint32_t)(4 * ENT);
+    const uint32_t nc_off = min(ncontrib - min(ncontrib, (uint32_t)c), 64u) * (uint32_t)(4 * ENT);
     constexpr int NACC = ALT ? 7 : 11;
     float acc[11];
 #pragma unroll
@@ -1445,8 +1260,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
     auto round = [&](int r, int nk) {
       PHASE(1);
       wave_lds_sync();
-      if (RED) mfma_round_quad(nk, lane, su, fxv, fyv, au_row);
-      else transpose_round_quad<ALT, ORG, NOC4>(nk, r, lane, sidx, slab, su, sv, spix, bx0, by0);
+      transpose_round_quad<ALT, ORG, NOC4>(nk, r, lane, sidx + QLEAD, slab, su, sv, spix, bx0, by0);
       wave_lds_sync();
       PHASE(2);
 #pragma unroll
@@ -1491,7 +1305,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
       const float dx = e.q0.x - pxf, dy = e.q0.y - pyf;
       const float p = power_of(e, dx, dy);
       const float G = __builtin_amdgcn_exp2f(p);
-      const float alpha = PLAIN ? e.q1.y * G : fminf(e.q1.y * G, 0.99f);
+      const float alpha = fminf(e.q1.y * G, 0.99f);
       const bool valid = (PLAIN || off < nc_off) && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);  // (the dummy: alpha = 0)
       // Keep the entry's third read a ds_read_b128 (4 LDS cycles) although 1/depth goes unused here: the compiler narrows it to
       // a ds_read_b96, which the LDS serves in 8 (MI355X_MICROARCH.md, LDS table), and this kernel keeps the LDS array busy for
@@ -1500,54 +1314,61 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
       if (!ALT && !HAVE_INV) asm volatile("" :: "v"(e.q2.w));
       float gc = ALT ? g[3] * e.q2.y : g[0] * e.q1.z + g[1] * e.q1.w + g[2] * e.q2.x + g[3] * e.q2.y + g[4] * e.q2.z;
       if (HAVE_INV) gc += ginv * e.q2.w;
+      // pixels that skip this entry behave as alpha = 0, G = 0 (selects, not multiplications: exp2 may have overflowed there):
+      // rinv = 1 exactly, so T and a keep their values. No zeroing when alpha was clamped (backward.cu:624).
       const float a_eff = valid ? alpha : 0.f;
       const float G_eff = valid ? G : 0.f;
-      const float wgt = a_eff * T;
-      Dacc += gc * wgt;
-      const float one_m = 1.f - a_eff;
-      const float dLda = T * gc - (Dfinal - Dacc) * __builtin_amdgcn_rcpf(one_m);
-      T = T * one_m;
-      uvlane[slot * ROWF] = wgt;
+      const float rinv = __builtin_amdgcn_rcpf(1.f - a_eff);
+      T = T * rinv;            // backward.cu:573
+      const float d = gc - a;  // (c_j - accum_rec_j) . g, backward.cu:586-609
+      const float dLda = __builtin_fmaf(d, T, bgT * rinv);
+      a = __builtin_fmaf(a_eff, d, a);
+      uvlane[slot * ROWF] = a_eff * T;
       vlane[slot * ROWF] = G_eff * dLda;  // v = G dL/dalpha
     };
     PHASE(0);
     if (nmax > 0 || noflag) {  // (flag-free: an entry that reaches no quad still gets its record of zeros)
-      // trips are never skipped: trip j is slot j & 7 of round j >> 3. Full rounds are unrolled (slots, sub-list reads and u/v
-      // rows at immediate offsets); the entry of trip j + 1 and the sub-list element of trip j + 2 are in flight during trip j
-      uint32_t o0 = myidx[0], o1 = myidx[1];
+      // Trips are never skipped: trip j is slot j & 7 of round j >> 3, walked from nmax - 1 down to 0. Rounds are unrolled (slots,
+      // sub-list reads and u/v rows at immediate offsets); the entry of trip j - 1 and the sub-list element of trip j - 2 are in
+      // flight during trip j. At the start of trip j: o0 = element j, o1 = element j - 1, ea = the entry at o0.
+      const int nfull = nmax >> 3, rem = nmax & 7;
+      uint32_t o0 = myidx[nmax - 1], o1 = myidx[nmax - 2];
       Ent ea = fetch_off(o0);
-      const int nfull = nmax >> 3;
-      for (int r = 0; r < nfull; r++) {
-        const uint32_t* ip = myidx + 8 * r;
-#pragma unroll
-        for (int t = 0; t < 8; t += 2) {
+      if (rem) {  // the chunk's partial round: its highest trips, taken first
+        const uint32_t* ip = myidx + 8 * nfull;
+        int t = rem - 1;
+        for (; t >= 1; t -= 2) {
           const Ent eb = fetch_off(o1);
-          const uint32_t o2 = ip[t + 2];
+          const uint32_t o2 = ip[t - 2];
           grad(ea, o0, t);
           ea = fetch_off(o2);
-          const uint32_t o3 = ip[t + 3];
-          grad(eb, o1, t + 1);
+          const uint32_t o3 = ip[t - 3];
+          grad(eb, o1, t - 1);
+          o0 = o2;
+          o1 = o3;
+        }
+        if (t == 0) {
+          grad(ea, o0, 0);
+          o0 = o1;
+          o1 = ip[-2];
+          ea = fetch_off(o0);
+        }
+        round(nfull, rem);
+      }
+      for (int r = nfull - 1; r >= 0; r--) {
+        const uint32_t* ip = myidx + 8 * r;
+#pragma unroll
+        for (int t = 7; t >= 1; t -= 2) {
+          const Ent eb = fetch_off(o1);
+          const uint32_t o2 = ip[t - 2];
+          grad(ea, o0, t);
+          ea = fetch_off(o2);
+          const uint32_t o3 = ip[t - 3];
+          grad(eb, o1, t - 1);
           o0 = o2;
           o1 = o3;
         }
         round(r, KSURV);
-      }
-      const int rem = nmax & 7;
-      if (rem) {  // the chunk's last, partial round
-        const uint32_t* ip = myidx + 8 * nfull;
-        int t = 0;
-        for (; t + 1 < rem; t += 2) {
-          const Ent eb = fetch_off(o1);
-          const uint32_t o2 = ip[t + 2];
-          grad(ea, o0, t);
-          ea = fetch_off(o2);
-          const uint32_t o3 = ip[t + 3];
-          grad(eb, o1, t + 1);
-          o0 = o2;
-          o1 = o3;
-        }
-        if (t < rem) grad(ea, o0, t);
-        round(nfull, rem);
       }
       // The prefetches that travel into the next chunk (its gathered entry, the peek behind it) are made "arrived" HERE, in front
       // of the record stores: loads and stores share one in-order counter, the loop's back edge copies the prefetched registers,
@@ -1563,7 +1384,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
         const float4 q0 = *reinterpret_cast<const float4*>(slab + lane * ENT);
         const float2 q1 = *reinterpret_cast<const float2*>(slab + lane * ENT + 4);
         const float A = q0.z, B = q0.w, Cq = q1.x, op = q1.y;
-        if (RED || ORG) {  // moments about the tile origin -> about the Gaussian centre: sum v (gx - x) = gx S0 - Sx, ...
+        if (ORG) {  // moments about the tile origin -> about the Gaussian centre: sum v (gx - x) = gx S0 - Sx, ...
           const float gxr = q0.x - bx0, gyr = q0.y - by0;
           const float S0 = acc[0], Sx = acc[1], Sy = acc[2], Sxx = acc[3], Sxy = acc[4], Syy = acc[5];
           const float Sdx = gxr * S0 - Sx, Sdy = gyr * S0 - Sy;
@@ -1590,271 +1411,13 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
         if (!noflag) live_flag[cur_slot] = 1;
       }
     }
-    jbase += (uint32_t)jn;
     PHASE(4);
   }
   };
-  if ((opts & 4) != 0) chunks(std::true_type{});
   chunks(std::false_type{});
+  chunks(std::true_type{});
   PHASE_FLUSH;
   WTRACE_END(1, tile);
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Backward with quad sub-lists, pixel reduction on the matrix pipe
-// ------------------------------------------------------------------------------------------------------
-// Same pixel-parallel pass as render_bwd_quad_kernel (every quad walks its own sub-list), but the reduction over pixels
-// — per (tile, Gaussian) six moments of v = G dL/dalpha and five colour sums of u = alpha T — is ONE dense product
-//     D[m][n] = sum_p A[m][p] * B[p][n],   p = 64 pixels (x 2: v-part and u-part),  n = 16 consecutive list entries,
-// evaluated by v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate: bit for bit a k-ordered fmaf chain, MI355X_MICROARCH.md).
-// north_star ruled MFMA out on the premise that the path is bandwidth-bound; the counters say the render backward is
-// VALU/LDS-latency-bound (profiles/r01_v15: 78 % VALU-active, 8.7 % of HBM peak), and this contraction was ~45 % of its
-// VALU instructions (transposition FMAs, DPP merges, staging + owner pull). Deviation recorded in DESIGN.md §2.6.
-//   * rows of B are indexed by list ENTRY, not by trip: a quad that evaluates entry e in any trip stores u, v at
-//     [e - 16 w][pixel]; entries a quad never visits keep zeros. The four quads' partial sums therefore merge inside the
-//     accumulator — no staging area, no owner pull, no DPP;
-//   * A is constant per lane: rows {1,x,y,x^2 | 1,x,y,xy | 1,y,y^2,-} (tile-local pixel coordinates, v-part) and the five
-//     upstream colour gradients of the pixel (u-part); the duplicated rows put everything a lane needs for its four
-//     outputs into that lane: lane (n, g) finishes outputs 4g..4g+3 of entry n (moments are shifted from the tile origin to
-//     the Gaussian centre: sum v (gx - x) = gx S0 - Sx, ...) and stores its 16-byte quarter of the record line;
-//   * per window: 8 ds_read_b128 + 32 MFMA + 8 zeroing stores per lane instead of ~200 VALU + 3 LDS round trips per 8 trips.
-namespace {
-
-#define MW 16            // list entries per window = MFMA N
-#define MRS 68           // row stride of the window matrices in floats (17 x 16 B: the b128 operand reads of 16 rows spread over all banks)
-#define MUV (MW * MRS)   // floats per matrix = 17 x 64 dwords: u and v of a pixel go out in one ds_write2st64_b32
-#define QBM 96           // bytes per quad sub-list (64 entries + the pipelined over-read past a window's trips)
-
-}  // namespace
-
-template <bool HAVE_INV>
-__global__ __launch_bounds__(RBLK) void render_bwd_mfma_kernel(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx, const uint4* __restrict__ desc, const uint32_t* __restrict__ sched, int lg16,
-    const float4* __restrict__ packed, const uint32_t* __restrict__ n_contrib,
-    const float* __restrict__ out_color, const float* __restrict__ out_invdepth, const float* __restrict__ dL_dpix,
-    const float* __restrict__ dL_dinv, float* __restrict__ records, uint8_t* __restrict__ live_flag, uint32_t rec_plane) {
-  __shared__ __attribute__((aligned(16))) float s_slab[RBLK / 64][64 * ENT];
-  __shared__ __attribute__((aligned(16))) float s_uv[RBLK / 64][2 * MUV];
-  __shared__ uint32_t s_slot[RBLK / 64][64];
-  __shared__ __attribute__((aligned(16))) uint8_t s_idx[RBLK / 64][4 * QBM];
-  static_assert(6 * 64 <= 2 * MUV, "the colour-gradient staging lives inside the window matrices");
-  const int lane = threadIdx.x & 63;
-  uint2 range = make_uint2(0u, 0u);
-  const int tile = tile_of_wave(desc, sched, lg16, gsx, range);
-  if (tile >= ntiles) return;
-  const int w = RBLK == 64 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  float* slab = s_slab[w];
-  float* su = s_uv[w];
-  uint32_t* sslot = s_slot[w];
-  uint8_t* sidx = s_idx[w];
-  int ox, oy;
-  quad_pixel(lane, ox, oy);
-  const int tx0 = (tile % gsx) * SUBX, ty0 = (tile / gsx) * SUBY;
-  const int px = tx0 + ox, py = ty0 + oy;
-  const bool inside = px < W && py < H;
-  const uint32_t pix_id = (uint32_t)py * (uint32_t)W + (uint32_t)px;
-  const float pxf = (float)px, pyf = (float)py;
-  if (desc == nullptr) range = ranges[tile];
-  const size_t HW = (size_t)H * W;
-  const int myq = lane >> 4;
-  const uint8_t* myidx = sidx + myq * QBM;
-
-  float g[NCH] = {0.f, 0.f, 0.f, 0.f, 0.f};
-  float ginv = 0.f, Dfinal = 0.f;
-  uint32_t ncontrib = 0;
-  if (inside) {
-    ncontrib = n_contrib[pix_id];
-#pragma unroll
-    for (int ch = 0; ch < NCH; ch++) {
-      g[ch] = dL_dpix[ch * HW + pix_id];
-      Dfinal += g[ch] * out_color[ch * HW + pix_id];
-    }
-    if (HAVE_INV) {
-      ginv = dL_dinv[pix_id];
-      Dfinal += ginv * out_invdepth[pix_id];
-    }
-  }
-  // ---- A operands. MFMA lane (m = lane & 15, kk = lane >> 4), k-step (j, i): pixel = lane 16 j + 4 kk + i of the pixel
-  //      pass, i.e. tile-local (x, y) = (4 (j & 1) + i, 4 (j >> 1) + kk) (quad_pixel) ----
-  const int mrow = lane & 15, kk = lane >> 4;
-  float Au[16], Av[16];
-  {
-    // u-part: rows 11..15 carry the pixel's upstream gradient of colour channel 0..4 (0 elsewhere); staged once through LDS
-#pragma unroll
-    for (int ch = 0; ch < NCH; ch++) su[ch * 64 + lane] = g[ch];
-    su[NCH * 64 + lane] = 0.f;
-    wave_lds_sync();
-    const float* src = su + (mrow >= 11 ? mrow - 11 : NCH) * 64 + 4 * kk;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const float4 t = *reinterpret_cast<const float4*>(src + 16 * j);
-      Au[4 * j] = t.x; Au[4 * j + 1] = t.y; Au[4 * j + 2] = t.z; Au[4 * j + 3] = t.w;
-    }
-    wave_lds_sync();
-    // v-part: rows 0..10 = {1, x, y, x^2 | 1, x, y, x y | 1, y, y^2}
-    const int ex = (mrow == 1 || mrow == 5 || mrow == 7) ? 1 : (mrow == 3 ? 2 : 0);
-    const int ey = (mrow == 2 || mrow == 6 || mrow == 7 || mrow == 9) ? 1 : (mrow == 10 ? 2 : 0);
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const float x = (float)(4 * (j & 1) + i), y = (float)(4 * (j >> 1) + kk);
-        const float fx = ex == 0 ? 1.f : (ex == 1 ? x : x * x), fy = ey == 0 ? 1.f : (ey == 1 ? y : y * y);
-        Av[4 * j + i] = mrow < 11 ? fx * fy : 0.f;
-      }
-  }
-  // the window matrices start (and are handed back by every window) all zero; sub-list bytes: valid slab positions
-  for (int t = lane; t < 2 * MUV / 4; t += 64) reinterpret_cast<float4*>(su)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int t = lane; t < 4 * QBM / 4; t += 64) reinterpret_cast<uint32_t*>(sidx)[t] = 0u;
-  const uint32_t tile_last = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max_u32(ncontrib));
-  const float kx = LN2 * 0.5f * W, ky = LN2 * 0.5f * H;
-  const float bx0 = (float)tx0, by0 = (float)ty0;
-  float T = 1.0f, Dacc = 0.f;
-  float* const uvlane = su + lane;
-  const float* const opnd = su + mrow * MRS + 4 * kk;  // this lane's B operands: row = entry, 4 pixels per quad
-
-  uint32_t jbase = 0;
-  Cand nxt = gather_cand<1>(peek_cand<1>(range.x + lane, range.y, keys, point_list), 0u, packed);
-  Peek pk = peek_cand<1>(range.x + 64 + lane, range.y, keys, point_list);
-  for (uint32_t c0 = range.x; c0 < range.y && jbase < tile_last; c0 += 64) {
-    wave_lds_sync();
-    unsigned long long bal[4];
-    {
-      const uint32_t qm = nxt.hit ? quad_mask(nxt, bx0, by0) : 0u;
-      // per-tile lists: the in-range entries are lanes 0..jn-1, parked at their own lane index
-      const bool listed = nxt.hit && jbase + (uint32_t)lane < tile_last;  // entries behind the last contributor are dead
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const bool in = listed && ((qm >> q) & 1u);
-        bal[q] = __builtin_amdgcn_ballot_w64(in);
-        if (in) {
-          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[q] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[q], 0u));
-          sidx[q * QBM + (int)rank] = (uint8_t)lane;
-        }
-      }
-    }
-    const unsigned long long mybal = myq == 0 ? bal[0] : (myq == 1 ? bal[1] : (myq == 2 ? bal[2] : bal[3]));
-    sslot[lane] = nxt.slot;
-    const int jn = park(slab, nullptr, lane, nxt, 0);
-    nxt = gather_cand<1>(pk, 0u, packed);
-    pk = peek_cand<1>(c0 + 128 + lane, range.y, keys, point_list);
-    wave_lds_sync();
-
-    for (int wdw = 0; wdw < 64 / MW; wdw++) {
-      const unsigned long long wm = 0xFFFFull << (MW * wdw);
-      const int ntr = max(max((int)__popcll(bal[0] & wm), (int)__popcll(bal[1] & wm)),
-                          max((int)__popcll(bal[2] & wm), (int)__popcll(bal[3] & wm)));
-      if (ntr == 0) continue;  // wave-uniform: no quad lists any entry of this window
-      const int start = (int)__popcll(mybal & ((1ull << (MW * wdw)) - 1ull));  // my quad's sub-list entries before this window
-      const int cnt = (int)__popcll(mybal & wm);
-      const int row0 = MW * wdw;
-      // ---- pixel pass over this window's sub-list segments ----
-      auto grad = [&](const Ent& e, int pos, int t) {
-        const float dx = e.q0.x - pxf, dy = e.q0.y - pyf;
-        const float p = power_of(e, dx, dy);
-        const float G = __builtin_amdgcn_exp2f(p);
-        const float alpha = fminf(e.q1.y * G, 0.99f);
-        const bool act = t < cnt;
-        const bool valid = act && (jbase + (uint32_t)pos < ncontrib) && !(p > 0.0f) && !(alpha < 1.0f / 255.0f);
-        float gc = g[0] * e.q1.z + g[1] * e.q1.w + g[2] * e.q2.x + g[3] * e.q2.y + g[4] * e.q2.z;
-        if (HAVE_INV) gc += ginv * e.q2.w;
-        const float a_eff = valid ? alpha : 0.f;
-        const float G_eff = valid ? G : 0.f;
-        const float wgt = a_eff * T;
-        Dacc += gc * wgt;
-        const float one_m = 1.f - a_eff;
-        const float dLda = T * gc - (Dfinal - Dacc) * __builtin_amdgcn_rcpf(one_m);
-        T = T * one_m;
-        if (act) {  // row = the entry's place in the window; quads whose segment is exhausted store nothing
-          float* const uv = uvlane + (pos - row0) * MRS;
-          uv[0] = wgt;
-          uv[MUV] = G_eff * dLda;  // v = G dL/dalpha
-        }
-      };
-      {
-        const uint8_t* wi = myidx + start;
-        int i0 = wi[0], i1 = wi[1];
-        Ent ea = fetch(slab, i0);
-        int t = 0;
-        for (; t + 1 < ntr; t += 2) {
-          const Ent eb = fetch(slab, i1);
-          const int i2 = wi[t + 2];
-          grad(ea, i0, t);
-          ea = fetch(slab, i2);
-          const int i3 = wi[t + 3];
-          grad(eb, i1, t + 1);
-          i0 = i2;
-          i1 = i3;
-        }
-        if (t < ntr) grad(ea, i0, t);
-      }
-      wave_lds_sync();
-      // ---- reduction over pixels: 32 MFMA, two accumulators (dependent-accumulator latency 40 cycles vs 32 issue) ----
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const float4 bu = *reinterpret_cast<const float4*>(opnd + 16 * j);
-        const float4 bv = *reinterpret_cast<const float4*>(opnd + MUV + 16 * j);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Av[4 * j + 0], bv.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Av[4 * j + 1], bv.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Av[4 * j + 2], bv.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Av[4 * j + 3], bv.w, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Au[4 * j + 0], bu.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Au[4 * j + 1], bu.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Au[4 * j + 2], bu.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Au[4 * j + 3], bu.w, acc1, 0, 0, 0);
-      }
-      // hand the matrices back all zero (LDS instructions of a wave execute in order: these follow the reads above)
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        *reinterpret_cast<float4*>(const_cast<float*>(opnd) + 16 * j) = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(const_cast<float*>(opnd) + MUV + 16 * j) = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      const float a0 = acc0[0] + acc1[0], a1 = acc0[1] + acc1[1], a2 = acc0[2] + acc1[2], a3 = acc0[3] + acc1[3];
-      // ---- lane (n = mrow, g = kk): outputs 4g..4g+3 of entry row0 + n -> its quarter of the record line ----
-      const unsigned long long nzb = __builtin_amdgcn_ballot_w64(a0 != 0.f || a1 != 0.f || a2 != 0.f || a3 != 0.f);
-      const uint32_t any16 = (uint32_t)(nzb | (nzb >> 16) | (nzb >> 32) | (nzb >> 48)) & 0xFFFFu;
-      if ((any16 >> mrow) & 1u) {  // entries no pixel blends leave no record (their live flag stays 0)
-        const int e = row0 + mrow;
-        const float4 q0 = *reinterpret_cast<const float4*>(slab + e * ENT);      // gx gy A B
-        const float2 q1 = *reinterpret_cast<const float2*>(slab + e * ENT + 4);  // C op
-        const uint32_t slot = sslot[e];
-        const float gxr = q0.x - bx0, gyr = q0.y - by0;  // centre relative to the tile origin
-        const float ho = -0.5f * q1.y;
-        float4 out;
-        if (kk == 0) {         // S0 Sx Sy Sxx
-          const float Sdx = gxr * a0 - a1, Sdy = gyr * a0 - a2;
-          const float Sdxdx = gxr * (Sdx - a1) + a3;
-          out = make_float4(q1.y * kx * (2.f * q0.z * Sdx - q0.w * Sdy), q1.y * ky * (2.f * q1.x * Sdy - q0.w * Sdx), ho * Sdxdx, a0);
-          live_flag[slot] = 1;
-        } else if (kk == 1) {  // S0 Sx Sy Sxy
-          out = make_float4(ho * (gxr * (gyr * a0 - a2) - gyr * a1 + a3), 0.f, 0.f, 0.f);
-        } else if (kk == 2) {  // S0 Sy Syy c0
-          out = make_float4(ho * (gyr * ((gyr * a0 - a1) - a1) + a2), a3, 0.f, 0.f);
-        } else {               // c1 c2 c3 c4
-          out = make_float4(a0, a1, a2, a3);
-        }
-        float4* r4 = reinterpret_cast<float4*>(records);  // every lane group stores its own pieces of the 48-byte record
-        float* const q1p = reinterpret_cast<float*>(r4 + rec_q(slot, 1, rec_plane, REC / 4));
-        if (kk == 0) r4[rec_q(slot, 0, rec_plane, REC / 4)] = out;
-        else if (kk == 1) q1p[0] = out.x;
-        else if (kk == 2) { q1p[1] = out.x; q1p[2] = out.y; }  // (8-byte store: misaligned at float 5)
-        else {
-          q1p[3] = out.x;
-          *reinterpret_cast<float3*>(r4 + rec_q(slot, 2, rec_plane, REC / 4)) = make_float3(out.y, out.z, out.w);
-        }
-      }
-    }
-    jbase += (uint32_t)jn;
-  }
-}
-
-static int bwd_mfma_on() {  // EOGS_BWD_MFMA: 0 = VALU transposition, 1 = entry-indexed MFMA kernel (2.6), 2 = trip-indexed MFMA transposition
-  static const int v = [] {
-    const char* e = getenv("EOGS_BWD_MFMA");
-    return e ? atoi(e) : 0;
-  }();
-  return v;
 }
 
 static double quad_bwd_switch() {  // EOGS_QUAD_BWD_SWITCH=<listed tiles per Gaussian>, 0 disables the quad backward
@@ -1868,9 +1431,7 @@ static double quad_bwd_switch() {  // EOGS_QUAD_BWD_SWITCH=<listed tiles per Gau
 int render_bwd_variant(int block, int64_t R, int P) {
   if (nr_alt(R)) return 6;  // altitude-only: the quad backward's one-channel variant
   if (block > 1) return 1;
-  if (nr_btf(R)) return 5;
-  if (!(quad_bwd_switch() > 0.0 && (double)nr_slots(R) <= quad_bwd_switch() * (double)P)) return 0;
-  return bwd_mfma_on() == 1 ? 3 : (bwd_mfma_on() == 2 ? 4 : 2);
+  return (quad_bwd_switch() > 0.0 && (double)nr_slots(R) <= quad_bwd_switch() * (double)P) ? 2 : 0;
 }
 
 // Does the backward that (block, R, P) selects write flag-free records (common.h noflag_scene)? 0 = no, 1 = where the scene
@@ -1881,7 +1442,7 @@ int render_bwd_noflag_ok(int block, int64_t R, int P) {
     return e ? atoi(e) : 1;
   }();
   const int v = render_bwd_variant(block, R, P);
-  if (mode <= 0 || !(v == 2 || v == 4 || v == 6)) return 0;
+  if (mode <= 0 || !(v == 2 || v == 6)) return 0;
   return mode >= 2 ? 3 : 1;
 }
 static bool fwd_masks_on() {  // EOGS_FWD_MASKS=0: the quad backward computes its quad masks itself (A/B)
@@ -1895,34 +1456,25 @@ static bool fwd_masks_on() {  // EOGS_FWD_MASKS=0: the quad backward computes it
 // bit 3 = the forward's quad masks are in BinWS::qmask
 static int render_bwd_opts(int block, int64_t R, int P) { return render_bwd_noflag_ok(block, R, P) | ((render_opts() & 1) ? 4 : 0); }
 
-void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R, const float* colors,
-                       const float* out_color, const float* out_invdepth, const float* dL_dcolor,
-                       const float* dL_dinvdepth, const float* bg, bool raw, hipStream_t s) {
+void launch_render_bwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, int H, int W, int64_t R,
+                       const float* dL_dcolor, const float* dL_dinvdepth, const float* bg, bool raw, hipStream_t s) {
   const int gsx = (W + SUBX - 1) / SUBX, gsy = (H + SUBY - 1) / SUBY, ntiles = gsx * gsy;
   const int variant = render_bwd_variant(b.block, R, P);
-  if (variant == 5) {
-    auto* kb = dL_dinvdepth ? render_bwd_btf_kernel<true> : render_bwd_btf_kernel<false>;
-    hipLaunchKernelGGL(kb, dim3(render_grid(ntiles, im, R)), dim3(RBLK), 0, s, im.ranges, b.point_list, W, H, gsx, ntiles, render_desc(im, R),
-                       g.sched, (int)(16u * im.sched_lg), g.packed, im.n_contrib, im.final_T, bg, dL_dcolor, dL_dinvdepth, b.records, b.live, b.cap_slots);
+  if (variant == 2 || variant == 6) {  // the quad backward (variant 6: altitude-only, no inverse-depth gradient: api.hip checks)
+    auto* kq = dL_dinvdepth ? render_bwd_quad_kernel<true, false> : render_bwd_quad_kernel<false, false>;
+    if (variant == 2 && raw) kq = dL_dinvdepth ? render_bwd_quad_kernel<true, false, true> : render_bwd_quad_kernel<false, false, true>;
+    if (variant == 6) kq = render_bwd_quad_kernel<false, true>;
+    const bool fwd_quad = render_fwd_variant(b.block, R, P) == 2 && b.qmask != nullptr && fwd_masks_on();
+    hipLaunchKernelGGL(kq, dim3(render_grid(ntiles, im, R)), dim3(RBLK), 0, s, im.ranges, b.qmask, b.point_list, W, H, gsx,
+                       ntiles, render_desc(im, R), g.sched, (int)(16u * im.sched_lg), g.packed, im.n_contrib, im.final_T, bg,
+                       dL_dcolor, dL_dinvdepth, b.records, b.live, b.cap_slots, g.misc, render_bwd_opts(b.block, R, P) | (fwd_quad ? 8 : 0));
     return;
   }
   auto* kern = variant == 1 ? (dL_dinvdepth ? render_bwd_kernel<BLOCK_BIG, true> : render_bwd_kernel<BLOCK_BIG, false>)
                             : (dL_dinvdepth ? render_bwd_kernel<1, true> : render_bwd_kernel<1, false>);
-  if (variant == 2 || variant == 4 || variant == 6) {  // the quad backward (variant 6: altitude-only, no inverse-depth gradient: api.hip checks)
-    auto* kq = dL_dinvdepth ? render_bwd_quad_kernel<true, 0, false> : render_bwd_quad_kernel<false, 0, false>;
-    if (variant == 2 && raw) kq = dL_dinvdepth ? render_bwd_quad_kernel<true, 0, false, true> : render_bwd_quad_kernel<false, 0, false, true>;
-    if (variant == 6) kq = render_bwd_quad_kernel<false, 0, true>;
-    if (variant == 4) kq = dL_dinvdepth ? render_bwd_quad_kernel<true, 1, false> : render_bwd_quad_kernel<false, 1, false>;
-    const bool fwd_quad = render_fwd_variant(b.block, R, P) == 2 && b.qmask != nullptr && fwd_masks_on();
-    hipLaunchKernelGGL(kq, dim3(render_grid(ntiles, im, R)), dim3(RBLK), 0, s, im.ranges, reinterpret_cast<const uint32_t*>(b.qmask), b.point_list, W, H, gsx,
-                       ntiles, (int)macro_grid_x(W, b.block), render_desc(im, R), g.sched, (int)(16u * im.sched_lg), g.packed, im.n_contrib, out_color,
-                       out_invdepth, dL_dcolor, dL_dinvdepth, b.records, b.live, b.cap_slots, g.misc, render_bwd_opts(b.block, R, P) | (fwd_quad ? 8 : 0));
-    return;
-  }
-  if (variant == 3) kern = dL_dinvdepth ? render_bwd_mfma_kernel<true> : render_bwd_mfma_kernel<false>;
   hipLaunchKernelGGL(kern, dim3(render_grid(ntiles, im, R)), dim3(RBLK), 0, s, im.ranges, b.sorted_keys, b.point_list, W, H, gsx,
-                     ntiles, (int)macro_grid_x(W, b.block), render_desc(im, R), g.sched, (int)(16u * im.sched_lg), g.packed, im.n_contrib, out_color,
-                     out_invdepth, dL_dcolor, dL_dinvdepth, b.records, b.live, b.cap_slots);
+                     ntiles, (int)macro_grid_x(W, b.block), render_desc(im, R), g.sched, (int)(16u * im.sched_lg), g.packed, im.n_contrib,
+                     im.final_T, bg, dL_dcolor, dL_dinvdepth, b.records, b.live, b.cap_slots);
 }
 
 #ifdef EOGS_BWD_PHASES

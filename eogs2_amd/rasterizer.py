@@ -184,10 +184,7 @@ class CapturedForward:
         exact = R.value
         _peak[self.key] = _merge_counts(_peak.get(self.key), exact)
         _spec[self.key] = _last_exact[dev] = exact
-        # (a forward that asks for the back-to-front backward — bit 60, image-sized opaque Gaussians — does not fit a graph
-        # recorded without it: eogs_rast_capacity_token; the next capture takes the flags of this forward from _peak)
-        btf_ok = not ((exact >> 60) & 1 and not (self.capacity >> 60) & 1)
-        return (exact & _SLOTS) <= (self.capacity & _SLOTS) and (exact & _ENTRIES) <= (self.capacity & _ENTRIES) and btf_ok
+        return (exact & _SLOTS) <= (self.capacity & _SLOTS) and (exact & _ENTRIES) <= (self.capacity & _ENTRIES)
 
 
 class record_captured:

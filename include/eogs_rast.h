@@ -37,7 +37,10 @@
 extern "C" {
 #endif
 
-#define EOGS_RAST_ABI_VERSION 7 /* 7: EOGS_FLAG_ALT_ONLY, token bit 59 (list entries now 27 bits), `have_scratch | 2`, tile schedule in the workspaces */
+#define EOGS_RAST_ABI_VERSION 8 /* 8: every backward walks back to front (the reference's recursion): `bg` is required by eogs_rast_backward,
+                                 * out_color / out_invdepth are ignored there, token bit 60 now carries the per-Gaussian kernel hint,
+                                 * n_contrib counts positions of the list a render wave walks; eogs_rast_backward_info, eogs_sum_into.
+                                 * 7: EOGS_FLAG_ALT_ONLY, token bit 59 (list entries now 27 bits), `have_scratch | 2`, tile schedule in the workspaces */
 #define EOGS_RAST_CHANNELS 5 /* DGR/cuda_rasterizer/config.h:15 NUM_CHANNELS */
 #define EOGS_RAST_TILE 16    /* DGR/cuda_rasterizer/config.h:16-17 BLOCK_X/BLOCK_Y */
 
@@ -89,7 +92,7 @@ extern "C" {
  * comes back with column 3 alone non-zero (raw mode: a zero f_dc gradient; the altitude's dependence on xyz is chained).
  * The choice travels in the token (bit 59): pass the flag to forward_prepare, hand `have_scratch | 2` to the calls that
  * build a token without flags (read_counts, mirror_token, capacity_token). Such a forward always takes per-tile lists and
- * the front-to-back quad kernels. Equal to the full render's channel 3 / to a full backward with zero upstream gradient
+ * the quad kernels. Equal to the full render's channel 3 / to a full backward with zero upstream gradient
  * on the other channels (tests/test_gpu_altonly.py). */
 #define EOGS_FLAG_ALT_ONLY 32u
 
@@ -124,9 +127,9 @@ int eogs_rast_scratch_bytes(int P, int H, int W, size_t* bytes);
  * Writes radii[P] and *num_rendered (host). num_rendered is an opaque token for the three calls below (it packs this
  * library's pair counts, list granularity and where the entries were sorted, see csrc/common.h nr_pack: record slots in
  * bits 0..30, list entries in bits 32..58, flags above); 0 means nothing is listed.
- * Beside the token the library keeps, per process, the mean list depth x mean pair opacity of the last 16 tokens it built from
- * counts (the token has no bit left for it; a capacity token inherits it): eogs_rast_backward picks between two builds of its
- * per-Gaussian kernel by it. A hint only: both builds compute the same bits, and a token the table no longer holds gets the default. */
+ * One of the flag bits (60) says whether the forward's lists are shallow in opacity (mean list depth x mean pair opacity):
+ * eogs_rast_backward picks between builds of its per-Gaussian kernel by it (a capacity token inherits it). A hint only: every
+ * build computes the same bits. */
 int eogs_rast_forward_prepare(
     int P, int H, int W,
     const float* means3D, const float* scales, const float* rotations,
@@ -160,9 +163,8 @@ int eogs_rast_mirror_token(int P, int H, int W, const void* host, int have_scrat
 /* A token whose workspaces hold `slack` (e.g. 0.25) more record slots and list entries than `num_rendered` (an exact token
  * of an earlier forward with the same P, H, W) describes, for a deferred-count forward; *fits (optional; pass NULL when there
  * is no exact token yet) receives whether the exact token `exact` fits inside it — its counts do (0 = nothing listed always
- * does) and it does not ask for the back-to-front backward while `num_rendered` was counted without it (the capacity token
- * keeps the earlier forward's list granularity and backward variant; that one choice matters for parity).
- * have_scratch: the caller passes a scratch buffer to both calls. */
+ * does). The capacity token keeps the earlier forward's list granularity and kernel hints: speed only, every choice computes
+ * the same values. have_scratch: the caller passes a scratch buffer to both calls. */
 int eogs_rast_capacity_token(int P, int64_t num_rendered, double slack, int have_scratch, int64_t exact,
                              int64_t* capacity, int* fits);
 
@@ -182,8 +184,10 @@ int eogs_rast_forward_render(
  * BACKWARD::render, computeCov2DCUDA, BACKWARD::preprocessCUDA) and the zero-filled
  * gradient allocation of DGR/rasterize_points.cu:163-174 — every gradient output is
  * fully (over)written here, the caller may pass uninitialised memory.
- *   out_color      forward's rendered image f32[5,H,W] (ignored by the oracle)
- *   out_invdepth   forward's inverse-depth image f32[H,W]; only read when dL_dout_invdepth != NULL
+ *   bg             f32[5], required (the background term of dL/dalpha, DGR/cuda_rasterizer/backward.cu:527-529,617-620)
+ *   out_color      forward's rendered image f32[5,H,W]: ignored since ABI 8 (as by the oracle), may be NULL — the walk starts
+ *                  from the final transmittance the forward left in the image workspace, as the reference's does
+ *   out_invdepth   forward's inverse-depth image f32[H,W]: ignored since ABI 8, may be NULL
  *   dL_dout_color  f32[5,H,W];  dL_dout_invdepth f32[H,W] or NULL
  *   dL_dmeans2D f32[P,3] (NDC units, z = 0)  dL_dcolors f32[P,5]  dL_dopacity f32[P]
  *   dL_dmeans3D f32[P,3]  dL_dcov3D f32[P,6]  dL_dscales f32[P,3]  dL_drotations f32[P,4]
@@ -260,16 +264,16 @@ int eogs_rast_profile_get(int slot, double* total_ms, int64_t* launches, const c
  * (DESIGN.md §2.3, §2.5); tests use this to record that every kernel was compared with the oracle.
  *   *list_block_px  8 (per-tile lists) or 32 (block lists)
  *   *fwd_kernel / *bwd_kernel  0 = one list per tile (render_*_kernel<1>), 1 = block lists (render_*_kernel<4>),
- *                              2 = quad sub-lists (render_*_quad_kernel); backward only: 3 = quad sub-lists with the
- *                              entry-indexed MFMA reduction, 4 = quad sub-lists with the MFMA transposition,
- *                              5 = back to front on per-tile lists: the reference's own recursion
- *                              (DGR/cuda_rasterizer/backward.cu:536-643), chosen for image-sized Gaussians
+ *                              2 = quad sub-lists (render_*_quad_kernel); backward only: 6 = the quad kernel's one-channel
+ *                              variant of an altitude-only render. (3, 4, 5 — two matrix-pipe experiments and a separate
+ *                              back-to-front kernel — existed up to ABI 7; every backward kernel now walks back to front,
+ *                              DGR/cuda_rasterizer/backward.cu:536-643.)
  * The oracle reports 16 / -1 / -1 (the reference's 16-px tiles, no kernel variants). */
 int eogs_rast_path_info(int P, int64_t num_rendered, int* list_block_px, int* fwd_kernel, int* bwd_kernel);
 /* Which build of the per-Gaussian backward kernel eogs_rast_backward would launch for this token right now: 0 = four records
  * in flight per lane (seven waves per SIMD), 1 / 2 = eight (four waves; 2: up to eight listed tiles in one trip). It depends on
- * the token AND on the per-process hint kept beside it (the forward's list depth x mean pair opacity, see forward_prepare):
- * unknown or deep in opacity -> 0. All three compute the same bits; tests use this to see the hint travel. The oracle reports -1. */
+ * the token's counts and its hint bit (the forward's list depth x mean pair opacity, see forward_prepare): deep in
+ * opacity -> 0. All three compute the same bits; tests use this to see the hint travel. The oracle reports -1. */
 int eogs_rast_backward_info(int P, int64_t num_rendered, int* gaussian_bwd_wide);
 /* Runs the library's wave64 primitive self-test (DPP reduction, readlane broadcast) on `stream` and returns,
  * after synchronising, a bit mask of failing primitives in *failed (0 = all good). scratch: >= 4 device bytes. */

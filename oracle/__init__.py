@@ -13,7 +13,8 @@ LIB_PATH = os.path.join(_HERE, "librast_oracle.so")
 def build(force=False):
     src = os.path.join(_HERE, "rast_oracle.c")
     hdr = os.path.join(_HERE, "..", "include", "eogs_rast.h")
-    stale = (not os.path.exists(LIB_PATH)) or (not os.path.exists(os.path.join(_HERE, "librast_oracle_fma.so"))) or any(
+    stale = (not os.path.exists(LIB_PATH)) or (not os.path.exists(os.path.join(_HERE, "librast_oracle_fma.so"))) or (
+        not os.path.exists(os.path.join(_HERE, "librast_oracle_f64.so"))) or any(
         os.path.getmtime(p) > os.path.getmtime(LIB_PATH) for p in (src, hdr)
     )
     if force or stale:
@@ -23,6 +24,20 @@ def build(force=False):
 
 _abi = None
 _abi_fma = None
+_abi_f64 = None
+
+
+def abi_f64():
+    """RastABI over the arbiter build (rast_oracle.c, -DORACLE_F64): the fp32 forward and its decisions, the backward's
+    differentiable quantities recomputed and chained in double. tests/parity_cases.py: who is right on an ill-conditioned gradient."""
+    global _abi_f64
+    if _abi_f64 is None:
+        from eogs2_amd._abi import RastABI
+
+        build()
+        _abi_f64 = RastABI(os.path.join(_HERE, "librast_oracle_f64.so"))
+        assert _abi_f64.cdll.eogs_oracle_is_f64() == 1
+    return _abi_f64
 
 
 def abi_fma():

@@ -63,7 +63,10 @@ int eogs_oracle_accum_float(int on) { const int old = g_acc_float; g_acc_float =
 static int g_suffix_by_subtraction = 0;
 /* 0: the reference's back-to-front recursion. 1: front to back, sum behind a Gaussian = rendered total (from out_color) minus running
  * prefix — the HIP path's formulation. 2: the same with the total taken from the running sum's own end value (a first walk over the list)
- * instead of the rendered image: tells how much of (1)'s deviation is the mismatch between the two differently associated totals. */
+ * instead of the rendered image: tells how much of (1)'s deviation is the mismatch between the two differently associated totals.
+ * 3: back to front like the reference, but with the colour behind a Gaussian carried as ONE number per pixel — the reference's accum_rec
+ * projected on the pixel's upstream gradient, a_j = g . accum_rec_j, with a_j = a_{j+1} + alpha_{j+1} (g.c_{j+1} - a_{j+1}) — and T
+ * recovered with a reciprocal: the HIP path's formulation since round 6 (csrc/render.hip). Same recursion, another association. */
 int eogs_oracle_suffix_by_subtraction(int on) { const int old = g_suffix_by_subtraction; g_suffix_by_subtraction = on; return old; }
 /* Diagnostic (tests/parity_cases.py, causal attribution of threshold flips): the reference's two data-dependent blend
  * decisions (forward.cu:374-382) evaluated with their thresholds moved by a stated number of ulp, per pixel:
@@ -291,6 +294,75 @@ static void cov2d(const float T[3][3], const float cov3D[6], float* cxx, float* 
   *cxy = A[1][0] * T[0][0] + A[1][1] * T[0][1] + A[1][2] * T[0][2]; /* glm cov[0][1] */
   *cyy = A[1][0] * T[1][0] + A[1][1] * T[1][1] + A[1][2] * T[1][2];
 }
+
+/* ---- the arbiter build (oracle/Makefile: librast_oracle_f64.so, -DORACLE_F64) ----
+ * `real` is the type the BACKWARD computes in: float in the oracle proper (the reference's fp32, bit for bit as restated), double in
+ * the arbiter build, which tests/parity_cases.py uses to decide who is right where the fp32 oracle and the HIP path disagree on an
+ * ill-conditioned gradient (covariance backward of strongly anisotropic Gaussians, backward.cu:239-394): an element is accepted iff the
+ * HIP value is no further from the double evaluation than twice what valid fp32 evaluations of the reference's algorithm are.
+ * The arbiter evaluates the SAME function — the same blend / skip / stop decisions per (pixel, Gaussian) pair, taken from the
+ * fp32 forward exactly as the oracle proper takes them — with every differentiable quantity recomputed in double from the inputs:
+ * the per-Gaussian forward chain (projection, cov3D, cov2D, conic, antialiasing scale, depth), the final transmittance of each
+ * pixel, the per-pixel recursion and the per-Gaussian backward chain. Its forward entry points are the fp32 ones, unchanged. */
+#ifdef ORACLE_F64
+typedef double real;
+#define R_EXP exp
+#define R_SQRT sqrt
+#define R_FMAX fmax
+#define R_FMIN fmin
+int eogs_oracle_is_f64(void) { return 1; }
+#else
+typedef float real;
+#define R_EXP expf
+#define R_SQRT sqrtf
+#define R_FMAX fmaxf
+#define R_FMIN fminf
+int eogs_oracle_is_f64(void) { return 0; }
+#endif
+#define RC(x) ((real)(x))
+
+/* (the helpers above once more in `real`: the same operations in the same order — in the fp32 build the same bits) */
+static void quat_to_Rm_r(const real q[4], real Rm[3][3]) {
+  real r = q[0], x = q[1], y = q[2], z = q[3];
+  Rm[0][0] = RC(1) - RC(2) * (y * y + z * z); Rm[1][0] = RC(2) * (x * y - r * z); Rm[2][0] = RC(2) * (x * z + r * y);
+  Rm[0][1] = RC(2) * (x * y + r * z); Rm[1][1] = RC(1) - RC(2) * (x * x + z * z); Rm[2][1] = RC(2) * (y * z - r * x);
+  Rm[0][2] = RC(2) * (x * z - r * y); Rm[1][2] = RC(2) * (y * z + r * x); Rm[2][2] = RC(1) - RC(2) * (x * x + y * y);
+}
+static void build_T_r(const float* vm, int W, int H, real T[3][3]) {
+  real s[3] = {(real)(W / 2.0), (real)(H / 2.0), RC(1)};
+  for (int i = 0; i < 3; i++)
+    for (int k = 0; k < 3; k++) T[i][k] = (real)vm[4 * k + i] * s[i];
+}
+static void sym_from6_r(const real c[6], real V[3][3]) {
+  V[0][0] = c[0]; V[0][1] = c[1]; V[0][2] = c[2];
+  V[1][0] = c[1]; V[1][1] = c[3]; V[1][2] = c[4];
+  V[2][0] = c[2]; V[2][1] = c[4]; V[2][2] = c[5];
+}
+static void cov2d_r(const real T[3][3], const real cov3D[6], real* cxx, real* cxy, real* cyy) {
+  real V[3][3], A[2][3];
+  sym_from6_r(cov3D, V);
+  for (int i = 0; i < 2; i++)
+    for (int l = 0; l < 3; l++)
+      A[i][l] = T[i][0] * V[0][l] + T[i][1] * V[1][l] + T[i][2] * V[2][l];
+  *cxx = A[0][0] * T[0][0] + A[0][1] * T[0][1] + A[0][2] * T[0][2];
+  *cxy = A[1][0] * T[0][0] + A[1][1] * T[0][1] + A[1][2] * T[0][2];
+  *cyy = A[1][0] * T[1][0] + A[1][1] * T[1][1] + A[1][2] * T[1][2];
+}
+#ifdef ORACLE_F64
+static void cov3d_from_scale_rot_r(const float s[3], float mod, const float q[4], real out[6]) {
+  real Rm[3][3], M[3][3], Sg[3][3];
+  const real qr[4] = {q[0], q[1], q[2], q[3]};
+  quat_to_Rm_r(qr, Rm);
+  real sc[3] = {(real)mod * s[0], (real)mod * s[1], (real)mod * s[2]};
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) M[i][j] = sc[i] * Rm[i][j];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      Sg[i][j] = M[0][i] * M[0][j] + M[1][i] * M[1][j] + M[2][i] * M[2][j];
+  out[0] = Sg[0][0]; out[1] = Sg[0][1]; out[2] = Sg[0][2];
+  out[3] = Sg[1][1]; out[4] = Sg[1][2]; out[5] = Sg[2][2];
+}
+#endif
 
 /* ------------------------------------------------------------------------------------------- */
 /* Forward phase 1: FORWARD::preprocessCUDA + InclusiveSum                                     */
@@ -576,8 +648,47 @@ static int backward_activated(
   double* acc_color = acc_opac + n;
   /* (after the colours: dL_dinvdepths, n doubles per band — computed, consumed by nobody: backward.cu:306-307 is commented out) */
 
+  /* The per-Gaussian quantities the pixel loop and the per-Gaussian chain read, in `real`. The oracle proper takes them from the
+   * forward's workspace (fp32, what the reference's backward re-reads: backward.cu:480-560); the arbiter build recomputes them in
+   * double from the inputs (forward.cu:182-283 restated once more), Gaussians the forward did not list left at zero. */
+  real* rG = (real*)calloc(n * 13, sizeof(real));
+  if (!rG) { free(acc_all); return fail(EOGS_ERR_DEVICE, "backward: out of host memory"); }
+  real* const r_mean2D = rG;          /* [P,2] pixel centre */
+  real* const r_conic_o = rG + n * 2; /* [P,4] conic, opacity x antialiasing scale */
+  real* const r_invd = rG + n * 6;    /* [P]   1 / depth */
+  real* const r_cov3D = rG + n * 7;   /* [P,6] */
+  real T[3][3];
+  build_T_r(viewmatrix, W, H, T);
+  for (size_t i = 0; i < n; i++) {
+#ifdef ORACLE_F64
+    if (!(radii[i] > 0)) continue;
+    const float* pm = means3D + 3 * i;
+    double pv[3];
+    for (int k = 0; k < 3; k++)
+      pv[k] = (double)viewmatrix[k] * pm[0] + (double)viewmatrix[4 + k] * pm[1] + (double)viewmatrix[8 + k] * pm[2] + (double)viewmatrix[12 + k];
+    if (have_sr) cov3d_from_scale_rot_r(scales + 3 * i, scale_modifier, rotations + 4 * i, r_cov3D + 6 * i);
+    else for (int k = 0; k < 6; k++) r_cov3D[6 * i + k] = cov3D_precomp[6 * i + k];
+    double cx, cy, cz;
+    cov2d_r(T, r_cov3D + 6 * i, &cx, &cy, &cz);
+    const double det_cov = cx * cz - cy * cy;
+    cx += (double)0.3f; cz += (double)0.3f; /* (the reference's constants are fp32 literals: the same function) */
+    const double det = cx * cz - cy * cy;
+    const double hcs = aa ? sqrt(fmax((double)0.000025f, det_cov / det)) : 1.0;
+    r_conic_o[4 * i] = cz / det; r_conic_o[4 * i + 1] = -cy / det; r_conic_o[4 * i + 2] = cx / det;
+    r_conic_o[4 * i + 3] = (double)opacities[i] * hcs;
+    r_mean2D[2 * i] = ((pv[0] + 1.0) * W - 1.0) * 0.5;
+    r_mean2D[2 * i + 1] = ((pv[1] + 1.0) * H - 1.0) * 0.5;
+    r_invd[i] = 1.0 / (200.0 - pv[2]);
+#else
+    r_mean2D[2 * i] = g.means2D[2 * i]; r_mean2D[2 * i + 1] = g.means2D[2 * i + 1];
+    for (int k = 0; k < 4; k++) r_conic_o[4 * i + k] = g.conic_opacity[4 * i + k];
+    r_invd[i] = 1.f / g.depths[i];
+    for (int k = 0; k < 6; k++) r_cov3D[6 * i + k] = g.cov3D[6 * i + k];
+#endif
+  }
+
   /* ---- BACKWARD::renderCUDA (backward.cu:457-643), back to front per pixel ---- */
-  const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
+  const real ddelx_dx = (real)(0.5 * W), ddely_dy = (real)(0.5 * H);
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 1) num_threads(oracle_threads() < nbands ? oracle_threads() : nbands)
 #endif
@@ -594,23 +705,40 @@ static int backward_activated(
       const uint32_t r0 = im.ranges[2 * tile], r1 = im.ranges[2 * tile + 1];
       const size_t pix_id = (size_t)W * py + px;
       const float pixfx = (float)px, pixfy = (float)py;
-      const float T_final = im.final_T[pix_id];
-      float T = T_final;
-      uint32_t contributor = r1 - r0;
       const uint32_t last_contributor = im.n_contrib[pix_id];
-      float accum_rec[C_] = {0}, dL_dpixel[C_], last_color[C_] = {0};
-      float dL_invdepth = 0, accum_invdepth_rec = 0, last_invdepth = 0, last_alpha = 0;
+      real T_final = im.final_T[pix_id];
+#ifdef ORACLE_F64
+      { /* the pixel's final transmittance in double: the product over the entries the fp32 forward blended (its decisions) */
+        T_final = 1.0;
+        for (uint32_t k = r0; k < r1 && k - r0 < last_contributor; k++) {
+          const uint32_t id = b.values[k];
+          const float fdx = g.means2D[2 * (size_t)id] - pixfx, fdy = g.means2D[2 * (size_t)id + 1] - pixfy;
+          const float* fco = g.conic_opacity + 4 * (size_t)id;
+          const float fpower = -0.5f * (fco[0] * fdx * fdx + fco[2] * fdy * fdy) - fco[1] * fdx * fdy;
+          if (fpower > 0.0f) continue;
+          if (fminf(0.99f, fco[3] * expf(fpower)) < alpha_min(nudge_sign(pix_id), fpower)) continue;
+          const real dx = r_mean2D[2 * (size_t)id] - (real)pixfx, dy = r_mean2D[2 * (size_t)id + 1] - (real)pixfy;
+          const real* co = r_conic_o + 4 * (size_t)id;
+          T_final *= 1.0 - fmin((double)0.99f, co[3] * exp(-0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy));
+        }
+      }
+#endif
+      real Tcur = T_final;
+      uint32_t contributor = r1 - r0;
+      real accum_rec[C_] = {0}, dL_dpixel[C_], last_color[C_] = {0};
+      real dL_invdepth = 0, accum_invdepth_rec = 0, last_invdepth = 0, last_alpha = 0;
       for (int ch = 0; ch < C_; ch++) dL_dpixel[ch] = dL_dout_color[ch * HW + pix_id];
       if (dL_dout_invdepth) dL_invdepth = dL_dout_invdepth[pix_id];
-      float bg_dot_dpixel = 0;
-      for (int ch = 0; ch < C_; ch++) bg_dot_dpixel += bg[ch] * dL_dpixel[ch];
+      real bg_dot_dpixel = 0;
+      for (int ch = 0; ch < C_; ch++) bg_dot_dpixel += (real)bg[ch] * dL_dpixel[ch];
 
-      float* alt = NULL; /* diagnostic: dL/dalpha per list entry in the front-to-back formulation */
-      if (g_suffix_by_subtraction && out_color && last_contributor > 0) {
+      float* alt = NULL; /* diagnostic: dL/dalpha per list entry in the front-to-back formulation (fp32) */
+      real proj_a = 0, proj_T = T_final; /* diagnostic 3: the projected recursion's state */
+      if (g_suffix_by_subtraction && g_suffix_by_subtraction != 3 && out_color && last_contributor > 0) {
         alt = (float*)calloc(r1 - r0, 4);
         float Dfinal = 0.f, Dacc = 0.f, Tf = 1.0f;
-        for (int ch = 0; ch < C_; ch++) Dfinal += dL_dpixel[ch] * out_color[ch * HW + pix_id];
-        if (dL_dout_invdepth && out_invdepth) Dfinal += dL_invdepth * out_invdepth[pix_id];
+        for (int ch = 0; ch < C_; ch++) Dfinal += (float)dL_dpixel[ch] * out_color[ch * HW + pix_id];
+        if (dL_dout_invdepth && out_invdepth) Dfinal += (float)dL_invdepth * out_invdepth[pix_id];
         if (g_suffix_by_subtraction == 2) { /* the running sum's own total: same operations, same order as the loop below */
           float Dt = 0.f, Tt = 1.0f;
           for (uint32_t k = r0; k < r1 && k - r0 < last_contributor; k++) {
@@ -622,12 +750,12 @@ static int backward_activated(
             const float alpha = fminf(0.99f, co[3] * expf(power));
             if (alpha < alpha_min(nudge_sign(pix_id), power)) continue;
             float gc = 0.f;
-            for (int ch = 0; ch < C_; ch++) gc += dL_dpixel[ch] * colors[(size_t)id * C_ + ch];
-            if (dL_dout_invdepth) gc += dL_invdepth * (1.f / g.depths[id]);
+            for (int ch = 0; ch < C_; ch++) gc += (float)dL_dpixel[ch] * colors[(size_t)id * C_ + ch];
+            if (dL_dout_invdepth) gc += (float)dL_invdepth * (1.f / g.depths[id]);
             Dt += gc * (alpha * Tt);
             Tt *= (1.f - alpha);
           }
-          Dfinal = Dt + T_final * bg_dot_dpixel;
+          Dfinal = Dt + (float)T_final * (float)bg_dot_dpixel;
         }
         for (uint32_t k = r0; alt && k < r1 && k - r0 < last_contributor; k++) {
           const uint32_t id = b.values[k];
@@ -638,8 +766,8 @@ static int backward_activated(
           const float alpha = fminf(0.99f, co[3] * expf(power));
           if (alpha < alpha_min(nudge_sign(pix_id), power)) continue;
           float gc = 0.f;
-          for (int ch = 0; ch < C_; ch++) gc += dL_dpixel[ch] * colors[(size_t)id * C_ + ch];
-          if (dL_dout_invdepth) gc += dL_invdepth * (1.f / g.depths[id]);
+          for (int ch = 0; ch < C_; ch++) gc += (float)dL_dpixel[ch] * colors[(size_t)id * C_ + ch];
+          if (dL_dout_invdepth) gc += (float)dL_invdepth * (1.f / g.depths[id]);
           Dacc += gc * (alpha * Tf);
           alt[k - r0] = Tf * gc - (Dfinal - Dacc) / (1.f - alpha);
           Tf *= (1.f - alpha);
@@ -650,46 +778,69 @@ static int backward_activated(
         contributor--;
         if (contributor >= last_contributor) continue;
         const uint32_t id = b.values[k];
-        const float dx = g.means2D[2 * (size_t)id] - pixfx, dy = g.means2D[2 * (size_t)id + 1] - pixfy;
-        const float* co = g.conic_opacity + 4 * (size_t)id;
-        const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-        if (power > 0.0f) continue;
-        const float G = expf(power);
-        const float alpha = fminf(0.99f, co[3] * G);
-        if (alpha < alpha_min(nudge_sign(pix_id), power)) continue; /* the same decision forward took */
+        /* the decisions: the forward's own fp32 evaluation (forward.cu:366-376), in every build */
+        const float fdx = g.means2D[2 * (size_t)id] - pixfx, fdy = g.means2D[2 * (size_t)id + 1] - pixfy;
+        const float* fco = g.conic_opacity + 4 * (size_t)id;
+        const float fpower = -0.5f * (fco[0] * fdx * fdx + fco[2] * fdy * fdy) - fco[1] * fdx * fdy;
+        if (fpower > 0.0f) continue;
+        const float fG = expf(fpower);
+        const float falpha = fminf(0.99f, fco[3] * fG);
+        if (falpha < alpha_min(nudge_sign(pix_id), fpower)) continue; /* the same decision forward took */
+#ifdef ORACLE_F64
+        const real dx = r_mean2D[2 * (size_t)id] - (real)pixfx, dy = r_mean2D[2 * (size_t)id + 1] - (real)pixfy;
+        const real* co = r_conic_o + 4 * (size_t)id;
+        const real power = -0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+        const real G = exp(power);
+        const real alpha = fmin((double)0.99f, co[3] * G);
+#else
+        const real dx = fdx, dy = fdy;
+        const real* co = fco;
+        const real G = fG;
+        const real alpha = falpha;
+#endif
 
-        T = T / (1.f - alpha);
-        const float dchannel_dcolor = alpha * T;
-        float dL_dalpha = 0.0f;
+        Tcur = Tcur / (RC(1) - alpha);
+        const real dchannel_dcolor = alpha * Tcur;
+        real dL_dalpha = 0;
         for (int ch = 0; ch < C_; ch++) {
-          const float c = colors[(size_t)id * C_ + ch];
-          accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+          const real c = colors[(size_t)id * C_ + ch];
+          accum_rec[ch] = last_alpha * last_color[ch] + (RC(1) - last_alpha) * accum_rec[ch];
           last_color[ch] = c;
-          const float dL_dchannel = dL_dpixel[ch];
+          const real dL_dchannel = dL_dpixel[ch];
           dL_dalpha += (c - accum_rec[ch]) * dL_dchannel;
           ACC(acc_color[(size_t)id * C_ + ch], dchannel_dcolor * dL_dchannel);
         }
         if (dL_dout_invdepth) {
-          const float invd = 1.f / g.depths[id];
-          accum_invdepth_rec = last_alpha * last_invdepth + (1.f - last_alpha) * accum_invdepth_rec;
+          const real invd = r_invd[id];
+          accum_invdepth_rec = last_alpha * last_invdepth + (RC(1) - last_alpha) * accum_invdepth_rec;
           last_invdepth = invd;
           dL_dalpha += (invd - accum_invdepth_rec) * dL_invdepth;
           ACC(acc_invd[id], dchannel_dcolor * dL_invdepth);
         }
-        dL_dalpha *= T;
+        dL_dalpha *= Tcur;
         last_alpha = alpha;
-        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+        dL_dalpha += (-T_final / (RC(1) - alpha)) * bg_dot_dpixel;
         if (alt) dL_dalpha = alt[k - r0];
+        if (g_suffix_by_subtraction == 3) {
+          real gc = 0;
+          for (int ch = 0; ch < C_; ch++) gc += dL_dpixel[ch] * (real)colors[(size_t)id * C_ + ch];
+          if (dL_dout_invdepth) gc += dL_invdepth * r_invd[id];
+          const real rinv = RC(1) / (RC(1) - alpha);
+          proj_T = proj_T * rinv;
+          const real d = gc - proj_a;
+          dL_dalpha = d * proj_T + (-T_final * bg_dot_dpixel) * rinv;
+          proj_a = proj_a + alpha * d;
+        }
 
-        const float dL_dG = co[3] * dL_dalpha;
-        const float gdx = G * dx, gdy = G * dy;
-        const float dG_ddelx = -gdx * co[0] - gdy * co[1];
-        const float dG_ddely = -gdy * co[2] - gdx * co[1];
+        const real dL_dG = co[3] * dL_dalpha;
+        const real gdx = G * dx, gdy = G * dy;
+        const real dG_ddelx = -gdx * co[0] - gdy * co[1];
+        const real dG_ddely = -gdy * co[2] - gdx * co[1];
         ACC(acc_mean2D[2 * (size_t)id], dL_dG * dG_ddelx * ddelx_dx);
         ACC(acc_mean2D[2 * (size_t)id + 1], dL_dG * dG_ddely * ddely_dy);
-        ACC(acc_conic[3 * (size_t)id], -0.5f * gdx * dx * dL_dG);
-        ACC(acc_conic[3 * (size_t)id + 1], -0.5f * gdx * dy * dL_dG);
-        ACC(acc_conic[3 * (size_t)id + 2], -0.5f * gdy * dy * dL_dG);
+        ACC(acc_conic[3 * (size_t)id], RC(-0.5) * gdx * dx * dL_dG);
+        ACC(acc_conic[3 * (size_t)id + 1], RC(-0.5) * gdx * dy * dL_dG);
+        ACC(acc_conic[3 * (size_t)id + 2], RC(-0.5) * gdy * dy * dL_dG);
         ACC(acc_opac[id], G * dL_dalpha);
       }
       free(alt);
@@ -717,48 +868,50 @@ static int backward_activated(
     for (int ch = 0; ch < C_; ch++) dL_dcolors[i * C_ + ch] = (float)acc_color[i * C_ + ch];
   }
 
-  float T[3][3];
-  build_T(viewmatrix, W, H, T);
   double dT_sum[6] = {0}, vm_mean[12] = {0};
 
   for (int idx = 0; idx < P; idx++) {
     if (!(radii[idx] > 0)) continue;
     const size_t i = (size_t)idx;
     /* ---- computeCov2DCUDA (backward.cu:147-327) ---- */
-    const float* c3 = g.cov3D + 6 * i;
-    const float dLc[3] = {(float)acc_conic[3 * i], (float)acc_conic[3 * i + 1], (float)acc_conic[3 * i + 2]};
-    float V[3][3];
-    sym_from6(c3, V);
-    float c_xx, c_xy, c_yy;
-    cov2d(T, c3, &c_xx, &c_xy, &c_yy);
-    const float h_var = 0.3f;
-    float d_inside_root = 0.f;
+    const real* c3 = r_cov3D + 6 * i;
+    const real dLc[3] = {(real)acc_conic[3 * i], (real)acc_conic[3 * i + 1], (real)acc_conic[3 * i + 2]};
+    real V[3][3];
+    sym_from6_r(c3, V);
+    real c_xx, c_xy, c_yy;
+    cov2d_r(T, c3, &c_xx, &c_xy, &c_yy);
+    const real h_var = RC(0.3f);
+    real d_inside_root = 0;
     if (aa) {
-      const float det_cov = c_xx * c_yy - c_xy * c_xy;
+      const real det_cov = c_xx * c_yy - c_xy * c_xy;
       c_xx += h_var;
       c_yy += h_var;
-      const float det_cov_plus_h_cov = c_xx * c_yy - c_xy * c_xy;
-      const float hcs = sqrtf(fmaxf(0.000025f, det_cov / det_cov_plus_h_cov));
-      const float dL_dopacity_v = dL_dopacity[i];
-      const float d_hcs = dL_dopacity_v * opacities[i];
-      dL_dopacity[i] = dL_dopacity_v * hcs;
-      d_inside_root = (det_cov / det_cov_plus_h_cov) <= 0.000025f ? 0.f : d_hcs / (2 * hcs);
+      const real det_cov_plus_h_cov = c_xx * c_yy - c_xy * c_xy;
+      const real hcs = R_SQRT(R_FMAX(RC(0.000025f), det_cov / det_cov_plus_h_cov));
+      const real dL_dopacity_v = (real)acc_opac[i];
+      const real d_hcs = dL_dopacity_v * (real)opacities[i];
+#ifdef ORACLE_F64
+      dL_dopacity[i] = (float)(dL_dopacity_v * hcs);
+#else
+      dL_dopacity[i] = dL_dopacity[i] * hcs; /* (the fp32 sum of the kernel above, rescaled in place: backward.cu:201-237) */
+#endif
+      d_inside_root = (det_cov / det_cov_plus_h_cov) <= RC(0.000025f) ? RC(0) : d_hcs / (2 * hcs);
     } else {
       c_xx += h_var;
       c_yy += h_var;
     }
-    float dL_dc_xx = 0, dL_dc_xy = 0, dL_dc_yy = 0;
+    real dL_dc_xx = 0, dL_dc_xy = 0, dL_dc_yy = 0;
     if (aa) {
-      const float x = c_xx, y = c_yy, z = c_xy, w = h_var;
-      const float sqv = w * w + w * (x + y) + x * y - z * z;
-      const float denom_f = d_inside_root / (sqv * sqv);
+      const real x = c_xx, y = c_yy, z = c_xy, w = h_var;
+      const real sqv = w * w + w * (x + y) + x * y - z * z;
+      const real denom_f = d_inside_root / (sqv * sqv);
       dL_dc_xx = w * (w * y + y * y + z * z) * denom_f;
       dL_dc_yy = w * (w * x + x * x + z * z) * denom_f;
-      dL_dc_xy = -2.f * w * z * (w + x + y) * denom_f;
+      dL_dc_xy = RC(-2) * w * z * (w + x + y) * denom_f;
     }
-    const float denom = c_xx * c_yy - c_xy * c_xy;
-    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
-    float* dcov = dL_dcov3D + 6 * i;
+    const real denom = c_xx * c_yy - c_xy * c_xy;
+    const real denom2inv = RC(1) / ((denom * denom) + RC(0.0000001f));
+    real dcov[6] = {0, 0, 0, 0, 0, 0};
     if (denom2inv != 0) {
       dL_dc_xx += denom2inv * (-c_yy * c_yy * dLc[0] + 2 * c_xy * c_yy * dLc[1] + (denom - c_xx * c_yy) * dLc[2]);
       dL_dc_yy += denom2inv * (-c_xx * c_xx * dLc[2] + 2 * c_xx * c_xy * dLc[1] + (denom - c_xx * c_yy) * dLc[0]);
@@ -769,14 +922,13 @@ static int backward_activated(
       dcov[1] = 2 * T[0][0] * T[0][1] * dL_dc_xx + (T[0][0] * T[1][1] + T[0][1] * T[1][0]) * dL_dc_xy + 2 * T[1][0] * T[1][1] * dL_dc_yy;
       dcov[2] = 2 * T[0][0] * T[0][2] * dL_dc_xx + (T[0][0] * T[1][2] + T[0][2] * T[1][0]) * dL_dc_xy + 2 * T[1][0] * T[1][2] * dL_dc_yy;
       dcov[4] = 2 * T[0][2] * T[0][1] * dL_dc_xx + (T[0][1] * T[1][2] + T[0][2] * T[1][1]) * dL_dc_xy + 2 * T[1][1] * T[1][2] * dL_dc_yy;
-    } else {
-      for (int k = 0; k < 6; k++) dcov[k] = 0;
     }
+    for (int k = 0; k < 6; k++) dL_dcov3D[6 * i + k] = (float)dcov[k];
     /* dL/dT (2x3), backward.cu:276-287.  Vrk[a][b] is symmetric so glm's [col][row] order is immaterial. */
-    float TV[2][3];
+    real TV[2][3];
     for (int r = 0; r < 2; r++)
       for (int k = 0; k < 3; k++) TV[r][k] = T[r][0] * V[k][0] + T[r][1] * V[k][1] + T[r][2] * V[k][2];
-    const float dLdT[6] = {
+    const real dLdT[6] = {
         2 * TV[0][0] * dL_dc_xx + TV[1][0] * dL_dc_xy,
         2 * TV[0][1] * dL_dc_xx + TV[1][1] * dL_dc_xy,
         2 * TV[0][2] * dL_dc_xx + TV[1][2] * dL_dc_xy,
@@ -789,48 +941,57 @@ static int backward_activated(
     for (int k = 0; k < 6; k++) dT_sum[k] += (double)dLdT[k];
 
     /* ---- BACKWARD::preprocessCUDA (backward.cu:399-454): dL_dmeans = 0 (cov2D kernel, :313-317) + A^T g ---- */
-    const float gxn = dL_dmeans2D[3 * i], gyn = dL_dmeans2D[3 * i + 1];
-    dL_dmeans3D[3 * i + 0] = projmatrix[0] * gxn + projmatrix[1] * gyn;
-    dL_dmeans3D[3 * i + 1] = projmatrix[4] * gxn + projmatrix[5] * gyn;
-    dL_dmeans3D[3 * i + 2] = projmatrix[8] * gxn + projmatrix[9] * gyn;
+#ifdef ORACLE_F64
+    const real gxn = acc_mean2D[2 * i], gyn = acc_mean2D[2 * i + 1];
+#else
+    const real gxn = dL_dmeans2D[3 * i], gyn = dL_dmeans2D[3 * i + 1];
+#endif
+    dL_dmeans3D[3 * i + 0] = (float)((real)projmatrix[0] * gxn + (real)projmatrix[1] * gyn);
+    dL_dmeans3D[3 * i + 1] = (float)((real)projmatrix[4] * gxn + (real)projmatrix[5] * gyn);
+    dL_dmeans3D[3 * i + 2] = (float)((real)projmatrix[8] * gxn + (real)projmatrix[9] * gyn);
 
     /* ---- computeCov3D backward (backward.cu:331-394) ---- */
     if (have_sr) {
-      const float* q = rotations + 4 * i;
-      const float r = q[0], x = q[1], y = q[2], z = q[3];
-      float Rm[3][3];
-      quat_to_Rm(q, Rm);
-      const float s[3] = {scale_modifier * scales[3 * i], scale_modifier * scales[3 * i + 1], scale_modifier * scales[3 * i + 2]};
-      float M[3][3];
+      const real q[4] = {rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]};
+      const real r = q[0], x = q[1], y = q[2], z = q[3];
+      real Rm[3][3];
+      quat_to_Rm_r(q, Rm);
+      const real sm = scale_modifier;
+      const real sc[3] = {sm * (real)scales[3 * i], sm * (real)scales[3 * i + 1], sm * (real)scales[3 * i + 2]};
+      real M[3][3];
       for (int a = 0; a < 3; a++)
-        for (int c = 0; c < 3; c++) M[a][c] = s[a] * Rm[a][c];
-      float dS[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
-                        {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
-                        {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
+        for (int c = 0; c < 3; c++) M[a][c] = sc[a] * Rm[a][c];
+      real dS[3][3] = {{dcov[0], RC(0.5) * dcov[1], RC(0.5) * dcov[2]},
+                       {RC(0.5) * dcov[1], dcov[3], RC(0.5) * dcov[4]},
+                       {RC(0.5) * dcov[2], RC(0.5) * dcov[4], dcov[5]}};
       /* dL_dM = 2 * M * dL_dSigma (glm) -> math: dM = 2 * M_math * dS  */
-      float dM[3][3];
+      real dM[3][3];
       for (int a = 0; a < 3; a++)
         for (int c = 0; c < 3; c++)
-          dM[a][c] = (2.0f * M[a][0]) * dS[0][c] + (2.0f * M[a][1]) * dS[1][c] + (2.0f * M[a][2]) * dS[2][c];
+          dM[a][c] = (RC(2) * M[a][0]) * dS[0][c] + (RC(2) * M[a][1]) * dS[1][c] + (RC(2) * M[a][2]) * dS[2][c];
       /* glm: Rt = transpose(R), dL_dMt = transpose(dL_dM); Rt[k] (glm column k of R^T) = math row k of R_math;
        * dL_dMt[k] = math row k of dM. dL_dscale_k = dot(Rm[k,:], dM[k,:]). */
       float* ds = dL_dscales + 3 * i;
-      for (int k = 0; k < 3; k++) ds[k] = Rm[k][0] * dM[k][0] + Rm[k][1] * dM[k][1] + Rm[k][2] * dM[k][2];
+      for (int k = 0; k < 3; k++) ds[k] = (float)(Rm[k][0] * dM[k][0] + Rm[k][1] * dM[k][1] + Rm[k][2] * dM[k][2]);
       /* dL_dMt[k] *= s_k; then dL_dMt[a][b] (glm col a, row b) = s_a * dM[a][b] */
-      float D[3][3];
+      real D[3][3];
       for (int a = 0; a < 3; a++)
-        for (int c = 0; c < 3; c++) D[a][c] = dM[a][c] * s[a];
+        for (int c = 0; c < 3; c++) D[a][c] = dM[a][c] * sc[a];
       float* dq = dL_drotations + 4 * i;
-      dq[0] = 2 * z * (D[0][1] - D[1][0]) + 2 * y * (D[2][0] - D[0][2]) + 2 * x * (D[1][2] - D[2][1]);
-      dq[1] = 2 * y * (D[1][0] + D[0][1]) + 2 * z * (D[2][0] + D[0][2]) + 2 * r * (D[1][2] - D[2][1]) - 4 * x * (D[2][2] + D[1][1]);
-      dq[2] = 2 * x * (D[1][0] + D[0][1]) + 2 * r * (D[2][0] - D[0][2]) + 2 * z * (D[1][2] + D[2][1]) - 4 * y * (D[2][2] + D[0][0]);
-      dq[3] = 2 * r * (D[0][1] - D[1][0]) + 2 * x * (D[2][0] + D[0][2]) + 2 * y * (D[1][2] + D[2][1]) - 4 * z * (D[1][1] + D[0][0]);
+      dq[0] = (float)(2 * z * (D[0][1] - D[1][0]) + 2 * y * (D[2][0] - D[0][2]) + 2 * x * (D[1][2] - D[2][1]));
+      dq[1] = (float)(2 * y * (D[1][0] + D[0][1]) + 2 * z * (D[2][0] + D[0][2]) + 2 * r * (D[1][2] - D[2][1]) - 4 * x * (D[2][2] + D[1][1]));
+      dq[2] = (float)(2 * x * (D[1][0] + D[0][1]) + 2 * r * (D[2][0] - D[0][2]) + 2 * z * (D[1][2] + D[2][1]) - 4 * y * (D[2][2] + D[0][0]));
+      dq[3] = (float)(2 * r * (D[0][1] - D[1][0]) + 2 * x * (D[2][0] + D[0][2]) + 2 * y * (D[1][2] + D[2][1]) - 4 * z * (D[1][1] + D[0][0]));
     }
   }
   /* wrapper-side reductions (__init__.py:193-201) over ALL Gaussians (invisible ones contribute zeros) */
   for (size_t i = 0; i < n; i++) {
     const float* m = means3D + 3 * i;
+#ifdef ORACLE_F64
+    const double gm[3] = {acc_mean2D[2 * i], acc_mean2D[2 * i + 1], 0.0};
+#else
     const float* gm = dL_dmeans2D + 3 * i;
+#endif
     for (int a = 0; a < 3; a++)
       for (int c = 0; c < 3; c++) vm_mean[3 * a + c] += (double)m[a] * (double)gm[c];
     for (int c = 0; c < 3; c++) vm_mean[9 + c] += (double)gm[c];
@@ -838,6 +999,7 @@ static int backward_activated(
   if (dL_dT_sum) for (int k = 0; k < 6; k++) dL_dT_sum[k] = (float)dT_sum[k];
   if (dL_dvm_mean) for (int k = 0; k < 12; k++) dL_dvm_mean[k] = (float)vm_mean[k];
 
+  free(rG);
   free(acc_all);
   return EOGS_OK;
 }

@@ -11,8 +11,10 @@ the oracle itself reproduces them with the decision moved: the oracle is re-run 
 per-pixel sign is chosen from the three images so that the oracle's image matches the HIP image, the oracle runs once more
 with that per-pixel map, and every output and gradient must then agree with THAT run to the plain tolerance (or, where one
 pixel holds several near pairs that flipped differently, lie inside the interval the four oracle runs span). What is still
-outside must be explained by the oracle's own ill-conditioning (sensitivity map) or the test fails. The number of accepted
-elements per tensor is capped: a regression cannot hide behind the mechanism.
+outside must be decided by the ARBITER — the oracle's backward evaluated in double with the same decisions
+(oracle/librast_oracle_f64.so): the HIP value may be no further from it than twice what valid fp32 evaluations of the
+reference's algorithm are — or the test fails. The number of accepted elements per tensor is capped: a regression cannot hide
+behind the mechanism.
 
 "1e-4" is meant PER QUANTITY (round 4): the scale an error is measured against is the largest reference magnitude of the
 element's own channel for [C, H, W] images and of its own column for [P, k] per-Gaussian gradients, not of the whole tensor.
@@ -76,9 +78,7 @@ def sweep_case(seed):
     case.update(H=H, W=W, antialiasing=aa)
     if dgrad:
         case["dL_dinvdepth"] = (torch.randn(1, H, W, generator=g) / (H * W) * 100).numpy()
-    # (the label only selects a tolerance where the back-to-front backward is switched off: tests/util.py GRAD_RTOL)
-    stress = scale_mult >= 6.0 and aniso >= 0.7
-    return case, ("seed15" if stress else f"sweep{seed}")
+    return case, f"sweep{seed}"
 
 
 def oracle_run(case, backend=None):
@@ -108,7 +108,7 @@ def oracle_cached(key, case):
     return _ORACLE_CACHE[key]
 
 
-SENS_ULPS, SENS_DRAWS, SENS_FACTOR = 4.0, 4, 4.0
+SENS_ULPS, SENS_DRAWS = 4.0, 4
 
 
 def nudged_run(case, uniform=0, sign_map=None):
@@ -160,55 +160,54 @@ def _take_prefetched(case):
         pool.terminate()
 
 
-def formulation_delta(case, base):
-    """|oracle evaluated with the HIP path's formulation of dL/dalpha - oracle|: front to back, the sum behind a Gaussian
-    taken as (rendered total - running prefix) instead of the reference's back-to-front recursion (render.hip; algebraically
-    identical). Where a Gaussian's contribution is orders below the pixel's total (image-sized opaque Gaussians stacked
-    hundreds deep) the subtraction carries an absolute error of an ulp of the TOTAL. This is a property of the implementation
-    under test, so it is NOT part of the sensitivity map: elements only it explains are reported and accepted under a
-    separate, much tighter allowance (check_close). tools/suffix_probe.py."""
+def fp32_variants(case):
+    """Other valid fp32 evaluations of the reference's algorithm on `case`, beside the oracle's own: its per-Gaussian sums
+    accumulated in fp32 in pixel order (an order the reference's atomicAdds can produce, backward.cu:598-640; the oracle proper
+    sums in double) and its build with fused multiply-adds (a second rounding of every expression, as nvcc contracts them)."""
     import oracle
 
-    lib = oracle.abi().cdll
-    lib.eogs_oracle_suffix_by_subtraction(1)
-    try:
-        res = oracle_run(case)
-    finally:
-        lib.eogs_oracle_suffix_by_subtraction(0)
-    return {k: np.abs(np.asarray(res[k], dtype=np.float64) - np.asarray(base[k], dtype=np.float64)) for k in base if k != "out_radii"}
-
-
-def sensitivity_map(case, base=None):
-    """{output name: max over SENS_DRAWS of |oracle(inputs (1 + SENS_ULPS ulp randn)) - oracle(inputs)|}.
-
-    Backward-error view of an fp32 evaluation: it returns the exact result for inputs perturbed by a few ulp. Where the
-    ORACLE's own output moves by more than the tolerance under such a perturbation (cancelling sums in the covariance
-    backward of strongly anisotropic Gaussians, backward.cu:239-394; or a pair sitting on a threshold), two correct
-    fp32 implementations cannot be expected to agree to the tolerance, and the movement bounds by how much."""
-    import oracle
-
-    base = base if base is not None else oracle_run(case)
-    out = {k: np.zeros_like(np.asarray(v), dtype=np.float64) for k, v in base.items() if k != "out_radii"}
-    # the summation order of the per-Gaussian sums: fp32 atomicAdds in the reference (backward.cu:598-640, order changes run
-    # to run), fp32 per-tile records here, double in the restatement. One evaluation with fp32 accumulation in pixel order
-    # (an order the reference itself can produce) measures how far that moves each output.
+    out = {}
     lib = oracle.abi().cdll
     lib.eogs_oracle_accum_float(1)
     try:
-        res = oracle_run(case)
+        out["fp32 sums"] = oracle_run(case)
     finally:
         lib.eogs_oracle_accum_float(0)
-    for k in out:
-        out[k] = np.maximum(out[k], np.abs(np.asarray(res[k], dtype=np.float64) - np.asarray(base[k], dtype=np.float64)))
-    # rounding alone: the same restatement built with fused multiply-adds (oracle/Makefile). Expressions of the reference
-    # that cancel (`denom - c_xx * c_yy` = -c_xy^2 computed from two rounded products, backward.cu:239-251) are numerically
-    # unstable rather than ill-conditioned: an input perturbation moves both products together and does not show it, a
-    # second valid rounding does.
     fma = oracle.abi_fma()
     if fma is not None:
-        res = oracle_run(case, backend=lambda: fma)
-        for k in out:
-            out[k] = np.maximum(out[k], np.abs(np.asarray(res[k], dtype=np.float64) - np.asarray(base[k], dtype=np.float64)))
+        out["fma"] = oracle_run(case, backend=lambda: fma)
+    return out
+
+
+def arbiter(case, base=None):
+    """({output: the arbiter's value}, {output: spread}) for the gradients of `case`.
+
+    The arbiter is the oracle's backward in double (oracle/rast_oracle.c "the arbiter build"): the same fp32 forward, the same
+    blend / skip / stop decision for every (pixel, Gaussian) pair, every differentiable quantity recomputed and chained in double
+    from the inputs — the value the fp32 evaluations scatter around. `spread` is, per element, the largest distance from it of
+    a VALID fp32 evaluation of the reference's algorithm:
+      * the oracle itself (one fp32 operation per operation of the reference, per-Gaussian sums in double);
+      * its per-Gaussian sums accumulated in fp32 in pixel order (an order the reference's atomicAdds can produce);
+      * its build with fused multiply-adds (a second rounding of every expression: nvcc contracts too);
+      * the oracle on inputs perturbed by SENS_ULPS ulp, SENS_DRAWS draws (an fp32 evaluation is the exact result for inputs
+        perturbed by a few ulp: backward error).
+    Where the reference's algorithm is ill-conditioned in fp32 (covariance backward of strongly anisotropic Gaussians,
+    backward.cu:239-394: cancelling sums such as `denom - c_xx c_yy`) these sit tens of per cent of a column's scale from the
+    arbiter and from each other; no fp32 implementation can be held to 1e-4 of ANOTHER fp32 implementation there, but each can
+    be held to being no worse than the others (check_close)."""
+    import oracle
+
+    base = base if base is not None else oracle_run(case)
+    f64 = oracle_run(case, backend=oracle.abi_f64)
+    keys = [k for k in base if k != "out_radii"]
+    spread = {k: np.abs(np.asarray(base[k], dtype=np.float64) - np.asarray(f64[k], dtype=np.float64)) for k in keys}
+
+    def widen(res):
+        for k in keys:
+            spread[k] = np.maximum(spread[k], np.abs(np.asarray(res[k], dtype=np.float64) - np.asarray(f64[k], dtype=np.float64)))
+
+    for res in fp32_variants(case).values():
+        widen(res)
     for draw in range(SENS_DRAWS):
         g = np.random.default_rng(1000 + draw)
         pert = dict(case)
@@ -218,10 +217,8 @@ def sensitivity_map(case, base=None):
             if k in case:
                 v = np.asarray(case[k])
                 pert[k] = (v * (1.0 + SENS_ULPS * ULP * g.standard_normal(v.shape))).astype(np.float32)
-        res = oracle_run(pert)
-        for k in out:
-            out[k] = np.maximum(out[k], np.abs(np.asarray(res[k], dtype=np.float64) - np.asarray(base[k], dtype=np.float64)))
-    return out
+        widen(oracle_run(pert))
+    return {k: np.asarray(f64[k], dtype=np.float64) for k in keys}, spread
 
 
 IMAGE_KEYS = ("out_color", "out_invdepth")
@@ -255,18 +252,13 @@ def _record(row):
             fh.write(json.dumps(row) + "\n")
 # accepted out-of-tolerance elements per tensor: at most this fraction of its elements (and never fewer than MIN allowed)
 ATTR_FRAC, ATTR_MIN = 5e-3, 32
-# elements explained only by the implementation's own dL/dalpha formulation (formulation_delta): count and size
-# the allowance for the front-to-back dL/dalpha of the fast backward kernels (check_close, 3.): only in processes that switch
-# the back-to-front kernel off to force those kernels onto the stress cases (tests/test_gpu_paths.py); 0 everywhere else —
-# the default suite and the extended sweeps pass without it (profiles/r03_sweeps.txt)
-FORM_MAX, FORM_RTOL = (2 if os.environ.get("EOGS_BTF_SWITCH") == "0" else 0), 1e-3
 
 
 class Attribution:
     """Lazily evaluated explanations of one case's out-of-tolerance elements: the nudged oracle runs (only computed when
-    some element is out of tolerance), the sensitivity map (only when the nudges do not explain them) and the formulation
-    delta (only when neither does). `cache`: a file prefix for the sensitivity map, which depends on the case alone, so
-    processes that replay the same case (tests/path_child.py) share it."""
+    some element is out of tolerance) and the arbiter with the spread of the fp32 evaluations around it (only when the nudges
+    do not explain them). `cache`: a file prefix for the arbiter's arrays, which depend on the case alone, so
+    processes that replay the same case (tests/path_child.py) share them."""
 
     def __init__(self, case, out, ref, cache=None):
         self.case = case
@@ -275,8 +267,7 @@ class Attribution:
         self.cache = cache
         self._matched = None
         self._hull = None
-        self._sens = None
-        self._form = None
+        self._arb = None
         self.flipped_pixels = 0
 
     def matched(self):
@@ -317,56 +308,51 @@ class Attribution:
             print(f"threshold nudges: {self.flipped_pixels} pixels re-decided, {time.perf_counter() - t0:.1f} s of oracle")
         return self._matched, self._hull
 
-    def sensitivity(self, key):
+    def arbiter(self, key):
+        """(the arbiter's value, the spread of the valid fp32 evaluations around it) of output `key`: arbiter()."""
         import os
         import time
 
-        if self._sens is None:
-            f = self.cache + ".sens.npz" if self.cache else None
+        if self._arb is None:
+            f = self.cache + ".arb.npz" if self.cache else None
             if f and os.path.exists(f):
                 z = np.load(f)
-                self._sens = {k: z[k] for k in z.files}
+                self._arb = ({k[4:]: z[k] for k in z.files if k.startswith("f64_")}, {k[7:]: z[k] for k in z.files if k.startswith("spread_")})
             else:
                 t0 = time.perf_counter()
-                self._sens = sensitivity_map(self.case, self.ref)
-                print(f"sensitivity map: {time.perf_counter() - t0:.1f} s")
+                self._arb = arbiter(self.case, self.ref)
+                print(f"arbiter (double) + {2 + SENS_DRAWS} fp32 evaluations: {time.perf_counter() - t0:.1f} s")
                 if f:  # (written whole, then renamed: the path children run two at a time and share this cache)
                     os.makedirs(os.path.dirname(f), exist_ok=True)
                     tmp = f"{f}.{os.getpid()}.tmp.npz"
-                    np.savez(tmp, **self._sens)
+                    np.savez(tmp, **{"f64_" + k: v for k, v in self._arb[0].items()}, **{"spread_" + k: v for k, v in self._arb[1].items()})
                     os.replace(tmp, f)
-        return torch.from_numpy(self._sens[key])
-
-    def formulation(self, key):
-        if self._form is None:
-            self._form = formulation_delta(self.case, self.ref)
-        return torch.from_numpy(self._form[key])
+        return torch.from_numpy(self._arb[0][key]), torch.from_numpy(self._arb[1][key])
 
 
-# bound on an error attributed to the oracle's own ill-conditioning, relative to its quantity's scale. Rounds 1-3: 1e-1 of the
-# TENSOR's scale. Round 4, per quantity: the default suite needs 6.5e-2 (sweep216, g_rotations, 7 elements: strongly anisotropic
-# Gaussians, the oracle itself moves by 0.13 there under 4-ulp perturbations), every other case stays below 3e-2 (profiles/r04_sweeps.txt).
-# The 1600 extended sweep seeds: 1598 pass at 7e-2; seeds 1259 and 4275 (axis spread 1.2, g_rotations) need 0.129 and 0.118 — the
-# oracle moves by more than a quarter of that itself — and pass with EOGS_SENS_RTOL=0.13 (tuning aid for such runs only).
-SENS_RTOL = float(os.environ.get("EOGS_SENS_RTOL", "7e-2"))
+# How far the HIP value may sit from the arbiter, in units of the valid fp32 evaluations' own largest distance from it. (Rounds
+# 1-5 bounded errors "attributed to ill-conditioning" by a tuned constant, SENS_RTOL = 7e-2 of the quantity's scale — raised to
+# 0.13 for two sweep seeds by hand, and every fresh range of 400 seeds found another case just above it; nothing said which of
+# HIP and oracle was closer to the truth. The arbiter does: on seed 1259 the ORACLE sits 0.21 of g_rotations' scale from the
+# double evaluation, tools/f64_probe.py.) 2 = "no worse than twice the worst valid fp32 evaluation, element by element".
+ARB_FACTOR = 2.0
 
 
-def check_close(got, ref, what, rtol, attribution=None, key=None, sens_rtol=None):
+def check_close(got, ref, what, rtol, attribution=None, key=None):
     """|got - ref| <= rtol * max|ref of the element's own quantity| (quantity_scale: channel of an image, column of a
     per-Gaussian gradient) elementwise. Elements beyond it must be explained, in this order:
       1. by a moved blend / stop decision: the element agrees to rtol with the oracle re-run whose per-pixel threshold
          nudges reproduce the HIP image, or lies (to rtol) inside the interval spanned by the oracle runs with the thresholds
          at -k, 0, +k ulp and that matched run;
-      2. by the oracle's own ill-conditioning: it moves by at least err / SENS_FACTOR when the oracle's inputs are perturbed
-         by SENS_ULPS ulp / its sums are accumulated in fp32 / it is built with FMA contraction (bounded by sens_rtol);
-      3. at most FORM_MAX elements per tensor, each below FORM_RTOL, by the HIP path's own dL/dalpha formulation.
+      2. by the arbiter: |got - f64| <= ARB_FACTOR * spread + rtol * scale, where f64 is the oracle's backward evaluated in double
+         with the same decisions and spread the largest distance from it of a valid fp32 evaluation of the reference's
+         algorithm (the oracle, its fp32-summing mode, its FMA build, the oracle on inputs perturbed by a few ulp): arbiter().
     Accepted elements are capped at max(ATTR_MIN, ATTR_FRAC x elements) per tensor (32 / 0.5 %). Returns (max error, accepted elements)."""
     a = torch.as_tensor(got, dtype=torch.float64).cpu()
     b = torch.as_tensor(np.asarray(ref), dtype=torch.float64)
     assert tuple(a.shape) == tuple(b.shape), f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
     if b.numel() == 0:
         return 0.0, 0
-    sens_rtol = SENS_RTOL if sens_rtol is None else sens_rtol
     scale = quantity_scale(b)
     err = (a - b).abs() / scale
     bad = err > rtol
@@ -390,29 +376,27 @@ def check_close(got, ref, what, rtol, attribution=None, key=None, sens_rtol=None
         print(f"{what}: {int((bad & ok).sum())} elements explained by moved blend / stop decisions "
               f"(max err vs the un-nudged oracle {float(err[bad & ok].max()):.3e})")
     if bool(unexplained.any()):
-        delta = attribution.sensitivity(key).reshape(err.shape) / scale
-        sens_ok = err <= SENS_FACTOR * delta + rtol
-        n_sens = int((unexplained & sens_ok).sum())
-        row.update(n_sens=n_sens, max_sens_err=float(err[unexplained & sens_ok].max()) if n_sens else 0.0)
-        if n_sens:
-            assert float(err[unexplained & sens_ok].max()) <= sens_rtol, (
-                f"{what}: sensitivity-attributed error {float(err[unexplained & sens_ok].max()):.3e} exceeds {sens_rtol:g}")
-            print(f"{what}: {n_sens} elements attributed to ill-conditioning (oracle moves by >= err/{SENS_FACTOR:g} under "
-                  f"{SENS_ULPS:g}-ulp input perturbation), max err {float(err[unexplained & sens_ok].max()):.3e}")
-        unexplained = unexplained & ~sens_ok
-    if FORM_MAX and bool(unexplained.any()) and key.startswith("g_"):
-        fd = attribution.formulation(key).reshape(err.shape) / scale
-        form_ok = unexplained & (err <= SENS_FACTOR * fd + rtol) & (err <= FORM_RTOL)
-        if bool(form_ok.any()) and int(form_ok.sum()) <= FORM_MAX:
-            print(f"{what}: {int(form_ok.sum())} element(s) at the precision limit of the front-to-back dL/dalpha formulation "
-                  f"(DESIGN.md 5), max err {float(err[form_ok].max()):.3e} — accepted under the separate allowance")
-            row.update(n_form=int(form_ok.sum()))
-            unexplained = unexplained & ~form_ok
+        f64, spread = attribution.arbiter(key)
+        d_hip = (a - f64.reshape(a.shape)).abs() / scale
+        d_ref = spread.reshape(a.shape) / scale
+        arb_ok = d_hip <= ARB_FACTOR * d_ref + rtol
+        sel = unexplained & arb_ok
+        n_arb = int(sel.sum())
+        row.update(n_sens=n_arb, max_sens_err=float(err[sel].max()) if n_arb else 0.0,
+                   max_hip_f64=float(d_hip[sel].max()) if n_arb else 0.0, max_fp32_f64=float(d_ref[sel].max()) if n_arb else 0.0)
+        if n_arb:
+            print(f"{what}: {n_arb} elements decided by the arbiter: |HIP - oracle| up to {float(err[sel].max()):.3e}, |HIP - f64| up to "
+                  f"{float(d_hip[sel].max()):.3e} where the fp32 evaluations sit up to {float(d_ref[sel].max()):.3e} from it")
+        unexplained = unexplained & ~arb_ok
+        if bool(unexplained.any()):
+            worst = int(torch.argmax(torch.where(unexplained, d_hip - ARB_FACTOR * d_ref, torch.full_like(d_hip, -1e30))))
+            print(f"{what}: arbiter REJECTS {int(unexplained.sum())} elements; worst: |HIP - f64| {float(d_hip.flatten()[worst]):.3e} against "
+                  f"a spread of {float(d_ref.flatten()[worst]):.3e}, |HIP - oracle| {float(err.flatten()[worst]):.3e}")
     row.update(n_unexplained=int(unexplained.sum()))
     _record(row)
     assert not bool(unexplained.any()), (
         f"{what}: {int(unexplained.sum())} of {nbad} out-of-tolerance elements are explained neither by a moved blend / stop "
-        f"decision nor by ill-conditioning (max unexplained err {float(err[unexplained].max()):.3e}, rtol {rtol:g}, "
+        f"decision nor accepted by the arbiter (max unexplained err {float(err[unexplained].max()):.3e}, rtol {rtol:g}, "
         f"scales {[f'{x:.3e}' for x in scale.flatten().tolist()]})")
     return float(err.max()), nbad
 
@@ -464,15 +448,16 @@ def _compare(out, ref, name, case, stats=None, cache=None):
             mt = torch.as_tensor(np.asarray(att.matched()[0]["g_viewmatrix"])).double()
             err = min(err, float((v.cpu().double() - mt).abs().max()) / scale)
         if err > lim:
-            # the [:3,:2] block comes from the covariance backward, the worst-conditioned part: accepted only as far as the
-            # ORACLE's own sums move under a few-ulp perturbation of its inputs (elementwise, same rule as check_close)
-            d = (v.cpu().double() - rt).abs() / scale
-            delta = att.sensitivity("g_viewmatrix").reshape(d.shape) / scale
-            assert bool((d <= SENS_FACTOR * delta + lim).all()) and err <= 1e-2, (
-                f"{name}:g_viewmatrix: {err:.3e} of the magnitude sum (limit {lim:g}; the oracle itself moves by "
-                f"{float(delta.max()):.3e} under {SENS_ULPS:g}-ulp input perturbation)")
-            print(f"{name}:g_viewmatrix: {err:.3e} of the magnitude sum attributed to ill-conditioning "
-                  f"(oracle moves by {float(delta.max()):.3e})")
+            # the [:3,:2] block comes from the covariance backward, the worst-conditioned part: the arbiter decides (check_close's
+            # rule 2, elementwise, against the magnitude sum)
+            f64, spread = att.arbiter("g_viewmatrix")
+            d_hip = (v.cpu().double() - f64.reshape(v.shape)).abs() / scale
+            d_ref = spread.reshape(v.shape) / scale
+            assert bool((d_hip <= ARB_FACTOR * d_ref + lim).all()), (
+                f"{name}:g_viewmatrix: {err:.3e} of the magnitude sum from the oracle (limit {lim:g}), {float(d_hip.max()):.3e} from the "
+                f"arbiter where the fp32 evaluations sit up to {float(d_ref.max()):.3e} from it")
+            print(f"{name}:g_viewmatrix: {err:.3e} of the magnitude sum from the oracle; accepted by the arbiter "
+                  f"(|HIP - f64| {float(d_hip.max()):.3e}, fp32 evaluations up to {float(d_ref.max()):.3e})")
             err = lim
         assert err <= lim, f"{name}:g_viewmatrix: {err:.3e} of the magnitude sum (limit {lim:g})"
     if stats is not None:

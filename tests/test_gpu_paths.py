@@ -21,33 +21,22 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 # name -> environment. The switches are thresholds in listed tiles per Gaussian (csrc/api.hip, csrc/render.hip).
-# EOGS_BTF_SWITCH: fraction of the image's tiles a Gaussian lists on average from which a forward takes per-tile lists and the
-# back-to-front backward (0 = never; the default 0.1 would take the image-sized sweep cases out of the other forced paths).
 FORCED = {  # (the default switches run in-process: tests/test_gpu_parity.py, same cases, same comparison)
     # (EOGS_TILE_SCHED=0 here: the band mapping of rounds 1-3 instead of the tile schedule — no descriptors, and block_lists_kernel
     # finds its block's start by summing the counts of the blocks before it instead of reading the schedule workgroup's prefixes)
     "tile": {"EOGS_BLOCK_SWITCH": "1000", "EOGS_DEPTH_SWITCH": "0", "EOGS_QUAD_SWITCH": "0", "EOGS_QUAD_BWD_SWITCH": "0",
-             "EOGS_BTF_SWITCH": "0", "EOGS_TILE_SCHED": "0"},
-    "block": {"EOGS_BLOCK_SWITCH": "0.5", "EOGS_DEPTH_SWITCH": "0.001", "EOGS_BTF_SWITCH": "0"},
+             "EOGS_TILE_SCHED": "0"},
+    "block": {"EOGS_BLOCK_SWITCH": "0.5", "EOGS_DEPTH_SWITCH": "0.001"},
     # (EOGS_NOFLAG=0: the quad backward with live flags on every case; the next entry forces its flag-free records on every case —
     # correct for any scene, chosen by default only where no tile comes near saturation: csrc/common.h noflag_scene)
     "quad": {"EOGS_BLOCK_SWITCH": "1000", "EOGS_DEPTH_SWITCH": "0", "EOGS_QUAD_SWITCH": "1000", "EOGS_QUAD_BWD_SWITCH": "1000",
-             "EOGS_BWD_MFMA": "0", "EOGS_BTF_SWITCH": "0", "EOGS_NOFLAG": "0"},
+             "EOGS_NOFLAG": "0"},
     "quad_noflag": {"EOGS_BLOCK_SWITCH": "1000", "EOGS_DEPTH_SWITCH": "0", "EOGS_QUAD_SWITCH": "1000", "EOGS_QUAD_BWD_SWITCH": "1000",
-                    "EOGS_BWD_MFMA": "0", "EOGS_BTF_SWITCH": "0", "EOGS_NOFLAG": "2", "EOGS_PLAIN_TRIPS": "0"},
-    "quad_mfma": {"EOGS_BLOCK_SWITCH": "1000", "EOGS_DEPTH_SWITCH": "0", "EOGS_QUAD_SWITCH": "1000",
-                  "EOGS_QUAD_BWD_SWITCH": "1000", "EOGS_BWD_MFMA": "1", "EOGS_BTF_SWITCH": "0"},
-    "quad_mfma_t": {"EOGS_BLOCK_SWITCH": "1000", "EOGS_DEPTH_SWITCH": "0", "EOGS_QUAD_SWITCH": "1000",
-                    "EOGS_QUAD_BWD_SWITCH": "1000", "EOGS_BWD_MFMA": "2", "EOGS_BTF_SWITCH": "0"},
-    # the reference's own back-to-front recursion on per-tile lists (render_bwd_btf_kernel), forced for every case
-    "btf": {"EOGS_BTF_SWITCH": "1e-9", "EOGS_QUAD_SWITCH": "1000"},
+                    "EOGS_NOFLAG": "2", "EOGS_PLAIN_TRIPS": "0"},
 }
-# The two MFMA backward variants are a recorded experiment (parity-green, slower, never selected by default):
-# their 2 x 40 oracle comparisons run only with EOGS_FULL=1, like every `slow` test (tests/conftest.py).
-EXPERIMENT_PATHS = ("quad_mfma", "quad_mfma_t")
-if os.environ.get("EOGS_FULL") != "1":
-    FORCED = {k: v for k, v in FORCED.items() if k not in EXPERIMENT_PATHS}
-KERNEL_NAMES = {0: "tile", 1: "block", 2: "quad", 3: "quad_mfma", 4: "quad_mfma_t", 5: "btf"}
+# (Rounds 2-5 also forced two matrix-pipe variants of the quad backward and, for image-sized Gaussians, a separate back-to-front
+# kernel; since round 6 every backward kernel walks back to front — the reference's recursion — and the variants are gone.)
+KERNEL_NAMES = {0: "tile", 1: "block", 2: "quad", 6: "quad_alt"}
 
 
 @pytest.fixture(scope="module")
@@ -129,18 +118,11 @@ def test_every_kernel_path_matches_oracle(dev, case_dir, tmp_path):
             assert sum(p[0] == 32 for p in paths) >= len(paths) * 0.8, report[tag]
         if tag in ("quad", "quad_noflag"):  # (quad_noflag also switches the forward's plain chunks off: its general loop on every case)
             assert all(p == (8, 2, 2) for p in paths), report[tag]
-        if tag == "quad_mfma":
-            assert all(p == (8, 2, 3) for p in paths), report[tag]
-        if tag == "quad_mfma_t":
-            assert all(p == (8, 2, 4) for p in paths), report[tag]
-        if tag == "btf":  # (a forward that lists nothing has no token bits to carry the choice)
-            off = {k: v["path"] for k, v in res.items() if v["path"][1] >= 0 and v["listed"] and tuple(v["path"]) != (8, 2, 5)}
-            assert not off, off
         seen_fwd |= {p[1] for p in paths}
         seen_bwd |= {p[2] for p in paths}
     print("kernel paths compared with the oracle:", json.dumps(report))
     assert seen_fwd == {0, 1, 2}, report
-    assert seen_bwd == ({0, 1, 2, 3, 4, 5} if os.environ.get("EOGS_FULL") == "1" else {0, 1, 2, 5}), report
+    assert seen_bwd == {0, 1, 2}, report
 
 
 def _full_size_case(P, H, W, seed, opacity, **kw):
@@ -292,19 +274,20 @@ def test_config4_2M_1024_properties(dev):
     assert_close(c1[:, y0:y0 + S, x0:x0 + S], crop, "2M crop")
 
 
-def test_image_sized_gaussians_select_the_back_to_front_backward(dev):
-    """The choice itself (csrc/api.hip token_from_counts): a forward whose Gaussians list a tenth of the image's tiles each
-    carries bit 60 — per-tile lists, backward kernel 5 — and ordinary footprints never do. Both against the oracle."""
+def test_image_sized_gaussians_take_the_same_kernels_as_everything_else(dev):
+    """Rounds 3-5 switched forwards whose Gaussians list a few per cent of the image's tiles each to a separate back-to-front
+    backward (a tuned threshold on a per-forward average; token bit 60). Every backward kernel now IS the reference's
+    back-to-front recursion (csrc/render.hip), so such a forward takes the ordinary kernels — block lists here — and holds
+    1e-4 against the oracle with them; so does the quad backward forced onto it (tests/test_gpu_paths.py FORCED, every case)."""
     from eogs2_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib
     from parity_cases import compare, oracle_run, seeded_case
 
     abi = _lib.get()
     big, label = seeded_case(400, 200, 168, 15, "trained", 14.0, False, False)   # rects > 64 internal tiles each
     got = run_case(big, dev, GaussianRasterizer, GaussianRasterizationSettings)
-    assert (got["_num_rendered_exact"] >> 60) & 1 == 1
-    assert abi.path_info(400, got["_num_rendered"]) == (8, 2, 5)
+    assert abi.path_info(400, got["_num_rendered"]) == (32, 1, 1)
     compare(got, oracle_run(big), label, big)
     small, label = seeded_case(5000, 160, 208, 10, "init", 2.0, False, False)
     got = run_case(small, dev, GaussianRasterizer, GaussianRasterizationSettings)
-    assert (got["_num_rendered_exact"] >> 60) & 1 == 0 and abi.path_info(5000, got["_num_rendered"])[2] == 2
+    assert abi.path_info(5000, got["_num_rendered"]) == (8, 2, 2)
     compare(got, oracle_run(small), label, small)

@@ -171,14 +171,16 @@ def test_threshold_nudge_moves_exactly_the_near_threshold_decision(oracle_backen
 
 @pytest.mark.parametrize("P,H,W,seed,opacity,scale_mult", [(1500, 32, 32, 3, 0.6, 10.0), (2000, 40, 48, 7, 0.95, 15.0)])
 def test_back_to_front_recursion_is_the_accurate_form_for_image_sized_gaussians(P, H, W, seed, opacity, scale_mult, oracle_backend):
-    """Why forwards of image-sized opaque Gaussians run the back-to-front backward (render_bwd_btf_kernel): against
-    the independent dense autograd renderer the reference's recursion (backward.cu:586-620) is an order of magnitude closer
-    than the front-to-back form the fast kernels use (sum behind a Gaussian = rendered total minus running prefix;
-    eogs_oracle_suffix_by_subtraction(1) evaluates it inside the oracle). Ordinary footprints show no difference."""
+    """Why every backward kernel walks back to front (csrc/render.hip): against the independent dense autograd
+    renderer the reference's recursion (backward.cu:586-620) is an order of magnitude closer than the front-to-back form the
+    kernels of rounds 1-5 used (sum behind a Gaussian = rendered total minus running prefix; eogs_oracle_suffix_by_subtraction(1)
+    evaluates it inside the oracle) — and so is the form the HIP kernels evaluate it in, the recursion projected on the pixel's
+    upstream gradient (one number per pixel instead of five; eogs_oracle_suffix_by_subtraction(3)). Ordinary footprints show
+    no difference."""
     sc = make_scene(P, H, W, seed=seed, opacity=opacity, scale_mult=scale_mult)
     _, _, _, gd = _dense_run(sc, H, W, False, None)
     err = {}
-    for mode in (0, 1):
+    for mode in (0, 1, 3):
         oracle_backend.cdll.eogs_oracle_suffix_by_subtraction(mode)
         try:
             _, _, _, g = _oracle_run(sc, H, W, False, None, oracle_backend)
@@ -187,6 +189,7 @@ def test_back_to_front_recursion_is_the_accurate_form_for_image_sized_gaussians(
         err[mode] = {k: _rel(g[k], gd[k]) for k in ("opacities", "means2D", "means3D", "scales")}
     for k in err[0]:
         assert err[0][k] < 2e-5, (k, err)          # the reference's form: at the level of fp32 rounding
+        assert err[3][k] < 2e-5, (k, err)          # ... and so is its projection on the upstream gradient (the HIP kernels' form)
         assert err[1][k] > 2.0 * err[0][k], (k, err)  # the front-to-back form: visibly worse on every gradient
     assert err[1]["opacities"] > 2e-5, err
     # an ordinary scene (footprints of a few tiles): both forms agree with the dense renderer alike

@@ -19,14 +19,11 @@ RTOL = 1e-4
 # We allow at most FLIP_FRAC of the elements outside RTOL, and none beyond FLIP_RTOL.
 FLIP_FRAC = 2e-5
 FLIP_RTOL = 1e-2
-# Rounds 1-2 gave the stress fixtures (image-sized opaque Gaussians stacked hundreds deep) 5e-4 on their gradients: there
-# the front-to-back dL/dalpha of the fast backward kernels differs from the reference's back-to-front recursion by a few
-# 1e-4 of the tensor scale. Since round 3 such forwards run the back-to-front backward (render_bwd_btf_kernel,
-# the reference's own arithmetic) and EVERY case is held to RTOL. The table only remains for the processes that switch that
-# kernel off to force the front-to-back kernels onto every case (tests/test_gpu_paths.py: EOGS_BTF_SWITCH=0).
-GRAD_RTOL_FRONT_TO_BACK = {"dense_termination": 5e-4, "seed15": 5e-4, "seed16": 5e-4, "aniso1.5": 5e-4, "aniso1.2": 5e-4,
-                           "aniso2.0": 5e-4}
-GRAD_RTOL = GRAD_RTOL_FRONT_TO_BACK if os.environ.get("EOGS_BTF_SWITCH") == "0" else {}
+# Every case is held to RTOL. (Rounds 1-5: the fast backward kernels walked front to back and differed from the reference's
+# back-to-front recursion by a few 1e-4 on image-sized opaque Gaussians stacked hundreds deep; such forwards were switched to a
+# second kernel by a threshold, and test processes that forced the fast kernels onto them carried a 5e-4 table here. Since
+# round 6 every backward kernel is the reference's recursion: no switch, no table. DESIGN.md 5.)
+GRAD_RTOL = {}
 
 
 def load_golden(name):

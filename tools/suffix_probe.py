@@ -19,7 +19,7 @@ for seed in map(int, sys.argv[1:] or ["1258"]):
     case, label = sweep_case(seed)
     base = oracle_run(case)
     alts = {}
-    for mode in (1, 2):  # 1: total from the rendered image (the HIP path); 2: total = the running sum's own end value (two walks)
+    for mode in (1, 2, 3):  # 1: total from the rendered image (the HIP path); 2: total = the running sum's own end value (two walks)
         lib.eogs_oracle_suffix_by_subtraction(mode)
         try:
             alts[mode] = oracle_run(case)
@@ -31,5 +31,6 @@ for seed in map(int, sys.argv[1:] or ["1258"]):
         sc = np.abs(base[k]).max()
         d = np.abs(alt[k].astype(np.float64) - base[k]) / max(sc, 1e-30)
         d2 = np.abs(alts[2][k].astype(np.float64) - base[k]) / max(sc, 1e-30)
+        d3 = np.abs(alts[3][k].astype(np.float64) - base[k]) / max(sc, 1e-30)
         print(f"   {k:12s} max |front-to-back - back-to-front| = {d.max():.2e} of the tensor scale ({int((d > 1e-4).sum())} elements beyond 1e-4);"
-              f" with a self-consistent total {d2.max():.2e}")
+              f" with a self-consistent total {d2.max():.2e}; back to front with the projected recursion {d3.max():.2e}")
