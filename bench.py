@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--gaussians", type=int, default=1 << 20)
     ap.add_argument("--size", type=int, default=1024)
-    ap.add_argument("--opacity", default="init", help="init (0.01, gs_config/train.yaml:55) | trained | float")
+    ap.add_argument("--opacity", default="init", help="init (0.01, gs_config/train.yaml:55) | trained | float | surface (the trained-scene shape, synthetic.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-iter", action="store_true", help="skip the extra synthetic training-iteration measurement")
     ap.add_argument("--force-dist", action="store_true",
@@ -100,7 +100,7 @@ def graph_extras(a):
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     P, H, W = a.gaussians, a.size, a.size
-    op = a.opacity if a.opacity in ("init", "trained") else float(a.opacity)
+    op = a.opacity if a.opacity in ("init", "trained", "surface") else float(a.opacity)
     sc = make_scene(P, H, W, seed=0, opacity=op, device=dev)
     rast = GaussianRasterizer(settings_for(sc, H, W))
     names = ("means3D", "colors", "opacities", "scales", "rotations")
@@ -945,9 +945,17 @@ def regime_scan(dev, steps=20):
     from eogs2_amd import GaussianRasterizer
     from eogs2_amd.synthetic import make_scene, settings_for
 
+    from eogs2_amd import _lib
+
+    abi = _lib.get()
     out = {}
+    # surface_*: the trained-scene SHAPE (eogs2_amd/synthetic.py kind="surface": flat disks on a terrain with buildings, log-normal
+    # in-plane sizes with sigma 1, bimodal opacities) at configs[1]'s, the headline's and configs[3]'s sizes; the others keep the
+    # reference's initialisation statistics (uniform in the box, near-isotropic) and vary opacity / image size alone
     for name, P, S, op in (("trained_1M_1024", 1 << 20, 1024, "trained"), ("opacity0.1_1M_1024", 1 << 20, 1024, 0.1),
-                           ("opacity0.01_1M_2048", 1 << 20, 2048, "init"), ("opacity0.1_2M_1024", 2_000_000, 1024, 0.1)):
+                           ("opacity0.01_1M_2048", 1 << 20, 2048, "init"), ("opacity0.1_2M_1024", 2_000_000, 1024, 0.1),
+                           ("surface_300k_800", 300_000, 800, "surface"), ("surface_1M_1024", 1 << 20, 1024, "surface"),
+                           ("surface_2M_1024", 2_000_000, 1024, "surface")):
         try:
             sc = make_scene(P, S, S, seed=0, opacity=op, device=dev)
             rast = GaussianRasterizer(settings_for(sc, S, S))
@@ -983,8 +991,21 @@ def regime_scan(dev, steps=20):
             nr = int(getattr(c.grad_fn, "num_rendered_exact", getattr(c.grad_fn, "num_rendered", -1)))
             R = nr & 0x7FFFFFFF
             by = 432 * P + 268 * R + 64 * S * S
+            # which kernels the library chose for this forward, and the step's kernel groups (a window of its own: every
+            # bracket costs two event records, so the timed windows above run without them)
+            block_px, fwd_k, bwd_k = abi.path_info(P, nr)
+            names = {0: "tile", 1: "block", 2: "quad", 6: "quad_alt"}
+            abi.profile_select(0xFFFFFFFF)
+            abi.profile_reset()
+            abi.profile_enable(1)
+            for _ in range(steps):
+                c = step()
+            torch.cuda.synchronize()
+            abi.profile_enable(0)
+            kern = {k: t / n for k, (t, n) in abi.profile().items() if n and k in ("preprocess_fwd", "depth_sort", "binning", "render_fwd", "render_bwd", "gaussian_bwd")}
             out[name] = {"gaussians": P, "size": S, "opacity": op, "steps": steps, "ms_per_step": ms, "views_per_s": 1e3 / ms,
-                         "num_rendered": R, "list_block_px": 32 if (nr >> 62) & 1 else 8, "algorithmic_bytes": by,
+                         "num_rendered": R, "list_block_px": block_px, "fwd_kernel": names.get(fwd_k, fwd_k), "bwd_kernel": names.get(bwd_k, bwd_k),
+                         "gaussian_bwd_wide": abi.backward_info(P, nr), "kernels_ms": kern, "algorithmic_bytes": by,
                          "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "windows_ms": windows}
             del sc, rast, params, m2, c
         except Exception as e:  # a regime must never cost the line

@@ -100,10 +100,11 @@ def _surface_scene(P, H, W, seed, g, scale_mult):
 
 
 def make_scene(P, H, W, seed=0, opacity="init", device="cpu", scale_mult=1.0, anisotropy=0.3, kind="volume"):
-    """Returns a dict of fp32 tensors on `device` shaped like the rasterizer's inputs. kind="surface": the trained-scene shape
-    (module docstring; `opacity` and `anisotropy` are then the generator's own)."""
+    """Returns a dict of fp32 tensors on `device` shaped like the rasterizer's inputs. kind="surface" (or opacity="surface",
+    for callers that pass the opacity law through: bench.py --opacity surface): the trained-scene shape (module docstring;
+    opacities and anisotropy are then the generator's own)."""
     g = torch.Generator().manual_seed(seed)
-    if kind == "surface":
+    if kind == "surface" or opacity == "surface":
         xyz, scales, q, op = _surface_scene(P, H, W, seed, g, scale_mult)
         return _finish_scene(P, H, W, seed, g, device, xyz, scales, q, op)
     assert kind == "volume", kind

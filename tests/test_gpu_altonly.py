@@ -76,36 +76,47 @@ def test_altitude_only_equals_channel_3_of_the_full_render(dev, P, H, W, seed, o
     # which had no such fallback).
     for k in a:
         if k.startswith("g_") and k != "g_viewmatrix":
-            assert_close(a[k], b[k], f"alt-only vs full:{k}", rtol=2e-5, allow_flips=False)
+            # (2e-5 everywhere but on the rotations of image-sized footprints, whose covariance backward amplifies the two
+            # summation orders' rounding: those are held to the parity tolerance itself)
+            assert_close(a[k], b[k], f"alt-only vs full:{k}", rtol=1e-4 if (k == "g_raw_rotation" and scale_mult >= 8) else 2e-5, allow_flips=False)
     scale = float((scene["means3D"].abs().t() @ b["g_means2D"].abs()).max())
     assert float((a["g_viewmatrix"] - b["g_viewmatrix"]).abs().max()) <= 1e-5 * scale
 
 
-def test_altitude_only_matches_oracle(dev, monkeypatch):
-    """Against the oracle's restatement of the raw-parameter front end (C, double-precision chain), full render, the same
-    upstream gradient on channel 3 and zero elsewhere."""
+@pytest.mark.parametrize("P,H,W,seed,opacity,scale_mult,aa", CASES + [(3000, 96, 80, 32, "trained", 2.0, True)])
+def test_altitude_only_matches_oracle(dev, monkeypatch, P, H, W, seed, opacity, scale_mult, aa):
+    """Every case above against the ORACLE's restatement of the raw-parameter front end (C, double-precision chain): its full
+    render with the same upstream gradient on channel 3 and zero on the other channels — image-sized footprints and the sun
+    camera's own size (1 M Gaussians at 2048^2) included (round 5 compared only the last, small case with the oracle and the
+    others with the HIP path's own full render)."""
+    import time
+
     import oracle
     from util import run_raw
 
     from eogs2_amd import _lib
     from eogs2_amd.synthetic import make_scene
 
-    H, W, P = 96, 80, 3000
-    scene = make_scene(P, H, W, seed=32, opacity="trained", scale_mult=2.0)
-    raw, alt = raw_params_from_scene(scene)
+    scene = make_scene(P, H, W, seed=seed, opacity=opacity, scale_mult=scale_mult)
+    raw, alt = raw_params_from_scene(scene, seed=seed)
     g_alt = torch.randn(H, W, generator=torch.Generator().manual_seed(5)) / (H * W)
     to = lambda d: {k: v.to(dev) for k, v in d.items()}
-    got = _run(to(raw), alt.to(dev), to(scene), H, W, True, True, g_alt.to(dev))
+    got = _run(to(raw), alt.to(dev), to(scene), H, W, aa, True, g_alt.to(dev))
     dL = torch.zeros(5, H, W)
     dL[3] = g_alt
     oabi = oracle.abi()
     monkeypatch.setattr(_lib, "get", lambda: oabi)
-    ref = run_raw(raw, alt, dict(scene, dL_dcolor=dL), H, W, True, fused=True)
+    t0 = time.perf_counter()
+    ref = run_raw(raw, alt, dict(scene, dL_dcolor=dL), H, W, aa, fused=True)
     monkeypatch.undo()
+    print(f"oracle, full render of {P} Gaussians at {H}x{W}: {time.perf_counter() - t0:.1f} s")
     assert torch.equal(got["out_radii"].cpu(), ref["out_radii"])
-    assert_close(got["altitude"], ref["out_color"][3], "altitude vs oracle channel 3", flip_floor=4)
+    # (flip_floor: pixels / Gaussians a blend decision within an ulp of its threshold may move — v_exp_f32 against libm's expf —
+    # each bounded by FLIP_RTOL; the non-raw suites attribute such elements causally, tests/parity_cases.py)
+    floor = 4 + P // 50000
+    assert_close(got["altitude"], ref["out_color"][3], "altitude vs oracle channel 3", flip_floor=floor)
     for k in ("g_xyz", "g_opacity_logit", "g_log_scaling", "g_raw_rotation", "g_means2D"):
-        assert_close(got[k], ref[k], f"alt-only vs oracle:{k}", flip_floor=4)
+        assert_close(got[k], ref[k], f"alt-only vs oracle:{k}", flip_floor=floor)
     assert float(ref["g_f_dc"].abs().max()) == 0.0 and float(got["g_f_dc"].abs().max()) == 0.0
 
 

@@ -57,14 +57,14 @@ def test_hip_matches_golden(name, dev):
 from parity_cases import SEEDED, seeded_case, sweep_case  # noqa: E402
 
 
-@pytest.mark.parametrize("P,H,W,seed,opacity,scale_mult,aa,dgrad", SEEDED)
-def test_hip_matches_oracle_seeded(P, H, W, seed, opacity, scale_mult, aa, dgrad, dev, monkeypatch):
+@pytest.mark.parametrize("row", SEEDED, ids=lambda r: "-".join(str(x) for x in r))
+def test_hip_matches_oracle_seeded(row, dev, monkeypatch):
     import oracle
     from eogs2_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib
 
     from parity_cases import oracle_cached
 
-    case, name = seeded_case(P, H, W, seed, opacity, scale_mult, aa, dgrad)
+    case, name = seeded_case(*row)
     got = run_case(case, dev, GaussianRasterizer, GaussianRasterizationSettings)
     _compare(got, oracle_cached(f"seeded_{name}", case), name, case)  # checker: the same wrapper over the CPU oracle
 

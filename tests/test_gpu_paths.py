@@ -158,7 +158,11 @@ def test_headline_1M_1024_matches_oracle(dev):
     ("opacity0.1_1M_1024", 1 << 20, 1024, 0.1),
     ("opacity0.01_1M_2048", 1 << 20, 2048, "init"),  # the sun camera's size (row-span listing)
     ("opacity0.1_2M_1024", 2_000_000, 1024, 0.1),
-    ("config4_2M_1024", 2_000_000, 1024, "trained")])
+    ("config4_2M_1024", 2_000_000, 1024, "trained"),
+    # the trained-scene SHAPE (synthetic.py kind="surface": flat disks on a terrain, log-normal sizes, bimodal opacities)
+    ("surface_300k_800", 300_000, 800, "surface"),
+    ("surface_1M_1024", 1 << 20, 1024, "surface"),
+    ("surface_2M_1024", 2_000_000, 1024, "surface")])
 def test_regimes_of_the_bench_line_match_oracle(dev, name, P, S, opacity):
     """Every regime bench.py reports beside the headline (bench.regime_scan), at its own size, in full against the C oracle:
     trained opacities (tiles saturate, most listed pairs dead: the backward's flags-first record sum), opacity 0.1 (lists twice
@@ -173,6 +177,31 @@ def test_regimes_of_the_bench_line_match_oracle(dev, name, P, S, opacity):
     got = run_case(case, dev, GaussianRasterizer, GaussianRasterizationSettings)
     flips = compare(got, _oracle(case), name, case)
     print(f"{name}: attributed out-of-tolerance elements: {flips}")
+
+
+def test_mixed_scale_scene(dev):
+    """A million-small-Gaussians scene that ALSO holds a few hundred image-sized opaque ones (ground splats of a trained scene):
+    300 k Gaussians at the synthetic statistics, trained opacities, 800 x 800, plus 200 Gaussians of sigma = 5-30 % of the image
+    with opacity 0.9-0.99 at altitudes throughout the box — deep lists under opaque fronts in EVERY tile while the per-forward
+    averages (listed tiles per Gaussian, list depth) stay those of an ordinary scene. Rounds 3-5 chose the backward's dL/dalpha
+    formulation by such an average and would have missed this composition; every backward kernel is the reference's
+    back-to-front recursion now (csrc/render.hip). Full compare with the oracle, on the kernels the defaults pick."""
+    from eogs2_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib
+    from parity_cases import prefetch_nudges
+
+    P, S, big = 300_000, 800, 200
+    case = _full_size_case(P, S, S, 5, "trained")
+    g = np.random.default_rng(55)
+    idx = g.choice(P, big, replace=False)
+    sig_px = S * g.uniform(0.05, 0.30, (big, 1))
+    case["scales"][idx] = (sig_px / (0.5 * S) * np.exp(0.2 * g.standard_normal((big, 3)))).astype(np.float32)
+    case["opacities"][idx] = g.uniform(0.9, 0.99, (big, 1)).astype(np.float32)
+    prefetch_nudges(case)
+    got = run_case(case, dev, GaussianRasterizer, GaussianRasterizationSettings)
+    info = _lib.get().path_info(P, got["_num_rendered"])
+    print("mixed-scale scene: pairs", got["_num_rendered_exact"] & 0x7FFFFFFF, "path", info)
+    flips = compare(got, _oracle(case), "mixed_scale", case)
+    print(f"mixed_scale: attributed out-of-tolerance elements: {flips}")
 
 
 def test_config2_300k_800_matches_oracle(dev):

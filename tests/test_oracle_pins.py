@@ -92,6 +92,33 @@ def test_oracle_matches_dense_autograd(P, H, W, seed, opacity, scale_mult, aa, d
     assert _rel(g1["viewmatrix"], expect) < tol_vm
 
 
+@pytest.mark.parametrize("mod", [0.5, 1.7])
+def test_scale_modifier_and_the_missing_factor_in_dL_dscale(mod, oracle_backend):
+    """raster_settings.scale_modifier: the covariance is built from mod * scale (forward.cu:117-151), and the reference returns
+    dL/d(mod * scale) AS dL/dscale — no factor mod (backward.cu:331-383: `dL_dscale->x = dot(Rt[0], dL_dMt[0])`, M built with
+    the modified scales). Against the dense autograd renderer fed mod * scale: same image, every other gradient equal, and the
+    oracle's dL/dscale equal to autograd's dL/dscale DIVIDED by mod."""
+    from eogs2_amd import GaussianRasterizer
+
+    P, H, W = 300, 48, 64
+    sc = make_scene(P, H, W, seed=21, opacity="trained", scale_mult=2.5)
+    leaves = {k: sc[k].clone().requires_grad_(True) for k in ["means3D", "scales", "rotations", "opacities", "colors"]}
+    rs = settings_for(sc, H, W)._replace(scale_modifier=mod)
+    color, radii, invd = GaussianRasterizer(rs)(leaves["means3D"], torch.zeros(P, 3), leaves["opacities"], colors_precomp=leaves["colors"],
+                                                scales=leaves["scales"], rotations=leaves["rotations"])
+    (color * sc["dL_dcolor"]).sum().backward()
+    g1 = {k: v.grad for k, v in leaves.items()}
+    dl = {k: sc[k].clone().requires_grad_(True) for k in ["means3D", "scales", "rotations", "opacities", "colors"]}
+    c2, r2, _ = render_dense(dl["means3D"], dl["opacities"], dl["colors"], sc["bg"], sc["viewmatrix"], H, W, scales=dl["scales"] * mod,
+                             rotations=dl["rotations"], antialiasing=False, block=32)
+    (c2 * sc["dL_dcolor"]).sum().backward()
+    assert torch.equal(radii, r2) and _rel(color.detach(), c2.detach()) < 2e-5
+    for k in ["means3D", "opacities", "colors", "rotations"]:
+        assert _rel(g1[k], dl[k].grad) < 1e-4, k
+    assert _rel(g1["scales"], dl["scales"].grad / mod) < 1e-4  # autograd's chain rule has the factor the reference leaves out
+    assert _rel(g1["scales"], dl["scales"].grad) > 0.2
+
+
 def test_oracle_altitude_trap(oracle_backend):
     from eogs2_amd import GaussianRasterizer, RastError
 

@@ -89,8 +89,8 @@ def run_case(case, device, rasterizer_mod, settings_cls):
     means2D = torch.zeros(P, 3, device=device, requires_grad=True)
     vm = leaf("viewmatrix")
     rs = settings_cls(
-        image_height=H, image_width=W, tanfovx=math.tan(0.5), tanfovy=math.tan(0.5), bg=t("bg"), scale_modifier=1.0,
-        viewmatrix=vm, projmatrix=vm.detach(), sh_degree=0, campos=torch.zeros(3, device=device), prefiltered=False,
+        image_height=H, image_width=W, tanfovx=math.tan(0.5), tanfovy=math.tan(0.5), bg=t("bg"),
+        scale_modifier=float(case.get("scale_modifier", 1.0)), viewmatrix=vm, projmatrix=vm.detach(), sh_degree=0, campos=torch.zeros(3, device=device), prefiltered=False,
         debug=False, antialiasing=bool(case["antialiasing"]))
     color, radii, invd = rasterizer_mod(rs)(
         means3D=means3D, means2D=means2D, opacities=opac, shs=None, colors_precomp=colors, scales=scales,
