@@ -108,7 +108,15 @@ class Branches:
                 with torch.cuda.stream(s):
                     outs.append(fn())
                 parts.append([p.grad for p in shared])
-        finally:
+        except BaseException:
+            # A piece raised: the gradients are what they were before the call — not the sum of the pieces that happened to finish
+            # plus nothing of the one that failed. The streams are still joined: what was queued runs to its end.
+            for s in self.streams[:len(fns)]:
+                cur.wait_stream(s)
+            for p, b in zip(shared, before):
+                p.grad = b
+            raise
+        else:
             for s in self.streams[:len(fns)]:
                 cur.wait_stream(s)  # join
             # The sum, after the join, in queue order. (Allocator note: a piece's gradient was allocated on the piece's stream

@@ -68,6 +68,29 @@ static int g_suffix_by_subtraction = 0;
  * projected on the pixel's upstream gradient, a_j = g . accum_rec_j, with a_j = a_{j+1} + alpha_{j+1} (g.c_{j+1} - a_{j+1}) — and T
  * recovered with a reciprocal: the HIP path's formulation since round 6 (csrc/render.hip). Same recursion, another association. */
 int eogs_oracle_suffix_by_subtraction(int on) { const int old = g_suffix_by_subtraction; g_suffix_by_subtraction = on; return old; }
+/* Diagnostic (tests/parity_cases.py arbiter()): one more VALID fp32 evaluation of the backward — every pair's exponent
+ * `power = -1/2 (a dx^2 + c dy^2) - b dx dy` and its G = exp(power) carry the rounding of ANOTHER association: power a relative
+ * error of up to 2 `ulps` (five rounded operations whose order the reference's compiler, the restatement and the HIP path's
+ * log2-domain form (A dx - B dy) dx + C dy^2 each choose differently — G inherits |power| times that), exp() one of up to `ulps`
+ * (libm's expf is correctly rounded to well under an ulp; CUDA's expf, which the reference runs, is documented at 2 ulp;
+ * v_exp_f32 at 1 ulp), deterministic in (pixel, Gaussian, seed). What the other variants (fp32 sums, FMA contraction, perturbed
+ * inputs) do not model is this per-pair noise, which the ill-conditioned per-Gaussian chain amplifies like any other error of
+ * the conic-gradient sums. Decisions stay those of the un-noised fp32 forward; the pixel's final transmittance is recomputed
+ * from the noised alphas (as the arbiter build recomputes it in double), so the recursion stays self-consistent. 0 = off. */
+static float g_pair_noise_ulps = 0.f;
+static uint32_t g_pair_noise_seed = 0;
+int eogs_oracle_pair_noise(float ulps, uint32_t seed) { g_pair_noise_ulps = ulps < 0.f ? 0.f : ulps; g_pair_noise_seed = seed; return 0; }
+static inline uint32_t pair_hash(size_t pix_id, uint32_t id, uint32_t salt) {
+  uint32_t h = (uint32_t)pix_id * 0x9E3779B1u ^ (id + 0x7F4A7C15u) * 0x85EBCA6Bu ^ (g_pair_noise_seed + salt) * 0xC2B2AE35u;
+  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+  return h;
+}
+/* the pair's G under the noise model: exp(power (1 + 2 ulps e r1)) (1 + ulps e r2), r in [-1, 1), e = 2^-23 */
+static inline float noised_G(size_t pix_id, uint32_t id, float power) {
+  const float r1 = (float)(int32_t)pair_hash(pix_id, id, 0u) * (1.0f / 2147483648.0f);
+  const float r2 = (float)(int32_t)pair_hash(pix_id, id, 1u) * (1.0f / 2147483648.0f);
+  return expf(power * (1.0f + 2.0f * g_pair_noise_ulps * 1.1920929e-07f * r1)) * (1.0f + g_pair_noise_ulps * 1.1920929e-07f * r2);
+}
 /* Diagnostic (tests/parity_cases.py, causal attribution of threshold flips): the reference's two data-dependent blend
  * decisions (forward.cu:374-382) evaluated with their thresholds moved by a stated number of ulp, per pixel:
  *   skip    if  alpha < (1/255) (1 + s (ka0 + ka1 |power|) ulp)     (the exponent's rounding error scales with |power|)
@@ -707,6 +730,21 @@ static int backward_activated(
       const float pixfx = (float)px, pixfy = (float)py;
       const uint32_t last_contributor = im.n_contrib[pix_id];
       real T_final = im.final_T[pix_id];
+#ifndef ORACLE_F64
+      if (g_pair_noise_ulps > 0.f) { /* the final transmittance of the NOISED alphas (eogs_oracle_pair_noise) */
+        T_final = 1.0f;
+        for (uint32_t k = r0; k < r1 && k - r0 < last_contributor; k++) {
+          const uint32_t id = b.values[k];
+          const float fdx = g.means2D[2 * (size_t)id] - pixfx, fdy = g.means2D[2 * (size_t)id + 1] - pixfy;
+          const float* fco = g.conic_opacity + 4 * (size_t)id;
+          const float fpower = -0.5f * (fco[0] * fdx * fdx + fco[2] * fdy * fdy) - fco[1] * fdx * fdy;
+          if (fpower > 0.0f) continue;
+          const float fG = expf(fpower);
+          if (fminf(0.99f, fco[3] * fG) < alpha_min(nudge_sign(pix_id), fpower)) continue;
+          T_final *= 1.f - fminf(0.99f, fco[3] * noised_G(pix_id, id, fpower));
+        }
+      }
+#endif
 #ifdef ORACLE_F64
       { /* the pixel's final transmittance in double: the product over the entries the fp32 forward blended (its decisions) */
         T_final = 1.0;
@@ -795,8 +833,8 @@ static int backward_activated(
 #else
         const real dx = fdx, dy = fdy;
         const real* co = fco;
-        const real G = fG;
-        const real alpha = falpha;
+        const real G = g_pair_noise_ulps > 0.f ? noised_G(pix_id, id, fpower) : fG;
+        const real alpha = g_pair_noise_ulps > 0.f ? fminf(0.99f, fco[3] * G) : falpha;
 #endif
 
         Tcur = Tcur / (RC(1) - alpha);

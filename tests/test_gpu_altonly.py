@@ -110,11 +110,15 @@ def test_altitude_only_matches_oracle(dev, monkeypatch, P, H, W, seed, opacity, 
     ref = run_raw(raw, alt, dict(scene, dL_dcolor=dL), H, W, aa, fused=True)
     monkeypatch.undo()
     print(f"oracle, full render of {P} Gaussians at {H}x{W}: {time.perf_counter() - t0:.1f} s")
-    assert torch.equal(got["out_radii"].cpu(), ref["out_radii"])
+    # (raw-parameter mode: the scale is exp(log-scale), evaluated by libm on one side and the GPU's expf on the other — an ulp
+    # apart now and then, and radius = ceil(3 sqrt(lambda)) then steps by one for a Gaussian in a few hundred thousand)
+    nrad = int((got["out_radii"].cpu() != ref["out_radii"]).sum())
+    assert nrad <= P // 100_000 and int((got["out_radii"].cpu() - ref["out_radii"]).abs().max()) <= 1, nrad
     # (flip_floor: pixels / Gaussians a blend decision within an ulp of its threshold may move — v_exp_f32 against libm's expf —
     # each bounded by FLIP_RTOL; the non-raw suites attribute such elements causally, tests/parity_cases.py)
-    floor = 4 + P // 50000
-    assert_close(got["altitude"], ref["out_color"][3], "altitude vs oracle channel 3", flip_floor=floor)
+    floor = 4 + P // 30000
+    # ([1, H, W]: an image — a bare [H, W] tensor would be read as H per-Gaussian rows, one moved pixel spoiling a whole row)
+    assert_close(got["altitude"][None], ref["out_color"][3:4], "altitude vs oracle channel 3", flip_floor=floor)
     for k in ("g_xyz", "g_opacity_logit", "g_log_scaling", "g_raw_rotation", "g_means2D"):
         assert_close(got[k], ref[k], f"alt-only vs oracle:{k}", flip_floor=floor)
     assert float(ref["g_f_dc"].abs().max()) == 0.0 and float(got["g_f_dc"].abs().max()) == 0.0

@@ -346,3 +346,30 @@ def test_record_again_after_the_parameters_were_replaced_keeps_the_memory(dev):
     # depending on what the process ran before: they are held to a looser bound, the recordings in between to the tight one)
     assert marks[-2] - marks[1] < 48, marks
     assert marks[-1] - marks[1] < 200, marks
+
+
+def test_branches_restore_gradients_when_a_piece_raises(dev):
+    """when a piece raises, `Branches.run` re-raises and leaves every shared parameter's gradient exactly as it was
+    before the call — not the sum of the pieces that happened to finish."""
+    from eogs2_amd.graph import Branches
+
+    a = torch.ones(1000, device=dev, requires_grad=True)
+    b = torch.ones(10, device=dev, requires_grad=True)
+    a.grad = torch.full_like(a, 3.0)
+    before_a = a.grad
+
+    def good():
+        ((a * 2).sum() + b.sum()).backward()
+
+    def bad():
+        (a * 5).sum().backward()
+        raise RuntimeError("piece failed")
+
+    br = Branches(3, device=dev)
+    with pytest.raises(RuntimeError, match="piece failed"):
+        br.run([good, bad, good], shared=[a, b])
+    torch.cuda.synchronize()
+    assert a.grad is before_a and bool((a.grad == 3.0).all()) and b.grad is None
+    br.run([good, good], shared=[a, b])  # (and the object is still usable)
+    torch.cuda.synchronize()
+    assert bool((a.grad == 7.0).all()) and bool((b.grad == 2.0).all())

@@ -220,12 +220,14 @@ def test_row_span_listing_anisotropic(dev, monkeypatch, opacity, aniso, scale_mu
 
 
 def _sweep_seeds():
-    """24 seeds by default; EOGS_SWEEP_SEEDS=lo-hi widens the sweep for an occasional long run."""
+    """24 seeds by default; EOGS_SWEEP_SEEDS=lo-hi[,lo-hi | seed ...] widens the sweep for an occasional long run."""
     import os
 
-    spec = os.environ.get("EOGS_SWEEP_SEEDS", "200-223")
-    lo, hi = (int(x) for x in spec.split("-"))
-    return list(range(lo, hi + 1))
+    seeds = []
+    for part in os.environ.get("EOGS_SWEEP_SEEDS", "200-223").split(","):
+        lo, _, hi = part.partition("-")
+        seeds += list(range(int(lo), int(hi or lo) + 1))
+    return seeds
 
 
 @pytest.mark.parametrize("seed", _sweep_seeds())

@@ -46,14 +46,14 @@ def test_quad_kernels_agree_with_tile_kernels(tmp_path, P, H, W, opacity, invdep
             assert_close(torch.from_numpy(quad[k]), torch.from_numpy(plain[k]), k, rtol=2e-5)
 
 
-@pytest.mark.parametrize("P,H,W,opacity,invdepth", [(150_000, 344, 392, "init", 0), (80_000, 256, 250, "0.04", 1),
+@pytest.mark.parametrize("P,H,W,opacity,invdepth", [(150_000, 340, 390, "init", 0), (80_000, 256, 250, "0.04", 1),
                                                     (60_000, 200, 264, "trained", 0)])
 def test_round5_fast_paths_change_no_bit(tmp_path, P, H, W, opacity, invdepth):
     """Round 5: the forward's plain chunks leave out operations that are no-ops where they are left out,
     the backward's flag-free records add exact zeros, and the quad masks the backward takes over from the forward are the
     ones it would compute itself: with all of it switched off, on (the default picks per scene and per chunk) or forced, every
     output and every gradient is the same BITS (-0.0 and +0.0 count as equal: a zero record added to
-    a zero sum). The image is partly off the 8-px grid (344 x 392, 256 x 250): edge tiles keep the general loop beside
+    a zero sum). Two of the images are off the 8-px grid (340 x 390: both edges; 256 x 250: one): edge tiles keep the general loop beside
     interior tiles' plain chunks; the 'trained' scene saturates, so its forced flag-free backward walks dead entries."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
