@@ -118,7 +118,9 @@ def test_altitude_only_matches_oracle(dev, monkeypatch, P, H, W, seed, opacity, 
     # each bounded by FLIP_RTOL; the non-raw suites attribute such elements causally, tests/parity_cases.py)
     floor = 4 + P // 30000
     # ([1, H, W]: an image — a bare [H, W] tensor would be read as H per-Gaussian rows, one moved pixel spoiling a whole row)
-    assert_close(got["altitude"][None], ref["out_color"][3:4], "altitude vs oracle channel 3", flip_floor=floor)
+    # (flip_rtol 2e-2: a moved pair changes its pixel by alpha T c <= 0.01 c at these opacities, and c — a Gaussian's altitude —
+    # can exceed the blended image's maximum, the scale; two moved pairs may share a pixel)
+    assert_close(got["altitude"][None], ref["out_color"][3:4], "altitude vs oracle channel 3", flip_floor=floor, flip_rtol=2e-2)
     for k in ("g_xyz", "g_opacity_logit", "g_log_scaling", "g_raw_rotation", "g_means2D"):
         assert_close(got[k], ref[k], f"alt-only vs oracle:{k}", flip_floor=floor)
     assert float(ref["g_f_dc"].abs().max()) == 0.0 and float(got["g_f_dc"].abs().max()) == 0.0
