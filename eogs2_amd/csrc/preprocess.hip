@@ -117,6 +117,20 @@ __device__ inline float wave_sum(float v) {
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// the same sum on the DPP path (six VALU instructions, no LDS round trips; the total read from lane 63: every lane gets it)
+__device__ inline float wave_sum_dpp(float v) {
+#define GB_DPP(x, ctrl, rows) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, rows, 0xF, true))
+  v += GB_DPP(v, 0x121, 0xF);  // row_ror:1
+  v += GB_DPP(v, 0x122, 0xF);  // row_ror:2
+  v += GB_DPP(v, 0x124, 0xF);  // row_ror:4
+  v += GB_DPP(v, 0x128, 0xF);  // row_ror:8: every lane holds its row's sum
+  v += GB_DPP(v, 0x142, 0xA);  // row_bcast15 into rows 1 and 3
+  v += GB_DPP(v, 0x143, 0xC);  // row_bcast31 into rows 2 and 3
+#undef GB_DPP
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// listed tiles from which a Gaussian's records are summed by its whole wave instead of by its own lane (gaussian_bwd_kernel)
+#define GB_COOP 64u
 
 }  // namespace
 
@@ -407,8 +421,10 @@ void launch_preprocess_fwd(const FwdPrepArgs& a, const GeomWS& g, hipStream_t s)
 // of them dead: flags first, few records) 0.0787 / 0.0827 / 0.0826 — there the seven waves hide the flags -> records chain better
 // than more loads per lane do.
 // ALT: the records of an altitude-only render (32 bytes, common.h REC_ALT): only colour 3 has a gradient.
+// (the wide builds sit exactly at the 128 VGPRs that four waves per SIMD leave: said to the compiler, which otherwise takes a
+// 129th for the cooperative section's sake and loses the wave)
 template <bool RAW, bool ALT, int WIDE>
-__global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
+__global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(WIDE ? (ALT ? 5 : 4) : 6, WIDE ? (ALT ? 5 : 4) : 8))) void gaussian_bwd_kernel(
     int P, int H, int W,
     const float* __restrict__ means3D, const float* __restrict__ scales, const float* __restrict__ rotations,
     const float* __restrict__ cov3D_precomp, const float* __restrict__ opacities, const float* __restrict__ vm,
@@ -423,6 +439,7 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
   __shared__ float s_m[3 * BLK];
   __shared__ float s_s[3 * BLK];
   __shared__ float s_red[BLK / 64][18];
+  __shared__ float s_coop[11][BLK];  // record sums of the Gaussians the waves summed cooperatively (GB_COOP)
   // A forward queued on a capacity token (EOGS_FLAG_DEFER_COUNTS) that needed more than its workspaces hold has built no
   // lists (binning.hip block_lists_kernel) and wrote no record: its slots would lie beyond `records` / `live`. The same
   // comparison here: such a backward reads none of them and returns zero gradients (the host repeats the forward).
@@ -464,6 +481,9 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
   stage_rows3_load(means3D, row0, rows, st_m);
   if (scales) stage_rows3_load(scales, row0, rows, st_s);
 
+  int radius_in = 0;
+  uint4 bi1 = make_uint4(0u, 0u, 0u, 0u);
+  uint32_t pb = 0;
   if (t < rows) {
     // Round 4: everything that does not depend on another load is requested up front (the kernel waited 45 % of its wave
     // time, profiles/r03_v30: radii -> binfo -> flags -> records -> rotation / opacity was a chain of five dependent round
@@ -471,15 +491,71 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
     // below are independent loads in flight together; a Gaussian with at most GB_DIRECT listed tiles (the usual case: four)
     // then reads its flags AND its records in ONE trip — a dead pair's record is read and discarded: never-written memory,
     // but only ever selected away — and only longer lists take the two-trip form (flags, then the live records alone).
-    const int radius_in = radii[idx];
-    const uint4 bi1 = binfo[(size_t)P + idx];  // (its own plane: this kernel reads 16 of a Gaussian's 32 bytes, and fetched all 32 while they shared a line)
-    const uint32_t pb = pblock[blk];
+    radius_in = radii[idx];
+    bi1 = binfo[(size_t)P + idx];  // (its own plane: this kernel reads 16 of a Gaussian's 32 bytes, and fetched all 32 while they shared a line)
+    pb = pblock[blk];
     if (!cov3D_precomp) rot_in = reinterpret_cast<const float4*>(rotations)[idx];
     if (RAW || antialiasing) op_raw = opacities[idx];
-    visible = radius_in > 0;
+  }
+  visible = t < rows && radius_in > 0;
+  const uint32_t n_all = (visible && fits) ? bi1.x : 0u;
+  const bool is_big = n_all > GB_COOP;
+
+  // ---- Gaussians that list more than GB_COOP tiles: summed by the whole wave, one after the other ----
+  // A lane sums its own Gaussian's records serially, four or eight per memory round trip. That is the right shape while
+  // footprints are a few tiles (every lane busy, the records of a wave one contiguous region) and the wrong one for the large
+  // splats a trained scene keeps (ground planes, roofs: hundreds to thousands of listed tiles): ONE lane then walks thousands of
+  // dependent trips while 63 idle, and the launch lasts as long as its largest Gaussian — 1.1 ms of a 1.6 ms step at 300 k
+  // surface-shaped Gaussians / 800^2, 0.6 of 1.2 ms at 1 M (profiles/r06_regime_scan_before_coop.txt; the synthetic scenes of
+  // rounds 1-5 had no such tail). Here lane l takes records l, l + 64, ... of the Gaussian (consecutive lanes on consecutive
+  // 48-byte records: coalesced) and the 64 partial sums are added by a fixed DPP tree: deterministic, another order of the
+  // same additions than the serial sum. The totals wait in LDS (s_coop) until the lane's own math below: this section sits in
+  // front of the serial sums, where few registers are live — behind them it cost the wide builds their fourth wave per SIMD.
+  {
+    const int lane = t & 63;
+    unsigned long long big = __builtin_amdgcn_ballot_w64(is_big);
+    while (big) {
+      const int src = (int)__builtin_ctzll(big);
+      big &= big - 1ull;
+      const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)n_all, src);
+      const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)(pb + bi1.y), src);  // (slots are below 2^31: api.hip)
+      constexpr int RQc = (ALT ? REC_ALT : REC) / 4;
+      const float4* r4c = reinterpret_cast<const float4*>(records);
+      float part[11];
+#pragma unroll
+      for (int k = 0; k < 11; k++) part[k] = 0.f;
+#pragma unroll 2
+      for (uint32_t q0 = 0; q0 < n; q0 += 64u) {
+        const uint32_t q = q0 + (uint32_t)lane;
+        const bool lv = q < n && (noflag || live[s0 + q] != 0);
+        const uint32_t qq = q < n ? q : 0u;  // a valid address either way
+        const float4 ra = r4c[rec_q((size_t)s0 + qq, 0, cap_slots, RQc)];
+        const float4 rb = r4c[rec_q((size_t)s0 + qq, 1, cap_slots, RQc)];
+        float3 rc = make_float3(0.f, 0.f, 0.f);
+        if (!ALT) rc = reinterpret_cast<const float3*>(r4c + rec_q((size_t)s0 + qq, 2, cap_slots, RQc))[0];
+        if (lv) {  // (a dead pair's record is never-written memory: read, selected away)
+          part[0] += ra.x; part[1] += ra.y; part[2] += ra.z; part[5] += ra.w;
+          part[3] += rb.x; part[4] += rb.y;
+          if (ALT) {
+            part[9] += rb.z;
+          } else {
+            part[6] += rb.z; part[7] += rb.w;
+            part[8] += rc.x; part[9] += rc.y; part[10] += rc.z;
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 11; k++) {  // (ALT: the sums it does not take are zeros, handed over like the others)
+        const float tot = wave_sum_dpp(part[k]);
+        if (lane == 0) s_coop[k][(t & ~63) + src] = tot;
+      }
+    }
+  }
+
+  {
     if (visible) {
       // fixed-order sum of this Gaussian's (tile,Gaussian) records: deterministic, no atomics
-      const uint32_t n = fits ? bi1.x : 0u;
+      const uint32_t n = is_big ? 0u : n_all;
       const size_t s0 = (size_t)pb + bi1.y;  // Gaussian-id order: a wave reads one contiguous region
       constexpr int RQ = (ALT ? REC_ALT : REC) / 4;  // quarters per record (common.h rec_q: quarter-major planes of cap_slots)
       const float4* r4 = reinterpret_cast<const float4*>(records);
@@ -591,6 +667,10 @@ __global__ __launch_bounds__(BLK) void gaussian_bwd_kernel(
   stage_rows3_store(rows, st_m, s_m);
   if (scales) stage_rows3_store(rows, st_s, s_s);
   __syncthreads();
+  if (is_big) {  // the wave-summed records of a large Gaussian (above)
+#pragma unroll
+    for (int k = 0; k < 11; k++) acc[k] = s_coop[k][t];
+  }
   if (t < rows) {
     // record layout: 0,1 = dL/dmean2D (NDC units)  2,3,4 = dL/dconic (a,b,c)  5 = dL/dopacity  6..10 = dL/dcolor
     const float gxn = acc[0], gyn = acc[1];

@@ -121,8 +121,10 @@ def test_altitude_only_matches_oracle(dev, monkeypatch, P, H, W, seed, opacity, 
     # (flip_rtol 2e-2: a moved pair changes its pixel by alpha T c <= 0.01 c at these opacities, and c — a Gaussian's altitude —
     # can exceed the blended image's maximum, the scale; two moved pairs may share a pixel)
     assert_close(got["altitude"][None], ref["out_color"][3:4], "altitude vs oracle channel 3", flip_floor=floor, flip_rtol=2e-2)
+    # (gradients: a moved pair changes the gradient rows of the Gaussians at its pixel by that pixel's term — with a white-noise
+    # upstream gradient up to a few per cent of a column's largest entry; counted per Gaussian, bounded at 5e-2)
     for k in ("g_xyz", "g_opacity_logit", "g_log_scaling", "g_raw_rotation", "g_means2D"):
-        assert_close(got[k], ref[k], f"alt-only vs oracle:{k}", flip_floor=floor)
+        assert_close(got[k], ref[k], f"alt-only vs oracle:{k}", flip_floor=floor, flip_rtol=5e-2)
     assert float(ref["g_f_dc"].abs().max()) == 0.0 and float(got["g_f_dc"].abs().max()) == 0.0
 
 
