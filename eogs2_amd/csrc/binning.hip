@@ -414,6 +414,7 @@ void launch_sort_u32(uint32_t* keyA, uint32_t* valA, uint32_t* keyB, uint32_t* v
 // =====================================================================================================================
 
 #define EXPAND_LANE_MAX 256u  // a single lane walks at most this many list entries
+#define EXPAND_COOP_MAX 6     // row-span footprints of three macro rows or more per wave up to which the wave walks them together
 #define EXPAND_STAGE 2048     // entries per LDS window (32 KB + 4 KB of owner lanes)
 struct ExpandItem {
   uint32_t id, c, pos0, rbase, sx0, sy0, sx1, sy1, kind, depth;
@@ -468,7 +469,15 @@ __global__ __launch_bounds__(BLK, 4) void expand_entries_kernel(const uint4* __r
   //      addresses (lanes storing their own entries straight to memory measured slower: 2.3x the bytes reach HBM as
   //      partial lines) ----
   __shared__ uint4 s_ent[EXPAND_STAGE];
-  const bool mine = it.c != 0u && it.c <= EXPAND_LANE_MAX;
+  // Lane-walked: a Gaussian with at most EXPAND_LANE_MAX entries — unless it is one of a FEW row-span footprints of its wave with
+  // three macro rows or more: in its own lane such a footprint costs rows x (four row spans + the block loop) instructions while
+  // the wave's other 63 lanes wait; walked by the whole wave below, one macro row per lane, it costs one row's worth. With the
+  // size-heterogeneous Gaussians of a trained scene two waves in three hold one or two such lanes (1 M surface-shaped Gaussians:
+  // expand 130 us against 25 at the uniform synthetic scene, profiles/r06_surface_front_end.txt); where a wave holds many
+  // (large images, every footprint wide) they run in parallel in their lanes as before.
+  const bool tall = it.c != 0u && it.kind != BK_MASK && ((int)it.sy1 - 1) / MACRO - (int)it.sy0 / MACRO >= 2;
+  const bool few = __popcll(__ballot(tall)) <= EXPAND_COOP_MAX;
+  const bool mine = it.c != 0u && it.c <= EXPAND_LANE_MAX && !(tall && few);
   uint32_t ltot;
   const uint32_t l0 = block_excl_scan(mine ? it.c : 0u, s_w, ltot);  // local position among the lane-walked entries
   // the lane-walked entries of this workgroup are NOT contiguous in the output when a large Gaussian sits between them:
@@ -497,7 +506,7 @@ __global__ __launch_bounds__(BLK, 4) void expand_entries_kernel(const uint4* __r
   }
 
   // ---- large Gaussians: the wave emits them cooperatively, one after the other, one macro row per lane ----
-  unsigned long long big = __ballot(it.c > EXPAND_LANE_MAX);
+  unsigned long long big = __ballot(it.c != 0u && !mine);
   while (big) {
     const int src = __builtin_ctzll(big);
     big &= big - 1ull;
@@ -517,11 +526,15 @@ __global__ __launch_bounds__(BLK, 4) void expand_entries_kernel(const uint4* __r
     for (int r0 = MY0; r0 <= MY1; r0 += 64) {
       const int MY = r0 + lane;
       uint32_t ne = 0, nf = 0;  // this lane's macro row: entries and listed internal tiles
-      if (MY <= MY1)
-        walk_macro_row<MACRO>(g.kind, g.m, gs, (int)g.sx0, (int)g.sy0, (int)g.sx1, (int)g.sy1, MY, [&](int, uint32_t sub) {
-          ne++;
-          nf += (uint32_t)__popc(sub);
-        });
+      if (MY <= MY1) {
+        if (g.kind == BK_MASK)
+          walk_macro_row<MACRO>(g.kind, g.m, gs, (int)g.sx0, (int)g.sy0, (int)g.sx1, (int)g.sy1, MY, [&](int, uint32_t sub) {
+            ne++;
+            nf += (uint32_t)__popc(sub);
+          });
+        else
+          count_macro_row<MACRO>(g.kind, gs, (int)g.sx0, (int)g.sy0, (int)g.sx1, (int)g.sy1, MY, ne, nf);  // (the same count, common.h)
+      }
       const uint32_t ie = wave_incl_scan_u32(ne), jf = wave_incl_scan_u32(nf);
       uint32_t l = done + ie - ne, slot = slot0 + jf - nf;
       if (MY <= MY1)

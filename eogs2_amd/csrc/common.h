@@ -282,6 +282,50 @@ __device__ inline void walk_macro_row(uint32_t kind, unsigned long long m, const
   }
 }
 
+// What walk_macro_row() emits for a listing WITHOUT a hit mask (BK_SPANS / BK_RECT), counted without walking the blocks: `ent` =
+// blocks with a non-empty sub-mask, `fine` = listed internal tiles of the macro row. Block MX gets a bit from tile row dy iff the
+// row's column interval [c0, c1) meets [MX M, MX M + M), i.e. iff MX lies in [c0 / M, (c1 - 1) / M]: the blocks are the union of
+// at most M such intervals (a 64-bit mask when the macro row spans at most 64 blocks — images up to 2048 px wide —, the walk
+// itself otherwise), the tiles the sum of the rows' lengths. The same row_span() on the same bits as the walk: the same count, at
+// ~40 instead of ~45 instructions per BLOCK of the row (a wave pays its widest footprint: preprocess_fwd_kernel).
+template <int MACRO>
+__device__ inline void count_macro_row(uint32_t kind, const SpanParams& sp, int sx0, int sy0, int sx1, int sy1, int MY,
+                                       uint32_t& ent, uint32_t& fine) {
+  int c0[MACRO], c1[MACRO];
+  int lo = 0x7FFFFFFF, hi = -1;
+#pragma unroll
+  for (int dy = 0; dy < MACRO; dy++) {
+    const int fy = MY * MACRO + dy;
+    c0[dy] = c1[dy] = 0;
+    if (fy < sy0 || fy >= sy1) continue;
+    if (kind == BK_SPANS) row_span(sp, fy, sx0, sx1, c0[dy], c1[dy]);
+    else { c0[dy] = sx0; c1[dy] = sx1; }
+    if (c1[dy] > c0[dy]) {
+      lo = min(lo, c0[dy]);
+      hi = max(hi, c1[dy] - 1);
+    }
+  }
+  if (hi < 0) return;
+  const int B0 = lo / MACRO, B1 = hi / MACRO;
+  if (B1 - B0 < 64) {
+    unsigned long long m = 0ull;
+#pragma unroll
+    for (int dy = 0; dy < MACRO; dy++) {
+      if (c1[dy] > c0[dy]) {
+        const int a = c0[dy] / MACRO - B0, len = (c1[dy] - 1) / MACRO - c0[dy] / MACRO + 1;
+        m |= (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << a;
+        fine += (uint32_t)(c1[dy] - c0[dy]);
+      }
+    }
+    ent += (uint32_t)__popcll(m);
+  } else {
+    walk_macro_row<MACRO>(kind, 0ull, sp, sx0, sy0, sx1, sy1, MY, [&](int, uint32_t sub) {
+      ent++;
+      fine += (uint32_t)__popc(sub);
+    });
+  }
+}
+
 static inline size_t ws_align(size_t x) { return (x + 255u) & ~(size_t)255u; }
 
 template <typename T>

@@ -314,10 +314,7 @@ __global__ __launch_bounds__(BLK) PP_ATTR void preprocess_fwd_kernel(
         if (my_tiles && kind != BK_MASK) {
           uint32_t ent = 0, fine = 0;
           for (int MY = sy0 / BLOCK_BIG; MY <= (sy1 - 1) / BLOCK_BIG; MY++)
-            walk_macro_row<BLOCK_BIG>(kind, m, sp, sx0, sy0, sx1, sy1, MY, [&](int, uint32_t sub) {
-              ent++;
-              fine += (uint32_t)__popc(sub);
-            });
+            count_macro_row<BLOCK_BIG>(kind, sp, sx0, sy0, sx1, sy1, MY, ent, fine);  // (= what expand's walk_macro_row emits)
           my_tiles = fine;
           my_entries = ent;
           if (kind == BK_SPANS && fine) {
