@@ -414,7 +414,6 @@ void launch_sort_u32(uint32_t* keyA, uint32_t* valA, uint32_t* keyB, uint32_t* v
 // =====================================================================================================================
 
 #define EXPAND_LANE_MAX 256u  // a single lane walks at most this many list entries
-#define EXPAND_COOP_MAX 6     // row-span footprints of three macro rows or more per wave up to which the wave walks them together
 #define EXPAND_STAGE 2048     // entries per LDS window (32 KB + 4 KB of owner lanes)
 struct ExpandItem {
   uint32_t id, c, pos0, rbase, sx0, sy0, sx1, sy1, kind, depth;
@@ -469,15 +468,21 @@ __global__ __launch_bounds__(BLK, 4) void expand_entries_kernel(const uint4* __r
   //      addresses (lanes storing their own entries straight to memory measured slower: 2.3x the bytes reach HBM as
   //      partial lines) ----
   __shared__ uint4 s_ent[EXPAND_STAGE];
-  // Lane-walked: a Gaussian with at most EXPAND_LANE_MAX entries — unless it is one of a FEW row-span footprints of its wave with
-  // three macro rows or more: in its own lane such a footprint costs rows x (four row spans + the block loop) instructions while
-  // the wave's other 63 lanes wait; walked by the whole wave below, one macro row per lane, it costs one row's worth. With the
+  // Lane-walked: a Gaussian with at most EXPAND_LANE_MAX entries — unless it is a row-span footprint of three macro rows or more
+  // in a wave where walking such footprints TOGETHER is cheaper: in its own lane a footprint costs rows x (four row spans + the
+  // block loop) instructions while the wave's other lanes wait for the tallest one; walked by the whole wave below, one macro row
+  // per lane, each costs about one row's worth, one after the other. The wave compares the two estimates (instructions:
+  // max over lanes of rows x (100 + 50 blocks per row) against the sum over those lanes of 350 + 50 blocks per row). With the
   // size-heterogeneous Gaussians of a trained scene two waves in three hold one or two such lanes (1 M surface-shaped Gaussians:
   // expand 130 us against 25 at the uniform synthetic scene, profiles/r06_surface_front_end.txt); where a wave holds many
-  // (large images, every footprint wide) they run in parallel in their lanes as before.
-  const bool tall = it.c != 0u && it.kind != BK_MASK && ((int)it.sy1 - 1) / MACRO - (int)it.sy0 / MACRO >= 2;
-  const bool few = __popcll(__ballot(tall)) <= EXPAND_COOP_MAX;
-  const bool mine = it.c != 0u && it.c <= EXPAND_LANE_MAX && !(tall && few);
+  // (large images, every footprint wide) they keep running in parallel in their lanes.
+  const int mrows = it.c != 0u ? ((int)it.sy1 - 1) / MACRO - (int)it.sy0 / MACRO + 1 : 0;
+  const int mcols = it.c != 0u ? ((int)it.sx1 - 1) / MACRO - (int)it.sx0 / MACRO + 1 : 0;
+  const bool tall = it.c != 0u && it.kind != BK_MASK && mrows >= 3 && it.c <= EXPAND_LANE_MAX;
+  const uint32_t walk_cost = wave_max_u32_dpp(tall ? (uint32_t)(mrows * (100 + 50 * mcols)) : 0u);
+  const uint32_t coop_cost = wave_sum_u32_dpp(tall ? (uint32_t)(350 + 50 * mcols) : 0u);
+  const bool together = coop_cost < walk_cost;
+  const bool mine = it.c != 0u && it.c <= EXPAND_LANE_MAX && !(tall && together);
   uint32_t ltot;
   const uint32_t l0 = block_excl_scan(mine ? it.c : 0u, s_w, ltot);  // local position among the lane-walked entries
   // the lane-walked entries of this workgroup are NOT contiguous in the output when a large Gaussian sits between them:
