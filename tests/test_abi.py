@@ -37,7 +37,7 @@ def hip_lib():
 
 def test_hip_library_exports_everything(hip_lib):
     assert hip_lib.backend == "hip-gfx950"
-    assert hip_lib.cdll.eogs_rast_abi_version() == 7
+    assert hip_lib.cdll.eogs_rast_abi_version() == 8
     for name in header_symbols():
         assert hasattr(hip_lib.cdll, name), name
 
