@@ -1002,7 +1002,8 @@ def regime_scan(dev, steps=20):
                 c = step()
             torch.cuda.synchronize()
             abi.profile_enable(0)
-            kern = {k: t / n for k, (t, n) in abi.profile().items() if n and k in ("preprocess_fwd", "depth_sort", "binning", "render_fwd", "render_bwd", "gaussian_bwd")}
+            # (per STEP, not per bracket: `binning` is two brackets a step — the count scan, then the entry sort)
+            kern = {k: t / steps for k, (t, n) in abi.profile().items() if n and k in ("preprocess_fwd", "depth_sort", "binning", "render_fwd", "render_bwd", "gaussian_bwd")}
             out[name] = {"gaussians": P, "size": S, "opacity": op, "steps": steps, "ms_per_step": ms, "views_per_s": 1e3 / ms,
                          "num_rendered": R, "list_block_px": block_px, "fwd_kernel": names.get(fwd_k, fwd_k), "bwd_kernel": names.get(bwd_k, bwd_k),
                          "gaussian_bwd_wide": abi.backward_info(P, nr), "kernels_ms": kern, "algorithmic_bytes": by,
