@@ -1180,7 +1180,7 @@ __global__ __launch_bounds__(BL_T, 8) void block_lists_kernel(const uint4* __res
   // 40 % of a workgroup's 32 us). Per-tile lists with four items per thread only: with eight the two arrays would leave one
   // workgroup per CU; and 1024-thread workgroups only: the smaller ones (few entries per block) measured no gain and would
   // lose a resident workgroup to the extra LDS.
-  constexpr bool IDS = MODE == 1 && ((BL_ITEMS == 4 && BL_T == 1024) || (BL_ITEMS == 8 && BL_T < 1024));
+  constexpr bool IDS = MODE == 1 && BL_ITEMS == 4 && BL_T == 1024;
   __shared__ uint2 s_ids[IDS ? BL_CH : 1];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const uint32_t b = blockIdx.x;
@@ -1583,9 +1583,9 @@ void launch_block_lists(const GeomWS& g, const SortWS& w, const BinWS& b, const 
   const double per_block = (double)nr_entries(R) / (double)nblocks;
   int T = wide ? 1024 : per_block <= BL_NARROW_256 ? 256 : per_block <= BL_NARROW_512 ? 512 : 1024;
   if (!wide && (forced == 256 || forced == 512 || forced == 1024)) T = forced;
-  // EOGS_BL_ITEMS=8 (tuning aid, per-tile lists): eight entries per thread in workgroups of 256 / 512 threads — a quarter / half of the
-  // waves per barrier, four / two blocks per CU at once
-  static const int forced_items = [] { const char* e = getenv("EOGS_BL_ITEMS"); return e ? atoi(e) : 0; }();
+  // (Round 6 tried eight entries per thread in workgroups of 256 / 512 threads — a quarter / half of the waves per barrier, four /
+  // two blocks per CU at once, ids in LDS: 61 / 50 us against 48 at the headline, 139 / 66 against 64 at trained opacities:
+  // profiles/r06_ab_block_lists_small_workgroups.txt. Not kept.)
   if (M > 1) (void)hipMemsetAsync(b.live, 0, (size_t)nr_slots(R), s);
 #define BL_LAUNCH(MODE_, ITEMS_, T_)                                                                                            \
   hipLaunchKernelGGL((block_lists_kernel<MODE_, ITEMS_, T_>), dim3(nblocks), dim3(T_), 0, s, ent, ki, g.bcount, g.bpairs, g.misc, \
@@ -1598,8 +1598,6 @@ void launch_block_lists(const GeomWS& g, const SortWS& w, const BinWS& b, const 
     else BL_LAUNCH(BLOCK_BIG, 4, 1024);
   } else {
     if (wide) BL_LAUNCH(1, 8, 1024);
-    else if (forced_items == 8 && T == 256) BL_LAUNCH(1, 8, 256);
-    else if (forced_items == 8 && T == 512) BL_LAUNCH(1, 8, 512);
     else if (T == 256) BL_LAUNCH(1, 4, 256);
     else if (T == 512) BL_LAUNCH(1, 4, 512);
     else BL_LAUNCH(1, 4, 1024);

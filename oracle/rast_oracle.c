@@ -28,6 +28,14 @@
  * and rounded once, i.e. the order-independent value every fp32 ordering
  * approximates.
  *
+ * Three builds of this one file (oracle/Makefile): librast_oracle.so, the restatement proper (fp32, one rounded operation per
+ * operation of the reference); librast_oracle_fma.so, the same with fused multiply-adds allowed (a second valid rounding); and
+ * librast_oracle_f64.so (-DORACLE_F64), the ARBITER: the fp32 forward and its decisions, the backward's differentiable quantities
+ * recomputed and chained in double — what tests/parity_cases.py measures every fp32 evaluation's distance from when two of them
+ * disagree on an ill-conditioned gradient (see "the arbiter build" below). Switches for the tests' attribution
+ * (eogs_oracle_threshold_nudge, _accum_float, _pair_noise, _suffix_by_subtraction) are documented where they are defined; none of
+ * them is part of include/eogs_rast.h.
+ *
  * Build: gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC (oracle/Makefile).
  * Threads (round 4): the two per-pixel loops run on the host's cores — the forward's pixels are independent; the backward
  * takes its per-Gaussian double sums per band of image rows (ORACLE_BANDS, a constant) and adds the bands in ascending
