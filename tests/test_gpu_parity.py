@@ -287,6 +287,62 @@ def test_backward_is_deterministic(dev):
         assert (a[k] == b[k]) if k.startswith("_") else torch.equal(a[k], b[k]), k
 
 
+def test_heavy_lanes_of_a_surface_shaped_scene(dev, monkeypatch):
+    """the size-heterogeneous Gaussians of a trained scene (synthetic.py kind="surface": a few splats tens of
+    pixels wide among many of one pixel) take the paths the uniform scenes never reach — gaussian_bwd's wave-summed records
+    (more than 64 listed tiles), preprocess's closed-form row counts, expand's footprints walked together. One scene, odd image
+    size, through (1) the drop-in API against the oracle with full attribution, (2) the raw-parameter front end against the
+    oracle's, (3) the range-split backward against the plain one, bit for bit (a wave-summed Gaussian must not depend on how
+    the launch was cut)."""
+    import oracle
+    from eogs2_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib
+    from eogs2_amd.parallel import GradBucket
+    from eogs2_amd.synthetic import make_scene, settings_for
+    from parity_cases import compare, oracle_run
+    from util import raw_params_from_scene, run_raw
+
+    P, H, W = 120_000, 500, 620
+    sc = make_scene(P, H, W, seed=41, kind="surface", scale_mult=1.5)
+    case = {k: v.numpy() for k, v in sc.items()}
+    case.update(H=H, W=W, antialiasing=True)
+    got = run_case(case, dev, GaussianRasterizer, GaussianRasterizationSettings)
+    assert int((got["out_radii"] > 60).sum()) > 50  # (the large splats are there: radius = ceil(3 sigma))
+    compare(got, oracle_run(case), "surface_heavy_lanes", case)
+    # (2) raw-parameter mode
+    raw, alt = raw_params_from_scene(sc, seed=41)
+    to = lambda d: {k: v.to(dev) for k, v in d.items()}
+    hip = run_raw(to(raw), alt.to(dev), to(sc), H, W, False, fused=True)
+    oabi = oracle.abi()
+    monkeypatch.setattr(_lib, "get", lambda: oabi)
+    ref = run_raw(raw, alt, sc, H, W, False, fused=True)
+    monkeypatch.undo()
+    assert int((hip["out_radii"].cpu() != ref["out_radii"]).sum()) <= 2
+    for k in ("out_color", "g_xyz", "g_f_dc", "g_opacity_logit", "g_log_scaling", "g_raw_rotation", "g_means2D"):
+        assert_close(hip[k], ref[k], f"surface raw vs oracle:{k}", flip_floor=8, flip_rtol=5e-2)
+    # (3) range-split backward == plain backward
+    scd = {k: v.to(dev) for k, v in sc.items()}
+    names = ("means3D", "colors", "opacities", "scales", "rotations")
+
+    def run(chunks):
+        leaves = {k: scd[k].clone().requires_grad_(True) for k in names}
+        m2 = torch.zeros(P, 3, device=dev, requires_grad=True)
+        b = None
+        if chunks:
+            b = GradBucket([leaves[k] for k in names], cols=[slice(0, 3), slice(0, 3), slice(0, 1), slice(0, 3), slice(0, 4)],
+                           names=names, chunks=chunks)
+            b.begin()
+        color, _, _ = GaussianRasterizer(settings_for(scd, H, W))(leaves["means3D"], m2, leaves["opacities"], colors_precomp=leaves["colors"],
+                                                                 scales=leaves["scales"], rotations=leaves["rotations"])
+        (color * scd["dL_dcolor"]).sum().backward()
+        if b is not None:
+            b.finish()
+        return {**{k: v.grad.clone() for k, v in leaves.items()}, "m2": m2.grad.clone()}
+
+    plain, ranged = run(0), run(3)
+    for k in plain:
+        assert torch.equal(plain[k], ranged[k]), k
+
+
 @pytest.mark.parametrize("chunks", [1, 3, 4])
 def test_range_backward_and_bucket_equal_plain_backward(dev, chunks):
     """eogs_rast_backward_range over ascending Gaussian ranges == eogs_rast_backward, bit for bit, and the data-parallel
