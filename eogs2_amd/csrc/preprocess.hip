@@ -138,7 +138,7 @@ __device__ inline float wave_sum_dpp(float v) {
 
 // RAW (EOGS_FLAG_RAW_PARAMS): scales/rotations/opacities/colors are the model's raw parameters; the activations and
 // the [rgb, altitude, 1] feature assembly of renderer.py:72-96 happen here instead of in ~10 PyTorch kernels.
-// Compiled for six waves per SIMD (80 VGPRs, 38 spilled to scratch on the rarely taken paths) instead of the four that its
+// Compiled for six waves per SIMD (80 VGPRs, 96 bytes of scratch per lane, on the rarely taken paths) instead of the four that its
 // 123 VGPRs allow: the kernel waits 62 % of its wave time on memory, 52 -> 48 us (trained 56 -> 50); five waves changed
 // nothing, eight spill in the main path (48 / 57). -DEOGS_PP_WAVES=n overrides.
 #ifndef EOGS_PP_WAVES
@@ -185,6 +185,10 @@ __global__ __launch_bounds__(BLK) PP_ATTR void preprocess_fwd_kernel(
   uint32_t my_tiles = 0, my_entries = 0, key_bits = 0, bkind = BK_RECT, my_err = 0;
   uint32_t op64 = 0;  // round(64 * opacity), for the mean pair opacity that picks the list granularity (api.hip)
   uint4 bi0 = make_uint4(0u, 0u, 0u, 0u);
+  bool need_count = false;  // a BK_RECT / BK_SPANS footprint: its entries (and listed tiles) are counted behind the nest
+  uint32_t c_kind = BK_RECT;
+  SpanParams c_sp = {};
+  int c_sx0 = 0, c_sy0 = 0, c_sx1 = 0, c_sy1 = 0;
   if (t < rows) {
     const float p[3] = {s_m[3 * t], s_m[3 * t + 1], s_m[3 * t + 2]};
     // transformPoint4x3 (auxiliary.h:70-78)
@@ -312,14 +316,12 @@ __global__ __launch_bounds__(BLK) PP_ATTR void preprocess_fwd_kernel(
           my_tiles = (uint32_t)(sw * sh);
         }
         // list entries at block size BLOCK_BIG = blocks with at least one listed internal tile (at block size 1 the
-        // entries are the listed tiles themselves); for BK_SPANS the walk also yields the number of listed tiles
+        // entries are the listed tiles themselves); for BK_SPANS the walk also yields the number of listed tiles: counted
+        // behind this nest (the wave may count tall footprints together)
         if (my_tiles && kind != BK_MASK) {
-          uint32_t ent = 0, fine = 0;
-          for (int MY = sy0 / BLOCK_BIG; MY <= (sy1 - 1) / BLOCK_BIG; MY++)
-            count_macro_row<BLOCK_BIG>(kind, sp, sx0, sy0, sx1, sy1, MY, ent, fine);  // (= what expand's walk_macro_row emits)
-          my_tiles = fine;
-          my_entries = ent;
-          if (kind == BK_SPANS && fine) {
+          need_count = true;
+          c_kind = kind; c_sp = sp; c_sx0 = sx0; c_sy0 = sy0; c_sx1 = sx1; c_sy1 = sy1;
+          if (kind == BK_SPANS) {  // (also for the rare footprint whose spans turn out to list no tile: never read then)
             bext[2 * idx] = make_float4(sp.gx, sp.gy, sp.ex, sp.ey);
             bext[2 * idx + 1] = make_float4(sp.boa, sp.boc, sp.ta, sp.da);
           }
@@ -351,6 +353,45 @@ __global__ __launch_bounds__(BLK) PP_ATTR void preprocess_fwd_kernel(
       }
     }
     radii[idx] = radius;
+  }
+  // ---- entries and listed tiles of the row-span / whole-rect footprints (= what expand's walk_macro_row emits): one closed-form
+  //      count per block row (common.h count_macro_row). In its own lane a footprint of R block rows keeps the wave's other lanes
+  //      waiting for R counts; counted by the whole wave, one block row per lane, it costs about two (the broadcast of its
+  //      parameters, one count, two wave sums). The wave compares the two: the tallest lane against two per tall footprint. With
+  //      the log-normal sizes of a trained scene most waves hold one or two footprints of 5-30 block rows
+  //      (profiles/r06_surface_front_end.txt); where every footprint is tall they stay in their lanes. ----
+  {
+    const int lane = t & 63;
+    const int my0 = c_sy0 / BLOCK_BIG, my1 = (c_sy1 - 1) / BLOCK_BIG;
+    const uint32_t mrows = need_count ? (uint32_t)(my1 - my0 + 1) : 0u;
+    const bool tall = mrows >= 4u;
+    const uint32_t walk_cost = wave_max_u32_dpp(mrows);
+    const uint32_t coop_cost = wave_sum_u32_dpp(tall ? 2u : 0u) + 3u;  // (+ the short ones, still in their lanes)
+    const bool together = coop_cost < walk_cost;
+    uint32_t ent = 0, fine = 0;
+    unsigned long long big = __ballot(tall && together);
+    while (big) {
+      const int src = __builtin_ctzll(big);
+      big &= big - 1ull;
+      SpanParams gs;
+      gs.gx = __shfl(c_sp.gx, src, 64); gs.gy = __shfl(c_sp.gy, src, 64); gs.ex = __shfl(c_sp.ex, src, 64);
+      gs.ey = __shfl(c_sp.ey, src, 64); gs.boa = __shfl(c_sp.boa, src, 64); gs.boc = __shfl(c_sp.boc, src, 64);
+      gs.ta = __shfl(c_sp.ta, src, 64); gs.da = __shfl(c_sp.da, src, 64);
+      const uint32_t gk = __shfl(c_kind, src, 64);
+      const int gx0 = __shfl(c_sx0, src, 64), gy0 = __shfl(c_sy0, src, 64), gx1 = __shfl(c_sx1, src, 64), gy1 = __shfl(c_sy1, src, 64);
+      uint32_t ne = 0, nf = 0;
+      for (int MY = gy0 / BLOCK_BIG + lane; MY <= (gy1 - 1) / BLOCK_BIG; MY += 64)
+        count_macro_row<BLOCK_BIG>(gk, gs, gx0, gy0, gx1, gy1, MY, ne, nf);
+      ne = wave_sum_u32_dpp(ne);
+      nf = wave_sum_u32_dpp(nf);
+      if (lane == src) { ent = ne; fine = nf; }
+    }
+    if (need_count) {
+      if (!(tall && together))
+        for (int MY = my0; MY <= my1; MY++) count_macro_row<BLOCK_BIG>(c_kind, c_sp, c_sx0, c_sy0, c_sx1, c_sy1, MY, ent, fine);
+      my_tiles = fine;
+      my_entries = ent;
+    }
   }
   // exclusive prefix of the tile counts inside the workgroup (record slots in Gaussian-id order) and the
   // workgroup total
