@@ -539,15 +539,13 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(WIDE ? (ALT
   }
   visible = t < rows && radius_in > 0;
   const uint32_t n_all = (visible && fits) ? bi1.x : 0u;
-  // Which Gaussians the wave sums together (next section): every one beyond GB_COOP listed tiles, and those beyond GB_COOP / 2
-  // where that is cheaper for THIS wave — in memory round trips: the slowest of them in its own lane, four (eight) records a
-  // trip, against all of them one after the other, 64 records a trip plus two trips' worth of reduction each. One or two such
-  // lanes in a wave (a trained scene's size spread) go together; a wave full of them (2048^2, every footprint wide) keeps them in
-  // their lanes (A/B of fixed thresholds 16 / 32 / 64 / 128: profiles/r06_ab_gb_coop_threshold.txt).
-  const bool cand = n_all > GB_COOP / 2u;
-  const uint32_t lane_trips = wave_max_u32_dpp(cand ? (n_all + (GB_WIDE ? 7u : 3u)) / (GB_WIDE ? 8u : 4u) : 0u);
-  const uint32_t wave_trips = wave_sum_u32_dpp(cand ? (n_all + 63u) / 64u + 2u : 0u);
-  const bool is_big = n_all > GB_COOP || (cand && wave_trips < lane_trips);
+  // Which Gaussians the wave sums together (next section): those beyond GB_COOP listed tiles — a rule of the Gaussian ALONE. A
+  // per-wave estimate (the wave's longest lane against all its candidates beyond GB_COOP / 2 together) measured 8 % / 11 % faster on
+  // 1 M / 2 M surface-shaped Gaussians (profiles/r06_ab_gb_coop_threshold.txt) and was withdrawn: the DPP tree adds in another
+  // order than the lane, so a Gaussian's bits then depend on which neighbours share its wave — a run that compacts the pruned
+  // Gaussians away and one that keeps them retired in place stopped agreeing bit for bit (tests/test_gpu_example.py), and so did
+  // the narrow and the wide builds of this kernel while the estimate was in units of the build's own trip width.
+  const bool is_big = n_all > GB_COOP;
 
   // ---- Gaussians that list more than GB_COOP tiles: summed by the whole wave, one after the other ----
   // A lane sums its own Gaussian's records serially, four or eight per memory round trip. That is the right shape while

@@ -78,7 +78,7 @@ def test_depth_ties_and_overlap_order(dev):
     from eogs2_amd.synthetic import make_scene, settings_for
     from oracle.torch_dense import render_dense
 
-    P, H, W = 12000, 256, 208  # (the dense CPU renderer is O(P x pixels): 45 s at 30000 / 320 x 272)
+    P, H, W = 8000, 208, 176  # (the dense CPU renderer is O(P x pixels): 45 s at 30000 / 320 x 272, 18 s at 12000 / 256 x 208)
     sc = make_scene(P, H, W, seed=3, opacity="trained", scale_mult=1.5, device=dev)
     z = sc["means3D"][:, 2].clone()
     z[::7] = z[1::7][: z[::7].shape[0]]          # exact duplicates, 1/7 of the Gaussians

@@ -47,14 +47,16 @@ def test_quad_kernels_agree_with_tile_kernels(tmp_path, P, H, W, opacity, invdep
 
 
 @pytest.mark.parametrize("P,H,W,opacity,invdepth", [(150_000, 340, 390, "init", 0), (80_000, 256, 250, "0.04", 1),
-                                                    (60_000, 200, 264, "trained", 0)])
+                                                    (60_000, 200, 264, "trained", 0), (100_000, 304, 296, "surface", 0)])
 def test_round5_fast_paths_change_no_bit(tmp_path, P, H, W, opacity, invdepth):
     """Round 5: the forward's plain chunks leave out operations that are no-ops where they are left out,
     the backward's flag-free records add exact zeros, and the quad masks the backward takes over from the forward are the
     ones it would compute itself: with all of it switched off, on (the default picks per scene and per chunk) or forced, every
     output and every gradient is the same BITS (-0.0 and +0.0 count as equal: a zero record added to
     a zero sum). Two of the images are off the 8-px grid (340 x 390: both edges; 256 x 250: one): edge tiles keep the general loop beside
-    interior tiles' plain chunks; the 'trained' scene saturates, so its forced flag-free backward walks dead entries."""
+    interior tiles' plain chunks; the 'trained' scene saturates, so its forced flag-free backward walks dead entries; the 'surface'
+    scene has the size spread in which waves of the per-Gaussian backward sum some Gaussians together (GB_COOP): which ones must not
+    depend on the build (round 6: an estimate in units of the build's own trip width made eager and replayed steps differ)."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     args = (P, H, W, opacity, invdepth)
