@@ -25,7 +25,10 @@
 //     on the pixel's upstream gradient g (a constant of the pixel):
 //       a_j = g . accum_rec_j,   a_j = a_{j+1} + alpha_{j+1} (g.c_{j+1} - a_{j+1}),   a_last = 0
 //       dL/dalpha_j = T_j (g.c_j - a_j) - T_final / (1 - alpha_j) (bg . g)
-//     — the same recursion, term for term, at one dot product, one reciprocal and six multiply-adds per pair. (Rounds 1-5 walked
+//     and the background term is the same recursion started at a_last = bg . g instead of 0 (the background is the colour behind
+//     the last contributor: T_final / (1 - alpha_j) = T_j x the transmittance of everything behind j, which is exactly the weight
+//     the recursion leaves of its initial value at j), so the kernels evaluate dL/dalpha_j = T_j (g.c_j - a_j) alone —
+//     the same sum, at one dot product, one reciprocal and five multiply-adds per pair; with bg = 0 the same bits. (Rounds 1-5 walked
 //     front to back and took the sum behind a Gaussian as "rendered total minus running prefix": the same instruction count, but
 //     an absolute error of an ulp of the TOTAL in a quantity that, deep under opaque Gaussians, is orders of magnitude smaller;
 //     forwards of image-sized Gaussians had to be switched to a second, slower kernel by a tuned threshold. DESIGN.md 5.)
@@ -853,8 +856,10 @@ __global__ __launch_bounds__(RBLK) void render_bwd_kernel(
   const uint32_t lend = range.x + n;
   const float kx = LN2 * 0.5f * W, ky = LN2 * 0.5f * H;  // d(pixel)/d(ndc) times the ln2 of the log2-domain conic
   const float bx0 = (float)tx0, by0 = (float)ty0;
-  const float bgT = -Tfin * bgdot;  // backward.cu:617-620: dL/dalpha += (-T_final / (1 - alpha)) (bg . g)
-  float T = Tfin, a = 0.f;          // transmittance behind the entry at hand; g . (colour behind it, normalised): file header
+  // The background is the colour behind the last contributor: `a` starts at bg . g instead of 0, and the reference's separate term
+  // dL/dalpha += (-T_final / (1 - alpha)) (bg . g) (backward.cu:617-620) is inside T (gc - a) — T_final / (1 - alpha_j) is T_j times
+  // the transmittance of the entries behind j, which is the weight the recursion gives the initial value (file header).
+  float T = Tfin, a = bgdot;        // transmittance in front of the entry at hand; g . (colour behind it, background included)
   float* const uvlane = su + uv_index(0, lane);
 
   int k = 0, kstashed = 0;       // survivors waiting in the current transposition round (rounds span chunks), and how many
@@ -913,7 +918,7 @@ __global__ __launch_bounds__(RBLK) void render_bwd_kernel(
       const float rinv = __builtin_amdgcn_rcpf(1.f - a_eff);
       T = T * rinv;                 // backward.cu:573
       const float d = gc - a;       // (c_j - accum_rec_j) . g, backward.cu:586-609
-      const float dLda = __builtin_fmaf(d, T, bgT * rinv);
+      const float dLda = d * T;
       a = __builtin_fmaf(a_eff, d, a);
       float* const uv = uvlane + k * UV_ROW;  // = su + uv_index(k, lane); k is wave-uniform
       uv[0] = a_eff * T;
@@ -1182,8 +1187,10 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
   }
   const uint32_t lend = range.x + n;
   const float bx0 = (float)tx0, by0 = (float)ty0;
-  const float bgT = -Tfin * bgdot;  // backward.cu:617-620: dL/dalpha += (-T_final / (1 - alpha)) (bg . g)
-  float T = Tfin, a = 0.f;          // transmittance behind the entry at hand; g . (colour behind it, normalised): file header
+  // The background is the colour behind the last contributor: `a` starts at bg . g instead of 0, and the reference's separate term
+  // dL/dalpha += (-T_final / (1 - alpha)) (bg . g) (backward.cu:617-620) is inside T (gc - a) — T_final / (1 - alpha_j) is T_j times
+  // the transmittance of the entries behind j, which is the weight the recursion gives the initial value (file header).
+  float T = Tfin, a = bgdot;        // transmittance in front of the entry at hand; g . (colour behind it, background included)
   float* const uvlane = su + uv_index(0, lane);
   constexpr int ROWF = UV_ROW;  // floats between the u/v rows of consecutive trips of a round
   float* const vlane = uvlane + UV_PITCH;
@@ -1321,7 +1328,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_BW, E
       const float rinv = __builtin_amdgcn_rcpf(1.f - a_eff);
       T = T * rinv;            // backward.cu:573
       const float d = gc - a;  // (c_j - accum_rec_j) . g, backward.cu:586-609
-      const float dLda = __builtin_fmaf(d, T, bgT * rinv);
+      const float dLda = d * T;
       a = __builtin_fmaf(a_eff, d, a);
       uvlane[slot * ROWF] = a_eff * T;
       vlane[slot * ROWF] = G_eff * dLda;  // v = G dL/dalpha
