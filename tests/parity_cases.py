@@ -199,8 +199,11 @@ def fp32_variants(case):
     return out
 
 
+COUNT_RTOL = 1e-4  # the tolerance at which arbiter() counts the fp32 evaluations' own out-of-tolerance elements
+
+
 def arbiter(case, base=None):
-    """({output: the arbiter's value}, {output: spread}) for the gradients of `case`.
+    """({output: the arbiter's value}, {output: spread}, {output: count}) for the gradients of `case`.
 
     The arbiter is the oracle's backward in double (oracle/rast_oracle.c "the arbiter build"): the same fp32 forward, the same
     blend / skip / stop decision for every (pixel, Gaussian) pair, every differentiable quantity recomputed and chained in double
@@ -224,13 +227,20 @@ def arbiter(case, base=None):
     f64 = oracle_run(case, backend=oracle.abi_f64)
     keys = [k for k in base if k != "out_radii"]
     spread = {k: np.abs(np.asarray(base[k], dtype=np.float64) - np.asarray(f64[k], dtype=np.float64)) for k in keys}
+    # ... and, per output, on how many elements such an evaluation itself sits beyond COUNT_RTOL of the ORACLE (the largest count
+    # among them): what check_close allows the HIP path when its own count passes the fixed share of a tensor
+    scales = {k: quantity_scale(base[k]).numpy() for k in keys}
+    count = {k: 0 for k in keys}
 
-    def widen(res):
+    def widen(res, counted=False):
         for k in keys:
-            spread[k] = np.maximum(spread[k], np.abs(np.asarray(res[k], dtype=np.float64) - np.asarray(f64[k], dtype=np.float64)))
+            r = np.asarray(res[k], dtype=np.float64)
+            spread[k] = np.maximum(spread[k], np.abs(r - np.asarray(f64[k], dtype=np.float64)))
+            if counted:  # (the evaluations on the SAME inputs only: perturbed inputs also move blend decisions)
+                count[k] = max(count[k], int((np.abs(r - np.asarray(base[k], dtype=np.float64)) / scales[k] > COUNT_RTOL).sum()))
 
     for res in fp32_variants(case).values():
-        widen(res)
+        widen(res, counted=True)
     for draw in range(SENS_DRAWS):
         g = np.random.default_rng(1000 + draw)
         pert = dict(case)
@@ -241,7 +251,7 @@ def arbiter(case, base=None):
                 v = np.asarray(case[k])
                 pert[k] = (v * (1.0 + SENS_ULPS * ULP * g.standard_normal(v.shape))).astype(np.float32)
         widen(oracle_run(pert))
-    return {k: np.asarray(f64[k], dtype=np.float64) for k in keys}, spread
+    return {k: np.asarray(f64[k], dtype=np.float64) for k in keys}, spread, count
 
 
 IMAGE_KEYS = ("out_color", "out_invdepth")
@@ -333,25 +343,15 @@ class Attribution:
             print(f"threshold nudges: {self.flipped_pixels} pixels re-decided, {time.perf_counter() - t0:.1f} s of oracle")
         return self._matched, self._hull
 
+    def fp32_count(self, key):
+        """On how many elements of output `key` a valid fp32 evaluation of the reference's algorithm itself sits beyond COUNT_RTOL
+        of the oracle (the largest count among the evaluations of arbiter())."""
+        self._load_arbiter()
+        return int(self._arb[2].get(key, 0))
+
     def arbiter(self, key):
         """(the arbiter's value, the spread of the valid fp32 evaluations around it) of output `key`: arbiter()."""
-        import os
-        import time
-
-        if self._arb is None:
-            f = self.cache + ".arb.npz" if self.cache else None
-            if f and os.path.exists(f):
-                z = np.load(f)
-                self._arb = ({k[4:]: z[k] for k in z.files if k.startswith("f64_")}, {k[7:]: z[k] for k in z.files if k.startswith("spread_")})
-            else:
-                t0 = time.perf_counter()
-                self._arb = arbiter(self.case, self.ref)
-                print(f"arbiter (double) + {2 + PAIR_NOISE_DRAWS + SENS_DRAWS} fp32 evaluations: {time.perf_counter() - t0:.1f} s")
-                if f:  # (written whole, then renamed: the path children run two at a time and share this cache)
-                    os.makedirs(os.path.dirname(f), exist_ok=True)
-                    tmp = f"{f}.{os.getpid()}.tmp.npz"
-                    np.savez(tmp, **{"f64_" + k: v for k, v in self._arb[0].items()}, **{"spread_" + k: v for k, v in self._arb[1].items()})
-                    os.replace(tmp, f)
+        self._load_arbiter()
         spread = self._arb[1][key]
         if self._nudged is not None and key in self._nudged[0]:
             # ... and the oracle with its blend / stop thresholds moved by their ulp margins, both ways (the runs the decision step
@@ -361,6 +361,27 @@ class Attribution:
             for r in self._nudged:
                 spread = np.maximum(spread, np.abs(np.asarray(r[key], dtype=np.float64) - self._arb[0][key]))
         return torch.from_numpy(self._arb[0][key]), torch.from_numpy(spread)
+
+    def _load_arbiter(self):
+        import os
+        import time
+
+        if self._arb is None:
+            f = self.cache + ".arb.npz" if self.cache else None
+            if f and os.path.exists(f):
+                z = np.load(f)
+                self._arb = ({k[4:]: z[k] for k in z.files if k.startswith("f64_")}, {k[7:]: z[k] for k in z.files if k.startswith("spread_")},
+                             {k[6:]: int(z[k]) for k in z.files if k.startswith("count_")})
+            else:
+                t0 = time.perf_counter()
+                self._arb = arbiter(self.case, self.ref)
+                print(f"arbiter (double) + {2 + PAIR_NOISE_DRAWS + SENS_DRAWS} fp32 evaluations: {time.perf_counter() - t0:.1f} s")
+                if f:  # (written whole, then renamed: the path children run two at a time and share this cache)
+                    os.makedirs(os.path.dirname(f), exist_ok=True)
+                    tmp = f"{f}.{os.getpid()}.tmp.npz"
+                    np.savez(tmp, **{"f64_" + k: v for k, v in self._arb[0].items()}, **{"spread_" + k: v for k, v in self._arb[1].items()},
+                             **{"count_" + k: np.int64(v) for k, v in self._arb[2].items()})
+                    os.replace(tmp, f)
 
 
 # How far the HIP value may sit from the arbiter, in units of the valid fp32 evaluations' own largest distance from it. (Rounds
@@ -386,7 +407,9 @@ def check_close(got, ref, what, rtol, attribution=None, key=None):
       2. by the arbiter: |got - f64| <= ARB_FACTOR * spread + rtol * scale, where f64 is the oracle's backward evaluated in double
          with the same decisions and spread the largest distance from it of a valid fp32 evaluation of the reference's
          algorithm (the oracle, its fp32-summing mode, its FMA build, the oracle on inputs perturbed by a few ulp): arbiter().
-    Accepted elements are capped at max(ATTR_MIN, ATTR_FRAC x elements) per tensor (32 / 0.5 %). Returns (max error, accepted elements)."""
+    Accepted elements are capped at max(ATTR_MIN, ATTR_FRAC x elements) per tensor (32 / 0.5 %) or, where that is more, at the
+    number of elements on which a valid fp32 evaluation of the reference's algorithm itself leaves the tolerance (Attribution.fp32_count).
+    Returns (max error, accepted elements)."""
     a = torch.as_tensor(got, dtype=torch.float64).cpu()
     b = torch.as_tensor(np.asarray(ref), dtype=torch.float64)
     assert tuple(a.shape) == tuple(b.shape), f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
@@ -403,6 +426,11 @@ def check_close(got, ref, what, rtol, attribution=None, key=None):
     assert attribution is not None and key is not None, (
         f"{what}: max err {float(err.max()):.3e} of its quantity's scale (scales {scale.flatten().tolist()}), {nbad} elements beyond {rtol:g}")
     cap = max(ATTR_MIN, int(ATTR_FRAC * b.numel()))
+    if nbad > cap and abs(rtol - COUNT_RTOL) <= 1e-12:
+        # ... or as many as a valid fp32 evaluation of the reference's algorithm has itself: on an ill-conditioned scene the
+        # oracle's FMA build or its fp32-summing mode leave the tolerance on more elements than the fixed share allows (sweep
+        # seed 7232, g_rotations: 45 / 37 of 6996 where the share is 34 and the HIP path has 34-37, profiles/r06_sweeps.txt)
+        cap = max(cap, attribution.fp32_count(key))
     assert nbad <= cap, f"{what}: {nbad} of {b.numel()} elements beyond {rtol:g} (max {float(err.max()):.3e}): more than attribution may accept ({cap})"
     m, hull = attribution.matched()
     mm = torch.as_tensor(np.asarray(m[key]), dtype=torch.float64).reshape(a.shape)
