@@ -101,7 +101,7 @@ static inline float noised_G(size_t pix_id, uint32_t id, float power) {
 }
 /* Diagnostic (tests/parity_cases.py, causal attribution of threshold flips): the reference's two data-dependent blend
  * decisions (forward.cu:374-382) evaluated with their thresholds moved by a stated number of ulp, per pixel:
- *   skip    if  alpha < (1/255) (1 + s (ka0 + ka1 |power|) ulp)     (the exponent's rounding error scales with |power|)
+ *   skip    if  alpha < (1/255) (1 + s (ka0 + ka1 M) ulp)     (M = the magnitude of the exponent's terms, alpha_min below)
  *   stop    if  T'    < 1e-4   (1 + s (kT0 + kT1 n) ulp),  n = Gaussians blended so far at the pixel
  * s in {-1, 0, +1}: g_nudge_map[pixel] when a map is installed, else g_nudge_uniform. s = 0 is the reference's arithmetic,
  * bit for bit. Two fp32 implementations that round the exponent differently can land on different sides of a threshold
@@ -126,8 +126,17 @@ int eogs_oracle_threshold_nudge(int uniform, const signed char* map, size_t n, c
   return 0;
 }
 static inline int nudge_sign(size_t pix_id) { return g_nudge_map ? (pix_id < g_nudge_n ? g_nudge_map[pix_id] : 0) : g_nudge_uniform; }
-static inline float alpha_min(int s, float power) {
-  return s ? (1.0f / 255.0f) * (1.0f + (float)s * (g_nk[0] + g_nk[1] * fabsf(power)) * ORACLE_ULP) : 1.0f / 255.0f;
+/* `co`, dx, dy: the pair's conic and offset. The margin grows with the MAGNITUDE of the exponent's terms, M = |a| dx^2 / 2 +
+ * |c| dy^2 / 2 + |b dx dy| — what the rounding error of its five operations scales with (about M ulp absolute, i.e. M ulp of alpha
+ * relative). M equals |power| unless the cross term cancels the squares: a thin rotated Gaussian evaluated far out along its long
+ * axis. Rounds 3-5 used |power|; round 6's fresh sweep range 9000-9399 held two such pairs — seed 9241: terms -1720.0, -1766.7,
+ * +3485.8 summing to a power of -0.94, alpha 1563 ulp below 1/255 where the margin was 24 ulp; seed 9376: -5004.2, -4899.6, +9899.0
+ * -> -4.75, 3510 ulp above — one pixel each on which the HIP path, which evaluates (A dx - B dy) dx + C dy^2 with a pre-scaled conic,
+ * decides the other way; the oracle run with the threshold moved by THIS margin reproduces those pixels channel for channel. */
+static inline float alpha_min(int s, const float* co, float dx, float dy) {
+  if (!s) return 1.0f / 255.0f;
+  const float mag = 0.5f * (fabsf(co[0]) * dx * dx + fabsf(co[2]) * dy * dy) + fabsf(co[1] * dx * dy);
+  return (1.0f / 255.0f) * (1.0f + (float)s * (g_nk[0] + g_nk[1] * mag) * ORACLE_ULP);
 }
 static inline float T_min(int s, uint32_t nblended) {
   return s ? 0.0001f * (1.0f + (float)s * (g_nk[2] + g_nk[3] * (float)nblended) * ORACLE_ULP) : 0.0001f;
@@ -604,7 +613,7 @@ int eogs_rast_forward_render(
         const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
         if (power > 0.0f) continue;
         const float alpha = fminf(0.99f, co[3] * expf(power));
-        if (alpha < alpha_min(ns, power)) continue;
+        if (alpha < alpha_min(ns, co, dx, dy)) continue;
         const float test_T = T * (1 - alpha);
         if (test_T < T_min(ns, nblended)) break; /* done = true: this Gaussian is not blended */
         for (int ch = 0; ch < C_; ch++) Cc[ch] += colors[(size_t)id * C_ + ch] * alpha * T;
@@ -748,7 +757,7 @@ static int backward_activated(
           const float fpower = -0.5f * (fco[0] * fdx * fdx + fco[2] * fdy * fdy) - fco[1] * fdx * fdy;
           if (fpower > 0.0f) continue;
           const float fG = expf(fpower);
-          if (fminf(0.99f, fco[3] * fG) < alpha_min(nudge_sign(pix_id), fpower)) continue;
+          if (fminf(0.99f, fco[3] * fG) < alpha_min(nudge_sign(pix_id), fco, fdx, fdy)) continue;
           T_final *= 1.f - fminf(0.99f, fco[3] * noised_G(pix_id, id, fpower));
         }
       }
@@ -762,7 +771,7 @@ static int backward_activated(
           const float* fco = g.conic_opacity + 4 * (size_t)id;
           const float fpower = -0.5f * (fco[0] * fdx * fdx + fco[2] * fdy * fdy) - fco[1] * fdx * fdy;
           if (fpower > 0.0f) continue;
-          if (fminf(0.99f, fco[3] * expf(fpower)) < alpha_min(nudge_sign(pix_id), fpower)) continue;
+          if (fminf(0.99f, fco[3] * expf(fpower)) < alpha_min(nudge_sign(pix_id), fco, fdx, fdy)) continue;
           const real dx = r_mean2D[2 * (size_t)id] - (real)pixfx, dy = r_mean2D[2 * (size_t)id + 1] - (real)pixfy;
           const real* co = r_conic_o + 4 * (size_t)id;
           T_final *= 1.0 - fmin((double)0.99f, co[3] * exp(-0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy));
@@ -794,7 +803,7 @@ static int backward_activated(
             const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
             if (power > 0.0f) continue;
             const float alpha = fminf(0.99f, co[3] * expf(power));
-            if (alpha < alpha_min(nudge_sign(pix_id), power)) continue;
+            if (alpha < alpha_min(nudge_sign(pix_id), co, dx, dy)) continue;
             float gc = 0.f;
             for (int ch = 0; ch < C_; ch++) gc += (float)dL_dpixel[ch] * colors[(size_t)id * C_ + ch];
             if (dL_dout_invdepth) gc += (float)dL_invdepth * (1.f / g.depths[id]);
@@ -810,7 +819,7 @@ static int backward_activated(
           const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
           if (power > 0.0f) continue;
           const float alpha = fminf(0.99f, co[3] * expf(power));
-          if (alpha < alpha_min(nudge_sign(pix_id), power)) continue;
+          if (alpha < alpha_min(nudge_sign(pix_id), co, dx, dy)) continue;
           float gc = 0.f;
           for (int ch = 0; ch < C_; ch++) gc += (float)dL_dpixel[ch] * colors[(size_t)id * C_ + ch];
           if (dL_dout_invdepth) gc += (float)dL_invdepth * (1.f / g.depths[id]);
@@ -831,7 +840,7 @@ static int backward_activated(
         if (fpower > 0.0f) continue;
         const float fG = expf(fpower);
         const float falpha = fminf(0.99f, fco[3] * fG);
-        if (falpha < alpha_min(nudge_sign(pix_id), fpower)) continue; /* the same decision forward took */
+        if (falpha < alpha_min(nudge_sign(pix_id), fco, fdx, fdy)) continue; /* the same decision forward took */
 #ifdef ORACLE_F64
         const real dx = r_mean2D[2 * (size_t)id] - (real)pixfx, dy = r_mean2D[2 * (size_t)id + 1] - (real)pixfy;
         const real* co = r_conic_o + 4 * (size_t)id;

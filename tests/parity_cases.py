@@ -7,7 +7,7 @@ would make T < 1e-4. Two fp32 implementations (libm expf on the host, v_exp_f32 
 association of the exponent) can land on different sides of a threshold for a pair that sits within a few ulp of it; the
 pixel then differs by up to alpha T |c| and so does every gradient fed by that pixel. Such elements are accepted ONLY when
 the oracle itself reproduces them with the decision moved: the oracle is re-run with both thresholds shifted by
--k / +k ulp (k = (16 + 8 |power|) for the alpha test, (16 + 4 n) for the stop test: `eogs_oracle_threshold_nudge`), a
+-k / +k ulp (k = (16 + 8 M) for the alpha test, M = the magnitude of the exponent's terms — |power| unless they cancel —, (16 + 4 n) for the stop test: `eogs_oracle_threshold_nudge`), a
 per-pixel sign is chosen from the three images so that the oracle's image matches the HIP image, the oracle runs once more
 with that per-pixel map, and every output and gradient must then agree with THAT run to the plain tolerance (or, where one
 pixel holds several near pairs that flipped differently, lie inside the interval the four oracle runs span). What is still

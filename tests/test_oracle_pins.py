@@ -155,7 +155,7 @@ def test_config1_plumbing_1k_128(oracle_backend):
 def test_threshold_nudge_moves_exactly_the_near_threshold_decision(oracle_backend):
     """eogs_oracle_threshold_nudge (the causal flip attribution of tests/parity_cases.py): a Gaussian centred on pixel
     (8, 8) with alpha = (1/255)(1 + 4 ulp) there is blended by the reference's arithmetic and with the thresholds moved
-    down, skipped with them moved up by their (16 + 8|power|)-ulp margin; no other pixel changes, a per-pixel map moves
+    down, skipped with them moved up by their (16 + 8 M)-ulp margin (M: the magnitude of the exponent's terms); no other pixel changes, a per-pixel map moves
     only its pixel, and sign 0 is the reference's arithmetic bit for bit."""
     import sys
     import os
