@@ -255,7 +255,7 @@ def measured_traffic(kernel, a):
         # a launch group of the library (kernels_ms key) -> the kernels it launches once per step
         group = {"depth_sort": ("block_lists_kernel",),
                  "binning": ("pblock_scan_kernel", "expand_entries_kernel", "entry_hist_kernel", "entry_colscan_kernel",
-                             "entry_scatter_kernel")}.get(kernel, (kernel + "_kernel", kernel + "_quad_kernel", kernel + "_mfma_kernel"))
+                             "entry_scatter_kernel")}.get(kernel, (kernel + "_kernel", kernel + "_quad_kernel"))
         total, hit = 0.0, False
         for name, c in pm.items():
             if name.startswith(group) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
@@ -395,7 +395,7 @@ def measured_valu(kernel, a, counter=None):
         except Exception:
             continue
         for name, c in pm.items():
-            if name.startswith((kernel + "_kernel", kernel + "_quad_kernel", kernel + "_mfma_kernel")) and "SQ_INSTS_VALU" in c:
+            if name.startswith((kernel + "_kernel", kernel + "_quad_kernel")) and "SQ_INSTS_VALU" in c:
                 if counter is not None:
                     return float(c[counter]) if counter in c else None
                 return float(c["SQ_INSTS_VALU"])
