@@ -196,6 +196,31 @@ def test_threshold_nudge_moves_exactly_the_near_threshold_decision(oracle_backen
         assert np.array_equal(pre[-1][k], down[k]) and np.array_equal(pre[1][k], up[k]), k
 
 
+def test_threshold_margin_follows_the_magnitude_of_the_exponents_terms(oracle_backend):
+    """The alpha-threshold margin of the moved-threshold runs is (16 + 8 M) ulp with M = |a| dx^2 / 2 + |c| dy^2 / 2 + |b dx dy|, not
+    (16 + 8 |power|): sweep seed 9241 holds a thin rotated Gaussian whose exponent at pixel (195, 69) is -1720.0 - 1766.7 + 3485.8 =
+    -0.94 — rounding of terms of that size moves alpha by ~M ulp — and whose alpha sits 1563 ulp below 1/255 (|power|-margin: 24 ulp).
+    The oracle skips it; with the threshold moved DOWN it blends it (all five channels of that pixel move: what the HIP path, which
+    associates the exponent differently, renders there); seed 9376's pixel (23, 6) is the mirror case, 3510 ulp above the threshold."""
+    import os
+    import sys
+
+    import numpy as np
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from parity_cases import nudged_run, oracle_run, sweep_case
+
+    for seed, (x, y), moving, hip in ((9241, (195, 69), -1, (0.8845484, 0.2205877, 0.6583073, -13.6817, 0.111772)),
+                                      (9376, (23, 6), +1, (0.4699688, None, None, 22.25215, 0.9587148))):
+        case, _ = sweep_case(seed)
+        base, moved, other = oracle_run(case), nudged_run(case, uniform=moving), nudged_run(case, uniform=-moving)
+        assert np.array_equal(base["out_color"][:, y, x], other["out_color"][:, y, x])  # the other direction leaves the pixel alone
+        assert not np.array_equal(base["out_color"][:, y, x], moved["out_color"][:, y, x])
+        for ch, v in enumerate(hip):  # the values the HIP path renders at that pixel (profiles/r06_sweeps.txt, tools/pixel_probe.py)
+            if v is not None:
+                assert abs(float(moved["out_color"][ch, y, x]) - v) <= 1e-5 * max(1.0, abs(v)), (seed, ch, moved["out_color"][ch, y, x], v)
+
+
 @pytest.mark.parametrize("P,H,W,seed,opacity,scale_mult", [(1500, 32, 32, 3, 0.6, 10.0), (2000, 40, 48, 7, 0.95, 15.0)])
 def test_back_to_front_recursion_is_the_accurate_form_for_image_sized_gaussians(P, H, W, seed, opacity, scale_mult, oracle_backend):
     """Why every backward kernel walks back to front (csrc/render.hip): against the independent dense autograd
