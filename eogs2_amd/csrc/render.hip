@@ -426,7 +426,9 @@ __device__ inline void quad_append(uint32_t* sidx, int lane, bool hit, int pos, 
 
 // ALT: an altitude-only render (EOGS_FLAG_ALT_ONLY): only feature channel 3 is blended and stored — out_color is ONE plane
 // f32[H, W], out_invdepth is not written — and a trip reads 28 of the entry's 48 bytes.
-template <int MACRO, bool ALT>
+// INVD = false: the caller passed no inverse-depth image (out_invdepth == NULL: the reference's render() drops that output,
+// gaussian_renderer/renderer.py:101,126) — its multiply-add per evaluated (pixel, entry) is left out, one of 22.
+template <int MACRO, bool ALT, bool INVD = true>
 __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_FW, EOGS_FW))) void render_fwd_quad_kernel(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ keys, const uint2* __restrict__ point_list, int W, int H, int gsx, int ntiles, int gmx, const uint4* __restrict__ desc, const uint32_t* __restrict__ sched, int lg16,
     const float4* __restrict__ packed, const float* __restrict__ bg,
@@ -564,7 +566,8 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_FW, E
         } else {
           C[0] += e.q1.z * wgt; C[1] += e.q1.w * wgt;
           C[2] += e.q2.x * wgt; C[3] += e.q2.y * wgt; C[4] += e.q2.z * wgt;
-          invd += e.q2.w * wgt;
+          if (INVD) invd += e.q2.w * wgt;
+          else asm volatile("" :: "v"(e.q2.w));  // (keeps the entry's third read a ds_read_b128: see render_bwd_quad_kernel's grad)
         }
       };
       // software pipeline: sub-list elements two trips ahead, entry reads one trip ahead, two register sets; groups of eight
@@ -618,7 +621,7 @@ __global__ __launch_bounds__(RBLK) __attribute__((amdgpu_waves_per_eu(EOGS_FW, E
     } else {
 #pragma unroll
       for (int ch = 0; ch < NCH; ch++) out_color[ch * HW + pix_id] = C[ch] + T * bg[ch];
-      if (out_invdepth) out_invdepth[pix_id] = invd;
+      if (INVD && out_invdepth) out_invdepth[pix_id] = invd;
     }
   }
   WTRACE_END(0, tile);
@@ -665,7 +668,7 @@ void launch_render_fwd(const GeomWS& g, const BinWS& b, const ImgWS& im, int P, 
                        const float* bg, float* out_color, float* out_invdepth, hipStream_t s) {
   const int gsx = (W + SUBX - 1) / SUBX, gsy = (H + SUBY - 1) / SUBY, ntiles = gsx * gsy;
   const int variant = render_fwd_variant(b.block, R, P);
-  auto* kern = variant == 1 ? render_fwd_kernel<BLOCK_BIG> : (variant == 2 ? (nr_alt(R) ? render_fwd_quad_kernel<1, true> : render_fwd_quad_kernel<1, false>) : render_fwd_kernel<1>);
+  auto* kern = variant == 1 ? render_fwd_kernel<BLOCK_BIG> : (variant == 2 ? (nr_alt(R) ? render_fwd_quad_kernel<1, true> : (out_invdepth ? render_fwd_quad_kernel<1, false> : render_fwd_quad_kernel<1, false, false>)) : render_fwd_kernel<1>);
   // (the quad forward leaves its quad masks for the backward in BinWS::qmask, handed over in place of the keys it does not read)
   const uint32_t* keys = variant == 2 ? reinterpret_cast<const uint32_t*>(b.qmask) : b.sorted_keys;
   hipLaunchKernelGGL(kern, dim3(render_grid(ntiles, im, R)), dim3(RBLK), 0, s, im.ranges, keys, b.point_list, W, H, gsx,

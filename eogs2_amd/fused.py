@@ -19,14 +19,14 @@ from .rasterizer import NUM_CHANNELS, _run_backward, _run_forward, last_exact_to
 class _RasterizeRaw(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, means2D, f_dc, opacity_logit, log_scaling, raw_rotation, viewmat, alt_affine, raster_settings,
-                altitude_only=False):
+                altitude_only=False, invdepth=True):
         rs = raster_settings
         P = xyz.shape[0]
         if f_dc.numel() != P * 3:
             raise RuntimeError("f_dc must have dimensions (num_points, 3) or (num_points, 1, 3)")
         num_rendered, color, radii, invdepths, geom, binning, img = _run_forward(
             rs, viewmat, xyz, f_dc.reshape(P, 3), opacity_logit, log_scaling, raw_rotation, None,
-            alt_affine=alt_affine, raw=True, alt_only=altitude_only,
+            alt_affine=alt_affine, raw=True, alt_only=altitude_only, want_invdepth=bool(invdepth),
         )
         ctx.altitude_only = bool(altitude_only)
         ctx.raster_settings = rs
@@ -48,18 +48,23 @@ class _RasterizeRaw(torch.autograd.Function):
         if P == 0:
             z = torch.zeros_like
             return (z(xyz), z(xyz), z(f_dc), z(opacity_logit), z(log_scaling), z(raw_rotation),
-                    torch.zeros_like(rs.viewmatrix) if want_vm else None, None, None, None)
+                    torch.zeros_like(rs.viewmatrix) if want_vm else None, None, None, None, None)
         d_means2D, d_fdc, d_logit, d_xyz, _cov, d_logscale, d_rawrot, grad_viewmatrix = _run_backward(
             rs, ctx.num_rendered, grad_out_color, grad_out_depth, xyz, None, opacity_logit,
             log_scaling, raw_rotation, None, radii, geom, binning, img, color, invdepths, want_vm, alt_affine=alt_affine, raw=True,
             alt_only=ctx.altitude_only,
         )
         return (d_xyz, d_means2D, d_fdc.view(f_dc.shape), d_logit.view(opacity_logit.shape), d_logscale, d_rawrot,
-                grad_viewmatrix, None, None, None)
+                grad_viewmatrix, None, None, None, None)
 
 
-def rasterize_raw(xyz, means2D, f_dc, opacity_logit, log_scaling, raw_rotation, alt_affine, raster_settings, altitude_only=False):
+def rasterize_raw(xyz, means2D, f_dc, opacity_logit, log_scaling, raw_rotation, alt_affine, raster_settings, altitude_only=False,
+                  invdepth=True):
     """(color[5,H,W], radii[P], invdepths[1,H,W]) from raw parameters.
+
+    `invdepth=False`: the inverse-depth image is not rendered (third result None; the C-ABI's out_invdepth = NULL) — for callers
+    that drop it, as the reference's own `render()` does (gaussian_renderer/renderer.py:101,126): one multiply-add less per
+    evaluated (pixel, Gaussian) in the forward, the colour image and every gradient the same bits.
 
     `altitude_only=True` (EOGS_FLAG_ALT_ONLY, include/eogs_rast.h): only the altitude feature is rendered — `color` is then
     [1,H,W], equal to channel 3 of the full render, and the third result is None (there is no inverse-depth image to read
@@ -77,7 +82,7 @@ def rasterize_raw(xyz, means2D, f_dc, opacity_logit, log_scaling, raw_rotation, 
     if alt_affine.numel() != 4:
         raise RuntimeError("alt_affine must have 4 elements (camera.affine[:, 2])")
     return _RasterizeRaw.apply(xyz, means2D, f_dc, opacity_logit, log_scaling, raw_rotation,
-                               raster_settings.viewmatrix, alt_affine, raster_settings, bool(altitude_only))
+                               raster_settings.viewmatrix, alt_affine, raster_settings, bool(altitude_only), bool(invdepth))
 
 
 __all__ = ["rasterize_raw", "NUM_CHANNELS"]

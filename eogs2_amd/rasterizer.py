@@ -275,12 +275,13 @@ def rasterize_gaussians(
 
 
 def _run_forward(rs, viewmat, means3D, colors, opacities, scales, rotations, cov3Ds_precomp, alt_affine=None, raw=False,
-                 alt_only=False):
+                 alt_only=False, want_invdepth=True):
     """Marshalling of DGR/rasterize_points.cu:35-131 over the C-ABI.
 
     Returns (num_rendered, color, radii, invdepths, geom, binning, img). With `raw` the per-Gaussian tensors are the
     model's raw parameters (EOGS_FLAG_RAW_PARAMS, include/eogs_rast.h) and `colors` is f_dc [P,3]. With `alt_only`
-    (EOGS_FLAG_ALT_ONLY) only feature channel 3 is rendered: `color` is [1, H, W] and `invdepths` is None.
+    (EOGS_FLAG_ALT_ONLY) only feature channel 3 is rendered: `color` is [1, H, W] and `invdepths` is None. With
+    `want_invdepth=False` the inverse-depth image is neither allocated nor blended (out_invdepth = NULL): `invdepths` is None.
     """
     abi = _backend()
     # DGR/rasterize_points.cu:58-60
@@ -295,7 +296,8 @@ def _run_forward(rs, viewmat, means3D, colors, opacities, scales, rotations, cov
     with _Ctx(abi, dev) as cx:
         # outputs as DGR/rasterize_points.cu:69-76 (zero images when P == 0: forward is skipped)
         color = torch.empty((1 if alt_only else NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
-        invdepths = None if alt_only else torch.empty((1, H, W), dtype=torch.float32, device=dev)  # (alt_only: no such output)
+        # (alt_only: no such output; want_invdepth=False: the caller drops it, as the reference's render() does)
+        invdepths = None if (alt_only or not want_invdepth) else torch.empty((1, H, W), dtype=torch.float32, device=dev)
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
         empty_u8 = torch.empty((0,), dtype=torch.uint8, device=dev)
         geom = binning = img = empty_u8
@@ -358,7 +360,7 @@ def _run_forward(rs, viewmat, means3D, colors, opacities, scales, rotations, cov
                     abi.forward_render(
                         P, H, W, token, _ptr(bg), flags,
                         _ptr(geom), geom.numel(), _ptr(ws), ws.numel(), _ptr(img), img.numel(),
-                        _ptr(scratch), n_scratch, _ptr(color), None if alt_only else _ptr(invdepths), cx.stream,
+                        _ptr(scratch), n_scratch, _ptr(color), None if invdepths is None else _ptr(invdepths), cx.stream,
                     )
                 )
                 return ws

@@ -63,8 +63,9 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, separate_
     viewspace_points = torch.zeros_like(pc._xyz, requires_grad=True)
     # altitude channel = xyz @ affine[:3, 2] + affine[3, 2]   (scene/cameras/affine_cameras.py:432-438)
     alt_affine = viewpoint_camera.affine[:, 2].detach().to(torch.float32).contiguous()
+    # (the reference's render() drops the rasterizer's inverse-depth image, renderer.py:101,126: it is not rendered here)
     image, radii, _ = rasterize_raw(pc._xyz, viewspace_points, pc._features_dc, pc._opacity, pc._scaling, pc._rotation,
-                                    alt_affine, settings, altitude_only=altitude_only)
+                                    alt_affine, settings, altitude_only=altitude_only, invdepth=False)
     if use_trained_exp:  # per-image 3x4 exposure on the rgb planes (renderer.py:112-120)
         e = pc.get_exposure_from_name(viewpoint_camera.image_name)
         image = torch.einsum("chw,cd->dhw", image, e[:3, :3]) + e[:3, 3].reshape(3, 1, 1)

@@ -171,7 +171,8 @@ int eogs_rast_capacity_token(int P, int64_t num_rendered, double slack, int have
 /* Forward, phase 2: duplicate-with-keys, (tile,depth) sort, tile ranges, alpha blend.
  * Replaces DGR/cuda_rasterizer/rasterizer_impl.cu:290-340 (duplicateWithKeys,
  * cub::DeviceRadixSort::SortPairs, identifyTileRanges, FORWARD::render).
- * out_invdepth may be NULL. Asynchronous on `stream`. */
+ * out_invdepth may be NULL: the inverse-depth image is then not blended at all (the reference's render() drops it,
+ * gaussian_renderer/renderer.py:101,126; eogs2_amd.render.render passes NULL). Asynchronous on `stream`. */
 int eogs_rast_forward_render(
     int P, int H, int W, int64_t num_rendered,
     const float* bg, unsigned flags,

@@ -211,3 +211,34 @@ def test_altitude_only_deferred_counts_and_graph(dev):
     got = [t.clone() for t in g()]
     for t, k in zip(got, [k for k in sorted(want) if not k.startswith("_")]):
         assert torch.equal(t, want[k]), k
+
+
+@pytest.mark.parametrize("P,H,W,seed,opacity,scale_mult,aa", [CASES[0], CASES[1], (120_000, 344, 392, 66, "init", 1.0, False)])
+def test_render_without_the_inverse_depth_image_changes_no_bit(dev, P, H, W, seed, opacity, scale_mult, aa):
+    """`rasterize_raw(..., invdepth=False)` (what eogs2_amd.render.render passes: the reference's render() drops the rasterizer's
+    inverse-depth image, renderer.py:101,126) hands the C-ABI out_invdepth = NULL; the quad forward then leaves that multiply-add
+    out of every evaluated pair. The colour image, the radii and every gradient are the same BITS as with the image rendered."""
+    from eogs2_amd.fused import rasterize_raw
+    from eogs2_amd.synthetic import make_scene, settings_for
+
+    scene = make_scene(P, H, W, seed=seed, opacity=opacity, scale_mult=scale_mult, device=dev)
+    raw, alt = raw_params_from_scene(scene, seed=seed)
+    g = torch.randn(5, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(seed)) / (H * W)
+
+    def run(invdepth):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in raw.items()}
+        vm = scene["viewmatrix"].clone().requires_grad_(True)
+        rs = settings_for(dict(scene, viewmatrix=vm), H, W, antialiasing=aa)._replace(projmatrix=vm.detach())
+        m2 = torch.zeros(P, 3, device=dev, requires_grad=True)
+        color, radii, invd = rasterize_raw(leaves["xyz"], m2, leaves["f_dc"], leaves["opacity_logit"], leaves["log_scaling"],
+                                           leaves["raw_rotation"], alt, rs, invdepth=invdepth)
+        assert (invd is None) == (not invdepth)
+        (color * g).sum().backward()
+        out = dict(color=color.detach(), radii=radii, g_means2D=m2.grad, g_viewmatrix=vm.grad)
+        out.update({"g_" + k: v.grad for k, v in leaves.items()})
+        return out
+
+    a, b = run(True), run(False)
+    assert float(a["color"].abs().max()) > 0.1 and float(a["g_xyz"].abs().max()) > 0
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
