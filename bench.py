@@ -1005,7 +1005,7 @@ def regime_scan(dev, steps=20):
             # (per STEP, not per bracket: `binning` is two brackets a step — the count scan, then the entry sort)
             kern = {k: t / steps for k, (t, n) in abi.profile().items() if n and k in ("preprocess_fwd", "depth_sort", "binning", "render_fwd", "render_bwd", "gaussian_bwd")}
             out[name] = {"gaussians": P, "size": S, "opacity": op, "steps": steps, "ms_per_step": ms, "views_per_s": 1e3 / ms,
-                         "num_rendered": R, "list_block_px": block_px, "fwd_kernel": names.get(fwd_k, fwd_k), "bwd_kernel": names.get(bwd_k, bwd_k),
+                         "num_rendered": R, "list_entries": (nr >> 32) & 0x07FFFFFF, "list_block_px": block_px, "fwd_kernel": names.get(fwd_k, fwd_k), "bwd_kernel": names.get(bwd_k, bwd_k),
                          "gaussian_bwd_wide": abi.backward_info(P, nr), "kernels_ms": kern, "algorithmic_bytes": by,
                          "frac": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "windows_ms": windows}
             del sc, rast, params, m2, c
