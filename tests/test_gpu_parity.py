@@ -148,6 +148,37 @@ def test_image_with_more_than_4096_blocks_takes_the_two_pass_sort(dev):
     _compare(got, {k: v.cpu().numpy() for k, v in ref.items() if not k.startswith('_')}, "two-pass", case)
 
 
+def test_footprints_taller_than_64_block_rows(dev):
+    """A 2304-pixel-high image has 72 rows of 32 x 32-px blocks: a footprint as tall as the image spans more block rows than a wave
+    has lanes, so the passes that deal a footprint's block rows to the lanes of a wave — preprocess_fwd's cooperative count and
+    expand_entries' cooperative walk (csrc/preprocess.hip, csrc/binning.hip: `MY += 64`) — go round twice. 600 ordinary Gaussians
+    plus 12 thin ones as tall as the image (sigma 450-700 px along the rows, 2-5 px across, some rotated a few degrees: row-span
+    listing), every output and gradient against the oracle."""
+    from eogs2_amd import GaussianRasterizationSettings, GaussianRasterizer
+    from eogs2_amd.synthetic import make_scene
+
+    H, W, P, tall = 2304, 160, 600, 12
+    assert (H + 31) // 32 > 64
+    sc = make_scene(P, H, W, seed=47, opacity="trained", scale_mult=1.0)
+    case = {k: v.numpy() for k, v in sc.items()}
+    g = np.random.default_rng(47)
+    idx = g.choice(P, tall, replace=False)
+    # (synthetic.make_camera: image rows run along world x, columns along world y; a scale s is s * H / 2 or s * W / 2 pixels)
+    case["scales"][idx] = np.stack([g.uniform(450, 700, tall) / (0.5 * H), g.uniform(2, 5, tall) / (0.5 * W),
+                                    np.full(tall, 0.01)], axis=1).astype(np.float32)
+    ang = np.deg2rad(g.uniform(-3, 3, tall))
+    case["rotations"][idx] = np.stack([np.cos(ang / 2), np.zeros(tall), np.zeros(tall), np.sin(ang / 2)], axis=1).astype(np.float32)
+    case["means3D"][idx, 0] = g.uniform(-0.2, 0.2, tall).astype(np.float32)
+    case["opacities"][idx] = g.uniform(0.3, 0.8, (tall, 1)).astype(np.float32)
+    case.update(H=H, W=W, antialiasing=False)
+    got = run_case(case, dev, GaussianRasterizer, GaussianRasterizationSettings)
+    radii = got["out_radii"].cpu().numpy()
+    assert int((radii[idx] > 1000).sum()) == tall, radii[idx]  # they do span the image
+    from parity_cases import oracle_run
+
+    _compare(got, oracle_run(case), "tall", case)
+
+
 def test_entry_sort_in_scratch_and_in_the_binning_workspace_agree(dev, monkeypatch, exact_counts):
     """The entry sort runs in the caller's scratch behind the count readback (ABI v5) or, without scratch / with more
     entries than its capacity, in the binning workspace after the readback: same kernels, same lists — outputs and
